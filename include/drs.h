@@ -1,0 +1,195 @@
+/*
+ * drs.h -- C ABI of the MI355X (gfx950) inference engine for the DeepRecSys
+ * hot path: the per-query DLRM-style forward (SparseLengthsSum gathers,
+ * bottom/top MLP, dot/cat feature interaction) that the reference dispatches
+ * from inferenceEngine.py / accelInferenceEngine.py.
+ *
+ * This header is the drop-in boundary.  The reference has no native FFI of its
+ * own (it is 100% Python on top of Caffe2), so each entry point below cites the
+ * reference Python interface / Caffe2 operator call site it replaces.  All
+ * paths are into the reference tree (harvard-acc/DeepRecSys).
+ *
+ * Conventions
+ *   - every function returns an int32 status: 0 = DRS_OK, negative = error;
+ *     no exception or abort ever crosses this boundary
+ *     (reference style is print + sys.exit(), accelInferenceEngine.py:28-31).
+ *   - h_* pointers are host memory owned by the caller (copied before return
+ *     unless the name says "pinned"); d_* pointers are device memory on the
+ *     engine's GPU.
+ *   - plain pointers and sizes only; no torch types.
+ *   - the library needs a GPU: drs_create fails with DRS_ERR_HIP when no
+ *     gfx950 device is visible.  There is no CPU fallback behind this ABI.
+ */
+#ifndef DRS_H_
+#define DRS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRS_ABI_VERSION 1
+
+typedef struct drs_engine* drs_handle;
+
+/* status codes */
+enum {
+  DRS_OK = 0,
+  DRS_ERR_BAD_ARG = -1,      /* null pointer, out-of-range id, shape mismatch          */
+  DRS_ERR_OOM = -2,          /* hipMalloc / hipHostMalloc failed                       */
+  DRS_ERR_HIP = -3,          /* any other HIP runtime error (see drs_last_error)       */
+  DRS_ERR_INDEX_RANGE = -4,  /* an index is <0 or >= rows  (Caffe2 CAFFE_ENFORCE)      */
+  DRS_ERR_LENGTHS_SUM = -5,  /* sum(lengths) != number of indices (Caffe2 ENFORCE)     */
+  DRS_ERR_STATE = -6,        /* e.g. forward before weights/batch were set             */
+  DRS_ERR_UNSUPPORTED = -7   /* shape outside what the kernels implement               */
+};
+
+/* model wiring: which reference graph builder the engine mirrors */
+enum {
+  DRS_MODEL_DLRM = 0, /* models/dlrm_s_caffe2.py:367-389  (RMC1/2/3)                   */
+  DRS_MODEL_WND = 1,  /* models/wide_and_deep.py:282-305  (SLS ++ raw dense -> top MLP) */
+  DRS_MODEL_NCF = 2   /* models/ncf.py:317-346            (MF Sum ++ MLP branch)        */
+};
+
+/* feature interaction (models/dlrm_s_caffe2.py:331-365) */
+enum { DRS_INTERACT_DOT = 0, DRS_INTERACT_CAT = 1 };
+
+/* FC epilogue (Relu / Sigmoid ops, models/dlrm_s_caffe2.py:268-272) */
+enum { DRS_ACT_NONE = 0, DRS_ACT_RELU = 1, DRS_ACT_SIGMOID = 2 };
+
+/* which MLP a layer belongs to in drs_set_fc */
+enum { DRS_MLP_BOT = 0, DRS_MLP_TOP = 1, DRS_MLP_FINAL = 2 /* NCF predictor */ };
+
+/* kernels that keep live HIP-event timings (drs_kernel_time) */
+enum {
+  DRS_KERNEL_SLS = 0,   /* multi-table gather-reduce (+ bottom MLP blocks)             */
+  DRS_KERNEL_MLP = 1,   /* all top-MLP / interaction launches of a forward             */
+  DRS_KERNEL_COUNT = 2
+};
+
+/*
+ * Shape algebra of DLRM_Net.__init__ (models/dlrm_s_caffe2.py:391-476).
+ * ln_bot / ln_top are the full width lists including the input width, i.e.
+ * ln_top[0] == num_int (":415-430").  drs_create re-derives num_int and
+ * rejects a mismatch exactly like the reference's sys.exit checks (:432-440).
+ */
+typedef struct drs_model_cfg {
+  int32_t model_kind;           /* DRS_MODEL_*                                          */
+  int32_t num_tables;           /* len(arch_embedding_size)                             */
+  const int64_t* table_rows;    /* [num_tables] rows of each table                      */
+  int32_t sparse_dim;           /* arch_sparse_feature_size (D); multiple of 4, <= 256  */
+  int32_t n_bot;                /* len(ln_bot)   (1 => no bottom MLP, W&D style)        */
+  const int32_t* ln_bot;        /* [n_bot]                                              */
+  int32_t n_top;                /* len(ln_top) including num_int                        */
+  const int32_t* ln_top;        /* [n_top]                                              */
+  int32_t interaction_op;       /* DRS_INTERACT_*                                       */
+  int32_t interaction_itself;   /* arch_interaction_itself                              */
+  int32_t sigmoid_top;          /* 1-based layer index that gets Sigmoid, -1 = none     */
+  int32_t max_batch;            /* max_mini_batch_size: rows of a staged batch          */
+  int32_t max_lookups;          /* upper bound on indices per bag (staging capacity)    */
+  int32_t num_staged_batches;   /* num_batches: how many input sets stay device-resident*/
+  int32_t num_slots;            /* in-flight queries (streams); >=1                     */
+} drs_model_cfg;
+
+/* ---- library / device ------------------------------------------------------ */
+int32_t drs_abi_version(void);
+int32_t drs_device_count(int32_t* out_count);
+/* last error text of this handle (or of the failed drs_create when h == NULL);
+ * owned by the library, valid until the next call on the same thread */
+const char* drs_last_error(drs_handle h);
+
+/* ---- lifecycle --------------------------------------------------------------
+ * replaces: DLRM_Wrapper(args) + .create(...)  (models/dlrm_s_caffe2.py:88-158)
+ * i.e. everything the engine does before inferenceEngineReadyQueue.put(True)
+ * (inferenceEngine.py:81-88,190; accelInferenceEngine.py:34).                  */
+int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out);
+int32_t drs_destroy(drs_handle h);
+
+/* ---- parameters -------------------------------------------------------------
+ * replaces: FeedBlob(tbl_s, W)            (models/dlrm_s_caffe2.py:297-303)
+ *           FeedBlob(tag_fc_w/_b, W / b)  (models/dlrm_s_caffe2.py:245-251)    */
+int32_t drs_set_table(drs_handle h, int32_t t, const float* h_W /*[rows,D]*/, int64_t rows);
+/* device-side fill for benchmark-sized tables; value(t,i) is a pure function
+ * of (seed, t, i) restated bit-exactly in oracle/               */
+int32_t drs_fill_table_uniform(drs_handle h, int32_t t, float lo, float hi, uint64_t seed);
+int32_t drs_set_fc(drs_handle h, int32_t mlp, int32_t layer /*0-based*/,
+                   const float* h_W /*[m,n] row-major, NOT transposed*/,
+                   const float* h_b /*[m]*/, int32_t m, int32_t n);
+
+/* ---- inputs -----------------------------------------------------------------
+ * replaces: the engine holding lX / lS_l / lS_i in process memory
+ * (inferenceEngine.py:83) and slicing a prefix per request (:200-206).
+ * h_idx[t] holds the concatenated indices of table t for all n_samples bags
+ * (int64 as fed by the reference, narrowed here = the Cast op,
+ * models/dlrm_s_caffe2.py:308-309); h_len[t][b] is the bag length.
+ * Validation = Caffe2's ENFORCEs: DRS_ERR_INDEX_RANGE / DRS_ERR_LENGTHS_SUM.  */
+int32_t drs_stage_batch(drs_handle h, int32_t batch_id, int32_t n_samples,
+                        const float* h_dense /*[n_samples, m_den] or NULL (NCF)*/,
+                        const int64_t* const* h_idx /*[T] -> [n_idx[t]]*/,
+                        const int64_t* n_idx /*[T]*/,
+                        const int32_t* const* h_len /*[T] -> [n_samples]*/);
+
+/* ---- hot path ---------------------------------------------------------------
+ * replaces: run_queues(...) + workspace.RunNet(net) + FetchBlob
+ * (models/dlrm_s_caffe2.py:162-174,568; inferenceEngine.py:33,211-215), and the
+ * predict_time()+sleep() of accelInferenceEngine.py:63-64.
+ * A query is the first `bs` samples of staged batch `batch_id`.
+ * h_out receives [bs, n_out] floats (n_out = ln_top[-1]).                      */
+int32_t drs_forward(drs_handle h, int32_t batch_id, int32_t bs, float* h_out);
+/* asynchronous form: enqueue on slot's stream; result lands in the slot's
+ * pinned buffer; drs_wait blocks for that slot and copies to h_out (may be NULL
+ * to only wait).  Slots are independent HIP streams and may overlap.           */
+int32_t drs_forward_async(drs_handle h, int32_t slot, int32_t batch_id, int32_t bs);
+int32_t drs_wait(drs_handle h, int32_t slot, float* h_out);
+int32_t drs_sync(drs_handle h);
+/* non-staged inputs (the run_queues(ids, lengths, fc, bs) signature,
+ * models/dlrm_s_caffe2.py:162-174): H2D through the slot's pinned staging
+ * area, then the same forward.                                                 */
+int32_t drs_forward_inputs(drs_handle h, int32_t slot, int32_t bs,
+                           const float* h_dense,
+                           const int64_t* const* h_idx, const int64_t* n_idx,
+                           const int32_t* const* h_len, float* h_out);
+/* read back an intermediate activation of the last forward on `slot`
+ * (parity tests): which = 0 interaction input R [bs, num_int] ... */
+int32_t drs_fetch_interaction(drs_handle h, int32_t slot, int32_t bs, float* h_R);
+int32_t drs_out_width(drs_handle h, int32_t* n_out);
+int32_t drs_interaction_width(drs_handle h, int32_t* num_int);
+
+/* ---- operator-level entry points (same semantics as the Caffe2 ops) ----------
+ * All pointers are DEVICE pointers on the engine's GPU; launches go to slot 0's
+ * stream and the call returns after the stream is idle.
+ *
+ * drs_sls  == SparseLengthsSum([tbl, idx, len]) (models/dlrm_s_caffe2.py:317-325)
+ *   out[b,:] = sum over the bag's indices of W[idx,:], fp32, sequential in
+ *   index order when exact_order != 0 (bit-identical to the Caffe2 CPU
+ *   perfkernel); empty bag -> zeros.                                           */
+int32_t drs_sls(drs_handle h, const float* d_W, int64_t rows, int32_t D,
+                const int32_t* d_idx, const int32_t* d_len, int64_t n_bags,
+                int64_t n_idx, float* d_out /*[n_bags, D]*/, int32_t exact_order);
+/* drs_fc == FC([x,W,b]) + Relu|Sigmoid (models/dlrm_s_caffe2.py:258-272)
+ *   y = act(x . W^T + b); accumulation is a k-ordered fp32 fma chain (MFMA).   */
+int32_t drs_fc(drs_handle h, const float* d_x, int64_t M, int32_t K, const float* d_W /*[N,K]*/,
+               const float* d_b /*[N]*/, int32_t N, int32_t act, float* d_y /*[M,N]*/);
+/* drs_interact_dot == Concat(add_axis) + BatchMatMul(trans_b) + Flatten +
+ * BatchGather(tril) + Concat  (models/dlrm_s_caffe2.py:334-354, :529-535)
+ *   d_T [B,F,D] -> d_R [B, D + F(F-1)/2 (+F if itself)]                        */
+int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, int32_t D,
+                         int32_t itself, float* d_R);
+
+/* ---- measurement ------------------------------------------------------------
+ * Live HIP-event timing of the engine's own launches (bench.py roofline leg).
+ * When enabled, every forward brackets its kernels with hipEvents recorded on
+ * the stream they are launched on.                                             */
+int32_t drs_set_profiling(drs_handle h, int32_t enabled);
+int32_t drs_kernel_time(drs_handle h, int32_t kernel /*DRS_KERNEL_*/,
+                        double* sum_ms, int64_t* launches);
+int32_t drs_reset_kernel_time(drs_handle h);
+/* algorithmic bytes of the gather for a query of `bs` samples of `batch_id`:
+ * sum over bags of len*D*4 + len*4 + 4 + D*4  (SURVEY.md 8d / BASELINE.md 2)   */
+int32_t drs_gather_bytes(drs_handle h, int32_t batch_id, int32_t bs, int64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRS_H_ */

@@ -1,0 +1,568 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by importing the REFERENCE's own Python (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py --reference /root/reference
+
+The reference tree never travels to the GPU box, so what this script captures is
+committed as small data fixtures (inputs + expected values, no reference text).
+
+Two provenance classes, recorded in every fixture's `provenance` field:
+
+  "reference-executed"
+      The reference function itself ran and produced the values: the data
+      generator (data_generator/dlrm_data_caffe2.py:69-148), cli()
+      (utils/utils.py:15-165), partition_requests / model_batch_size_distribution
+      / model_arrival_times (loadGenerator.py:14-54), Scheduler.run
+      (scheduler.py:48-178), predict_time (accelerator/predict_execution.py:67-96),
+      the engine's request slicing + run_queues feed order
+      (inferenceEngine.py:200-215, models/dlrm_s_caffe2.py:162-174) and the numpy
+      weight initialisation inside the graph builders
+      (models/dlrm_s_caffe2.py:245-249,297-299 and the W&D / NCF siblings).
+
+  "reference-graph-recorded"
+      models/*.py import `caffe2.python`, which is a third-party dependency that
+      is not in the reference tree and not installable here.  They are imported
+      against a RECORDING stand-in (class _Rec below) that performs no arithmetic:
+      it only logs every operator the reference's builder emits (type, input and
+      output blob names, kwargs) and every FeedBlob tensor.  The op list, blob
+      names, dtypes, weights and tril indices in the fixtures are therefore the
+      reference's; the *expected outputs* stored next to them are computed by
+      oracle/c2ops.py (numpy restatement of the published Caffe2 op semantics) and
+      are labelled "restated", never "reference output".
+"""
+import argparse
+import hashlib
+import io
+import json
+import math
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+
+sys.dont_write_bytecode = True  # never write __pycache__ into the read-only reference tree
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+FULL_BYTES = 48 * 1024  # arrays above this are stored as sha256 + shape (+ a few rows)
+
+
+# --------------------------------------------------------------------------------------
+# recording stand-in for caffe2.python  (no arithmetic, see module docstring)
+# --------------------------------------------------------------------------------------
+class _Rec(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.ops = []        # every op emitted on any net, in emission order
+        self.feeds = []      # (blob name, array) in FeedBlob order
+        self.blobs = {}      # latest value per blob
+        self.queues = {}     # queue blob name -> list of enqueued arrays
+        self.events = []     # RunNetOnce / CreateNet / RunNet order
+        self.nets = {}
+
+
+REC = _Rec()
+
+
+class _Proto(object):
+    def __init__(self, net):
+        self._net = net
+        self.type = "simple"
+        self.num_workers = 1
+
+
+class _Net(object):
+    def __init__(self, name):
+        self._name = name
+        self._proto = _Proto(self)
+        self._ops = []
+        REC.nets[name] = self
+
+    def Name(self):
+        return self._name
+
+    def Proto(self):
+        return self._proto
+
+    def __getattr__(self, op_type):
+        if op_type.startswith("_"):
+            raise AttributeError(op_type)
+
+        def emit(inputs, outputs=None, **kwargs):
+            ins = [inputs] if isinstance(inputs, str) else [str(i) for i in inputs]
+            if outputs is None:
+                outs = []
+            elif isinstance(outputs, str):
+                outs = [outputs]
+            else:
+                outs = [str(o) for o in outputs]
+            op = {"net": self._name, "type": op_type, "inputs": ins, "outputs": outs,
+                  "kwargs": {k: (v if isinstance(v, (int, float, str, bool)) or v is None
+                                 else str(v)) for k, v in kwargs.items()}}
+            self._ops.append(op)
+            REC.ops.append(op)
+            if isinstance(outputs, str):
+                return outputs
+            return outs[0] if len(outs) == 1 else tuple(outs)
+
+        return emit
+
+
+def _as_net(x):
+    return x._net if isinstance(x, _Proto) else x
+
+
+def _install_caffe2_recorder():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    caffe2 = mod("caffe2")
+    proto = mod("caffe2.proto")
+    pb2 = mod("caffe2.proto.caffe2_pb2")
+    pb2.CPU, pb2.CUDA = 0, 1
+    python = mod("caffe2.python")
+    core = mod("caffe2.python.core")
+    workspace = mod("caffe2.python.workspace")
+    model_helper = mod("caffe2.python.model_helper")
+    for extra in ("brew", "dyndep", "net_drawer", "rnn_cell"):
+        setattr(python, extra, mod("caffe2.python." + extra))
+    cext = mod("caffe2.python._import_c_extension")
+    cext.num_cuda_devices = 0
+
+    class DeviceScope(object):
+        def __init__(self, opt):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class DataType(object):
+        INT32 = 2
+
+    core.Net = _Net
+    core.DeviceOption = lambda *a, **k: ("device_option",) + a
+    core.DeviceScope = DeviceScope
+    core.DataType = DataType
+
+    def FeedBlob(name, val, device_option=None):
+        arr = np.array(val)
+        REC.feeds.append((str(name), arr))
+        REC.blobs[str(name)] = arr
+        return True
+
+    def RunNetOnce(net):
+        net = _as_net(net)
+        REC.events.append(("RunNetOnce", net.Name()))
+        for op in net._ops:
+            if op["type"] == "EnqueueBlobs":   # inputs = [queue, blob]
+                REC.queues.setdefault(op["inputs"][0], []).append(
+                    np.array(REC.blobs[op["inputs"][1]]))
+        return True
+
+    def _event(kind):
+        def f(net, *a, **k):
+            REC.events.append((kind, _as_net(net).Name() if not isinstance(net, str) else net))
+            return True
+        return f
+
+    workspace.FeedBlob = FeedBlob
+    workspace.RunNetOnce = RunNetOnce
+    workspace.CreateNet = _event("CreateNet")
+    workspace.RunNet = _event("RunNet")
+    workspace.GlobalInit = lambda *a, **k: True
+    workspace.FetchBlob = lambda name: np.zeros(1, dtype=np.float32)
+    workspace.C = cext
+
+    class ModelHelper(object):
+        def __init__(self, name="model", init_params=True):
+            self.name = name
+            self.net = _Net(name)
+            self.param_init_net = _Net(name + "_init")
+
+    model_helper.ModelHelper = ModelHelper
+    python.core, python.workspace, python.model_helper = core, workspace, model_helper
+    python._import_c_extension = cext
+    caffe2.proto, caffe2.python, proto.caffe2_pb2 = proto, python, pb2
+
+
+# --------------------------------------------------------------------------------------
+# fixture helpers
+# --------------------------------------------------------------------------------------
+def sha(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def describe(a):
+    a = np.asarray(a)
+    return {"dtype": str(a.dtype), "shape": list(a.shape), "sha256": sha(a)}
+
+
+class Fixture(object):
+    """npz of arrays + a json manifest; big arrays are stored as digests only."""
+
+    def __init__(self, name, provenance):
+        self.name = name
+        self.arrays = {}
+        self.meta = {"provenance": provenance, "digests": {}}
+
+    def put(self, key, arr, force_full=False):
+        arr = np.asarray(arr)
+        self.meta["digests"][key] = describe(arr)
+        if force_full or arr.nbytes <= FULL_BYTES:
+            self.arrays[key] = arr
+
+    def save(self):
+        os.makedirs(GOLDEN, exist_ok=True)
+        with open(os.path.join(GOLDEN, self.name + ".json"), "w") as f:
+            json.dump(self.meta, f, indent=1, sort_keys=True)
+        buf = io.BytesIO()
+        np.savez_compressed(buf, **self.arrays)
+        with open(os.path.join(GOLDEN, self.name + ".npz"), "wb") as f:
+            f.write(buf.getvalue())
+        print("wrote %s (%d arrays, %d bytes npz)" % (self.name, len(self.arrays), buf.tell()))
+
+
+def run_cli(ref_cli, argv):
+    with mock.patch.object(sys, "argv", ["prog"] + list(argv)):
+        return ref_cli()
+
+
+def jsonable(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, (np.integer,)):
+            v = int(v)
+        elif isinstance(v, (np.floating,)):
+            v = float(v)
+        out[k] = v
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# model cases
+# --------------------------------------------------------------------------------------
+def capture_model(case, ref, argv, queue_requests=None):
+    """Mirror the engine start-up of inferenceEngine.py:72-135 with the reference's own
+    cli / data generator / graph builder; record graph, weights, inputs."""
+    from oracle import c2ops
+
+    REC.reset()
+    args = run_cli(ref["cli"], argv)
+    np.random.seed(args.numpy_rand_seed)           # inferenceEngine.py:72
+    datagen = ref["DLRMDataGenerator"](args)       # :81 (same generator for every model_type)
+    nb, lX, lS_l, lS_i = datagen.generate_input_data()
+    nb, lT = datagen.generate_output_data()
+    wrapper_cls = {"dlrm": ref["DLRM_Wrapper"], "wnd": ref["Wide_and_Deep_Wrapper"],
+                   "ncf": ref["NCF_Wrapper"]}[args.model_type]
+    with mock.patch("builtins.print"):
+        model = wrapper_cls(args)
+        model.create(lX[0], lS_l[0], lS_i[0], lT[0])
+
+    fx = Fixture(case, "reference-graph-recorded (ops, weights, tril) + reference-executed "
+                       "(inputs, cli); expected_* are restated by oracle/c2ops.py")
+    fx.meta["argv"] = list(argv)
+    fx.meta["args"] = jsonable(vars(args))
+    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF"}[args.model_type]
+    ops = [op for op in REC.ops if op["net"] == net_name]
+    fx.meta["ops"] = ops
+    fx.meta["feed_order"] = [n for n, _ in REC.feeds]
+    fx.meta["feed_dtypes"] = {n: str(a.dtype) for n, a in REC.feeds}
+    fx.meta["events"] = REC.events
+    fx.meta["net_type"] = REC.nets[net_name].Proto().type
+    fx.meta["num_workers"] = int(REC.nets[net_name].Proto().num_workers)
+    for name, arr in REC.blobs.items():
+        fx.put("blob/" + name, arr)
+    fx.meta["nbatches"] = int(nb)
+    for j in range(nb):
+        fx.put("lX/%d" % j, lX[j])
+        fx.put("lS_l/%d" % j, np.array(lS_l[j], dtype=np.int32))
+        for t in range(len(lS_i[j])):
+            fx.put("lS_i/%d/%d" % (j, t), np.array(lS_i[j][t], dtype=np.int64))
+        fx.put("lT/%d" % j, lT[j])
+
+    # restated expected values: run the recorded graph on batch 0 (non-queue feed)
+    run_ops_list = [op for op in ops if op["type"] not in ("DequeueBlobs", "Cast")] \
+        if not args.queue else ops
+    blobs = dict(REC.blobs)
+    queues = None
+    if args.queue:
+        # emulate one run_queues() of the full batch 0 through the reference wrapper
+        REC.queues.clear()
+        with mock.patch("builtins.print"):
+            ids = np.array(lS_i[0])
+            model.run_queues(ids, np.array(lS_l[0], dtype=np.int32), lX[0], lX[0].shape[0])
+        queues = {k: list(v) for k, v in REC.queues.items()}
+    ws = c2ops.run_ops(run_ops_list, blobs, queues)
+    for op in ops:
+        for o in op["outputs"]:
+            if o in ws and not o.endswith("_info") and op["type"] not in ("DequeueBlobs",):
+                fx.put("expected/" + o, ws[o])
+    fx.meta["output_blob"] = "prob_click"
+
+    if queue_requests:
+        # the reference engine's own request slicing (inferenceEngine.py:191-230), executed
+        import queue as pyqueue
+        rq, resp, ready = pyqueue.Queue(), pyqueue.Queue(), pyqueue.Queue()
+        for (bid, bs) in queue_requests:
+            rq.put(ref["ServiceRequest"](batch_id=bid, epoch=0, arrival_time=0.0, batch_size=bs,
+                                        sub_id=0, total_sub_batches=1, exp_packet=False))
+        rq.put(None)
+        REC.reset()
+        with mock.patch("builtins.print"), mock.patch("time.sleep"):
+            ref["inferenceEngine"](args, rq, 0, resp, ready)
+        # every run_queues call feeds fc then (ids_i, len_i) per table (dlrm_s_caffe2.py:162-174)
+        T = len(args.arch_embedding_size.split("-"))
+        feeds = [(n, a) for n, a in REC.feeds if n.endswith(tuple("_inputs_%d" % i for i in range(T)))
+                 or n == "fc_inputs"]
+        per_req = 1 + 2 * T
+        assert len(feeds) == per_req * len(queue_requests), (len(feeds), per_req)
+        fx.meta["queue_requests"] = [list(r) for r in queue_requests]
+        for r, (bid, bs) in enumerate(queue_requests):
+            chunk = feeds[r * per_req:(r + 1) * per_req]
+            fx.meta.setdefault("queue_feed_names", [n for n, _ in chunk])
+            for n, a in chunk:
+                fx.put("req/%d/%s" % (r, n), a)
+            # restated expectation for this request
+            q = {}
+            for n, a in chunk:
+                if n == "fc_inputs":
+                    q["fc_q_blob"] = [a]
+                else:
+                    tag, _, qid = n.partition("_inputs_")
+                    q["%s_q_blob_%s" % (tag, qid)] = [a]
+            ws = c2ops.run_ops(ops, blobs, q)
+            fx.put("req/%d/expected/prob_click" % r, ws["prob_click"])
+    fx.save()
+    return fx
+
+
+def write_tmp_config(cfg, path):
+    with open(path, "w") as f:
+        json.dump(cfg, f)
+    return path
+
+
+# --------------------------------------------------------------------------------------
+# harness cases (all reference-executed)
+# --------------------------------------------------------------------------------------
+def capture_harness(ref, ref_root):
+    import loadGenerator as LG
+    import scheduler as SCH
+    from accelerator import predict_execution as PE
+
+    out = {"provenance": "reference-executed"}
+
+    # partition_requests (loadGenerator.py:46-54)
+    pr = []
+    for stb in (16, 32, 64):
+        for n in (1, 15, 16, 31, 32, 33, 165, 1000, 1024):
+            a = types.SimpleNamespace(sub_task_batch_size=stb)
+            pr.append({"sub_task_batch_size": stb, "batch_size": n,
+                       "chunks": [int(x) for x in LG.partition_requests(a, n)]})
+    out["partition_requests"] = pr
+
+    # model_batch_size_distribution / model_arrival_times (loadGenerator.py:14-43)
+    dists = []
+    for kind, avg, var in (("normal", 165, 16), ("lognormal", 5.1, 0.2), ("fixed", 256, 0),
+                           ("normal", 1000, 200), ("normal", 2, 4)):
+        a = types.SimpleNamespace(batch_size_distribution=kind, avg_mini_batch_size=avg,
+                                  var_mini_batch_size=var, num_batches=32,
+                                  max_mini_batch_size=1024, nepochs=2, avg_arrival_rate=10)
+        np.random.seed(123)
+        sizes = [int(x) for x in LG.model_batch_size_distribution(a)]
+        np.random.seed(123)
+        arr = [int(x) for x in LG.model_arrival_times(a)]
+        dists.append({"kind": kind, "avg": avg, "var": var, "seed": 123, "sizes": sizes,
+                      "arrival_delays": arr})
+    out["batch_size_distribution"] = dists
+
+    # Scheduler.run trajectories (scheduler.py:48-178) on scripted latency sequences
+    class FakeQ(object):
+        def __init__(self, n=0):
+            self.n = n
+
+        def qsize(self):
+            return self.n
+
+        def get(self, *a):
+            self.n -= 1
+            return 0
+
+    trajs = []
+    rng = np.random.RandomState(7)
+    scripts = {
+        "always_high": [40.0] * 40,
+        "always_low": [5.0] * 40,
+        "in_band": [24.0] * 20,
+        "sawtooth": [30.0, 10.0] * 30,
+        "random": [float(x) for x in rng.uniform(5, 45, size=120)],
+        "decreasing": [float(x) for x in np.linspace(60, 5, 90)],
+    }
+    for mode in ("cpu", "accel"):
+        for name, lat in scripts.items():
+            a = types.SimpleNamespace(min_arr_range=1, max_arr_range=20, arr_steps=50,
+                                      avg_arrival_rate=10.0, batch_configs="512-256-128",
+                                      accel_configs="96-128-192-256-384-512", target_latency=25.0,
+                                      stable_region=0.10, sched_timeout=16,
+                                      sub_task_batch_size=512, accel_request_size_thres=1024)
+            with mock.patch("builtins.print"), mock.patch("time.sleep"):
+                s = SCH.Scheduler(a, FakeQ(3), FakeQ(2), FakeQ(1), mode=mode)
+                steps = []
+                for x in lat:
+                    args_o, rate, tuning = s.run(x)
+                    steps.append({"arr_id": int(s.arr_id), "arrival_rate": float(rate),
+                                  "tuning": bool(tuning),
+                                  "sub_task_batch_size": int(args_o.sub_task_batch_size),
+                                  "accel_request_size_thres": int(args_o.accel_request_size_thres)})
+            trajs.append({"mode": mode, "script": name, "latencies": lat, "steps": steps,
+                          "possible_arrival_rates": [float(v) for v in s.possible_arrival_rates]})
+    out["scheduler"] = trajs
+
+    # predict_time (accelerator/predict_execution.py:67-96) on a synthetic 6-point table
+    gd = types.SimpleNamespace()
+    table = np.array([0.5, 0.7, 1.1, 2.3, 6.9, 25.0])
+    for m in ("wnd", "rm1", "rm2", "rm3", "ncf", "mtwnd", "din", "dien"):
+        setattr(gd, m + "_exec_time", table * (1 + 0.1 * len(m)))
+    pts = []
+    for m in ("rm1", "wnd", "ncf"):
+        for bs in (1, 2, 4, 5, 16, 100, 165, 256, 1000, 1024, 4096):
+            pts.append({"model": m, "batch_size": bs,
+                        "ms": float(PE.predict_time(m, bs, gd))})
+    out["predict_time"] = {"table_scale": "table*(1+0.1*len(model_name))",
+                           "table": [float(x) for x in table], "points": pts}
+
+    # GPU_Data.parse_gpu line format (predict_execution.py:10-29): six "***" lines per point
+    txt = []
+    for i in range(2):
+        base = 1.0 + i
+        txt += ["Total data loading time: *** %f  ms" % (base * 10),
+                "Total data loading time: *** %f  ms/iter" % (base * 0.1),
+                "Total computation time: *** %f  ms" % (base * 30),
+                "Total computation time: *** %f  ms/iter" % (base * 0.3),
+                "Total execution time: *** %f  ms" % (base * 40),
+                "Total execution time: *** %f  ms/iter" % (base * 0.4)]
+    tmp = "/tmp/_drs_results_probe.txt"
+    with open(tmp, "w") as f:
+        f.write("\n".join(txt) + "\n")
+    parsed = PE.GPU_Data.parse_gpu(None, tmp)
+    out["parse_gpu"] = {"lines": txt, "tuples": [[float(v) for v in t] for t in parsed]}
+
+    # cli(): defaults and every shipped config (utils/utils.py:15-165)
+    clis = {"defaults": jsonable(vars(run_cli(ref["cli"], [])))}
+    cfg_dir = os.path.join(ref_root, "models", "configs")
+    for fn in sorted(os.listdir(cfg_dir)):
+        a = run_cli(ref["cli"], ["--config_file", os.path.join(cfg_dir, fn)])
+        d = jsonable(vars(a))
+        d["config_file"] = "models/configs/" + fn
+        clis[fn] = d
+        with open(os.path.join(cfg_dir, fn)) as f:
+            clis[fn + ":json"] = json.load(f)
+    # the canonical run_DeepRecSys.sh flag bundle (run_DeepRecSys.sh:17-67)
+    bundle = ("--nepochs 64 --num_batches 32 --inference_engines 32 --caffe2_net_type async_dag "
+              "--batch_size_distribution normal --max_mini_batch_size 1024 "
+              "--avg_mini_batch_size 165 --var_mini_batch_size 16 --sub_task_batch_size 32 "
+              "--target_latency 25 --min_arr_range 1 --max_arr_range 20 --arr_steps 50 "
+              "--batch_configs 512-256-128 --req_granularity 64 --sched_timeout 128 "
+              "--accel_configs 96-128-192-256-384-512 --model_accel --queue --tune_batch_qps "
+              "--tune_accel_qps").split()
+    clis["run_DeepRecSys.sh"] = jsonable(vars(run_cli(
+        ref["cli"], bundle + ["--config_file", os.path.join(cfg_dir, "dlrm_rm1.json")])))
+    clis["run_DeepRecSys.sh"]["config_file"] = "models/configs/dlrm_rm1.json"
+    clis["run_DeepRecSys.sh:argv"] = bundle
+    out["cli"] = clis
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    with open(os.path.join(GOLDEN, "harness.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote harness.json")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    opt = ap.parse_args()
+    ref_root = os.path.abspath(opt.reference)
+    if not os.path.isdir(ref_root):
+        sys.exit("reference tree not found: fixtures can only be regenerated where it is mounted")
+    _install_caffe2_recorder()
+    sys.path.insert(0, ref_root)
+    cwd = os.getcwd()
+    os.chdir(ref_root)  # models/*.py do sys.path.append("..")
+    try:
+        from utils.utils import cli
+        from utils.packets import ServiceRequest
+        from data_generator.dlrm_data_caffe2 import DLRMDataGenerator
+        from models.dlrm_s_caffe2 import DLRM_Wrapper
+        from models.wide_and_deep import Wide_and_Deep_Wrapper
+        from models.ncf import NCF_Wrapper
+        from inferenceEngine import inferenceEngine
+    finally:
+        os.chdir(cwd)
+    ref = dict(cli=cli, ServiceRequest=ServiceRequest, DLRMDataGenerator=DLRMDataGenerator,
+               DLRM_Wrapper=DLRM_Wrapper, Wide_and_Deep_Wrapper=Wide_and_Deep_Wrapper,
+               NCF_Wrapper=NCF_Wrapper, inferenceEngine=inferenceEngine)
+
+    small = ["--arch_sparse_feature_size", "8", "--arch_embedding_size", "60-40-50",
+             "--arch_mlp_bot", "6-12-8", "--num_indices_per_lookup", "4",
+             "--num_indices_per_lookup_fixed", "1", "--num_batches", "2",
+             "--max_mini_batch_size", "6", "--mini_batch_size", "6"]
+    capture_model("dlrm_dot_small", ref, small + ["--arch_mlp_top", "16-8-1",
+                                                   "--arch_interaction_op", "dot"])
+    capture_model("dlrm_dot_itself_small", ref, small + ["--arch_mlp_top", "16-8-1",
+                                                          "--arch_interaction_op", "dot",
+                                                          "--arch_interaction_itself"])
+    capture_model("dlrm_cat_small", ref, small + ["--arch_mlp_top", "16-8-1",
+                                                   "--arch_interaction_op", "cat",
+                                                   "--numpy_rand_seed", "7"])
+    capture_model("dlrm_cat_queue_small", ref,
+                  small + ["--arch_mlp_top", "16-8-1", "--arch_interaction_op", "cat", "--queue"],
+                  queue_requests=[(0, 6), (1, 3), (0, 1), (1, 5)])
+    capture_model("dlrm_dot_queue_small", ref,
+                  small + ["--arch_mlp_top", "16-8-1", "--arch_interaction_op", "dot", "--queue"],
+                  queue_requests=[(1, 4), (0, 2)])
+
+    # the shipped RM1/RM2/RM3 architectures with the tables shrunk (config json overrides
+    # the CLI, utils/utils.py:151-160, so the shrink goes through a temporary config)
+    cfg_dir = os.path.join(ref_root, "models", "configs")
+    for name, rows, nb, mb in (("dlrm_rm1", 3000, 2, 16), ("dlrm_rm2", 1500, 1, 8),
+                               ("dlrm_rm3", 2000, 1, 8)):
+        with open(os.path.join(cfg_dir, name + ".json")) as f:
+            cfg = json.load(f)
+        T = len(cfg["arch_embedding_size"].split("-"))
+        cfg["arch_embedding_size"] = "-".join([str(rows)] * T)
+        p = write_tmp_config(cfg, "/tmp/_drs_%s_mini.json" % name)
+        fx = capture_model(name + "_mini", ref,
+                           ["--config_file", p, "--num_batches", str(nb),
+                            "--max_mini_batch_size", str(mb), "--mini_batch_size", str(mb)])
+
+    # W&D and NCF wiring (models/wide_and_deep.py, models/ncf.py), shrunk tables
+    with open(os.path.join(cfg_dir, "wide_and_deep.json")) as f:
+        cfg = json.load(f)
+    cfg["arch_embedding_size"] = "-".join(["500"] * 27)
+    p = write_tmp_config(cfg, "/tmp/_drs_wnd_mini.json")
+    capture_model("wnd_mini", ref, ["--config_file", p, "--num_batches", "1",
+                                    "--max_mini_batch_size", "8", "--mini_batch_size", "8"])
+    with open(os.path.join(cfg_dir, "ncf.json")) as f:
+        cfg = json.load(f)
+    cfg["arch_embedding_size"] = "700-700-140-140"
+    p = write_tmp_config(cfg, "/tmp/_drs_ncf_mini.json")
+    capture_model("ncf_mini", ref, ["--config_file", p, "--num_batches", "1",
+                                    "--max_mini_batch_size", "8", "--mini_batch_size", "8"])
+
+    capture_harness(ref, ref_root)
+
+
+if __name__ == "__main__":
+    main()
