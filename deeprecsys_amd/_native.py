@@ -1,0 +1,267 @@
+"""ctypes binding of include/drs.h (libdrs_hip.so) -- the only way into the kernels.
+
+Fails loudly: a missing library raises at first use, and drs_create fails when no
+HIP device is visible.  Nothing here (or anywhere in this package) falls back to a
+CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrs_hip.so")
+
+# status codes (include/drs.h)
+OK, ERR_BAD_ARG, ERR_OOM, ERR_HIP, ERR_INDEX_RANGE, ERR_LENGTHS_SUM, ERR_STATE, ERR_UNSUPPORTED = \
+    0, -1, -2, -3, -4, -5, -6, -7
+MODEL_DLRM, MODEL_WND, MODEL_NCF = 0, 1, 2
+INTERACT_DOT, INTERACT_CAT = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+MLP_BOT, MLP_TOP, MLP_FINAL = 0, 1, 2
+KERNEL_SLS, KERNEL_MLP = 0, 1
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+# every symbol include/drs.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("drs_abi_version", C.c_int32, []),
+    ("drs_device_count", C.c_int32, [_i32p]),
+    ("drs_last_error", C.c_char_p, [C.c_void_p]),
+    ("drs_create", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("drs_destroy", C.c_int32, [C.c_void_p]),
+    ("drs_set_table", C.c_int32, [C.c_void_p, C.c_int32, _f32p, C.c_int64]),
+    ("drs_fill_table_uniform", C.c_int32, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_uint64]),
+    ("drs_set_fc", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, _f32p, C.c_int32, C.c_int32]),
+    ("drs_stage_batch", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
+                                    C.POINTER(_i32p)]),
+    ("drs_forward", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
+    ("drs_forward_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    ("drs_wait", C.c_int32, [C.c_void_p, C.c_int32, _f32p]),
+    ("drs_sync", C.c_int32, [C.c_void_p]),
+    ("drs_forward_inputs", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
+                                       C.POINTER(_i32p), _f32p]),
+    ("drs_fetch_interaction", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
+    ("drs_out_width", C.c_int32, [C.c_void_p, _i32p]),
+    ("drs_interaction_width", C.c_int32, [C.c_void_p, _i32p]),
+    ("drs_sls", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                            C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
+    ("drs_fc", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                           C.c_int32, C.c_int32, C.c_void_p]),
+    ("drs_interact_dot", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p]),
+    ("drs_set_option", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("drs_set_profiling", C.c_int32, [C.c_void_p, C.c_int32]),
+    ("drs_kernel_time", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), _i64p]),
+    ("drs_reset_kernel_time", C.c_int32, [C.c_void_p]),
+    ("drs_gather_bytes", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i64p]),
+]
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [
+        ("model_kind", C.c_int32), ("num_tables", C.c_int32), ("table_rows", _i64p),
+        ("sparse_dim", C.c_int32), ("n_bot", C.c_int32), ("ln_bot", _i32p),
+        ("n_top", C.c_int32), ("ln_top", _i32p),
+        ("interaction_op", C.c_int32), ("interaction_itself", C.c_int32),
+        ("sigmoid_top", C.c_int32), ("max_batch", C.c_int32), ("max_lookups", C.c_int32),
+        ("num_staged_batches", C.c_int32), ("num_slots", C.c_int32),
+    ]
+
+
+class DrsError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        super().__init__("%s failed with status %d%s" % (what, code, (": " + detail) if detail else ""))
+        self.code = code
+        self.detail = detail
+
+
+_lib = None
+
+
+def lib():
+    """Load libdrs_hip.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `make -C deeprecsys_amd/csrc` (hipcc, gfx950). "
+                "deeprecsys_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def device_count():
+    n = C.c_int32(0)
+    rc = lib().drs_device_count(C.byref(n))
+    return int(n.value) if rc == OK else 0
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine(object):
+    """Thin object wrapper over a drs_handle (one GPU, one process)."""
+
+    def __init__(self, kind, table_rows, sparse_dim, ln_bot, ln_top, interaction_op=INTERACT_CAT,
+                 interaction_itself=False, sigmoid_top=-1, max_batch=1, max_lookups=1,
+                 num_staged_batches=1, num_slots=1, device=0):
+        L = lib()
+        self._rows = np.ascontiguousarray(table_rows, dtype=np.int64)
+        self._ln_bot = np.ascontiguousarray(ln_bot, dtype=np.int32)
+        self._ln_top = np.ascontiguousarray(ln_top, dtype=np.int32)
+        cfg = ModelCfg(kind, self._rows.size, self._rows.ctypes.data_as(_i64p), int(sparse_dim),
+                       self._ln_bot.size, self._ln_bot.ctypes.data_as(_i32p),
+                       self._ln_top.size, self._ln_top.ctypes.data_as(_i32p),
+                       int(interaction_op), int(bool(interaction_itself)), int(sigmoid_top),
+                       int(max_batch), int(max_lookups), int(num_staged_batches), int(num_slots))
+        h = C.c_void_p()
+        rc = L.drs_create(C.byref(cfg), int(device), C.byref(h))
+        if rc != OK:
+            raise DrsError(rc, "drs_create", (L.drs_last_error(None) or b"").decode())
+        self._h = h
+        self.kind = kind
+        self.T = int(self._rows.size)
+        self.D = int(sparse_dim)
+        self.max_batch = int(max_batch)
+        self.num_slots = int(num_slots)
+        self.device = int(device)
+
+    # -- helpers ------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != OK:
+            raise DrsError(rc, what, (lib().drs_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().drs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_out(self):
+        n = C.c_int32(0)
+        lib().drs_out_width(self._h, C.byref(n))
+        return int(n.value)
+
+    @property
+    def num_int(self):
+        n = C.c_int32(0)
+        lib().drs_interaction_width(self._h, C.byref(n))
+        return int(n.value)
+
+    # -- parameters ---------------------------------------------------------------
+    def set_table(self, t, W):
+        W = _f32(W)
+        self._check(lib().drs_set_table(self._h, t, W.ctypes.data_as(_f32p), W.shape[0]), "drs_set_table")
+
+    def fill_table_uniform(self, t, lo, hi, seed):
+        self._check(lib().drs_fill_table_uniform(self._h, t, lo, hi, seed), "drs_fill_table_uniform")
+
+    def set_fc(self, mlp, layer, W, b):
+        W, b = _f32(W), _f32(b)
+        self._check(lib().drs_set_fc(self._h, mlp, layer, W.ctypes.data_as(_f32p),
+                                     b.ctypes.data_as(_f32p), W.shape[0], W.shape[1]), "drs_set_fc")
+
+    # -- inputs -------------------------------------------------------------------
+    @staticmethod
+    def _pack_sparse(idx, lengths):
+        idx = [np.ascontiguousarray(i, dtype=np.int64) for i in idx]
+        lengths = [np.ascontiguousarray(l, dtype=np.int32) for l in lengths]
+        T = len(idx)
+        n_idx = np.array([i.size for i in idx], dtype=np.int64)
+        ip = (_i64p * T)(*[i.ctypes.data_as(_i64p) for i in idx])
+        lp = (_i32p * T)(*[l.ctypes.data_as(_i32p) for l in lengths])
+        return idx, lengths, n_idx, ip, lp
+
+    def stage_batch(self, batch_id, dense, idx, lengths):
+        idx, lengths, n_idx, ip, lp = self._pack_sparse(idx, lengths)
+        n = int(lengths[0].size)
+        dp = None
+        if dense is not None:
+            dense = _f32(dense)
+            dp = dense.ctypes.data_as(_f32p)
+        self._check(lib().drs_stage_batch(self._h, batch_id, n, dp, ip, n_idx.ctypes.data_as(_i64p), lp),
+                    "drs_stage_batch")
+
+    # -- hot path -----------------------------------------------------------------
+    def forward(self, batch_id, bs):
+        out = np.empty((bs, self.n_out), dtype=np.float32)
+        self._check(lib().drs_forward(self._h, batch_id, bs, out.ctypes.data_as(_f32p)), "drs_forward")
+        return out
+
+    def forward_async(self, slot, batch_id, bs):
+        self._check(lib().drs_forward_async(self._h, slot, batch_id, bs), "drs_forward_async")
+
+    def wait(self, slot, bs=None):
+        if bs is None:
+            self._check(lib().drs_wait(self._h, slot, None), "drs_wait")
+            return None
+        out = np.empty((bs, self.n_out), dtype=np.float32)
+        self._check(lib().drs_wait(self._h, slot, out.ctypes.data_as(_f32p)), "drs_wait")
+        return out
+
+    def sync(self):
+        self._check(lib().drs_sync(self._h), "drs_sync")
+
+    def forward_inputs(self, dense, idx, lengths, bs, slot=0):
+        idx, lengths, n_idx, ip, lp = self._pack_sparse(idx, lengths)
+        dp = None
+        if dense is not None:
+            dense = _f32(dense)
+            dp = dense.ctypes.data_as(_f32p)
+        out = np.empty((bs, self.n_out), dtype=np.float32)
+        self._check(lib().drs_forward_inputs(self._h, slot, bs, dp, ip, n_idx.ctypes.data_as(_i64p), lp,
+                                             out.ctypes.data_as(_f32p)), "drs_forward_inputs")
+        return out
+
+    def fetch_interaction(self, bs, slot=0):
+        R = np.empty((bs, self.num_int), dtype=np.float32)
+        self._check(lib().drs_fetch_interaction(self._h, slot, bs, R.ctypes.data_as(_f32p)),
+                    "drs_fetch_interaction")
+        return R
+
+    # -- operator level (device pointers, e.g. torch.Tensor.data_ptr()) -------------
+    def sls(self, d_W, rows, D, d_idx, d_len, n_bags, n_idx, d_out, exact_order=True):
+        self._check(lib().drs_sls(self._h, d_W, rows, D, d_idx, d_len, n_bags, n_idx, d_out,
+                                  int(bool(exact_order))), "drs_sls")
+
+    def fc(self, d_x, M, K, d_W, d_b, N, act, d_y):
+        self._check(lib().drs_fc(self._h, d_x, M, K, d_W, d_b, N, act, d_y), "drs_fc")
+
+    def interact_dot(self, d_T, B, F, D, itself, d_R):
+        self._check(lib().drs_interact_dot(self._h, d_T, B, F, D, int(bool(itself)), d_R),
+                    "drs_interact_dot")
+
+    # -- tuning / measurement -------------------------------------------------------
+    def set_option(self, key, value):
+        self._check(lib().drs_set_option(self._h, key.encode(), int(value)), "drs_set_option")
+
+    def set_profiling(self, enabled):
+        self._check(lib().drs_set_profiling(self._h, int(bool(enabled))), "drs_set_profiling")
+
+    def kernel_time(self, kernel):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._check(lib().drs_kernel_time(self._h, kernel, C.byref(ms), C.byref(n)), "drs_kernel_time")
+        return float(ms.value), int(n.value)
+
+    def reset_kernel_time(self):
+        self._check(lib().drs_reset_kernel_time(self._h), "drs_reset_kernel_time")
+
+    def gather_bytes(self, batch_id, bs):
+        b = C.c_int64(0)
+        self._check(lib().drs_gather_bytes(self._h, batch_id, bs, C.byref(b)), "drs_gather_bytes")
+        return int(b.value)

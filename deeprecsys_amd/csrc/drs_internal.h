@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP translation units of libdrs_hip.so.
+// Public surface: include/drs.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/drs.h"
+
+namespace drs {
+
+// One launch of the multi-table gather-reduce (SparseLengthsSum x T tables).
+// Bags are numbered sample-major: bag = b * T + t, so the T pooled vectors of a
+// sample land next to each other in the interaction buffer
+//   out[b * ld_out + col0 + t * D + d]
+// which is the [B, F, D] / Concat(axis=1) layout of
+// models/dlrm_s_caffe2.py:337-342,358-360 with the dense slot in front.
+struct SlsArgs {
+  const float* tables;        // base of the table arena
+  const int64_t* tab_off;     // [T] element offset of table t in the arena
+  const int64_t* tab_rows;    // [T]
+  const int32_t* idx;         // [T][idx_stride] int32 indices (already narrowed = Cast op)
+  const int32_t* off;         // [T][off_stride] exclusive prefix sums of the lengths, off[t][b]
+  int64_t idx_stride;
+  int64_t off_stride;
+  float* out;
+  int64_t ld_out;             // floats between consecutive samples
+  int32_t col0;               // first output column of table 0
+  int32_t T;
+  int32_t D;
+  int32_t n_samples;          // bs
+  int32_t* err;               // device error word: bit0 = index out of range
+};
+
+// launch on `stream`; exact != 0 selects the sequential-order variant.
+hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t stream);
+
+// y[M, N] (ld = ldy) = act(x[M, K] (ld = ldx) . W[N, K]^T + b), k-ordered fp32 MFMA chain
+hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
+                     const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
+                     hipStream_t stream);
+
+// Fused chain of up to DRS_MAX_CHAIN FC layers on 16-row slabs; intermediate
+// activations never leave LDS.
+#define DRS_MAX_CHAIN 6
+struct ChainArgs {
+  const float* x;
+  int64_t ldx;
+  int64_t M;
+  int32_t n_layers;
+  int32_t width[DRS_MAX_CHAIN + 1];   // width[0] = K of first layer
+  const float* W[DRS_MAX_CHAIN];
+  const float* b[DRS_MAX_CHAIN];
+  int32_t act[DRS_MAX_CHAIN];
+  float* y;
+  int64_t ldy;
+};
+hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
+size_t chain_lds_bytes(const ChainArgs& a);
+
+// T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot
+hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F, int32_t D,
+                               int32_t itself, float* R, int64_t ldr, hipStream_t stream);
+
+// out[i] = a[i] + b[i] rows of width D (NCF Sum, models/ncf.py:301-305) and strided copies
+hipError_t launch_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
+                           int64_t ldo, int64_t M, int32_t D, hipStream_t stream);
+hipError_t launch_copy_rows(const float* a, int64_t lda, float* out, int64_t ldo, int64_t M,
+                            int32_t D, hipStream_t stream);
+
+hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
+                               hipStream_t stream);
+
+}  // namespace drs

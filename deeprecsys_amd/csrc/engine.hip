@@ -1,0 +1,799 @@
+// Host side of libdrs_hip.so: the C ABI of include/drs.h on top of the kernels in
+// sls.hip / mlp.hip.  One engine = one GPU = one process (accelInferenceEngine
+// counterpart, reference accelInferenceEngine.py:18-86).
+//
+// HBM layout (all hipMalloc'ed once in drs_create / first use):
+//   tables   one arena, table t at a 256-B aligned offset, rows*D fp32 row-major
+//   weights  per layer W [N, K] dense row-major + b [N]   (as fed by the reference)
+//   batches  per staged batch: dense [max_batch, m_den] f32 | idx [T, cap] i32 |
+//            off [T, max_batch+1] i32 (exclusive prefix sums of the lengths)
+//   slots    per in-flight query: interaction buffer(s), layer scratch,
+//            [err | out] device words + the same in pinned host memory
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "drs_internal.h"
+
+namespace drs {
+extern int g_sls_u;
+extern int g_sls_v_d32;
+}  // namespace drs
+
+using namespace drs;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct Layer {
+  float* W = nullptr;
+  float* b = nullptr;
+  int32_t m = 0, n = 0;  // W is [m, n]
+  bool set = false;
+};
+
+struct Mlp {
+  std::vector<int32_t> ln;
+  std::vector<Layer> layers;  // ln.size()-1
+  int32_t sigmoid_layer = -1; // 1-based, -1 none
+};
+
+struct Batch {
+  float* dense = nullptr;
+  int32_t* idx = nullptr;
+  int32_t* off = nullptr;
+  int32_t n_samples = 0;
+  std::vector<int32_t> h_off;  // [T][max_batch+1] host copy (gather_bytes, validation)
+  bool staged = false;
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  float* T = nullptr;        // [max_batch, ldT]  concat buffer: dense_out | emb_0 | ...
+  float* R = nullptr;        // [max_batch, ldR]  dot-interaction output (dot only)
+  float* H = nullptr;        // [max_batch, ldH]  inter-segment MLP scratch (ping)
+  float* Hb = nullptr;       // (pong)
+  float* H2 = nullptr;       // NCF: concat(mf, mlp_out)
+  uint32_t* d_out = nullptr; // [1 + max_batch*n_out]: word 0 = error flags, then outputs
+  uint32_t* h_out = nullptr; // pinned mirror
+  Batch scratch;             // drs_forward_inputs staging
+  void* h_stage = nullptr;   // pinned host staging for forward_inputs
+  size_t h_stage_bytes = 0;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool ev_pending = false;
+  int32_t last_bs = 0;
+  bool busy = false;
+};
+
+}  // namespace
+
+struct drs_engine {
+  int device = 0;
+  int32_t kind = 0, T = 0, D = 0;
+  std::vector<int64_t> rows;
+  std::vector<int64_t> tab_off;  // element offsets
+  float* tables = nullptr;
+  int64_t* d_tab_off = nullptr;
+  int64_t* d_tab_rows = nullptr;
+  std::vector<bool> table_set;
+  Mlp bot, top, fin;
+  int32_t interaction_op = DRS_INTERACT_CAT, itself = 0;
+  int32_t max_batch = 0, max_lookups = 0, n_batches = 0, n_slots = 0;
+  int32_t m_den = 0, w0 = 0;     // dense input width, dense_out width
+  int32_t num_int = 0, n_out = 0;
+  int64_t ldT = 0, ldR = 0, ldH = 0, cap = 0;
+  std::vector<Batch> batches;
+  std::vector<Slot> slots;
+  // op-level scratch
+  int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
+  // options
+  int sls_exact = 1, mlp_split = 1;
+  // profiling
+  bool profiling = false;
+  double k_ms[DRS_KERNEL_COUNT] = {0, 0};
+  int64_t k_n[DRS_KERNEL_COUNT] = {0, 0};
+  std::string err;
+};
+
+namespace {
+
+int32_t fail(drs_engine* e, int32_t code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                   \
+  do {                                                                                     \
+    hipError_t _r = (call);                                                                \
+    if (_r != hipSuccess)                                                                  \
+      return fail((e), _r == hipErrorOutOfMemory ? DRS_ERR_OOM : DRS_ERR_HIP, "%s: %s",    \
+                  #call, hipGetErrorString(_r));                                           \
+  } while (0)
+
+int32_t set_device(drs_engine* e) {
+  HIP_TRY(e, hipSetDevice(e->device));
+  return DRS_OK;
+}
+
+int32_t alloc_batch(drs_engine* e, Batch& b) {
+  if (e->m_den > 0)
+    HIP_TRY(e, hipMalloc(&b.dense, sizeof(float) * (size_t)e->max_batch * e->m_den));
+  HIP_TRY(e, hipMalloc(&b.idx, sizeof(int32_t) * (size_t)e->T * e->cap));
+  HIP_TRY(e, hipMalloc(&b.off, sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1)));
+  b.h_off.assign((size_t)e->T * (e->max_batch + 1), 0);
+  return DRS_OK;
+}
+
+void free_batch(Batch& b) {
+  if (b.dense) (void)hipFree(b.dense);
+  if (b.idx) (void)hipFree(b.idx);
+  if (b.off) (void)hipFree(b.off);
+  b = Batch();
+}
+
+// Validate (the Caffe2 ENFORCEs) and narrow int64 -> int32 (the Cast op,
+// models/dlrm_s_caffe2.py:308-309) into caller-provided host buffers.
+int32_t convert_inputs(drs_engine* e, int32_t n, const int64_t* const* h_idx, const int64_t* n_idx,
+                       const int32_t* const* h_len, int32_t* idx32 /*[T][cap]*/,
+                       int32_t* off /*[T][max_batch+1]*/) {
+  for (int t = 0; t < e->T; ++t) {
+    if (!h_idx[t] && n_idx[t] > 0) return fail(e, DRS_ERR_BAD_ARG, "h_idx[%d] is NULL", t);
+    if (!h_len[t]) return fail(e, DRS_ERR_BAD_ARG, "h_len[%d] is NULL", t);
+    if (n_idx[t] < 0 || n_idx[t] > e->cap)
+      return fail(e, DRS_ERR_BAD_ARG, "table %d: %lld indices exceed staging capacity %lld", t,
+                  (long long)n_idx[t], (long long)e->cap);
+    int32_t* o = off + (size_t)t * (e->max_batch + 1);
+    int64_t total = 0;
+    o[0] = 0;
+    for (int b = 0; b < n; ++b) {
+      if (h_len[t][b] < 0) return fail(e, DRS_ERR_LENGTHS_SUM, "table %d bag %d: negative length", t, b);
+      total += h_len[t][b];
+      if (total > n_idx[t]) break;
+      o[b + 1] = (int32_t)total;
+    }
+    if (total != n_idx[t])
+      return fail(e, DRS_ERR_LENGTHS_SUM, "table %d: sum(lengths)=%lld != len(indices)=%lld", t,
+                  (long long)total, (long long)n_idx[t]);
+    for (int b = n; b < e->max_batch; ++b) o[b + 1] = (int32_t)total;
+    int32_t* dst = idx32 + (size_t)t * e->cap;
+    const int64_t R = e->rows[t];
+    for (int64_t j = 0; j < n_idx[t]; ++j) {
+      const int64_t v = h_idx[t][j];
+      if (v < 0 || v >= R)
+        return fail(e, DRS_ERR_INDEX_RANGE, "table %d: index %lld at position %lld outside [0, %lld)",
+                    t, (long long)v, (long long)j, (long long)R);
+      dst[j] = (int32_t)v;
+    }
+  }
+  return DRS_OK;
+}
+
+int32_t mlp_ready(drs_engine* e, const Mlp& m, const char* name) {
+  for (size_t i = 0; i < m.layers.size(); ++i)
+    if (!m.layers[i].set) return fail(e, DRS_ERR_STATE, "%s layer %zu has no weights", name, i);
+  return DRS_OK;
+}
+
+// Run all layers of `m` on x -> y.  A wide layer runs as its own 2-D launch (more
+// workgroups); runs of narrow layers are fused into one LDS-resident chain.
+// Segment outputs that are not the final one ping-pong between s.H and s.Hb.
+int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ldx, int64_t M,
+                float* y, int64_t ldy) {
+  const int n_layers = (int)m.layers.size();
+  auto act_of = [&](int l) { return (l + 1 == m.sigmoid_layer) ? DRS_ACT_SIGMOID : DRS_ACT_RELU; };
+  auto is_wide = [&](int l) {
+    return e->mlp_split && (int64_t)m.ln[l] * m.ln[l + 1] >= 64 * 1024 && m.ln[l + 1] > 64;
+  };
+  int l0 = 0;
+  const float* in = x;
+  int64_t ldin = ldx;
+  while (l0 < n_layers) {
+    int cnt = 1;
+    ChainArgs c;
+    memset(&c, 0, sizeof c);
+    const bool standalone = is_wide(l0);
+    if (!standalone) {
+      // longest run of narrow layers that fits LDS
+      cnt = 0;
+      while (l0 + cnt < n_layers && cnt < DRS_MAX_CHAIN && !is_wide(l0 + cnt)) ++cnt;
+      for (;;) {
+        c.x = in; c.ldx = ldin; c.M = M; c.n_layers = cnt;
+        for (int i = 0; i <= cnt; ++i) c.width[i] = m.ln[l0 + i];
+        for (int i = 0; i < cnt; ++i) {
+          c.W[i] = m.layers[l0 + i].W;
+          c.b[i] = m.layers[l0 + i].b;
+          c.act[i] = act_of(l0 + i);
+        }
+        if (chain_lds_bytes(c) <= 150 * 1024 || cnt == 1) break;
+        --cnt;
+      }
+    }
+    const bool last = l0 + cnt == n_layers;
+    float* out = last ? y : (in == s.H ? s.Hb : s.H);
+    const int64_t ldo = last ? ldy : e->ldH;
+    if (standalone || chain_lds_bytes(c) > 150 * 1024) {
+      HIP_TRY(e, launch_fc(in, ldin, M, m.ln[l0], m.layers[l0].W, m.layers[l0].b, m.ln[l0 + 1],
+                           act_of(l0), out, ldo, s.stream));
+    } else {
+      c.y = out; c.ldy = ldo;
+      HIP_TRY(e, launch_chain(c, s.stream));
+    }
+    in = out; ldin = ldo; l0 += cnt;
+  }
+  return DRS_OK;
+}
+
+int32_t enqueue_forward(drs_engine* e, Slot& s, const Batch& bt, int32_t bs) {
+  if (bs < 0 || bs > bt.n_samples) return fail(e, DRS_ERR_BAD_ARG, "bs=%d outside [0, %d]", bs, bt.n_samples);
+  for (int t = 0; t < e->T; ++t)
+    if (!e->table_set[t]) return fail(e, DRS_ERR_STATE, "table %d has no data", t);
+  int32_t rc;
+  if ((rc = mlp_ready(e, e->bot, "bottom")) || (rc = mlp_ready(e, e->top, "top")) ||
+      (rc = mlp_ready(e, e->fin, "final")))
+    return rc;
+  s.last_bs = bs;
+  s.busy = true;
+  if (bs == 0) return DRS_OK;
+  const bool prof = e->profiling;
+  if (prof) HIP_TRY(e, hipEventRecord(s.ev[0], s.stream));
+
+  SlsArgs a;
+  a.tables = e->tables; a.tab_off = e->d_tab_off; a.tab_rows = e->d_tab_rows;
+  a.idx = bt.idx; a.off = bt.off; a.idx_stride = e->cap; a.off_stride = e->max_batch + 1;
+  a.out = s.T; a.ld_out = e->ldT; a.col0 = e->kind == DRS_MODEL_NCF ? 0 : e->w0;
+  a.T = e->T; a.D = e->D; a.n_samples = bs; a.err = reinterpret_cast<int32_t*>(s.d_out);
+  HIP_TRY(e, launch_sls(a, e->sls_exact, s.stream));
+  if (prof) HIP_TRY(e, hipEventRecord(s.ev[1], s.stream));
+
+  float* out = reinterpret_cast<float*>(s.d_out + 1);
+  if (e->kind == DRS_MODEL_NCF) {
+    // mf = Sum(sls0, sls1); mlp = Concat(sls2, sls3) -> MLP; Concat(mf, mlp_out) -> FC+Relu
+    const int D = e->D;
+    const int wl = e->top.ln.back();
+    const int64_t ldc = D + wl;
+    HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, bs, D, s.stream));
+    if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, bs, s.H2 + D, ldc))) return rc;
+    if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, bs, out, e->n_out))) return rc;
+  } else {
+    if (e->bot.layers.empty()) {
+      HIP_TRY(e, launch_copy_rows(bt.dense, e->m_den, s.T, e->ldT, bs, e->w0, s.stream));
+    } else {
+      if ((rc = run_mlp(e, s, e->bot, bt.dense, e->m_den, bs, s.T, e->ldT))) return rc;
+    }
+    const float* top_in = s.T;
+    int64_t ld_top = e->ldT;
+    if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
+      HIP_TRY(e, launch_interact_dot(s.T, e->ldT, bs, e->T + 1, e->D, e->itself, s.R, e->ldR, s.stream));
+      top_in = s.R;
+      ld_top = e->ldR;
+    }
+    if ((rc = run_mlp(e, s, e->top, top_in, ld_top, bs, out, e->n_out))) return rc;
+  }
+  if (prof) {
+    HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
+    s.ev_pending = true;
+  }
+  HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, sizeof(uint32_t) * (1 + (size_t)bs * e->n_out),
+                            hipMemcpyDeviceToHost, s.stream));
+  return DRS_OK;
+}
+
+int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
+  if (!s.busy) return DRS_OK;
+  HIP_TRY(e, hipStreamSynchronize(s.stream));
+  s.busy = false;
+  if (s.ev_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) { e->k_ms[DRS_KERNEL_SLS] += ms; e->k_n[DRS_KERNEL_SLS]++; }
+    if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) { e->k_ms[DRS_KERNEL_MLP] += ms; e->k_n[DRS_KERNEL_MLP]++; }
+    s.ev_pending = false;
+  }
+  if (s.last_bs > 0 && s.h_out[0] != 0) {
+    s.h_out[0] = 0;
+    HIP_TRY(e, hipMemsetAsync(s.d_out, 0, sizeof(uint32_t), s.stream));
+    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    return fail(e, DRS_ERR_INDEX_RANGE, "an embedding index was out of range on the device");
+  }
+  if (h_out && s.last_bs > 0)
+    memcpy(h_out, s.h_out + 1, sizeof(float) * (size_t)s.last_bs * e->n_out);
+  return DRS_OK;
+}
+
+int32_t check_handle(drs_engine* e) {
+  if (!e) return fail(nullptr, DRS_ERR_BAD_ARG, "null handle");
+  return set_device(e);
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int32_t drs_abi_version(void) { return DRS_ABI_VERSION; }
+
+int32_t drs_device_count(int32_t* out_count) {
+  if (!out_count) return DRS_ERR_BAD_ARG;
+  int n = 0;
+  hipError_t r = hipGetDeviceCount(&n);
+  if (r != hipSuccess) {
+    *out_count = 0;
+    return fail(nullptr, DRS_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(r));
+  }
+  *out_count = n;
+  return DRS_OK;
+}
+
+const char* drs_last_error(drs_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out) {
+  if (!cfg || !out) return fail(nullptr, DRS_ERR_BAD_ARG, "null cfg/out");
+  *out = nullptr;
+  if (cfg->num_tables <= 0 || !cfg->table_rows || cfg->n_bot < 1 || !cfg->ln_bot || cfg->n_top < 2 ||
+      !cfg->ln_top || cfg->max_batch <= 0 || cfg->max_lookups <= 0 || cfg->num_staged_batches < 0)
+    return fail(nullptr, DRS_ERR_BAD_ARG, "bad model config");
+  const int D = cfg->sparse_dim;
+  if (D <= 0 || D > 256 || (D & 3))
+    return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d must be a multiple of 4 in [4, 256]", D);
+  int ndev = 0;
+  hipError_t r = hipGetDeviceCount(&ndev);
+  if (r != hipSuccess || ndev <= 0)
+    return fail(nullptr, DRS_ERR_HIP, "no HIP device visible (%s); this library has no CPU fallback",
+                r == hipSuccess ? "device count 0" : hipGetErrorString(r));
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, DRS_ERR_BAD_ARG, "device %d of %d", device_id, ndev);
+
+  drs_engine* e = new drs_engine();
+  e->device = device_id;
+  e->kind = cfg->model_kind; e->T = cfg->num_tables; e->D = D;
+  e->rows.assign(cfg->table_rows, cfg->table_rows + e->T);
+  e->interaction_op = cfg->interaction_op; e->itself = cfg->interaction_itself ? 1 : 0;
+  e->max_batch = cfg->max_batch; e->max_lookups = cfg->max_lookups;
+  e->n_batches = cfg->num_staged_batches; e->n_slots = cfg->num_slots > 0 ? cfg->num_slots : 1;
+  e->bot.ln.assign(cfg->ln_bot, cfg->ln_bot + cfg->n_bot);
+  e->top.ln.assign(cfg->ln_top, cfg->ln_top + cfg->n_top);
+  e->bot.layers.resize(cfg->n_bot - 1);
+  e->top.layers.resize(cfg->n_top - 1);
+  e->top.sigmoid_layer = cfg->sigmoid_top;
+  const int T = e->T, F = T + 1;
+
+  auto bail = [&](int32_t code, const char* msg) {
+    g_create_error = msg;
+    drs_destroy(e);
+    return code;
+  };
+  // shape algebra of the reference builders
+  switch (e->kind) {
+    case DRS_MODEL_DLRM: {
+      e->m_den = e->bot.ln.front();
+      e->w0 = e->bot.ln.back();
+      if (e->w0 != D) return bail(DRS_ERR_BAD_ARG, "arch_sparse_feature_size does not match last dim of bottom mlp");
+      if (e->interaction_op == DRS_INTERACT_DOT)
+        e->num_int = (e->itself ? F * (F + 1) / 2 : F * (F - 1) / 2) + D;
+      else if (e->interaction_op == DRS_INTERACT_CAT)
+        e->num_int = F * D;
+      else
+        return bail(DRS_ERR_BAD_ARG, "unknown interaction op");
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
+      e->n_out = e->top.ln.back();
+      break;
+    }
+    case DRS_MODEL_WND: {
+      if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "W&D has no bottom MLP layers");
+      e->m_den = e->w0 = e->bot.ln.front();
+      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
+      e->num_int = T * D + e->w0;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
+      e->n_out = e->top.ln.back();
+      break;
+    }
+    case DRS_MODEL_NCF: {
+      if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
+      if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
+      e->m_den = 0; e->w0 = 0;
+      e->num_int = D + e->top.ln.back();
+      e->top.sigmoid_layer = -1;
+      e->fin.ln = {e->num_int, 0};  // output width arrives with drs_set_fc(DRS_MLP_FINAL)
+      e->fin.layers.resize(1);
+      e->n_out = 0;
+      break;
+    }
+    default:
+      return bail(DRS_ERR_BAD_ARG, "unknown model kind");
+  }
+  for (int t = 0; t < T; ++t) {
+    if (e->rows[t] <= 0) return bail(DRS_ERR_BAD_ARG, "table with no rows");
+    if (e->rows[t] * (int64_t)D >= (1ll << 32)) return bail(DRS_ERR_UNSUPPORTED, "rows*D must be < 2^32 per table");
+  }
+
+  if (set_device(e)) return bail(DRS_ERR_HIP, e->err.c_str());
+  // table arena
+  int64_t off = 0;
+  e->tab_off.resize(T);
+  for (int t = 0; t < T; ++t) {
+    e->tab_off[t] = off;
+    off += round_up(e->rows[t] * D, 64);  // 256-B aligned
+  }
+  e->table_set.assign(T, false);
+  auto hip_ok = [&](hipError_t rr) { if (rr != hipSuccess) { e->err = hipGetErrorString(rr); return false; } return true; };
+#define CREATE_TRY(call) if (!hip_ok(call)) return bail(DRS_ERR_OOM, (std::string(#call ": ") + e->err).c_str())
+  CREATE_TRY(hipMalloc(&e->tables, sizeof(float) * (size_t)off));
+  CREATE_TRY(hipMalloc(&e->d_tab_off, sizeof(int64_t) * T));
+  CREATE_TRY(hipMalloc(&e->d_tab_rows, sizeof(int64_t) * T));
+  CREATE_TRY(hipMalloc(&e->d_op_tab, sizeof(int64_t) * 2));
+  CREATE_TRY(hipMemcpy(e->d_tab_off, e->tab_off.data(), sizeof(int64_t) * T, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemcpy(e->d_tab_rows, e->rows.data(), sizeof(int64_t) * T, hipMemcpyHostToDevice));
+
+  e->cap = (int64_t)e->max_batch * e->max_lookups;
+  e->ldT = e->kind == DRS_MODEL_NCF ? 4 * D : e->w0 + (int64_t)T * D;
+  e->ldR = round_up(e->num_int, 4);
+  int maxw = 4;
+  for (int w : e->bot.ln) maxw = w > maxw ? w : maxw;
+  for (int w : e->top.ln) maxw = w > maxw ? w : maxw;
+  e->ldH = round_up(maxw, 4);
+  e->batches.resize(e->n_batches);
+  for (auto& b : e->batches)
+    if (alloc_batch(e, b)) return bail(DRS_ERR_OOM, e->err.c_str());
+  e->slots.resize(e->n_slots);
+  const int n_out_cap = e->kind == DRS_MODEL_NCF ? 1024 : e->n_out;
+  for (auto& s : e->slots) {
+    CREATE_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&s.T, sizeof(float) * (size_t)e->max_batch * e->ldT));
+    CREATE_TRY(hipMemset(s.T, 0, sizeof(float) * (size_t)e->max_batch * e->ldT));
+    CREATE_TRY(hipMalloc(&s.R, sizeof(float) * (size_t)e->max_batch * e->ldR));
+    CREATE_TRY(hipMemset(s.R, 0, sizeof(float) * (size_t)e->max_batch * e->ldR));
+    CREATE_TRY(hipMalloc(&s.H, sizeof(float) * (size_t)e->max_batch * e->ldH));
+    CREATE_TRY(hipMalloc(&s.Hb, sizeof(float) * (size_t)e->max_batch * e->ldH));
+    CREATE_TRY(hipMalloc(&s.H2, sizeof(float) * (size_t)e->max_batch * (e->num_int + 4)));
+    const size_t out_words = 1 + (size_t)e->max_batch * n_out_cap;
+    CREATE_TRY(hipMalloc(&s.d_out, sizeof(uint32_t) * out_words));
+    CREATE_TRY(hipMemset(s.d_out, 0, sizeof(uint32_t) * out_words));
+    CREATE_TRY(hipHostMalloc(&s.h_out, sizeof(uint32_t) * out_words, hipHostMallocDefault));
+    memset(s.h_out, 0, sizeof(uint32_t) * out_words);
+    for (auto& ev : s.ev) CREATE_TRY(hipEventCreate(&ev));
+    if (alloc_batch(e, s.scratch)) return bail(DRS_ERR_OOM, e->err.c_str());
+    s.scratch.n_samples = 0;
+    s.h_stage_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1) +
+                      sizeof(int32_t) * (size_t)T * e->cap +
+                      sizeof(int32_t) * (size_t)T * (e->max_batch + 1);
+    CREATE_TRY(hipHostMalloc(&s.h_stage, s.h_stage_bytes, hipHostMallocDefault));
+  }
+#undef CREATE_TRY
+  *out = e;
+  return DRS_OK;
+}
+
+int32_t drs_destroy(drs_handle e) {
+  if (!e) return DRS_OK;
+  (void)hipSetDevice(e->device);
+  for (auto& s : e->slots) {
+    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+    if (s.T) (void)hipFree(s.T);
+    if (s.R) (void)hipFree(s.R);
+    if (s.H) (void)hipFree(s.H);
+    if (s.Hb) (void)hipFree(s.Hb);
+    if (s.H2) (void)hipFree(s.H2);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.h_stage) (void)hipHostFree(s.h_stage);
+    for (auto& ev : s.ev) if (ev) (void)hipEventDestroy(ev);
+    free_batch(s.scratch);
+  }
+  for (auto& b : e->batches) free_batch(b);
+  for (Mlp* m : {&e->bot, &e->top, &e->fin})
+    for (auto& l : m->layers) { if (l.W) (void)hipFree(l.W); if (l.b) (void)hipFree(l.b); }
+  if (e->tables) (void)hipFree(e->tables);
+  if (e->d_tab_off) (void)hipFree(e->d_tab_off);
+  if (e->d_tab_rows) (void)hipFree(e->d_tab_rows);
+  if (e->d_op_tab) (void)hipFree(e->d_op_tab);
+  delete e;
+  return DRS_OK;
+}
+
+int32_t drs_set_table(drs_handle e, int32_t t, const float* h_W, int64_t rows) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (t < 0 || t >= e->T || !h_W) return fail(e, DRS_ERR_BAD_ARG, "bad table id / null data");
+  if (rows != e->rows[t]) return fail(e, DRS_ERR_BAD_ARG, "table %d has %lld rows, got %lld", t, (long long)e->rows[t], (long long)rows);
+  HIP_TRY(e, hipMemcpy(e->tables + e->tab_off[t], h_W, sizeof(float) * (size_t)rows * e->D, hipMemcpyHostToDevice));
+  e->table_set[t] = true;
+  return DRS_OK;
+}
+
+int32_t drs_fill_table_uniform(drs_handle e, int32_t t, float lo, float hi, uint64_t seed) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (t < 0 || t >= e->T) return fail(e, DRS_ERR_BAD_ARG, "bad table id");
+  HIP_TRY(e, launch_fill_uniform(e->tables + e->tab_off[t], e->rows[t] * e->D, t, lo, hi, seed, e->slots[0].stream));
+  HIP_TRY(e, hipStreamSynchronize(e->slots[0].stream));
+  e->table_set[t] = true;
+  return DRS_OK;
+}
+
+int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, const float* h_b,
+                   int32_t m, int32_t n) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (!h_W || !h_b) return fail(e, DRS_ERR_BAD_ARG, "null weights");
+  Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
+  if (!M || layer < 0 || layer >= (int)M->layers.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
+  if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
+    if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");
+    M->ln[1] = m;
+    e->n_out = m;
+  }
+  if (n != M->ln[layer] || m != M->ln[layer + 1])
+    return fail(e, DRS_ERR_BAD_ARG, "layer %d expects W[%d,%d], got [%d,%d]", layer, M->ln[layer + 1], M->ln[layer], m, n);
+  Layer& L = M->layers[layer];
+  if (!L.W) HIP_TRY(e, hipMalloc(&L.W, sizeof(float) * (size_t)m * n));
+  if (!L.b) HIP_TRY(e, hipMalloc(&L.b, sizeof(float) * (size_t)m));
+  HIP_TRY(e, hipMemcpy(L.W, h_W, sizeof(float) * (size_t)m * n, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(L.b, h_b, sizeof(float) * (size_t)m, hipMemcpyHostToDevice));
+  L.m = m; L.n = n; L.set = true;
+  return DRS_OK;
+}
+
+static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_dense,
+                          const int64_t* const* h_idx, const int64_t* n_idx,
+                          const int32_t* const* h_len, hipStream_t stream, void* pinned) {
+  if (n < 0 || n > e->max_batch) return fail(e, DRS_ERR_BAD_ARG, "n_samples=%d exceeds max_batch=%d", n, e->max_batch);
+  if (!h_idx || !n_idx || !h_len) return fail(e, DRS_ERR_BAD_ARG, "null index/length arrays");
+  if (e->m_den > 0 && !h_dense && n > 0) return fail(e, DRS_ERR_BAD_ARG, "null dense input");
+  const size_t dense_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1);
+  const size_t idx_bytes = sizeof(int32_t) * (size_t)e->T * e->cap;
+  const size_t off_bytes = sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1);
+  std::vector<int32_t> tmp_idx;
+  int32_t* idx32;
+  int32_t* off32;
+  float* dense_stage = nullptr;
+  if (pinned) {
+    dense_stage = reinterpret_cast<float*>(pinned);
+    idx32 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(pinned) + dense_bytes);
+    off32 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(pinned) + dense_bytes + idx_bytes);
+  } else {
+    tmp_idx.resize((size_t)e->T * e->cap);
+    idx32 = tmp_idx.data();
+    off32 = b.h_off.data();
+  }
+  int32_t rc = convert_inputs(e, n, h_idx, n_idx, h_len, idx32, off32);
+  if (rc) return rc;
+  if (pinned) memcpy(b.h_off.data(), off32, off_bytes);
+  // copy only what is used of each table's index row
+  for (int t = 0; t < e->T; ++t)
+    if (n_idx[t] > 0)
+      HIP_TRY(e, hipMemcpyAsync(b.idx + (size_t)t * e->cap, idx32 + (size_t)t * e->cap,
+                                sizeof(int32_t) * (size_t)n_idx[t], hipMemcpyHostToDevice, stream));
+  HIP_TRY(e, hipMemcpyAsync(b.off, off32, off_bytes, hipMemcpyHostToDevice, stream));
+  if (e->m_den > 0 && n > 0) {
+    const float* src = h_dense;
+    if (pinned) {
+      memcpy(dense_stage, h_dense, sizeof(float) * (size_t)n * e->m_den);
+      src = dense_stage;
+    }
+    HIP_TRY(e, hipMemcpyAsync(b.dense, src, sizeof(float) * (size_t)n * e->m_den, hipMemcpyHostToDevice, stream));
+  }
+  if (!pinned) HIP_TRY(e, hipStreamSynchronize(stream));
+  b.n_samples = n;
+  b.staged = true;
+  return DRS_OK;
+}
+
+int32_t drs_stage_batch(drs_handle e, int32_t batch_id, int32_t n_samples, const float* h_dense,
+                        const int64_t* const* h_idx, const int64_t* n_idx,
+                        const int32_t* const* h_len) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (batch_id < 0 || batch_id >= e->n_batches) return fail(e, DRS_ERR_BAD_ARG, "batch_id %d of %d", batch_id, e->n_batches);
+  // make sure no in-flight query still reads this batch
+  for (auto& s : e->slots) if (s.busy) HIP_TRY(e, hipStreamSynchronize(s.stream));
+  return stage_into(e, e->batches[batch_id], n_samples, h_dense, h_idx, n_idx, h_len, e->slots[0].stream, nullptr);
+}
+
+int32_t drs_forward_async(drs_handle e, int32_t slot, int32_t batch_id, int32_t bs) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  if (batch_id < 0 || batch_id >= e->n_batches || !e->batches[batch_id].staged)
+    return fail(e, DRS_ERR_STATE, "batch %d is not staged", batch_id);
+  Slot& s = e->slots[slot];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  return enqueue_forward(e, s, e->batches[batch_id], bs);
+}
+
+int32_t drs_wait(drs_handle e, int32_t slot, float* h_out) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  return wait_slot(e, e->slots[slot], h_out);
+}
+
+int32_t drs_forward(drs_handle e, int32_t batch_id, int32_t bs, float* h_out) {
+  int32_t rc = drs_forward_async(e, 0, batch_id, bs);
+  if (rc) return rc;
+  return drs_wait(e, 0, h_out);
+}
+
+int32_t drs_sync(drs_handle e) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  int32_t first = DRS_OK;
+  for (auto& s : e->slots) {
+    rc = wait_slot(e, s, nullptr);
+    if (rc && !first) first = rc;
+  }
+  return first;
+}
+
+int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
+                           const int64_t* const* h_idx, const int64_t* n_idx,
+                           const int32_t* const* h_len, float* h_out) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  Slot& s = e->slots[slot];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  if ((rc = stage_into(e, s.scratch, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage))) return rc;
+  if ((rc = enqueue_forward(e, s, s.scratch, bs))) return rc;
+  return wait_slot(e, s, h_out);
+}
+
+int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots || !h_R || bs < 0 || bs > e->max_batch) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
+  Slot& s = e->slots[slot];
+  HIP_TRY(e, hipStreamSynchronize(s.stream));
+  const float* src;
+  int64_t ld;
+  if (e->kind == DRS_MODEL_NCF) { src = s.H2; ld = e->num_int; }
+  else if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) { src = s.R; ld = e->ldR; }
+  else { src = s.T; ld = e->ldT; }
+  HIP_TRY(e, hipMemcpy2D(h_R, sizeof(float) * e->num_int, src, sizeof(float) * ld,
+                         sizeof(float) * e->num_int, bs, hipMemcpyDeviceToHost));
+  return DRS_OK;
+}
+
+int32_t drs_out_width(drs_handle e, int32_t* n_out) {
+  if (!e || !n_out) return DRS_ERR_BAD_ARG;
+  *n_out = e->n_out;
+  return DRS_OK;
+}
+
+int32_t drs_interaction_width(drs_handle e, int32_t* num_int) {
+  if (!e || !num_int) return DRS_ERR_BAD_ARG;
+  *num_int = e->num_int;
+  return DRS_OK;
+}
+
+// ---- operator-level entry points ---------------------------------------------
+int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const int32_t* d_idx,
+                const int32_t* d_len, int64_t n_bags, int64_t n_idx, float* d_out, int32_t exact_order) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (!d_W || !d_len || !d_out || (!d_idx && n_idx > 0) || n_bags < 0 || n_idx < 0 || rows <= 0)
+    return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
+  if (D <= 0 || D > 256 || (D & 3)) return fail(e, DRS_ERR_UNSUPPORTED, "D=%d must be a multiple of 4 in [4,256]", D);
+  if (rows * (int64_t)D >= (1ll << 32) || n_bags >= (1ll << 31) || n_idx >= (1ll << 31))
+    return fail(e, DRS_ERR_UNSUPPORTED, "operand too large");
+  if (n_bags == 0) return n_idx == 0 ? DRS_OK : fail(e, DRS_ERR_LENGTHS_SUM, "indices without bags");
+  Slot& s = e->slots[0];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  std::vector<int32_t> len((size_t)n_bags), off((size_t)n_bags + 1);
+  HIP_TRY(e, hipMemcpy(len.data(), d_len, sizeof(int32_t) * (size_t)n_bags, hipMemcpyDeviceToHost));
+  int64_t total = 0;
+  off[0] = 0;
+  for (int64_t b = 0; b < n_bags; ++b) {
+    if (len[b] < 0) return fail(e, DRS_ERR_LENGTHS_SUM, "negative length");
+    total += len[b];
+    if (total > n_idx) return fail(e, DRS_ERR_LENGTHS_SUM, "sum(lengths) exceeds len(indices)");
+    off[b + 1] = (int32_t)total;
+  }
+  if (total != n_idx) return fail(e, DRS_ERR_LENGTHS_SUM, "sum(lengths)=%lld != len(indices)=%lld", (long long)total, (long long)n_idx);
+  int32_t* d_off = nullptr;
+  int32_t* d_err = nullptr;
+  HIP_TRY(e, hipMalloc(&d_off, sizeof(int32_t) * ((size_t)n_bags + 1)));
+  hipError_t r = hipMalloc(&d_err, sizeof(int32_t));
+  if (r != hipSuccess) { (void)hipFree(d_off); return fail(e, DRS_ERR_OOM, "hipMalloc"); }
+  const int64_t tab[2] = {0, rows};
+  int32_t h_err = 0;
+  r = hipMemcpy(d_off, off.data(), sizeof(int32_t) * ((size_t)n_bags + 1), hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = hipMemcpy(e->d_op_tab, tab, sizeof tab, hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = hipMemset(d_err, 0, sizeof(int32_t));
+  if (r == hipSuccess) {
+    SlsArgs a;
+    a.tables = d_W; a.tab_off = e->d_op_tab; a.tab_rows = e->d_op_tab + 1;
+    a.idx = d_idx; a.off = d_off; a.idx_stride = 0; a.off_stride = 0;
+    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.n_samples = (int32_t)n_bags; a.err = d_err;
+    r = launch_sls(a, exact_order, s.stream);
+  }
+  if (r == hipSuccess) r = hipStreamSynchronize(s.stream);
+  if (r == hipSuccess) r = hipMemcpy(&h_err, d_err, sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_off);
+  (void)hipFree(d_err);
+  if (r != hipSuccess) return fail(e, DRS_ERR_HIP, "drs_sls: %s", hipGetErrorString(r));
+  if (h_err) return fail(e, DRS_ERR_INDEX_RANGE, "an index is outside [0, %lld)", (long long)rows);
+  return DRS_OK;
+}
+
+int32_t drs_fc(drs_handle e, const float* d_x, int64_t M, int32_t K, const float* d_W, const float* d_b,
+               int32_t N, int32_t act, float* d_y) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (!d_x || !d_W || !d_y || M < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
+  Slot& s = e->slots[0];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  HIP_TRY(e, launch_fc(d_x, K, M, K, d_W, d_b, N, act, d_y, N, s.stream));
+  HIP_TRY(e, hipStreamSynchronize(s.stream));
+  return DRS_OK;
+}
+
+int32_t drs_interact_dot(drs_handle e, const float* d_T, int64_t B, int32_t F, int32_t D, int32_t itself, float* d_R) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (!d_T || !d_R || B < 0 || F <= 0 || D <= 0) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
+  Slot& s = e->slots[0];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  const int P = itself ? F * (F + 1) / 2 : F * (F - 1) / 2;
+  hipError_t r = launch_interact_dot(d_T, (int64_t)F * D, B, F, D, itself, d_R, D + P, s.stream);
+  if (r == hipErrorInvalidValue) return fail(e, DRS_ERR_UNSUPPORTED, "F=%d D=%d does not fit LDS", F, D);
+  HIP_TRY(e, r);
+  HIP_TRY(e, hipStreamSynchronize(s.stream));
+  return DRS_OK;
+}
+
+// ---- tuning / measurement ------------------------------------------------------
+int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
+  if (!e || !key) return DRS_ERR_BAD_ARG;
+  if (!strcmp(key, "sls_exact")) e->sls_exact = value ? 1 : 0;
+  else if (!strcmp(key, "sls_u") && (value == 4 || value == 8 || value == 16 || value == 20)) g_sls_u = (int)value;
+  else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
+  else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
+  else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
+  return DRS_OK;
+}
+
+int32_t drs_set_profiling(drs_handle e, int32_t enabled) {
+  if (!e) return DRS_ERR_BAD_ARG;
+  int32_t rc = drs_sync(e);
+  e->profiling = enabled != 0;
+  return rc;
+}
+
+int32_t drs_kernel_time(drs_handle e, int32_t kernel, double* sum_ms, int64_t* launches) {
+  if (!e || kernel < 0 || kernel >= DRS_KERNEL_COUNT || !sum_ms || !launches) return DRS_ERR_BAD_ARG;
+  *sum_ms = e->k_ms[kernel];
+  *launches = e->k_n[kernel];
+  return DRS_OK;
+}
+
+int32_t drs_reset_kernel_time(drs_handle e) {
+  if (!e) return DRS_ERR_BAD_ARG;
+  for (int i = 0; i < DRS_KERNEL_COUNT; ++i) { e->k_ms[i] = 0; e->k_n[i] = 0; }
+  return DRS_OK;
+}
+
+int32_t drs_gather_bytes(drs_handle e, int32_t batch_id, int32_t bs, int64_t* bytes) {
+  if (!e || !bytes) return DRS_ERR_BAD_ARG;
+  if (batch_id < 0 || batch_id >= e->n_batches || !e->batches[batch_id].staged) return fail(e, DRS_ERR_STATE, "batch %d is not staged", batch_id);
+  const Batch& b = e->batches[batch_id];
+  if (bs < 0 || bs > b.n_samples) return fail(e, DRS_ERR_BAD_ARG, "bs out of range");
+  int64_t total = 0;
+  for (int t = 0; t < e->T; ++t) {
+    const int64_t n = b.h_off[(size_t)t * (e->max_batch + 1) + bs];
+    total += n * ((int64_t)e->D * 4 + 4) + (int64_t)bs * (4 + (int64_t)e->D * 4);
+  }
+  *bytes = total;
+  return DRS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// FC / MLP / dot-interaction kernels for gfx950 on the fp32 matrix cores.
+//
+// Replaces the FC + Relu|Sigmoid operator pairs of create_mlp (reference
+// models/dlrm_s_caffe2.py:223-279) and the Concat/BatchMatMul/Flatten/BatchGather/
+// Concat chain of create_interactions (:331-365).
+//
+// Arithmetic contract (see oracle/drs_oracle.c): every output element is
+//     act( fma-chain over k = 0..K-1 in order, starting from 0 )  + bias
+// v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fp32 fma chain, and the
+// operands are fed so that MFMA step s carries k = 4s .. 4s+3, so GPU and oracle
+// agree bitwise up to the final expf of the sigmoid.
+//
+// Tiling: a workgroup (4 waves) owns a 16-row slab of the batch and 64 output
+// columns at a time (one 16x16 tile per wave).  W (stored [N, K], K contiguous --
+// already the "B^T" layout MFMA wants) streams through LDS in 64-deep K chunks,
+// double-buffered; rows are padded to 68 floats so the staging ds_write_b128 and
+// the per-lane ds_read_b32 operand fetches stay (almost) conflict free.  In the
+// chained form the activations of a slab never leave LDS between layers.
+#include "drs_internal.h"
+
+namespace drs {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 64;         // K chunk staged per step
+constexpr int LDS_LD = KC + 4; // padded row of a staged chunk
+constexpr int BM = 16;         // rows per slab
+constexpr int BN = 64;         // columns per pass (4 waves x 16)
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == DRS_ACT_RELU) return v > 0.0f ? v : 0.0f;
+  if (act == DRS_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// 4 consecutive floats of row `row` starting at column k of a [rows, K] matrix with
+// leading dimension ld; zero outside.  `vec_ok` = base pointer 16-B aligned and ld % 4 == 0.
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t ld, int64_t row,
+                                        int64_t rows, int k, int K, bool vec_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < rows) {
+    const float* q = p + row * ld + k;
+    if (vec_ok && k + 3 < K) {
+      v = *reinterpret_cast<const float4*>(q);
+    } else {
+      if (k + 0 < K) v.x = q[0];
+      if (k + 1 < K) v.y = q[1];
+      if (k + 2 < K) v.z = q[2];
+      if (k + 3 < K) v.w = q[3];
+    }
+  }
+  return v;
+}
+
+struct LayerIo {
+  const float* a_glb;   // A operand in global memory (first layer) or nullptr
+  int64_t lda_glb;
+  const float* a_lds;   // A operand: activation slab in LDS (later layers) or nullptr
+  int lda_lds;
+  float* o_glb;         // output to global (last layer) or nullptr
+  int64_t ldo_glb;
+  float* o_lds;         // output slab in LDS or nullptr
+  int ldo_lds;
+};
+
+// One layer for the slab rows [m0, m0+16) and the columns [n_begin, n_end).
+// sA: [2][16][LDS_LD] (used only when A comes from global), sB: [2][64][LDS_LD].
+template <bool A_LDS, bool O_LDS>
+__device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K, const float* __restrict__ W,
+                           int64_t ldw, const float* __restrict__ bias, int N, int n_begin,
+                           int n_end, int act, bool a_vec, bool w_vec, float* sA, float* sB) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 15;   // row of A / column of the tile
+  const int g = lane >> 4;   // k within an MFMA step
+  const int n_chunks = (K + KC - 1) / KC;
+
+  for (int n0 = n_begin; n0 < n_end; n0 += BN) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+    // prologue: stage chunk 0
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb[4];
+    auto fetch = [&](int kc) {
+      if (!A_LDS) ra = load4(io.a_glb, io.lda_glb, m0 + (tid >> 4), M, kc + (tid & 15) * 4, K, a_vec);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + i * 16;   // 0..63
+        rb[i] = load4(W, ldw, n0 + row, N, kc + (tid & 15) * 4, K, w_vec);
+      }
+    };
+    auto stash = [&](int buf) {
+      if (!A_LDS)
+        *reinterpret_cast<float4*>(sA + (buf * BM + (tid >> 4)) * LDS_LD + (tid & 15) * 4) = ra;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + i * 16;
+        *reinterpret_cast<float4*>(sB + (buf * BN + row) * LDS_LD + (tid & 15) * 4) = rb[i];
+      }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; ++c) {
+      const int buf = c & 1;
+      const bool more = c + 1 < n_chunks;
+      if (more) fetch((c + 1) * KC);   // global loads for the next chunk fly during the MFMAs
+
+      const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
+                              : sA + (buf * BM + r) * LDS_LD + g;
+      const float* pb = sB + (buf * BN + wave * 16 + r) * LDS_LD + g;
+      const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k (tail is zero padded)
+      float av[KC / 4], bv[KC / 4];
+#pragma unroll
+      for (int s = 0; s < KC / 4; ++s) {
+        // an LDS activation slab may hold stale columns past K: mask them (the
+        // staged chunks are already zero filled there)
+        const bool live = s < ksteps && (!A_LDS || c * KC + 4 * s + g < K);
+        av[s] = live ? pa[4 * s] : 0.f;
+        bv[s] = s < ksteps ? pb[4 * s] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < KC / 4; ++s)
+        if (s < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+    }
+
+    // epilogue: bias + activation; lane holds rows g*4+i, column r
+    const int col = n0 + wave * 16 + r;
+    if (col < N) {
+      const float bcol = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = g * 4 + i;
+        const float v = act_apply(acc[i] + bcol, act);
+        if (O_LDS) {
+          io.o_lds[row * io.ldo_lds + col] = v;
+        } else if (m0 + row < M) {
+          io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64-column group.
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
+                                                 int K, const float* __restrict__ W, int64_t ldw,
+                                                 const float* __restrict__ b, int N, int act,
+                                                 float* __restrict__ y, int64_t ldy) {
+  __shared__ __attribute__((aligned(16))) float sA[2 * BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sB[2 * BN * LDS_LD];
+  LayerIo io = {x, ldx, nullptr, 0, y, ldy, nullptr, 0};
+  const int n0 = blockIdx.y * BN;
+  layer_pass<false, false>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0, min(n0 + BN, N), act,
+             aligned16(x) && (ldx & 3) == 0, aligned16(W) && (ldw & 3) == 0, sA, sB);
+}
+
+// Chain of layers on a 16-row slab; activations ping-pong between two LDS slabs.
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                            // [2][16][LDS_LD]
+  float* sB = sA + 2 * BM * LDS_LD;            // [2][64][LDS_LD]
+  float* slab0 = sB + 2 * BN * LDS_LD;         // [16][slab_ld]
+  float* slab1 = slab0 + BM * slab_ld;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+  // zero both slabs once: padded K tails of later layers must read 0
+  for (int i = threadIdx.x; i < 2 * BM * slab_ld; i += blockDim.x) slab0[i] = 0.f;
+  __syncthreads();
+
+  float* cur = nullptr;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const bool first = l == 0, last = l == a.n_layers - 1;
+    float* nxt = (l & 1) ? slab1 : slab0;
+    LayerIo io;
+    io.a_glb = first ? a.x : nullptr;
+    io.lda_glb = a.ldx;
+    io.a_lds = first ? nullptr : cur;
+    io.lda_lds = slab_ld;
+    io.o_glb = last ? a.y : nullptr;
+    io.ldo_glb = a.ldy;
+    io.o_lds = last ? nullptr : nxt;
+    io.ldo_lds = slab_ld;
+    const int K = a.width[l], N = a.width[l + 1];
+    const bool av = aligned16(a.x) && (a.ldx & 3) == 0;
+    const bool wv = aligned16(a.W[l]) && (K & 3) == 0;
+    if (first && last)
+      layer_pass<false, false>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+    else if (first)
+      layer_pass<false, true>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+    else if (last)
+      layer_pass<true, false>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+    else
+      layer_pass<true, true>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+    __syncthreads();
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dot interaction: one wave per sample.  T[b] is [F, D]; Z = T T^T is computed
+// in 16x16 MFMA tiles (A and B operands are the same register: B[k][j] = T[j][k]),
+// the strictly-lower (or lower, with `itself`) triangle is scattered in the
+// row-major BatchGather order i*(i-1)/2 + j (resp. i*(i+1)/2 + j) behind a copy
+// of the dense row T[b][0][:].
+__global__ __launch_bounds__(256) void interact_dot_kernel(const float* __restrict__ T, int64_t ldt,
+                                                           int64_t B, int F, int D, int itself,
+                                                           float* __restrict__ R, int64_t ldr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const int Fp = (F + 15) & ~15;
+  const int ldl = D + 1;                       // odd stride: conflict-free column reads
+  float* t = smem + (size_t)wave * Fp * ldl;
+  if (b >= B) return;                          // whole wave exits together
+  const float* src = T + b * ldt;
+  for (int i = lane; i < Fp * D; i += 64) {
+    const int f = i / D, d = i - f * D;
+    t[f * ldl + d] = f < F ? src[(int64_t)f * D + d] : 0.f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float* out = R + b * ldr;
+  for (int d = lane; d < D; d += 64) out[d] = t[d];
+  const int r = lane & 15, g = lane >> 4;
+  const int ksteps = (D + 3) / 4;
+  for (int ti = 0; ti < Fp; ti += 16)
+    for (int tj = 0; tj <= ti; tj += 16) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < ksteps; ++s) {
+        const int k = 4 * s + g;
+        const float av = k < D ? t[(ti + r) * ldl + k] : 0.f;
+        const float bv = k < D ? t[(tj + r) * ldl + k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+      const int j = tj + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ti + g * 4 + q;
+        if (i < F && (itself ? j <= i : j < i)) {
+          const int p = itself ? i * (i + 1) / 2 + j : i * (i - 1) / 2 + j;
+          out[D + p] = acc[q];
+        }
+      }
+    }
+}
+
+__global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                int64_t ldb, float* __restrict__ o, int64_t ldo, int64_t M, int D) {
+  const int64_t n = M * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D;
+    const int d = (int)(i - m * D);
+    const float v = b ? a[m * lda + d] + b[m * ldb + d] : a[m * lda + d];
+    o[m * ldo + d] = v;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
+                     const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
+                     hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+  hipLaunchKernelGGL(fc_kernel, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy);
+  return hipGetLastError();
+}
+
+static int chain_slab_ld(const ChainArgs& a) {
+  int w = 0;
+  for (int l = 1; l < a.n_layers; ++l) w = a.width[l] > w ? a.width[l] : w;  // slabs hold layer outputs
+  w = (w + KC - 1) / KC * KC;   // K-chunk padding of the consumer layer
+  return w + 4;
+}
+
+size_t chain_lds_bytes(const ChainArgs& a) {
+  return sizeof(float) * ((size_t)2 * BM * LDS_LD + (size_t)2 * BN * LDS_LD +
+                          (size_t)2 * BM * chain_slab_ld(a));
+}
+
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN) return hipErrorInvalidValue;
+  const size_t lds = chain_lds_bytes(a);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((a.M + BM - 1) / BM)), dim3(256), lds, s, a,
+                     chain_slab_ld(a));
+  return hipGetLastError();
+}
+
+hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F, int32_t D,
+                               int32_t itself, float* R, int64_t ldr, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const int Fp = (F + 15) & ~15;
+  const size_t lds = sizeof(float) * 4 * (size_t)Fp * (D + 1);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(interact_dot_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(interact_dot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, s, T, ldt,
+                     B, F, D, itself, R, ldr);
+  return hipGetLastError();
+}
+
+static unsigned ew_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+hipError_t launch_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
+                           int64_t ldo, int64_t M, int32_t D, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(ew_grid(M * D)), dim3(256), 0, s, a, lda, b, ldb, out,
+                     ldo, M, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_rows(const float* a, int64_t lda, float* out, int64_t ldo, int64_t M,
+                            int32_t D, hipStream_t s) {
+  return launch_add_rows(a, lda, nullptr, 0, out, ldo, M, D, s);
+}
+
+}  // namespace drs

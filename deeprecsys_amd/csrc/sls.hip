@@ -1,0 +1,279 @@
+// Multi-table SparseLengthsSum gather-reduce for gfx950 (MI355X).
+//
+// Replaces the T x SparseLengthsSum([tbl, idx, len]) operators emitted by
+// create_emb (reference models/dlrm_s_caffe2.py:281-329, op at :317-325) with ONE
+// launch over all B*T bags of a query.  HBM-bound: every pooled row is a random
+// D*4-byte read (128 B at D=32, 256 B at D=64) out of multi-GB tables.
+//
+// Mapping to CDNA4
+//   - a row is read by G = D/V adjacent lanes, V floats (16 B for V=4) per lane:
+//     one global_load_dwordx4 per lane, 64/G whole rows per wave-instruction,
+//     each row a single contiguous, aligned segment (tables are 256-B aligned and
+//     D*4 is a multiple of 16).
+//   - EXACT variant: each G-lane group owns one bag and walks its rows in index
+//     order, so every output column is the sequential fp32 sum
+//     ((r0 + r1) + r2) + ... -- bit-identical to the Caffe2 CPU perfkernel the
+//     reference runs.  64/G bags progress concurrently in a wave; U independent
+//     row loads are kept in flight per lane to cover the ~0.5-1 us HBM latency.
+//   - SPLIT variant: the wave owns one bag, lane group g takes rows g, g+64/G, ...
+//     and the partial sums are combined with a wave-wide xor butterfly
+//     (different fp32 summation order -> tolerance compare, not bitwise).
+//   - the bag's offsets come from the staged prefix-sum vector; its indices are
+//     staged in LDS by one coalesced read per wave (CH at a time) and then
+//     broadcast-read by the lanes of the group; no __syncthreads: a wave only
+//     reads what it wrote itself.
+//   - 64-thread workgroups: B*T bags of a single query are few (2048 at RMC1
+//     b=256), so the launch is cut into as many workgroups as possible to cover
+//     all 256 CUs; workgroups never cooperate.
+//   - index range is checked per row (Caffe2 ENFORCEs it): an out-of-range index
+//     raises bit 0 of *err and contributes zero instead of faulting.
+#include "drs_internal.h"
+
+namespace drs {
+namespace {
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+  using type = float4;
+};
+template <>
+struct Vec<2> {
+  using type = float2;
+};
+
+__device__ __forceinline__ float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float2 vzero2() { return make_float2(0.f, 0.f); }
+template <int V>
+__device__ __forceinline__ typename Vec<V>::type vzero();
+template <>
+__device__ __forceinline__ float4 vzero<4>() { return vzero4(); }
+template <>
+__device__ __forceinline__ float2 vzero<2>() { return vzero2(); }
+
+__device__ __forceinline__ void vadd(float4& a, const float4& b) {
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+__device__ __forceinline__ void vadd(float2& a, const float2& b) {
+  a.x += b.x; a.y += b.y;
+}
+__device__ __forceinline__ float4 vshfl_xor(const float4& a, int m) {
+  return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m),
+                     __shfl_xor(a.w, m));
+}
+__device__ __forceinline__ float2 vshfl_xor(const float2& a, int m) {
+  return make_float2(__shfl_xor(a.x, m), __shfl_xor(a.y, m));
+}
+
+constexpr int kChunk = 128;  // indices staged in LDS per bag per round
+
+template <int V>
+__device__ __forceinline__ typename Vec<V>::type vsel(bool keep, const typename Vec<V>::type& v);
+template <>
+__device__ __forceinline__ float4 vsel<4>(bool keep, const float4& v) {
+  return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
+template <>
+__device__ __forceinline__ float2 vsel<2>(bool keep, const float2& v) {
+  return make_float2(keep ? v.x : 0.f, keep ? v.y : 0.f);
+}
+
+// G lanes per row, V floats per lane, U row loads in flight per lane.
+template <int G, int V, int U, bool EXACT>
+__global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
+  using vec = typename Vec<V>::type;
+  constexpr int NG = 64 / G;                  // lane groups per wave
+  constexpr int BAGS = EXACT ? NG : 1;        // bags per wave
+  constexpr int STEP = EXACT ? 1 : NG;        // row stride between a lane's loads
+  constexpr int OWNERS = EXACT ? G : 64;      // lanes that stage one bag's indices
+  __shared__ __attribute__((aligned(16))) int32_t s_idx[BAGS][kChunk];
+
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int col = min(gl * V, a.D - V);       // clamp idle lanes onto valid columns
+  const bool col_ok = gl * V < a.D;
+
+  const int64_t n_bags = (int64_t)a.n_samples * a.T;
+  const int64_t bag = (int64_t)blockIdx.x * BAGS + (EXACT ? g : 0);
+  const bool bag_ok = bag < n_bags;
+  const int b = bag_ok ? (int)(bag / a.T) : 0;
+  const int t = bag_ok ? (int)(bag - (int64_t)b * a.T) : 0;
+
+  const int32_t* __restrict__ offp = a.off + (int64_t)t * a.off_stride;
+  const int beg = bag_ok ? offp[b] : 0;
+  const int end = bag_ok ? offp[b + 1] : 0;
+  const int32_t* __restrict__ ip = a.idx + (int64_t)t * a.idx_stride;
+  const float* __restrict__ W = a.tables + a.tab_off[t] + col;
+  const uint32_t rows = (uint32_t)a.tab_rows[t];
+  const int64_t D = a.D;
+  const uint32_t Du = (uint32_t)a.D;   // rows * D < 2^32 is enforced at table creation
+
+  int32_t* my_idx = s_idx[EXACT ? g : 0];
+  const int me = EXACT ? gl : lane;           // my slot among the owners
+  const int first = EXACT ? 0 : g;            // first row (within a chunk) of this lane
+  vec acc = vzero<V>();
+  bool bad = false;
+
+  // Control flow is kept WAVE-UNIFORM: every lane runs as many rounds as the
+  // longest bag in the wave needs (shorter bags re-read their last row, an L1
+  // hit, and add +0.0f).  With scalar branches each pipeline arm below is one
+  // straight-line block, so the compiler's s_waitcnt vmcnt(N) counts stay exact
+  // and U..2U row loads per lane remain outstanding.
+  const int len = end - beg;
+  int len_max = len;
+#pragma unroll
+  for (int m = G; m < 64; m <<= 1) len_max = max(len_max, __shfl_xor(len_max, m));
+  len_max = __builtin_amdgcn_readfirstlane(len_max);
+
+  for (int c = 0; c < len_max; c += kChunk) {
+    const int n = min(kChunk, len - c);            // this lane's rows in the chunk (may be <= 0)
+    const int n_u = min(kChunk, len_max - c);      // uniform: rounds the wave runs
+    const int last = max(n - 1, 0);
+    const int j0 = beg + c;
+    // stage the next indices of each bag in LDS: coalesced, clamped (branch-free)
+    for (int c0 = 0; c0 < n_u; c0 += 4 * OWNERS) {
+      int32_t tmp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tmp[q] = n > 0 ? ip[j0 + min(c0 + q * OWNERS + me, last)] : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c0 + q * OWNERS + me < kChunk) my_idx[c0 + q * OWNERS + me] = tmp[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // U independent, unconditional row loads
+    auto issue = [&](vec (&ring)[U], int pos) {
+      uint32_t r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[u] = (uint32_t)my_idx[min(pos + u * STEP, last)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bad |= (pos + u * STEP < n) && (r[u] >= rows);
+        r[u] = r[u] < rows ? r[u] : 0u;
+        ring[u] = *reinterpret_cast<const vec*>(W + (uint64_t)(r[u] * Du));
+      }
+    };
+    auto consume = [&](const vec (&ring)[U], int pos) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) vadd(acc, vsel<V>(pos + u * STEP < n, ring[u]));
+    };
+
+    // software pipeline over two register rings: while ring A (round k) is summed
+    // in index order, ring B (round k+1) is already in flight, and vice versa.
+    // Each arm holds its own issue+consume pair; the distinct asm comments keep
+    // SimplifyCFG from sinking the common tails into a join.
+    constexpr int R = U * STEP;
+    vec ringA[U], ringB[U];
+    int jj = first;                                 // per-lane row position
+    int ju = 0;                                     // uniform round position
+    issue(ringA, jj);
+    for (;;) {
+      if (ju + R < n_u) {
+        issue(ringB, jj + R);
+        __builtin_amdgcn_sched_barrier(0);   // loads first, then the sums
+        consume(ringA, jj);
+        asm volatile("; drs sls: A summed, B in flight" ::: "memory");
+      } else {
+        consume(ringA, jj);
+        asm volatile("; drs sls: A summed, tail" ::: "memory");
+        break;
+      }
+      if (ju + 2 * R < n_u) {
+        issue(ringA, jj + 2 * R);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(ringB, jj + R);
+        asm volatile("; drs sls: B summed, A in flight" ::: "memory");
+      } else {
+        consume(ringB, jj + R);
+        asm volatile("; drs sls: B summed, tail" ::: "memory");
+        break;
+      }
+      jj += 2 * R;
+      ju += 2 * R;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (!EXACT) {
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) vadd(acc, vshfl_xor(acc, m));
+  }
+  if (bad) atomicOr(a.err, 1);
+  if (bag_ok && col_ok && (EXACT || g == 0)) {
+    float* o = a.out + (int64_t)b * a.ld_out + a.col0 + (int64_t)t * D + col;
+    *reinterpret_cast<vec*>(o) = acc;
+  }
+}
+
+template <int G, int V, int U>
+hipError_t launch_variant(const SlsArgs& a, int exact, hipStream_t s) {
+  const int64_t n_bags = (int64_t)a.n_samples * a.T;
+  if (n_bags == 0) return hipSuccess;
+  if (exact) {
+    constexpr int BAGS = 64 / G;
+    const unsigned grid = (unsigned)((n_bags + BAGS - 1) / BAGS);
+    hipLaunchKernelGGL((sls_kernel<G, V, U, true>), dim3(grid), dim3(64), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((sls_kernel<G, V, U, false>), dim3((unsigned)n_bags), dim3(64), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+template <int G, int V>
+hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s) {
+  switch (u) {
+    case 4: return launch_variant<G, V, 4>(a, exact, s);
+    case 8: return launch_variant<G, V, 8>(a, exact, s);
+    case 20: return launch_variant<G, V, 20>(a, exact, s);
+    default: return launch_variant<G, V, 16>(a, exact, s);
+  }
+}
+
+}  // namespace
+
+// Tunables (set through drs_set_option): rows in flight per lane and the lane
+// width used for D == 32 (8 lanes x 16 B or 16 lanes x 8 B).
+int g_sls_u = 16;
+int g_sls_v_d32 = 4;
+
+hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s) {
+  const int D = a.D;
+  if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
+  const int u = g_sls_u;
+  if (D == 32 && g_sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s);
+  if (D <= 8) return launch_u<2, 4>(a, exact, u, s);
+  if (D <= 16) return launch_u<4, 4>(a, exact, u, s);
+  if (D <= 32) return launch_u<8, 4>(a, exact, u, s);
+  if (D <= 64) return launch_u<16, 4>(a, exact, u, s);
+  if (D <= 128) return launch_u<32, 4>(a, exact, u, s);
+  return launch_u<64, 4>(a, exact, u, s);
+}
+
+// ---------------------------------------------------------------------------
+// device-side table fill, bit-identical to oracle/drs_oracle.c fill_value()
+__global__ void fill_uniform_kernel(float* W, int64_t n, int32_t t, float lo, float hi,
+                                    uint64_t seed) {
+  const float span = hi - lo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)i + ((uint64_t)(uint32_t)t << 40) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+    W[i] = __fmaf_rn(u, span, lo);
+  }
+}
+
+hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
+                               hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int64_t want = (n + 255) / 256;
+  const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid), dim3(256), 0, s, W, n, t, lo, hi, seed);
+  return hipGetLastError();
+}
+
+}  // namespace drs

@@ -1,0 +1,309 @@
+"""Model objects of the hot path: host-side mirrors of the reference's graph builders.
+
+    DLRM_Net / DLRM_Wrapper               <- models/dlrm_s_caffe2.py:79-569
+    Wide_and_Deep / Wide_and_Deep_Wrapper <- models/wide_and_deep.py:165-477
+    NCF / NCF_Wrapper                     <- models/ncf.py:140-523
+
+Same constructor arguments, the same shape algebra and sys.exit() checks, the same
+numpy RNG consumption order for the weights (embeddings, then bottom MLP, then top
+MLP: models/dlrm_s_caffe2.py:245-249,297-299,367-386), the same
+create()/run()/run_queues() calls.  Where the reference emits Caffe2 operators into
+a net, these classes fill a drs_model_cfg and hand the weights to libdrs_hip.so
+(include/drs.h); the forward itself is the HIP kernels -- there is no Python or CPU
+implementation of the arithmetic in this package.
+
+Differences that are deliberate:
+  * run_queues() executes the query synchronously (the reference enqueues blobs for
+    a second thread blocked in RunNet; HIP stream order replaces the BlobsQueues);
+  * fetch_output() replaces workspace.FetchBlob("prob_click");
+  * stage_batches()/run_staged() keep all `num_batches` input sets resident in HBM
+    (the reference keeps lX/lS_l/lS_i in process memory, inferenceEngine.py:83) so a
+    request is served from (batch_id, batch_size) alone.
+"""
+import sys
+import time
+
+import numpy as np
+
+from . import _native as N
+
+
+def _ints(s):
+    return np.array([int(x) for x in str(s).split("-")], dtype=int)
+
+
+def _init_table(n, m):
+    # models/dlrm_s_caffe2.py:297-299
+    return np.random.uniform(low=-np.sqrt(1 / n), high=np.sqrt(1 / n), size=(n, m)).astype(np.float32)
+
+
+def _init_mlp(ln):
+    # models/dlrm_s_caffe2.py:240-249: W ~ N(0, sqrt(2/(m+n))) [m, n]; b ~ N(0, sqrt(1/m)) [m]
+    layers = []
+    for i in range(1, ln.size):
+        n, m = int(ln[i - 1]), int(ln[i])
+        W = np.random.normal(0.0, np.sqrt(2 / (m + n)), size=(m, n)).astype(np.float32)
+        b = np.random.normal(0.0, np.sqrt(1 / m), size=m).astype(np.float32)
+        layers.append((W, b))
+    return layers
+
+
+class _HipNet(object):
+    """State shared by the three model mirrors: weights on the host until create(),
+    then one Engine (one GPU)."""
+
+    kind = None
+
+    def _common_init(self, cli_args):
+        self.args = cli_args
+        self.accel_en = getattr(cli_args, "use_accel", False)
+        self.engine = None
+        self._out = None
+        self._device = int(getattr(cli_args, "_drs_device", 0))
+        self._table_init = getattr(cli_args, "accel_table_init", "numpy")
+        self.tout = "prob_click"
+
+    # -- weights ------------------------------------------------------------------
+    def _make_tables(self, m, ln_emb):
+        if self._table_init == "device":
+            return [None] * ln_emb.size        # filled on the GPU in create()
+        return [_init_table(int(n), m) for n in ln_emb]
+
+    # -- device -------------------------------------------------------------------
+    def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top):
+        a = self.args
+        n_stage = max(int(getattr(a, "num_batches", 0)), 1)
+        max_batch = max(int(getattr(a, "max_mini_batch_size", 1)), int(getattr(a, "mini_batch_size", 1)), 1)
+        eng = N.Engine(self.kind, self.ln_emb, self.m_spa, ln_bot_cfg, ln_top_cfg,
+                       interaction_op=interaction_op, interaction_itself=itself,
+                       sigmoid_top=sigmoid_top, max_batch=max_batch,
+                       max_lookups=max(int(a.num_indices_per_lookup), 1),
+                       num_staged_batches=n_stage,
+                       num_slots=max(int(getattr(a, "accel_slots", 1)), 1), device=self._device)
+        seed = int(getattr(a, "numpy_rand_seed", 0))
+        for t, W in enumerate(self.emb_w):
+            if W is None:
+                n = int(self.ln_emb[t])
+                eng.fill_table_uniform(t, -float(np.sqrt(1 / n)), float(np.sqrt(1 / n)), seed)
+            else:
+                eng.set_table(t, W)
+        return eng
+
+    def create(self, X, S_lengths, S_indices, T, id_qs=None, len_qs=None):
+        """Build the device model (reference: create_input + create_model,
+        models/dlrm_s_caffe2.py:509-546).  X/S_* are the first input set; they are kept as
+        the "current blobs" exactly like the reference's initial FeedBlobs."""
+        self._create_engine()
+        self._cur_inputs = (X, S_lengths, S_indices)
+
+    def parameters(self):
+        return self
+
+    # -- execution ----------------------------------------------------------------
+    def run(self, X=None, S_lengths=None, S_indices=None, enable_prof=False):
+        """One forward of a fed batch; returns the time at which input hand-over ended,
+        like the reference's run() (models/dlrm_s_caffe2.py:549-569)."""
+        if X is None and S_indices is None:
+            X, S_lengths, S_indices = self._cur_inputs
+        else:
+            self._cur_inputs = (X, S_lengths, S_indices)
+        bs = len(S_lengths[0])
+        load_time = time.time()
+        self._out = self.engine.forward_inputs(X, S_indices, S_lengths, bs)
+        return load_time
+
+    def run_queued(self, ids, lengths, fc, batch_size):
+        self._out = self.engine.forward_inputs(fc, list(ids), list(lengths), int(batch_size))
+        return self._out
+
+    def stage_batches(self, lX, lS_l, lS_i):
+        for j in range(len(lS_l)):
+            self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
+
+    def run_staged(self, batch_id, batch_size):
+        self._out = self.engine.forward(int(batch_id), int(batch_size))
+        return self._out
+
+    def fetch_output(self):
+        """FetchBlob("prob_click") counterpart: [bs, n_out] float32 of the last run."""
+        return self._out
+
+
+# =====================================================================================
+class DLRM_Net(_HipNet):
+    kind = N.MODEL_DLRM
+
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None,
+                 fc_q=None):
+        self._common_init(cli_args)
+        # shape algebra + checks of models/dlrm_s_caffe2.py:403-440
+        ln_bot = _ints(cli_args.arch_mlp_bot)
+        m_den = ln_bot[0]
+        m_spa = cli_args.arch_sparse_feature_size
+        ln_emb = _ints(cli_args.arch_embedding_size)
+        num_fea = ln_emb.size + 1
+        m_den_out = ln_bot[ln_bot.size - 1]
+        if cli_args.arch_interaction_op == "dot":
+            if cli_args.arch_interaction_itself:
+                num_int = (num_fea * (num_fea + 1)) // 2 + m_den_out
+            else:
+                num_int = (num_fea * (num_fea - 1)) // 2 + m_den_out
+        elif cli_args.arch_interaction_op == "cat":
+            num_int = num_fea * m_den_out
+        else:
+            sys.exit("ERROR: --arch-interaction-op=" + cli_args.arch_interaction_op
+                     + " is not supported")
+        ln_top = _ints(str(num_int) + "-" + cli_args.arch_mlp_top)
+        if m_spa != m_den_out:
+            sys.exit("ERROR: arch-sparse-feature-size " + str(m_spa)
+                     + " does not match last dim of bottom mlp " + str(m_den_out))
+        if num_int != ln_top[0]:
+            sys.exit("ERROR: # of feature interactions " + str(num_int)
+                     + " does not match first dim of top mlp " + str(ln_top[0]))
+        self.m_spa, self.ln_emb, self.ln_bot, self.ln_top = m_spa, ln_emb, ln_bot, ln_top
+        self.arch_interaction_op = cli_args.arch_interaction_op
+        self.arch_interaction_itself = cli_args.arch_interaction_itself
+        self.sigmoid_bot = -1
+        self.sigmoid_top = ln_top.size - 1
+        # create_sequential_forward_ops order (:367-386): embeddings, bottom, top
+        self.emb_w = self._make_tables(m_spa, ln_emb)
+        self.bot_w = _init_mlp(ln_bot)
+        self.top_w = _init_mlp(ln_top)
+
+    def _create_engine(self):
+        op = N.INTERACT_DOT if self.arch_interaction_op == "dot" else N.INTERACT_CAT
+        self.engine = self._build_engine(self.ln_bot, self.ln_top, op, self.arch_interaction_itself,
+                                         self.sigmoid_top)
+        for i, (W, b) in enumerate(self.bot_w):
+            self.engine.set_fc(N.MLP_BOT, i, W, b)
+        for i, (W, b) in enumerate(self.top_w):
+            self.engine.set_fc(N.MLP_TOP, i, W, b)
+
+    def tril_indices(self):
+        """interaction_tril_indices blob (models/dlrm_s_caffe2.py:529-535)."""
+        offset = 1 if self.arch_interaction_itself else 0
+        num_fea = self.ln_emb.size + 1
+        return np.array([j + i * num_fea for i in range(num_fea) for j in range(i + offset)])
+
+
+class Wide_and_Deep(_HipNet):
+    kind = N.MODEL_WND
+
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None,
+                 fc_q=None):
+        self._common_init(cli_args)
+        # models/wide_and_deep.py:307-346
+        if cli_args.arch_interaction_op != "cat":
+            sys.exit("ERROR: sparse and dense features must be concatenated in wide and deep")
+        ln_bot = _ints(cli_args.arch_mlp_bot)
+        if ln_bot.size != 1:
+            sys.exit("ERROR: wide and deep has no MLP layers for the continuous features")
+        m_spa = cli_args.arch_sparse_feature_size
+        ln_emb = _ints(cli_args.arch_embedding_size)
+        num_fea = ln_emb.size + 1
+        num_int = (num_fea - 1) * int(m_spa) + int(ln_bot[0])
+        ln_top = _ints(str(num_int) + "-" + cli_args.arch_mlp_top)
+        self.m_spa, self.ln_emb, self.ln_bot, self.ln_top = m_spa, ln_emb, ln_bot, ln_top
+        self.arch_interaction_op = "cat"
+        self.arch_interaction_itself = cli_args.arch_interaction_itself
+        self.sigmoid_bot = -1
+        self.sigmoid_top = ln_top.size - 1
+        self.emb_w = self._make_tables(m_spa, ln_emb)     # :282-287
+        self.top_w = _init_mlp(ln_top)                    # :299-302
+
+    def _create_engine(self):
+        self.engine = self._build_engine(self.ln_bot, self.ln_top, N.INTERACT_CAT, False, self.sigmoid_top)
+        for i, (W, b) in enumerate(self.top_w):
+            self.engine.set_fc(N.MLP_TOP, i, W, b)
+
+
+class NCF(_HipNet):
+    kind = N.MODEL_NCF
+
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None):
+        self._common_init(cli_args)
+        # models/ncf.py:348-392
+        if cli_args.arch_interaction_op != "cat":
+            sys.exit("ERROR: sparse and dense features must be concatenated in NCF")
+        ln_emb = _ints(cli_args.arch_embedding_size)
+        if ln_emb.size != 4:
+            sys.exit("ERROR: NCF only has 4 embedding tables")
+        if cli_args.num_indices_per_lookup != 1:
+            sys.exit("ERROR: NCF has 1 lookup per table")
+        m_spa = cli_args.arch_sparse_feature_size
+        num_int = 2 * int(m_spa)
+        ln_top = _ints(str(num_int) + "-" + cli_args.arch_mlp_top)
+        self.m_spa, self.ln_emb, self.ln_top = m_spa, ln_emb, ln_top
+        self.ln_bot = np.array([0], dtype=int)
+        self.arch_interaction_op = "cat"
+        self.arch_interaction_itself = cli_args.arch_interaction_itself
+        # create_emb: MF tables 0,1 then MLP tables 2,3 (:198-299); MLP over ln_top[:-1]
+        # (:332-333); predictor [m_spa + ln_top[-2], ln_top[-1]] (:341-345); all Relu
+        self.emb_w = self._make_tables(m_spa, ln_emb)
+        self.top_w = _init_mlp(ln_top[:-1])
+        self.final_w = _init_mlp(np.array([int(m_spa) + int(ln_top[-2]), int(ln_top[-1])]))
+
+    def _create_engine(self):
+        self.engine = self._build_engine(np.array([0]), self.ln_top[:-1], N.INTERACT_CAT, False, -1)
+        for i, (W, b) in enumerate(self.top_w):
+            self.engine.set_fc(N.MLP_TOP, i, W, b)
+        W, b = self.final_w[0]
+        self.engine.set_fc(N.MLP_FINAL, 0, W, b)
+
+    def run(self, X=None, S_lengths=None, S_indices=None, enable_prof=False):
+        if S_indices is None:
+            X, S_lengths, S_indices = self._cur_inputs
+        else:
+            self._cur_inputs = (X, S_lengths, S_indices)
+        bs = len(S_lengths[0])
+        load_time = time.time()
+        self._out = self.engine.forward_inputs(None, S_indices, S_lengths, bs)   # NCF has no dense input
+        return load_time
+
+    def run_queued(self, ids, lengths, fc, batch_size):
+        self._out = self.engine.forward_inputs(None, list(ids), list(lengths), int(batch_size))
+        return self._out
+
+    def stage_batches(self, lX, lS_l, lS_i):
+        for j in range(len(lS_l)):
+            self.engine.stage_batch(j, None, lS_i[j], lS_l[j])
+
+
+# =====================================================================================
+class _Wrapper(object):
+    """X_Wrapper(args): .create(...), .run_queues(ids, lengths, fc, batch_size)
+    (models/dlrm_s_caffe2.py:79-174).  The 2T+1 Caffe2 BlobsQueues the reference
+    builds here (:127-139,179-211) have no counterpart: a HIP stream orders the work."""
+
+    net_cls = None
+    attr = None
+
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False):
+        self.args = cli_args
+        self.accel_en = getattr(cli_args, "use_accel", False)
+        setattr(self, self.attr, self.net_cls(cli_args, model, tag, enable_prof))
+
+    @property
+    def net(self):
+        return getattr(self, self.attr)
+
+    def create(self, X, S_lengths, S_indices, T):
+        self.net.create(X, S_lengths, S_indices, T)
+
+    def run_queues(self, ids, lengths, fc, batch_size):
+        return self.net.run_queued(ids, lengths, fc, batch_size)
+
+
+class DLRM_Wrapper(_Wrapper):
+    net_cls, attr = DLRM_Net, "dlrm"
+
+
+class Wide_and_Deep_Wrapper(_Wrapper):
+    net_cls, attr = Wide_and_Deep, "wnd"
+
+
+class NCF_Wrapper(_Wrapper):
+    net_cls, attr = NCF, "ncf"
+
+
+WRAPPERS = {"dlrm": DLRM_Wrapper, "wnd": Wide_and_Deep_Wrapper, "ncf": NCF_Wrapper}

@@ -1,0 +1,58 @@
+"""Wire packets between load generator, engines and the orchestrator.
+
+Field-for-field the reference's packets (utils/packets.py:6-22, :32-59): they are
+pickled through multiprocessing.Queue, so attribute names are the contract.  Note
+the reference stores the `process_start_time` argument as `queue_start_time`.
+"""
+
+
+class ServiceRequest(object):
+    __slots__ = ("batch_id", "batch_size", "epoch", "arrival_time", "total_sub_batches", "sub_id",
+                 "exp_packet")
+
+    def __init__(self, batch_id=None, epoch=None, arrival_time=None, batch_size=None, sub_id=None,
+                 total_sub_batches=None, exp_packet=None):
+        self.batch_id = batch_id
+        self.batch_size = batch_size
+        self.epoch = epoch
+        self.arrival_time = arrival_time
+        self.total_sub_batches = total_sub_batches
+        self.sub_id = sub_id
+        self.exp_packet = exp_packet
+
+    def __str__(self):
+        # the reference's __str__ raises (packets.py:24-27); this one works
+        return "Request[%s] -> arrival_time %s" % ((self.epoch, self.batch_id, self.batch_size),
+                                                   self.arrival_time)
+
+
+class ServiceResponse(object):
+    __slots__ = ("consumer_id", "epoch", "batch_id", "batch_size", "arrival_time", "queue_start_time",
+                 "queue_end_time", "inference_end_time", "out_batch_size", "total_sub_batches",
+                 "exp_packet", "sub_id")
+
+    def __init__(self, consumer_id=None, epoch=None, batch_id=None, batch_size=None,
+                 arrival_time=None, process_start_time=None, queue_end_time=None,
+                 inference_end_time=None, out_batch_size=None, sub_id=None, total_sub_batches=None,
+                 exp_packet=None):
+        self.consumer_id = consumer_id
+        self.epoch = epoch
+        self.batch_id = batch_id
+        self.batch_size = batch_size
+        self.arrival_time = arrival_time
+        self.queue_start_time = process_start_time
+        self.queue_end_time = queue_end_time
+        self.inference_end_time = inference_end_time
+        self.out_batch_size = out_batch_size
+        self.total_sub_batches = total_sub_batches
+        self.exp_packet = exp_packet
+        self.sub_id = sub_id
+
+    def as_dict(self):
+        """What the orchestrator logs per response (reference uses response.__dict__)."""
+        return {k: getattr(self, k) for k in self.__slots__}
+
+    def __str__(self):
+        return "Response[%s] -> arrival %s start %s end %s inference_end %s" % (
+            (self.epoch, self.batch_id, self.batch_size, self.consumer_id), self.arrival_time,
+            self.queue_start_time, self.queue_end_time, self.inference_end_time)

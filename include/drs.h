@@ -177,6 +177,15 @@ int32_t drs_fc(drs_handle h, const float* d_x, int64_t M, int32_t K, const float
 int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, int32_t D,
                          int32_t itself, float* d_R);
 
+/* ---- tuning ------------------------------------------------------------------
+ * integer knobs, for A/B measurements inside one process (bench.py --sweep):
+ *   "sls_exact"  1 (default) sequential-order gather | 0 wave-split gather
+ *   "sls_u"      row loads kept in flight per lane: 4 | 8 | 16 (default) | 20
+ *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
+ *   "mlp_split"  1 (default) first wide top/bottom layer as its own 2-D launch | 0
+ * unknown key -> DRS_ERR_BAD_ARG                                               */
+int32_t drs_set_option(drs_handle h, const char* key, int64_t value);
+
 /* ---- measurement ------------------------------------------------------------
  * Live HIP-event timing of the engine's own launches (bench.py roofline leg).
  * When enabled, every forward brackets its kernels with hipEvents recorded on

@@ -1,0 +1,242 @@
+"""GPU parity suite (-m gpu): the HIP path through the C ABI (include/drs.h) against
+the CPU oracle on the same seeded inputs, and against the golden fixtures.
+
+Bars: bit-exact for everything integer/ordering (pooling with the sequential
+variant, concat layout, tril order) and for the k-ordered fp32 MFMA chains against
+the oracle's fmaf chains; 1e-4 relative (BASELINE.json north_star) for fp32 MLP
+outputs against the fp64-accumulated golden values.
+"""
+import numpy as np
+import pytest
+
+from deeprecsys_amd import _native as N
+from oracle import oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def op_engine():
+    """A tiny engine only used as the handle for operator-level entry points."""
+    e = N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
+                 max_batch=4, max_lookups=2, num_staged_batches=1, num_slots=1)
+    yield e
+    e.close()
+
+
+# ------------------------------------------------------------------------------------
+# whole forward, every golden model case
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_forward_matches_oracle_and_golden(case):
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    om = H.oracle_model(net)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    try:
+        net.stage_batches(None if args.model_type == "ncf" else lX, lS_l, lS_i)
+        n = len(lS_l[0][0])
+        for bid in range(len(lS_l)):
+            for bs in sorted({n, 1, max(1, n // 2)}):
+                got = net.run_staged(bid, bs)
+                R = net.engine.fetch_interaction(bs)
+                dense = None if args.model_type == "ncf" else lX[bid]
+                exp, R_exp = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, want_R=True)
+                # pooled embeddings + concat layout + (dot) tril order + bottom MLP: bitwise
+                assert np.array_equal(R, R_exp), (case, bid, bs, np.abs(R - R_exp).max())
+                # outputs: identical chains up to the last expf -> a few ulp
+                assert H.close(got, exp, rtol=1e-6, atol=1e-7), np.abs(got - exp).max()
+        full = net.run_staged(0, n)
+        assert H.close(full, z["expected/prob_click"], rtol=H.RTOL_OUT)
+        # non-staged inputs (run_queues signature) give the same bits as the staged path
+        again = net.run_queued(lS_i[0], lS_l[0], None if args.model_type == "ncf" else lX[0], n)
+        assert np.array_equal(full, again)
+    finally:
+        net.engine.close()
+
+
+@pytest.mark.parametrize("case", ["dlrm_cat_queue_small", "dlrm_dot_queue_small"])
+def test_queue_requests_from_reference_engine(case):
+    """Inputs are exactly what the reference engine enqueued per request."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    w = H.M.DLRM_Wrapper.__new__(H.M.DLRM_Wrapper)
+    w.args, w.dlrm = args, net
+    w.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    try:
+        T = len(net.emb_w)
+        for r, (bid, bs) in enumerate(meta["queue_requests"]):
+            ids = np.stack([z["req/%d/id_inputs_%d" % (r, t)] for t in range(T)])
+            lens = np.stack([z["req/%d/len_inputs_%d" % (r, t)] for t in range(T)])
+            out = w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)
+            assert out.shape == (bs, 1)
+            assert H.close(out, z["req/%d/expected/prob_click" % r], rtol=H.RTOL_OUT)
+    finally:
+        net.engine.close()
+
+
+# ------------------------------------------------------------------------------------
+# operator level
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 48, 64, 128, 256])
+@pytest.mark.parametrize("L", [1, 20, 80, 300])
+def test_sls_exact_is_bitwise_and_split_is_close(op_engine, D, L):
+    torch = torch_cuda()
+    rng = np.random.RandomState(D + L)
+    rows, bags = 5003, 257
+    W = rng.uniform(-1, 1, (rows, D)).astype(np.float32)
+    lengths = rng.randint(0, L + 1, size=bags).astype(np.int32)
+    lengths[::3] = L
+    lengths[5] = 0
+    idx = rng.randint(0, rows, size=int(lengths.sum())).astype(np.int32)
+    exp = orc.sls(W, idx, lengths)
+    dW, di, dl = (torch.from_numpy(a).cuda() for a in (W, idx, lengths))
+    out = torch.full((bags, D), float("nan"), device="cuda")
+    for u in (4, 8, 16, 20):
+        op_engine.set_option("sls_u", u)
+        out.fill_(float("nan"))
+        op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
+                      out.data_ptr(), exact_order=True)
+        assert np.array_equal(out.cpu().numpy(), exp), (D, L, u)
+        out.fill_(float("nan"))
+        op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
+                      out.data_ptr(), exact_order=False)
+        assert H.close(out.cpu().numpy(), exp, rtol=1e-5, atol_scale=1e-6), (D, L, u)
+    op_engine.set_option("sls_u", 16)
+    if D == 32:
+        op_engine.set_option("sls_v_d32", 2)
+        out.fill_(float("nan"))
+        op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
+                      out.data_ptr(), exact_order=True)
+        op_engine.set_option("sls_v_d32", 4)
+        assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_sls_enforces_like_caffe2(op_engine):
+    torch = torch_cuda()
+    W = torch.ones(10, 8, device="cuda")
+    out = torch.zeros(2, 8, device="cuda")
+    idx = torch.tensor([1, 10, 2], dtype=torch.int32, device="cuda")
+    ln = torch.tensor([2, 1], dtype=torch.int32, device="cuda")
+    with pytest.raises(N.DrsError) as e:
+        op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 3, out.data_ptr())
+    assert e.value.code == N.ERR_INDEX_RANGE
+    idx = torch.tensor([1, -1, 2], dtype=torch.int32, device="cuda")
+    with pytest.raises(N.DrsError) as e:
+        op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 3, out.data_ptr())
+    assert e.value.code == N.ERR_INDEX_RANGE
+    ln = torch.tensor([2, 2], dtype=torch.int32, device="cuda")
+    with pytest.raises(N.DrsError) as e:
+        op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 3, out.data_ptr())
+    assert e.value.code == N.ERR_LENGTHS_SUM
+    # all-empty bags -> zeros
+    ln = torch.zeros(2, dtype=torch.int32, device="cuda")
+    out.fill_(7.0)
+    op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 0, out.data_ptr())
+    assert float(out.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N_", [(1, 3, 1), (5, 6, 12), (16, 128, 64), (33, 576, 256), (256, 100, 64),
+                                    (7, 14, 16), (300, 2560, 1024), (64, 64, 1)])
+@pytest.mark.parametrize("act", [N.ACT_NONE, N.ACT_RELU, N.ACT_SIGMOID])
+def test_fc_matches_oracle_chain(op_engine, M, K, N_, act):
+    torch = torch_cuda()
+    rng = np.random.RandomState(M + K + N_)
+    x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = rng.normal(0, 0.1, (N_, K)).astype(np.float32)
+    b = rng.normal(0, 0.1, N_).astype(np.float32)
+    exp = orc.fc(x, W, b, act)
+    dx, dW, db = (torch.from_numpy(a).cuda() for a in (x, W, b))
+    y = torch.full((M, N_), float("nan"), device="cuda")
+    op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, act, y.data_ptr())
+    got = y.cpu().numpy()
+    if act == N.ACT_SIGMOID:
+        assert H.close(got, exp, rtol=1e-6, atol=1e-7)
+    else:
+        assert np.array_equal(got, exp)   # MFMA == k-ordered fmaf chain, bit for bit
+
+
+@pytest.mark.parametrize("F,D,itself", [(4, 8, False), (4, 8, True), (9, 32, False), (9, 64, True),
+                                        (33, 64, False), (11, 32, False), (17, 16, False)])
+def test_interact_dot_is_bitwise(op_engine, F, D, itself):
+    torch = torch_cuda()
+    rng = np.random.RandomState(F * D)
+    B = 37
+    T = rng.uniform(-1, 1, (B, F, D)).astype(np.float32)
+    exp = orc.interact_dot(T, itself)
+    dT = torch.from_numpy(T).cuda()
+    R = torch.full(exp.shape, float("nan"), device="cuda")
+    op_engine.interact_dot(dT.data_ptr(), B, F, D, itself, R.data_ptr())
+    assert np.array_equal(R.cpu().numpy(), exp)
+
+
+# ------------------------------------------------------------------------------------
+# BASELINE.json sizes: device-filled tables, oracle on the same counter-based fill
+def _big_case(rows, D, T, L, bot, top, B, nb=2, seed=99):
+    from deeprecsys_amd.data_generator.dlrm_data import generate_fast_input_data
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join([str(rows)] * T),
+                       arch_mlp_bot=bot, arch_mlp_top=top, arch_interaction_op="cat",
+                       num_indices_per_lookup=L, num_batches=nb, max_mini_batch_size=B,
+                       mini_batch_size=B, numpy_rand_seed=seed, accel_table_init="device",
+                       model_type="dlrm", accel_slots=3)
+    np.random.seed(seed)
+    net = H.M.DLRM_Net(args)
+    m_den = int(bot.split("-")[0])
+    nb, lX, lS_l, lS_i = generate_fast_input_data(nb, B, m_den, [rows] * T, L, seed)
+    return args, net, lX, lS_l, lS_i
+
+
+def test_full_size_rmc1_baseline_shape_matches_oracle():
+    """BASELINE.json config 2: DLRM-RMC1 8 tables x 1M rows x 64, L=80, batch 256."""
+    rows, D, T, L, B = 1_000_000, 64, 8, 80, 256
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, "128-64-64", "256-64-1", B)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
+        tables = [orc.fill_table_uniform(rows, D, t, lo, hi, args.numpy_rand_seed, nthreads=0)
+                  for t in range(T)]
+        net.emb_w = tables
+        om = H.oracle_model(net)
+        for bid in (0, 1):
+            for bs in (256, 165, 1):
+                got = net.run_staged(bid, bs)
+                R = net.engine.fetch_interaction(bs)
+                exp, R_exp = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+                assert np.array_equal(R, R_exp)
+                assert H.close(got, exp, rtol=1e-6, atol=1e-7)
+        # size-independent properties: pooling count is exact (sum over a bag of an all-ones
+        # column would be L); slots are independent and deterministic
+        eng = net.engine
+        for s in range(3):
+            eng.forward_async(s, s % 2, 256 - s)
+        outs = [eng.wait(s, 256 - s) for s in range(3)]
+        for s in range(3):
+            assert np.array_equal(outs[s], eng.forward(s % 2, 256 - s))
+        assert eng.gather_bytes(0, 256) == 256 * T * (L * D * 4 + L * 4 + 4 + D * 4)
+    finally:
+        net.engine.close()
+
+
+def test_split_variant_within_tolerance_full_size():
+    rows, D, T, L, B = 200_000, 32, 8, 80, 128
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, "128-64-32", "256-64-1", B, nb=1)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        exact = net.run_staged(0, B)
+        R_exact = net.engine.fetch_interaction(B)
+        net.engine.set_option("sls_exact", 0)
+        split = net.run_staged(0, B)
+        R_split = net.engine.fetch_interaction(B)
+        assert H.close(R_split, R_exact, rtol=1e-5, atol_scale=2e-6)
+        assert H.close(split, exact, rtol=H.RTOL_OUT)
+    finally:
+        net.engine.close()

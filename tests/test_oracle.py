@@ -1,0 +1,148 @@
+"""CPU suite: the oracle (oracle/drs_oracle.c) against the golden fixtures captured
+from the reference and against torch-CPU ops (the Caffe2 kernels' lineal
+descendants).  No GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c2ops
+from oracle import oracle as orc
+from tests import helpers as H
+
+
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_oracle_forward_matches_golden(case):
+    """Graph, weights and inputs come from the reference's own builders; the expected
+    prob_click is the recorded op list run by oracle/c2ops.py (fp64 contractions).
+    The C oracle (fp32 k-ordered fma chains) must agree to fp32 round-off."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    om = H.oracle_model(net)
+    dense = None if args.model_type == "ncf" else lX[0]
+    out, R = om.forward(dense, lS_i[0], lS_l[0], want_R=True)
+    exp = z["expected/prob_click"]
+    assert out.shape == exp.shape
+    # fp32 k-ordered chains vs fp64-accumulated truth: well inside the 1e-4 north-star bar
+    assert H.close(out, exp, rtol=2e-5, atol=1e-6), np.abs(out - exp).max()
+    # interaction tensor (input of the top MLP) where the fixture has it; RM3's bottom
+    # MLP has K=2560 all-positive inputs, so allow cancellation noise relative to max|R|
+    key = {"dlrm": "expected/interaction", "wnd": "expected/interaction",
+           "ncf": "expected/feat_int"}[args.model_type]
+    if key in z.files:
+        assert H.close(R, z[key], rtol=2e-5, atol_scale=2e-6)
+
+
+@pytest.mark.parametrize("case", ["dlrm_cat_queue_small", "dlrm_dot_queue_small"])
+def test_oracle_matches_golden_queue_requests(case):
+    """Per-request inputs are the arrays the reference engine itself enqueued
+    (inferenceEngine.py:200-215): a query is a prefix of a pre-generated batch."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    om = H.oracle_model(net)
+    T = len(net.emb_w)
+    for r, (bid, bs) in enumerate(meta["queue_requests"]):
+        ids = [z["req/%d/id_inputs_%d" % (r, t)] for t in range(T)]
+        lens = [z["req/%d/len_inputs_%d" % (r, t)] for t in range(T)]
+        fc = z["req/%d/fc_inputs" % r]
+        # the reference's slicing == prefix of the staged batch
+        for t in range(T):
+            assert np.array_equal(ids[t], lS_i[bid][t][:bs * args.num_indices_per_lookup])
+            assert np.array_equal(lens[t], lS_l[bid][t][:bs])
+            assert ids[t].dtype == np.int64 and lens[t].dtype == np.int32
+        assert np.array_equal(fc, lX[bid][:bs])
+        out = om.forward(fc, ids, lens)
+        out2 = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs)
+        assert np.array_equal(out, out2)
+        exp = z["req/%d/expected/prob_click" % r]
+        assert H.close(out, exp, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("D", [4, 8, 32, 48, 64, 128])
+@pytest.mark.parametrize("L", [0, 1, 7, 80, 130])
+def test_oracle_sls_bitexact_vs_torch_embedding_bag(D, L):
+    """torch-CPU embedding_bag(sum) descends from the Caffe2 EmbeddingLookup perfkernel
+    (sequential fp32 sum per column): the oracle must be bit-identical to it."""
+    rng = np.random.RandomState(D * 1000 + L)
+    rows, bags = 997, 33
+    W = rng.uniform(-1, 1, size=(rows, D)).astype(np.float32)
+    lengths = rng.randint(0, L + 1, size=bags).astype(np.int32)
+    lengths[::5] = L
+    idx = rng.randint(0, rows, size=int(lengths.sum())).astype(np.int64)
+    out = orc.sls(W, idx, lengths)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    ref = torch.nn.functional.embedding_bag(torch.from_numpy(idx), torch.from_numpy(W),
+                                            torch.from_numpy(offsets), mode="sum").numpy()
+    assert np.array_equal(out, ref)
+    assert np.array_equal(out, c2ops.sparse_lengths_sum(W, idx, lengths))
+    out32 = orc.sls(W, idx.astype(np.int32), lengths)
+    assert np.array_equal(out, out32)
+
+
+def test_oracle_sls_enforces_like_caffe2():
+    W = np.ones((10, 4), np.float32)
+    with pytest.raises(orc.OracleError) as e:
+        orc.sls(W, np.array([0, 10], np.int64), np.array([2], np.int32))
+    assert e.value.code == orc.ERR_INDEX_RANGE
+    with pytest.raises(orc.OracleError) as e:
+        orc.sls(W, np.array([0, -1], np.int64), np.array([2], np.int32))
+    assert e.value.code == orc.ERR_INDEX_RANGE
+    with pytest.raises(orc.OracleError) as e:
+        orc.sls(W, np.array([0, 1, 2], np.int64), np.array([2], np.int32))
+    assert e.value.code == orc.ERR_LENGTHS_SUM
+    assert np.array_equal(orc.sls(W, np.zeros(0, np.int64), np.zeros(3, np.int32)), np.zeros((3, 4)))
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 3, 1), (5, 6, 12), (16, 128, 64), (33, 576, 256), (7, 100, 5)])
+@pytest.mark.parametrize("act", [orc.ACT_NONE, orc.ACT_RELU, orc.ACT_SIGMOID])
+def test_oracle_fc_vs_torch_addmm(M, K, N, act):
+    rng = np.random.RandomState(M + K + N)
+    x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = rng.normal(0, 0.1, (N, K)).astype(np.float32)
+    b = rng.normal(0, 0.1, N).astype(np.float32)
+    y = orc.fc(x, W, b, act)
+    ref = torch.addmm(torch.from_numpy(b), torch.from_numpy(x), torch.from_numpy(W).t())
+    if act == orc.ACT_RELU:
+        ref = torch.relu(ref)
+    elif act == orc.ACT_SIGMOID:
+        ref = torch.sigmoid(ref)
+    # two fp32 summation orders (torch sgemm vs k-ordered chain): round-off relative to max|y|
+    assert H.close(y, ref.numpy(), rtol=1e-5, atol_scale=2e-6)
+    # and against an explicit k-ordered fp32 fma chain in numpy (the oracle's definition)
+    acc = np.zeros((M, N), np.float32)
+    for k in range(K):
+        acc = (x[:, k:k + 1].astype(np.float64) * W[:, k][None, :].astype(np.float64)
+               + acc.astype(np.float64)).astype(np.float32)   # one rounding per fma
+    z = acc + b
+    if act == orc.ACT_RELU:
+        z = np.maximum(z, 0)
+    if act != orc.ACT_SIGMOID:
+        assert np.array_equal(y, z.astype(np.float32))
+
+
+@pytest.mark.parametrize("F,D,itself", [(4, 8, False), (4, 8, True), (9, 32, False), (33, 64, False)])
+def test_oracle_interact_dot_vs_recorded_op_chain(F, D, itself):
+    """Concat(add_axis) + BatchMatMul(trans_b) + Flatten + BatchGather(tril) + Concat
+    (models/dlrm_s_caffe2.py:334-354) evaluated op by op in numpy vs the fused oracle."""
+    rng = np.random.RandomState(F * D)
+    B = 5
+    T = rng.uniform(-1, 1, (B, F, D)).astype(np.float32)
+    R = orc.interact_dot(T, itself)
+    Z = c2ops.batch_matmul(T, T, trans_b=1)
+    off = 1 if itself else 0
+    tril = np.array([j + i * F for i in range(F) for j in range(i + off)])
+    ref = c2ops.concat([T[:, 0, :], c2ops.batch_gather(c2ops.flatten(Z, 1), tril)], axis=1)
+    assert R.shape == ref.shape
+    assert H.close(R, ref, rtol=1e-5, atol=1e-6)
+    tb = torch.from_numpy(T)
+    assert H.close(c2ops.batch_matmul(T, T, 1), torch.bmm(tb, tb.transpose(1, 2)).numpy(), 1e-5, 1e-6)
+
+
+def test_fill_value_is_deterministic_and_in_range():
+    W = orc.fill_table_uniform(1000, 32, 3, -0.5, 0.25, 12345)
+    assert W.min() >= -0.5 and W.max() <= 0.25
+    assert abs(float(W.mean()) + 0.125) < 0.01
+    W2 = orc.fill_table_uniform(1000, 32, 3, -0.5, 0.25, 12345, nthreads=4)
+    assert np.array_equal(W, W2)
+    assert not np.array_equal(W, orc.fill_table_uniform(1000, 32, 4, -0.5, 0.25, 12345))
