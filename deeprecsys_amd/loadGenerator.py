@@ -1,0 +1,149 @@
+"""Load generator: Poisson arrivals, query-size distributions, CPU/accelerator routing.
+
+Mirror of the reference's loadGenerator.py:14-227 (same function names and
+signatures; distributions and partitioning pinned by tests/golden/harness.json).
+Extension for this build: `num_accels` accelerator engines, one per
+GPU, all pulling from the single accelRequestQueue; with no CPU engines configured
+every query goes to the accelerators whatever its size.
+"""
+import math
+import sys
+import time
+
+import numpy as np
+
+from .scheduler import Scheduler
+from .utils.packets import ServiceRequest
+from .utils.utils import debugPrint
+
+
+def model_arrival_times(args):
+    # loadGenerator.py:14-17
+    return np.random.poisson(lam=args.avg_arrival_rate, size=args.nepochs * args.num_batches)
+
+
+def model_batch_size_distribution(args):
+    """Query sizes for the num_batches query slots, clamped to [1, max_mini_batch_size]
+    (loadGenerator.py:20-43)."""
+    kind, n = args.batch_size_distribution, args.num_batches
+    if kind == "normal":
+        sizes = np.random.normal(args.avg_mini_batch_size, args.var_mini_batch_size, n)
+    elif kind == "lognormal":
+        sizes = np.random.lognormal(args.avg_mini_batch_size, args.var_mini_batch_size, n)
+    elif kind == "fixed":
+        sizes = np.array([args.avg_mini_batch_size for _ in range(n)])
+    elif kind == "file":
+        with open(args.batch_dist_file, "r") as f:
+            percentiles = [float(line.rstrip()) for line in f.readlines()]
+        sizes = [int(percentiles[int(np.random.uniform(0, len(percentiles)))]) for _ in range(n)]
+    else:
+        raise ValueError("unknown batch_size_distribution " + str(kind))
+    for i in range(n):
+        sizes[i] = int(max(min(sizes[i], args.max_mini_batch_size), 1))
+    return sizes
+
+
+def partition_requests(args, batch_size):
+    """Cut a query into sub_task_batch_size pieces, remainder last (loadGenerator.py:46-54)."""
+    full, rest = divmod(int(batch_size), int(args.sub_task_batch_size))
+    return [args.sub_task_batch_size] * full + ([rest] if rest > 0 else [])
+
+
+def loadGenSleep(sleeptime):
+    # OS sleep is too coarse below ~5.5 ms: spin instead (loadGenerator.py:57-64)
+    if sleeptime > 0.0055:
+        time.sleep(sleeptime)
+        return
+    t0 = time.time()
+    while (time.time() - t0) < sleeptime:
+        pass
+
+
+def accel_engine_count(args):
+    return int(getattr(args, "num_accels", 1)) if args.model_accel else 0
+
+
+def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineReadyQueue, pidQueue,
+                  accelRequestQueue):
+    for _ in range(args.inference_engines):        # block until every engine built its model
+        inferenceEngineReadyQueue.get()
+
+    model_arrival_times(args)                      # consumed for RNG-stream parity (unused, as in the reference)
+    batch_size_distributions = model_batch_size_distribution(args)
+    n_accel = accel_engine_count(args)
+    n_cpu = args.inference_engines - n_accel
+
+    cpu_sub_requests = cpu_requests = accel_requests = 0
+    tune_batch, tune_accel = args.tune_batch_qps, args.tune_accel_qps
+    tuning_batch_qps, tuning_accel_qps = args.tune_batch_qps, False
+    if tuning_batch_qps:
+        rates = np.logspace(math.log(args.min_arr_range, 10), math.log(args.max_arr_range, 10),
+                            num=args.arr_steps)
+        print("Arrival rates to try: ", rates)
+        sys.stdout.flush()
+        batch_configs = np.array([int(x) for x in args.batch_configs.split("-")], dtype=int)
+        args.sub_task_batch_size = batch_configs[0]
+        args.accel_request_size_thres = 1024     # accelerator sweep starts after the batch sweep
+    arrival_rate = args.avg_arrival_rate
+
+    query_scheduler = Scheduler(args, requestQueue, accelRequestQueue, pidQueue, mode="cpu")
+    accel_query_scheduler = Scheduler(args, requestQueue, accelRequestQueue, pidQueue, mode="accel")
+
+    epoch = exp_epochs = 0
+    while tuning_batch_qps or (exp_epochs < args.nepochs):
+        for batch_id in range(args.num_batches):
+            if tuning_batch_qps and pidQueue.qsize() > 0:
+                args, arrival_rate, tuning_batch_qps = query_scheduler.run(pidQueue.get())
+                if not tuning_batch_qps:
+                    print("Finished batch size scheduler ")
+                    if args.model_accel and args.tune_accel_qps:
+                        print("Starting accel scheduler")
+                        tuning_accel_qps = True
+                    continue
+            if args.model_accel and tuning_accel_qps and pidQueue.qsize() > 0:
+                args, arrival_rate, tuning_accel_qps = accel_query_scheduler.run(pidQueue.get())
+                if not tuning_accel_qps:
+                    continue
+
+            request_size = int(batch_size_distributions[batch_id])
+            exploring = bool(tuning_batch_qps or tuning_accel_qps)
+            to_accel = n_accel > 0 and (n_cpu == 0 or request_size >= args.accel_request_size_thres)
+            if to_accel:
+                # whole query to an accelerator (loadGenerator.py:162-177)
+                request = ServiceRequest(batch_id=batch_id, epoch=epoch, batch_size=request_size,
+                                         sub_id=0, total_sub_batches=1, exp_packet=exploring)
+                accel_requests += 1
+                request.arrival_time = time.time()
+                accelRequestQueue.put(request)
+            else:
+                pieces = partition_requests(args, request_size)
+                for i, piece in enumerate(pieces):
+                    request = ServiceRequest(batch_id=batch_id, epoch=epoch, batch_size=piece, sub_id=i,
+                                             total_sub_batches=len(pieces), exp_packet=exploring)
+                    cpu_sub_requests += 1
+                    request.arrival_time = time.time()
+                    requestQueue.put(request)
+                cpu_requests += 1
+            loadGenSleep(np.random.poisson(lam=arrival_rate, size=1)[0] / 1000.)
+        epoch += 1
+        if not tuning_batch_qps and not tuning_accel_qps:
+            exp_epochs += 1
+
+    # one shutdown sentinel per engine (loadGenerator.py:208-214)
+    for i in range(n_cpu):
+        debugPrint(args, "Load Generator", "sending done signal to " + str(i) + " cpu engine")
+        requestQueue.put(None)
+    for i in range(n_accel):
+        debugPrint(args, "Load Generator", "sending done signal to " + str(i) + " accel engine")
+        accelRequestQueue.put(None)
+    loadGeneratorReturnQueue.put((cpu_sub_requests, cpu_requests, accel_requests))
+
+    if tune_batch and not tune_accel:
+        print("Scheduler's Optimal batch_size configuration: ", query_scheduler.args.sub_task_batch_size,
+              " @ arrival rate of ", query_scheduler.arrival_rate, "ms")
+    elif tune_batch and tune_accel:
+        print("Scheduler's Optimal batch_size configuration: ", query_scheduler.args.sub_task_batch_size)
+        print("Scheduler's Optimal accel_size configuration: ",
+              accel_query_scheduler.args.accel_request_size_thres, " @ arrival rate of",
+              accel_query_scheduler.arrival_rate, "ms")
+    sys.stdout.flush()
