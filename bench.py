@@ -117,6 +117,18 @@ def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0):
     return time.perf_counter() - t0
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(opt, net, data, budget_s):
     """The CPU oracle (a port of the reference's CPU path, oracle/drs_oracle.c) timed on
     this host's cores on a bounded sample of the same workload."""
@@ -124,17 +136,17 @@ def cpu_baseline(opt, net, data, budget_s):
     from tests import helpers as H
     w = WORKLOADS[opt.workload]
     lX, lS_l, lS_i = data
-    cores = orc.max_threads()
+    cores = host_cores()
     lo, hi = -float(np.sqrt(1 / w["rows"])), float(np.sqrt(1 / w["rows"]))
     t0 = time.perf_counter()
-    net.emb_w = [orc.fill_table_uniform(w["rows"], w["D"], t, lo, hi, opt.seed, nthreads=0)
+    net.emb_w = [orc.fill_table_uniform(w["rows"], w["D"], t, lo, hi, opt.seed, nthreads=cores)
                  for t in range(w["T"])]
     om = H.oracle_model(net)
     fill_s = time.perf_counter() - t0
-    om.forward(lX[0], lS_i[0], lS_l[0], bs=opt.batch, nthreads=0)   # warm
+    om.forward(lX[0], lS_i[0], lS_l[0], bs=opt.batch, nthreads=cores)   # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        om.forward(lX[n % len(lX)], lS_i[n % len(lX)], lS_l[n % len(lX)], bs=opt.batch, nthreads=0)
+        om.forward(lX[n % len(lX)], lS_i[n % len(lX)], lS_l[n % len(lX)], bs=opt.batch, nthreads=cores)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 20000:

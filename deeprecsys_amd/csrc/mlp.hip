@@ -35,22 +35,30 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 // 4 consecutive floats of row `row` starting at column k of a [rows, K] matrix with
-// leading dimension ld; zero outside.  `vec_ok` = base pointer 16-B aligned and ld % 4 == 0.
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int64_t ld, int64_t row,
-                                        int64_t rows, int k, int K, bool vec_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < rows) {
-    const float* q = p + row * ld + k;
-    if (vec_ok && k + 3 < K) {
-      v = *reinterpret_cast<const float4*>(q);
-    } else {
-      if (k + 0 < K) v.x = q[0];
-      if (k + 1 < K) v.y = q[1];
-      if (k + 2 < K) v.z = q[2];
-      if (k + 3 < K) v.w = q[3];
-    }
+// leading dimension ld; zero outside.  Branch-free on purpose: every load is issued
+// unconditionally from a clamped (always valid) address and masked afterwards, so the
+// compiler can keep all of a chunk's loads in flight behind ONE s_waitcnt (a load
+// inside divergent control flow gets its own vmcnt(0) at the join, which serialised
+// the five loads of a chunk and cost ~5x).  VEC: base 16-B aligned, ld % 4 == 0 and
+// K % 4 == 0, so a float4 never straddles the end of a row.
+template <bool VEC>
+__device__ __forceinline__ float4 load4_raw(const float* __restrict__ p, int64_t ld, int64_t row,
+                                            int64_t rows, int k, int K) {
+  // rows past the end are clamped, not masked: they only feed output rows/columns that
+  // are never stored
+  const float* q = p + (row < rows ? row : rows - 1) * ld;
+  if (VEC) {
+    return *reinterpret_cast<const float4*>(q + (k < K ? k : 0));
+  } else {
+    return make_float4(q[min(k + 0, K - 1)], q[min(k + 1, K - 1)], q[min(k + 2, K - 1)],
+                       q[min(k + 3, K - 1)]);
   }
-  return v;
+}
+// zero the k >= K tail; applied when the value is written to LDS (i.e. after the MFMA
+// block of the previous chunk), so the loads stay in flight across that block
+__device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
+  return make_float4(k + 0 < K ? v.x : 0.f, k + 1 < K ? v.y : 0.f, k + 2 < K ? v.z : 0.f,
+                     k + 3 < K ? v.w : 0.f);
 }
 
 struct LayerIo {
@@ -66,10 +74,10 @@ struct LayerIo {
 
 // One layer for the slab rows [m0, m0+16) and the columns [n_begin, n_end).
 // sA: [2][16][LDS_LD] (used only when A comes from global), sB: [2][64][LDS_LD].
-template <bool A_LDS, bool O_LDS>
+template <bool A_LDS, bool O_LDS, bool VEC>
 __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K, const float* __restrict__ W,
                            int64_t ldw, const float* __restrict__ bias, int N, int n_begin,
-                           int n_end, int act, bool a_vec, bool w_vec, float* sA, float* sB) {
+                           int n_end, int act, float* sA, float* sB) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -82,25 +90,24 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
 
     // prologue: stage chunk 0
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb[4];
+    const int kq = (tid & 15) * 4;             // this thread's k offset inside a chunk
     auto fetch = [&](int kc) {
-      if (!A_LDS) ra = load4(io.a_glb, io.lda_glb, m0 + (tid >> 4), M, kc + (tid & 15) * 4, K, a_vec);
+      if (!A_LDS) ra = load4_raw<VEC>(io.a_glb, io.lda_glb, m0 + (tid >> 4), M, kc + kq, K);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + i * 16;   // 0..63
-        rb[i] = load4(W, ldw, n0 + row, N, kc + (tid & 15) * 4, K, w_vec);
-      }
+      for (int i = 0; i < 4; ++i)
+        rb[i] = load4_raw<VEC>(W, ldw, n0 + (tid >> 4) + i * 16, N, kc + kq, K);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int kc) {
       if (!A_LDS)
-        *reinterpret_cast<float4*>(sA + (buf * BM + (tid >> 4)) * LDS_LD + (tid & 15) * 4) = ra;
+        *reinterpret_cast<float4*>(sA + (buf * BM + (tid >> 4)) * LDS_LD + kq) = mask4(ra, kc + kq, K);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 4) + i * 16;
-        *reinterpret_cast<float4*>(sB + (buf * BN + row) * LDS_LD + (tid & 15) * 4) = rb[i];
+        *reinterpret_cast<float4*>(sB + (buf * BN + row) * LDS_LD + kq) = mask4(rb[i], kc + kq, K);
       }
     };
     fetch(0);
-    stash(0);
+    stash(0, 0);
     __syncthreads();
 
     for (int c = 0; c < n_chunks; ++c) {
@@ -111,21 +118,27 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
                               : sA + (buf * BM + r) * LDS_LD + g;
       const float* pb = sB + (buf * BN + wave * 16 + r) * LDS_LD + g;
-      const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k (tail is zero padded)
+      const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
+      // all 32 operand reads are unconditional (one lgkmcnt wait); staged chunks are zero
+      // filled past K, an LDS activation slab may hold stale columns there -> select
       float av[KC / 4], bv[KC / 4];
 #pragma unroll
       for (int s = 0; s < KC / 4; ++s) {
-        // an LDS activation slab may hold stale columns past K: mask them (the
-        // staged chunks are already zero filled there)
-        const bool live = s < ksteps && (!A_LDS || c * KC + 4 * s + g < K);
-        av[s] = live ? pa[4 * s] : 0.f;
-        bv[s] = s < ksteps ? pb[4 * s] : 0.f;
+        av[s] = pa[4 * s];
+        bv[s] = pb[4 * s];
+        if (A_LDS) av[s] = (c * KC + 4 * s + g < K) ? av[s] : 0.f;
       }
+      // fma(0, 0, acc) == acc, so a padded step is exact; skip whole groups of 4 uniformly
 #pragma unroll
-      for (int s = 0; s < KC / 4; ++s)
-        if (s < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+      for (int q = 0; q < KC / 16; ++q) {
+        if (4 * q < ksteps) {
+#pragma unroll
+          for (int s = 4 * q; s < 4 * q + 4; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+        }
+      }
 
-      if (more) stash(buf ^ 1);
+      if (more) stash(buf ^ 1, (c + 1) * KC);
       __syncthreads();
     }
 
@@ -147,9 +160,8 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
   }
 }
 
-__device__ __forceinline__ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-
 // Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64-column group.
+template <bool VEC>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
@@ -158,11 +170,12 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, in
   __shared__ __attribute__((aligned(16))) float sB[2 * BN * LDS_LD];
   LayerIo io = {x, ldx, nullptr, 0, y, ldy, nullptr, 0};
   const int n0 = blockIdx.y * BN;
-  layer_pass<false, false>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0, min(n0 + BN, N), act,
-             aligned16(x) && (ldx & 3) == 0, aligned16(W) && (ldw & 3) == 0, sA, sB);
+  layer_pass<false, false, VEC>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0,
+                                min(n0 + BN, N), act, sA, sB);
 }
 
 // Chain of layers on a 16-row slab; activations ping-pong between two LDS slabs.
+template <bool VEC>
 __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                            // [2][16][LDS_LD]
@@ -171,9 +184,11 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld) {
   float* slab1 = slab0 + BM * slab_ld;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
 
-  // zero both slabs once: padded K tails of later layers must read 0
-  for (int i = threadIdx.x; i < 2 * BM * slab_ld; i += blockDim.x) slab0[i] = 0.f;
-  __syncthreads();
+  // zero both slabs once: padded K tails of later layers must read finite values
+  if (a.n_layers > 1) {
+    for (int i = threadIdx.x; i < 2 * BM * slab_ld; i += blockDim.x) slab0[i] = 0.f;
+    __syncthreads();
+  }
 
   float* cur = nullptr;
   for (int l = 0; l < a.n_layers; ++l) {
@@ -189,16 +204,14 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld) {
     io.o_lds = last ? nullptr : nxt;
     io.ldo_lds = slab_ld;
     const int K = a.width[l], N = a.width[l + 1];
-    const bool av = aligned16(a.x) && (a.ldx & 3) == 0;
-    const bool wv = aligned16(a.W[l]) && (K & 3) == 0;
     if (first && last)
-      layer_pass<false, false>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+      layer_pass<false, false, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
     else if (first)
-      layer_pass<false, true>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+      layer_pass<false, true, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
     else if (last)
-      layer_pass<true, false>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+      layer_pass<true, false, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
     else
-      layer_pass<true, true>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], av, wv, sA, sB);
+      layer_pass<true, true, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
     __syncthreads();
     cur = nxt;
   }
@@ -266,12 +279,18 @@ __global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const 
 
 }  // namespace
 
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
                      hipStream_t s) {
   if (M <= 0) return hipSuccess;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-  hipLaunchKernelGGL(fc_kernel, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy);
+  const bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
+  if (vec)
+    hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy);
+  else
+    hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy);
   return hipGetLastError();
 }
 
@@ -294,13 +313,21 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)((a.M + BM - 1) / BM)), dim3(256), lds, s, a,
-                     chain_slab_ld(a));
+  bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
+  for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
+  const dim3 grid((unsigned)((a.M + BM - 1) / BM));
+  if (vec)
+    hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(256), lds, s, a, chain_slab_ld(a));
+  else
+    hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(256), lds, s, a, chain_slab_ld(a));
   return hipGetLastError();
 }
 
