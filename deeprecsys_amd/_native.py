@@ -19,7 +19,7 @@ MODEL_DLRM, MODEL_WND, MODEL_NCF = 0, 1, 2
 INTERACT_DOT, INTERACT_CAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MLP_BOT, MLP_TOP, MLP_FINAL = 0, 1, 2
-KERNEL_SLS, KERNEL_MLP = 0, 1
+KERNEL_SLS, KERNEL_MLP, KERNEL_SLS_CLOCK = 0, 1, 2
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

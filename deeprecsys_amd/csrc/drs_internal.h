@@ -29,15 +29,29 @@ struct SlsArgs {
   int32_t D;
   int32_t n_samples;          // bs
   int32_t* err;               // device error word: bit0 = index out of range
+  uint64_t* ts;               // optional [2 * gridDim.x] start/end wall_clock64() per workgroup
 };
 
 // launch on `stream`; exact != 0 selects the sequential-order variant.
 hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t stream);
+int64_t sls_grid_blocks(int D, int64_t n_bags, int exact);
+
+// Completion hand-off to the host without a copy or a stream sync: the LAST kernel of a
+// query stores its outputs straight into host-mapped pinned memory and, once every one
+// of its workgroups has done so (device-scope arrival counter), the last arriver copies
+// the device error word and publishes `seq` in a host flag the CPU is polling.
+struct Done {
+  uint32_t* counter;        // device arrival counter (zero between uses); nullptr = disabled
+  uint32_t* host_flag;      // host-mapped: receives seq
+  uint32_t* host_err;       // host-mapped: receives *dev_err
+  const uint32_t* dev_err;  // device error word written by earlier kernels of the query
+  uint32_t seq;
+};
 
 // y[M, N] (ld = ldy) = act(x[M, K] (ld = ldx) . W[N, K]^T + b), k-ordered fp32 MFMA chain
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                     hipStream_t stream);
+                     hipStream_t stream, const Done* done = nullptr);
 
 // Fused chain of up to DRS_MAX_CHAIN FC layers on 16-row slabs; intermediate
 // activations never leave LDS.
@@ -54,7 +68,7 @@ struct ChainArgs {
   float* y;
   int64_t ldy;
 };
-hipError_t launch_chain(const ChainArgs& a, hipStream_t stream);
+hipError_t launch_chain(const ChainArgs& a, hipStream_t stream, const Done* done = nullptr);
 size_t chain_lds_bytes(const ChainArgs& a);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot

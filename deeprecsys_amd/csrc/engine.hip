@@ -13,7 +13,8 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <mutex>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -61,8 +62,15 @@ struct Slot {
   float* H = nullptr;        // [max_batch, ldH]  inter-segment MLP scratch (ping)
   float* Hb = nullptr;       // (pong)
   float* H2 = nullptr;       // NCF: concat(mf, mlp_out)
-  uint32_t* d_out = nullptr; // [1 + max_batch*n_out]: word 0 = error flags, then outputs
-  uint32_t* h_out = nullptr; // pinned mirror
+  float* d_out = nullptr;    // [max_batch*n_out] device outputs (copy path only)
+  uint32_t* d_err = nullptr; // device error word (bit0: index out of range)
+  uint32_t* d_counter = nullptr;  // arrival counter of the completion hand-off
+  uint32_t* h_out = nullptr; // pinned host: [flag | err | outputs...]
+  uint32_t* dm_out = nullptr;// the same memory as seen from the device (zero-copy path)
+  uint32_t seq = 0;          // sequence number of the query in flight on this slot
+  uint64_t* d_ts = nullptr;  // [2 * max gather workgroups] device clock stamps (profiling)
+  std::vector<uint64_t> h_ts;
+  int64_t ts_blocks = 0;
   Batch scratch;             // drs_forward_inputs staging
   void* h_stage = nullptr;   // pinned host staging for forward_inputs
   size_t h_stage_bytes = 0;
@@ -70,6 +78,7 @@ struct Slot {
   bool ev_pending = false;
   int32_t last_bs = 0;
   bool busy = false;
+  bool polled = false;       // completion arrives through the host flag
 };
 
 }  // namespace
@@ -94,11 +103,12 @@ struct drs_engine {
   // op-level scratch
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
-  int sls_exact = 1, mlp_split = 1;
+  int sls_exact = 1, mlp_split = 1, zero_copy = 1;
   // profiling
   bool profiling = false;
-  double k_ms[DRS_KERNEL_COUNT] = {0, 0};
-  int64_t k_n[DRS_KERNEL_COUNT] = {0, 0};
+  double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
+  int64_t k_n[DRS_KERNEL_COUNT] = {0, 0, 0};
+  double wall_clock_khz = 100000.0;
   std::string err;
 };
 
@@ -190,7 +200,7 @@ int32_t mlp_ready(drs_engine* e, const Mlp& m, const char* name) {
 // workgroups); runs of narrow layers are fused into one LDS-resident chain.
 // Segment outputs that are not the final one ping-pong between s.H and s.Hb.
 int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ldx, int64_t M,
-                float* y, int64_t ldy) {
+                float* y, int64_t ldy, const Done* done = nullptr) {
   const int n_layers = (int)m.layers.size();
   auto act_of = [&](int l) { return (l + 1 == m.sigmoid_layer) ? DRS_ACT_SIGMOID : DRS_ACT_RELU; };
   auto is_wide = [&](int l) {
@@ -225,10 +235,10 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
     const int64_t ldo = last ? ldy : e->ldH;
     if (standalone || chain_lds_bytes(c) > 150 * 1024) {
       HIP_TRY(e, launch_fc(in, ldin, M, m.ln[l0], m.layers[l0].W, m.layers[l0].b, m.ln[l0 + 1],
-                           act_of(l0), out, ldo, s.stream));
+                           act_of(l0), out, ldo, s.stream, last ? done : nullptr));
     } else {
       c.y = out; c.ldy = ldo;
-      HIP_TRY(e, launch_chain(c, s.stream));
+      HIP_TRY(e, launch_chain(c, s.stream, last ? done : nullptr));
     }
     in = out; ldin = ldo; l0 += cnt;
   }
@@ -253,11 +263,19 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, const Batch& bt, int32_t bs) {
   a.tables = e->tables; a.tab_off = e->d_tab_off; a.tab_rows = e->d_tab_rows;
   a.idx = bt.idx; a.off = bt.off; a.idx_stride = e->cap; a.off_stride = e->max_batch + 1;
   a.out = s.T; a.ld_out = e->ldT; a.col0 = e->kind == DRS_MODEL_NCF ? 0 : e->w0;
-  a.T = e->T; a.D = e->D; a.n_samples = bs; a.err = reinterpret_cast<int32_t*>(s.d_out);
+  a.T = e->T; a.D = e->D; a.n_samples = bs; a.err = reinterpret_cast<int32_t*>(s.d_err);
+  a.ts = prof ? s.d_ts : nullptr;
+  s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)bs * e->T, e->sls_exact) : 0;
   HIP_TRY(e, launch_sls(a, e->sls_exact, s.stream));
   if (prof) HIP_TRY(e, hipEventRecord(s.ev[1], s.stream));
 
-  float* out = reinterpret_cast<float*>(s.d_out + 1);
+  // last kernel of the query: outputs either go straight to host-mapped pinned memory
+  // followed by a flag store (zero copy, no stream sync), or to a device buffer + memcpy
+  s.seq += 1;
+  if (s.seq == 0) s.seq = 1;
+  Done done = {s.d_counter, s.dm_out, s.dm_out + 1, s.d_err, s.seq};
+  const Done* dp = e->zero_copy ? &done : nullptr;
+  float* out = e->zero_copy ? reinterpret_cast<float*>(s.dm_out + 2) : s.d_out;
   if (e->kind == DRS_MODEL_NCF) {
     // mf = Sum(sls0, sls1); mlp = Concat(sls2, sls3) -> MLP; Concat(mf, mlp_out) -> FC+Relu
     const int D = e->D;
@@ -265,7 +283,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, const Batch& bt, int32_t bs) {
     const int64_t ldc = D + wl;
     HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, bs, D, s.stream));
     if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, bs, s.H2 + D, ldc))) return rc;
-    if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, bs, out, e->n_out))) return rc;
+    if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, bs, out, e->n_out, dp))) return rc;
   } else {
     if (e->bot.layers.empty()) {
       HIP_TRY(e, launch_copy_rows(bt.dense, e->m_den, s.T, e->ldT, bs, e->w0, s.stream));
@@ -279,35 +297,69 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, const Batch& bt, int32_t bs) {
       top_in = s.R;
       ld_top = e->ldR;
     }
-    if ((rc = run_mlp(e, s, e->top, top_in, ld_top, bs, out, e->n_out))) return rc;
+    if ((rc = run_mlp(e, s, e->top, top_in, ld_top, bs, out, e->n_out, dp))) return rc;
   }
   if (prof) {
     HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
     s.ev_pending = true;
   }
-  HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, sizeof(uint32_t) * (1 + (size_t)bs * e->n_out),
-                            hipMemcpyDeviceToHost, s.stream));
+  if (!e->zero_copy) {
+    HIP_TRY(e, hipMemcpyAsync(s.h_out + 2, s.d_out, sizeof(float) * (size_t)bs * e->n_out,
+                              hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(e, hipMemcpyAsync(s.h_out + 1, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  }
+  s.polled = e->zero_copy != 0;
   return DRS_OK;
 }
 
 int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
   if (!s.busy) return DRS_OK;
-  HIP_TRY(e, hipStreamSynchronize(s.stream));
+  if (s.polled && s.last_bs > 0) {
+    // spin on the flag the last kernel publishes (bounded: fall back to a stream sync)
+    volatile uint32_t* flag = s.h_out;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (*flag != s.seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffff) == 0 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+        HIP_TRY(e, hipStreamSynchronize(s.stream));
+        if (*flag != s.seq) {
+          s.busy = false;
+          return fail(e, DRS_ERR_HIP, "completion flag never arrived (seq %u, flag %u)", s.seq, *flag);
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    HIP_TRY(e, hipStreamSynchronize(s.stream));
+  }
   s.busy = false;
   if (s.ev_pending) {
+    HIP_TRY(e, hipEventSynchronize(s.ev[2]));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) { e->k_ms[DRS_KERNEL_SLS] += ms; e->k_n[DRS_KERNEL_SLS]++; }
     if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) { e->k_ms[DRS_KERNEL_MLP] += ms; e->k_n[DRS_KERNEL_MLP]++; }
     s.ev_pending = false;
+    if (s.ts_blocks > 0) {
+      HIP_TRY(e, hipMemcpy(s.h_ts.data(), s.d_ts, sizeof(uint64_t) * 2 * (size_t)s.ts_blocks, hipMemcpyDeviceToHost));
+      uint64_t lo = ~0ull, hi = 0;
+      for (int64_t i = 0; i < s.ts_blocks; ++i) {
+        lo = s.h_ts[2 * i] < lo ? s.h_ts[2 * i] : lo;
+        hi = s.h_ts[2 * i + 1] > hi ? s.h_ts[2 * i + 1] : hi;
+      }
+      e->k_ms[DRS_KERNEL_SLS_CLOCK] += (double)(hi - lo) / e->wall_clock_khz;
+      e->k_n[DRS_KERNEL_SLS_CLOCK]++;
+    }
   }
-  if (s.last_bs > 0 && s.h_out[0] != 0) {
-    s.h_out[0] = 0;
-    HIP_TRY(e, hipMemsetAsync(s.d_out, 0, sizeof(uint32_t), s.stream));
+  if (s.last_bs > 0 && s.h_out[1] != 0) {
+    s.h_out[1] = 0;
+    HIP_TRY(e, hipMemsetAsync(s.d_err, 0, sizeof(uint32_t), s.stream));
     HIP_TRY(e, hipStreamSynchronize(s.stream));
     return fail(e, DRS_ERR_INDEX_RANGE, "an embedding index was out of range on the device");
   }
   if (h_out && s.last_bs > 0)
-    memcpy(h_out, s.h_out + 1, sizeof(float) * (size_t)s.last_bs * e->n_out);
+    memcpy(h_out, s.h_out + 2, sizeof(float) * (size_t)s.last_bs * e->n_out);
   return DRS_OK;
 }
 
@@ -417,6 +469,11 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   }
 
   if (set_device(e)) return bail(DRS_ERR_HIP, e->err.c_str());
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) == hipSuccess && khz > 0)
+      e->wall_clock_khz = khz;
+  }
   // table arena
   int64_t off = 0;
   e->tab_off.resize(T);
@@ -455,11 +512,18 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipMalloc(&s.H, sizeof(float) * (size_t)e->max_batch * e->ldH));
     CREATE_TRY(hipMalloc(&s.Hb, sizeof(float) * (size_t)e->max_batch * e->ldH));
     CREATE_TRY(hipMalloc(&s.H2, sizeof(float) * (size_t)e->max_batch * (e->num_int + 4)));
-    const size_t out_words = 1 + (size_t)e->max_batch * n_out_cap;
-    CREATE_TRY(hipMalloc(&s.d_out, sizeof(uint32_t) * out_words));
-    CREATE_TRY(hipMemset(s.d_out, 0, sizeof(uint32_t) * out_words));
-    CREATE_TRY(hipHostMalloc(&s.h_out, sizeof(uint32_t) * out_words, hipHostMallocDefault));
+    const size_t out_words = 2 + (size_t)e->max_batch * n_out_cap;
+    CREATE_TRY(hipMalloc(&s.d_out, sizeof(float) * out_words));
+    CREATE_TRY(hipMalloc(&s.d_err, sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&s.d_counter, sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(s.d_err, 0, sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(s.d_counter, 0, sizeof(uint32_t)));
+    // coherent (fine-grained) pinned memory: device stores become visible to a polling CPU
+    CREATE_TRY(hipHostMalloc(&s.h_out, sizeof(uint32_t) * out_words, hipHostMallocMapped | hipHostMallocCoherent));
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_out), s.h_out, 0));
+    CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_batch * T));
+    s.h_ts.resize(2 * (size_t)e->max_batch * T);
     for (auto& ev : s.ev) CREATE_TRY(hipEventCreate(&ev));
     if (alloc_batch(e, s.scratch)) return bail(DRS_ERR_OOM, e->err.c_str());
     s.scratch.n_samples = 0;
@@ -484,6 +548,9 @@ int32_t drs_destroy(drs_handle e) {
     if (s.Hb) (void)hipFree(s.Hb);
     if (s.H2) (void)hipFree(s.H2);
     if (s.d_out) (void)hipFree(s.d_out);
+    if (s.d_err) (void)hipFree(s.d_err);
+    if (s.d_ts) (void)hipFree(s.d_ts);
+    if (s.d_counter) (void)hipFree(s.d_counter);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_stage) (void)hipHostFree(s.h_stage);
     for (auto& ev : s.ev) if (ev) (void)hipEventDestroy(ev);
@@ -713,7 +780,7 @@ int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const i
     SlsArgs a;
     a.tables = d_W; a.tab_off = e->d_op_tab; a.tab_rows = e->d_op_tab + 1;
     a.idx = d_idx; a.off = d_off; a.idx_stride = 0; a.off_stride = 0;
-    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.n_samples = (int32_t)n_bags; a.err = d_err;
+    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.n_samples = (int32_t)n_bags; a.err = d_err; a.ts = nullptr;
     r = launch_sls(a, exact_order, s.stream);
   }
   if (r == hipSuccess) r = hipStreamSynchronize(s.stream);
@@ -758,6 +825,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_u") && (value == 4 || value == 8 || value == 16 || value == 20)) g_sls_u = (int)value;
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
+  else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;
 }

@@ -61,6 +61,24 @@ __device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
                      k + 3 < K ? v.w : 0.f);
 }
 
+// see Done in drs_internal.h.  Every thread fences its own output stores at system
+// scope, the workgroup joins, then one lane takes a ticket; the workgroup that draws
+// the last ticket knows all outputs are visible and publishes the flag.
+__device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks) {
+  if (!d.counter) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == n_blocks - 1) {
+      __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 struct LayerIo {
   const float* a_glb;   // A operand in global memory (first layer) or nullptr
   int64_t lda_glb;
@@ -165,18 +183,19 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
-                                                 float* __restrict__ y, int64_t ldy) {
+                                                 float* __restrict__ y, int64_t ldy, Done done) {
   __shared__ __attribute__((aligned(16))) float sA[2 * BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float sB[2 * BN * LDS_LD];
   LayerIo io = {x, ldx, nullptr, 0, y, ldy, nullptr, 0};
   const int n0 = blockIdx.y * BN;
   layer_pass<false, false, VEC>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0,
                                 min(n0 + BN, N), act, sA, sB);
+  signal_done(done, gridDim.x * gridDim.y);
 }
 
 // Chain of layers on a 16-row slab; activations ping-pong between two LDS slabs.
 template <bool VEC>
-__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld) {
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, Done done) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                            // [2][16][LDS_LD]
   float* sB = sA + 2 * BM * LDS_LD;            // [2][64][LDS_LD]
@@ -215,6 +234,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld) {
     __syncthreads();
     cur = nxt;
   }
+  signal_done(done, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -283,14 +303,16 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                     hipStream_t s) {
+                     hipStream_t s, const Done* done) {
   if (M <= 0) return hipSuccess;
+  Done d = {nullptr, nullptr, nullptr, nullptr, 0};
+  if (done) d = *done;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   const bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
   if (vec)
-    hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy);
+    hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy, d);
   else
-    hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy);
+    hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy, d);
   return hipGetLastError();
 }
 
@@ -306,8 +328,10 @@ size_t chain_lds_bytes(const ChainArgs& a) {
                           (size_t)2 * BM * chain_slab_ld(a));
 }
 
-hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done) {
   if (a.M <= 0) return hipSuccess;
+  Done d = {nullptr, nullptr, nullptr, nullptr, 0};
+  if (done) d = *done;
   if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN) return hipErrorInvalidValue;
   const size_t lds = chain_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -325,9 +349,9 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
   const dim3 grid((unsigned)((a.M + BM - 1) / BM));
   if (vec)
-    hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(256), lds, s, a, chain_slab_ld(a));
+    hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(256), lds, s, a, chain_slab_ld(a), d);
   else
-    hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(256), lds, s, a, chain_slab_ld(a));
+    hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(256), lds, s, a, chain_slab_ld(a), d);
   return hipGetLastError();
 }
 

@@ -89,6 +89,10 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   constexpr int OWNERS = EXACT ? G : 64;      // lanes that stage one bag's indices
   __shared__ __attribute__((aligned(16))) int32_t s_idx[BAGS][kChunk];
 
+  // live timing (bench.py roofline leg): first/last constant-rate clock tick of every
+  // workgroup; the host takes max(end) - min(start) as the launch duration
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+
   const int lane = threadIdx.x;
   const int g = lane / G;
   const int gl = lane - g * G;
@@ -205,6 +209,10 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
     float* o = a.out + (int64_t)b * a.ld_out + a.col0 + (int64_t)t * D + col;
     *reinterpret_cast<vec*>(o) = acc;
   }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);   // include the output store in the span
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
 }
 
 template <int G, int V, int U>
@@ -237,6 +245,14 @@ hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s) {
 // width used for D == 32 (8 lanes x 16 B or 16 lanes x 8 B).
 int g_sls_u = 16;
 int g_sls_v_d32 = 4;
+
+int64_t sls_grid_blocks(int D, int64_t n_bags, int exact) {
+  if (!exact) return n_bags;
+  int G = D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
+  if (D == 32 && g_sls_v_d32 == 2) G = 16;
+  const int bags = 64 / G;
+  return (n_bags + bags - 1) / bags;
+}
 
 hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s) {
   const int D = a.D;

@@ -65,7 +65,11 @@ enum { DRS_MLP_BOT = 0, DRS_MLP_TOP = 1, DRS_MLP_FINAL = 2 /* NCF predictor */ }
 enum {
   DRS_KERNEL_SLS = 0,   /* multi-table gather-reduce (+ bottom MLP blocks)             */
   DRS_KERNEL_MLP = 1,   /* all top-MLP / interaction launches of a forward             */
-  DRS_KERNEL_COUNT = 2
+  DRS_KERNEL_SLS_CLOCK = 2, /* the gather launch again, timed by the device's own constant-
+                           rate clock: max(end) - min(start) over its workgroups.  HIP
+                           events bracket a ~10 us launch with several us of packet
+                           processing, this does not (Measurement)     */
+  DRS_KERNEL_COUNT = 3
 };
 
 /*
@@ -183,6 +187,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_u"      row loads kept in flight per lane: 4 | 8 | 16 (default) | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "mlp_split"  1 (default) first wide top/bottom layer as its own 2-D launch | 0
+ *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
+ *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG                                               */
 int32_t drs_set_option(drs_handle h, const char* key, int64_t value);
 
