@@ -23,10 +23,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KC = 64;         // K chunk staged per step
-constexpr int LDS_LD = KC + 4; // padded row of a staged chunk
 constexpr int BM = 16;         // rows per slab
 constexpr int BN = 64;         // columns per pass (4 waves x 16)
+// K chunk staged per step is a template parameter KC in {64, 128, 192, 256}: a dependent
+// global-load round costs ~1 us on this chip (Infinity-Cache latency; per-XCD L2s start
+// cold every launch), far more than the MFMAs it feeds, so layers are cut into as few
+// rounds as LDS allows.  Rows of a staged chunk are padded to KC+4 floats.
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == DRS_ACT_RELU) return v > 0.0f ? v : 0.0f;
@@ -91,11 +93,17 @@ struct LayerIo {
 };
 
 // One layer for the slab rows [m0, m0+16) and the columns [n_begin, n_end).
-// sA: [2][16][LDS_LD] (used only when A comes from global), sB: [2][64][LDS_LD].
-template <bool A_LDS, bool O_LDS, bool VEC>
-__device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K, const float* __restrict__ W,
-                           int64_t ldw, const float* __restrict__ bias, int N, int n_begin,
-                           int n_end, int act, float* sA, float* sB) {
+// sA: [nbuf][16][KC+4] (used only when A comes from global), sB: [nbuf][64][KC+4];
+// nbuf = 2 (double buffered) when the layer needs more than one K chunk, else 1.
+template <bool A_LDS, bool O_LDS, bool VEC, int KC>
+__device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K,
+                                           const float* __restrict__ W, int64_t ldw,
+                                           const float* __restrict__ bias, int N, int n_begin,
+                                           int n_end, int act, int nbuf, float* sA, float* sB) {
+  constexpr int LD = KC + 4;
+  constexpr int QPR = KC / 4;          // float4 per staged row
+  constexpr int NA = KC / 64;          // float4 of A per thread per chunk
+  constexpr int NB = KC / 16;          // float4 of W per thread per chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -105,23 +113,32 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
 
   for (int n0 = n_begin; n0 < n_end; n0 += BN) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-
-    // prologue: stage chunk 0
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb[4];
-    const int kq = (tid & 15) * 4;             // this thread's k offset inside a chunk
+    float4 ra[NA], rb[NB];
     auto fetch = [&](int kc) {
-      if (!A_LDS) ra = load4_raw<VEC>(io.a_glb, io.lda_glb, m0 + (tid >> 4), M, kc + kq, K);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        rb[i] = load4_raw<VEC>(W, ldw, n0 + (tid >> 4) + i * 16, N, kc + kq, K);
+      for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * 256;
+        if (!A_LDS) ra[i] = load4_raw<VEC>(io.a_glb, io.lda_glb, m0 + idx / QPR, M, kc + (idx % QPR) * 4, K);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * 256;
+        rb[i] = load4_raw<VEC>(W, ldw, n0 + idx / QPR, N, kc + (idx % QPR) * 4, K);
+      }
     };
     auto stash = [&](int buf, int kc) {
-      if (!A_LDS)
-        *reinterpret_cast<float4*>(sA + (buf * BM + (tid >> 4)) * LDS_LD + kq) = mask4(ra, kc + kq, K);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + i * 16;
-        *reinterpret_cast<float4*>(sB + (buf * BN + row) * LDS_LD + kq) = mask4(rb[i], kc + kq, K);
+      for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * 256;
+        if (!A_LDS)
+          *reinterpret_cast<float4*>(sA + (buf * BM + idx / QPR) * LD + (idx % QPR) * 4) =
+              mask4(ra[i], kc + (idx % QPR) * 4, K);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * 256;
+        *reinterpret_cast<float4*>(sB + (buf * BN + idx / QPR) * LD + (idx % QPR) * 4) =
+            mask4(rb[i], kc + (idx % QPR) * 4, K);
       }
     };
     fetch(0);
@@ -129,33 +146,37 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
     __syncthreads();
 
     for (int c = 0; c < n_chunks; ++c) {
-      const int buf = c & 1;
+      const int buf = c & (nbuf - 1);
       const bool more = c + 1 < n_chunks;
-      if (more) fetch((c + 1) * KC);   // global loads for the next chunk fly during the MFMAs
+      if (more) fetch((c + 1) * KC);   // next chunk's global loads fly during the MFMAs
 
       const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
-                              : sA + (buf * BM + r) * LDS_LD + g;
-      const float* pb = sB + (buf * BN + wave * 16 + r) * LDS_LD + g;
+                              : sA + (buf * BM + r) * LD + g;
+      const float* pb = sB + (buf * BN + wave * 16 + r) * LD + g;
       const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
-      // all 32 operand reads are unconditional (one lgkmcnt wait); staged chunks are zero
-      // filled past K, an LDS activation slab may hold stale columns there -> select
-      float av[KC / 4], bv[KC / 4];
 #pragma unroll
-      for (int s = 0; s < KC / 4; ++s) {
-        av[s] = pa[4 * s];
-        bv[s] = pb[4 * s];
-        if (A_LDS) av[s] = (c * KC + 4 * s + g < K) ? av[s] : 0.f;
-      }
-      // fma(0, 0, acc) == acc, so a padded step is exact; skip whole groups of 4 uniformly
+      for (int sg = 0; sg < KC / 64; ++sg) {
+        if (16 * sg < ksteps) {                         // uniform
+          // 32 unconditional operand reads (one lgkmcnt wait); staged chunks are zero
+          // filled past K, an LDS activation slab may hold stale columns there -> select
+          float av[16], bv[16];
 #pragma unroll
-      for (int q = 0; q < KC / 16; ++q) {
-        if (4 * q < ksteps) {
+          for (int s = 0; s < 16; ++s) {
+            av[s] = pa[4 * (16 * sg + s)];
+            bv[s] = pb[4 * (16 * sg + s)];
+            if (A_LDS) av[s] = (c * KC + 4 * (16 * sg + s) + g < K) ? av[s] : 0.f;
+          }
+          // fma(0, 0, acc) == acc, so a padded step is exact; skip groups of 4 uniformly
 #pragma unroll
-          for (int s = 4 * q; s < 4 * q + 4; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+          for (int q = 0; q < 4; ++q) {
+            if (16 * sg + 4 * q < ksteps) {
+#pragma unroll
+              for (int s = 4 * q; s < 4 * q + 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+            }
+          }
         }
       }
-
       if (more) stash(buf ^ 1, (c + 1) * KC);
       __syncthreads();
     }
@@ -179,27 +200,29 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
 }
 
 // Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64-column group.
-template <bool VEC>
+template <bool VEC, int KC>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
-                                                 float* __restrict__ y, int64_t ldy, Done done) {
-  __shared__ __attribute__((aligned(16))) float sA[2 * BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float sB[2 * BN * LDS_LD];
+                                                 float* __restrict__ y, int64_t ldy, int nbuf,
+                                                 Done done) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                              // [nbuf][16][KC+4]
+  float* sB = sA + nbuf * BM * (KC + 4);         // [nbuf][64][KC+4]
   LayerIo io = {x, ldx, nullptr, 0, y, ldy, nullptr, 0};
   const int n0 = blockIdx.y * BN;
-  layer_pass<false, false, VEC>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0,
-                                min(n0 + BN, N), act, sA, sB);
+  layer_pass<false, false, VEC, KC>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0,
+                                    min(n0 + BN, N), act, nbuf, sA, sB);
   signal_done(done, gridDim.x * gridDim.y);
 }
 
 // Chain of layers on a 16-row slab; activations ping-pong between two LDS slabs.
-template <bool VEC>
-__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, Done done) {
+template <bool VEC, int KC>
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, int nbuf, Done done) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                            // [2][16][LDS_LD]
-  float* sB = sA + 2 * BM * LDS_LD;            // [2][64][LDS_LD]
-  float* slab0 = sB + 2 * BN * LDS_LD;         // [16][slab_ld]
+  float* sA = smem;                              // [nbuf][16][KC+4]
+  float* sB = sA + nbuf * BM * (KC + 4);         // [nbuf][64][KC+4]
+  float* slab0 = sB + nbuf * BN * (KC + 4);      // [16][slab_ld]
   float* slab1 = slab0 + BM * slab_ld;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
 
@@ -224,13 +247,13 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, Do
     io.ldo_lds = slab_ld;
     const int K = a.width[l], N = a.width[l + 1];
     if (first && last)
-      layer_pass<false, false, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
+      layer_pass<false, false, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     else if (first)
-      layer_pass<false, true, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
+      layer_pass<false, true, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     else if (last)
-      layer_pass<true, false, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
+      layer_pass<true, false, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     else
-      layer_pass<true, true, VEC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], sA, sB);
+      layer_pass<true, true, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     __syncthreads();
     cur = nxt;
   }
@@ -301,31 +324,96 @@ __global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const 
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+constexpr size_t kLdsBudget = 150 * 1024;
+
+static size_t stage_bytes(int kc, int nbuf) { return sizeof(float) * (size_t)nbuf * (BM + BN) * (kc + 4); }
+
+// Fewest K rounds that fit the LDS budget next to `extra` bytes of slabs.
+static bool pick_kc(int maxK, size_t extra, int* kc_out, int* nbuf_out) {
+  const int cands[4] = {256, 192, 128, 64};
+  int best_kc = 0, best_nbuf = 0, best_rounds = 1 << 30;
+  for (int kc : cands) {
+    const int rounds = (maxK + kc - 1) / kc;
+    const int nbuf = rounds > 1 ? 2 : 1;
+    if (stage_bytes(kc, nbuf) + extra > kLdsBudget) continue;
+    if (rounds < best_rounds || (rounds == best_rounds && kc < best_kc)) {
+      best_rounds = rounds; best_kc = kc; best_nbuf = nbuf;
+    }
+  }
+  if (!best_kc) return false;
+  *kc_out = best_kc; *nbuf_out = best_nbuf;
+  return true;
+}
+
+template <typename F>
+static hipError_t set_max_lds(F kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+#define DRS_FOR_EACH_KC(X) X(64) X(128) X(192) X(256)
+
+static hipError_t init_mlp_kernels() {
+  static bool done = false;
+  if (done) return hipSuccess;
+  hipError_t e = hipSuccess;
+#define SET_ATTR(KC_)                                                        \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_>);                \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_>);               \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_>);             \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
+  DRS_FOR_EACH_KC(SET_ATTR)
+#undef SET_ATTR
+  if (e == hipSuccess) done = true;
+  return e;
+}
+
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
                      hipStream_t s, const Done* done) {
   if (M <= 0) return hipSuccess;
   Done d = {nullptr, nullptr, nullptr, nullptr, 0};
   if (done) d = *done;
+  hipError_t e = init_mlp_kernels();
+  if (e != hipSuccess) return e;
+  int kc = 64, nbuf = 2;
+  if (!pick_kc(K, 0, &kc, &nbuf)) return hipErrorInvalidValue;
+  const size_t lds = stage_bytes(kc, nbuf);
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   const bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
-  if (vec)
-    hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy, d);
-  else
-    hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(256), 0, s, x, ldx, M, K, W, (int64_t)K, b, N, act, y, ldy, d);
+#define LAUNCH(KC_)                                                                               \
+  if (kc == KC_) {                                                                                \
+    if (vec)                                                                                      \
+      hipLaunchKernelGGL((fc_kernel<true, KC_>), grid, dim3(256), lds, s, x, ldx, M, K, W,        \
+                         (int64_t)K, b, N, act, y, ldy, nbuf, d);                                 \
+    else                                                                                          \
+      hipLaunchKernelGGL((fc_kernel<false, KC_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
+                         (int64_t)K, b, N, act, y, ldy, nbuf, d);                                 \
+  }
+  DRS_FOR_EACH_KC(LAUNCH)
+#undef LAUNCH
   return hipGetLastError();
 }
 
 static int chain_slab_ld(const ChainArgs& a) {
-  int w = 0;
+  int w = 4;
   for (int l = 1; l < a.n_layers; ++l) w = a.width[l] > w ? a.width[l] : w;  // slabs hold layer outputs
-  w = (w + KC - 1) / KC * KC;   // K-chunk padding of the consumer layer
-  return w + 4;
+  return (w + 3) / 4 * 4 + 4;
+}
+
+static bool chain_plan(const ChainArgs& a, int* kc, int* nbuf, size_t* lds) {
+  int maxK = 1;
+  for (int l = 0; l < a.n_layers; ++l) maxK = a.width[l] > maxK ? a.width[l] : maxK;
+  const size_t slabs = a.n_layers > 1 ? sizeof(float) * (size_t)2 * BM * chain_slab_ld(a) : 0;
+  if (!pick_kc(maxK, slabs, kc, nbuf)) return false;
+  *lds = stage_bytes(*kc, *nbuf) + slabs;
+  return true;
 }
 
 size_t chain_lds_bytes(const ChainArgs& a) {
-  return sizeof(float) * ((size_t)2 * BM * LDS_LD + (size_t)2 * BN * LDS_LD +
-                          (size_t)2 * BM * chain_slab_ld(a));
+  int kc, nbuf;
+  size_t lds;
+  return chain_plan(a, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done) {
@@ -333,25 +421,25 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done) {
   Done d = {nullptr, nullptr, nullptr, nullptr, 0};
   if (done) d = *done;
   if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN) return hipErrorInvalidValue;
-  const size_t lds = chain_lds_bytes(a);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  hipError_t e = init_mlp_kernels();
+  if (e != hipSuccess) return e;
+  int kc = 64, nbuf = 2;
+  size_t lds = 0;
+  if (!chain_plan(a, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
   bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
   const dim3 grid((unsigned)((a.M + BM - 1) / BM));
-  if (vec)
-    hipLaunchKernelGGL(chain_kernel<true>, grid, dim3(256), lds, s, a, chain_slab_ld(a), d);
-  else
-    hipLaunchKernelGGL(chain_kernel<false>, grid, dim3(256), lds, s, a, chain_slab_ld(a), d);
+#define LAUNCH(KC_)                                                                               \
+  if (kc == KC_) {                                                                                \
+    if (vec)                                                                                      \
+      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, chain_slab_ld(a), \
+                         nbuf, d);                                                                \
+    else                                                                                          \
+      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a,                  \
+                         chain_slab_ld(a), nbuf, d);                                              \
+  }
+  DRS_FOR_EACH_KC(LAUNCH)
+#undef LAUNCH
   return hipGetLastError();
 }
 
