@@ -56,6 +56,7 @@ SYMBOLS = [
     ("drs_set_profiling", C.c_int32, [C.c_void_p, C.c_int32]),
     ("drs_kernel_time", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), _i64p]),
     ("drs_reset_kernel_time", C.c_int32, [C.c_void_p]),
+    ("drs_debug_gather_stamps", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _i64p]),
     ("drs_gather_bytes", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i64p]),
 ]
 
@@ -260,6 +261,13 @@ class Engine(object):
 
     def reset_kernel_time(self):
         self._check(lib().drs_reset_kernel_time(self._h), "drs_reset_kernel_time")
+
+    def gather_stamps(self, slot=0, cap=1 << 16):
+        buf = np.zeros(2 * cap, dtype=np.uint64)
+        n = C.c_int64(0)
+        self._check(lib().drs_debug_gather_stamps(self._h, slot, buf.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                  2 * cap, C.byref(n)), "drs_debug_gather_stamps")
+        return buf[:2 * n.value].reshape(-1, 2)
 
     def gather_bytes(self, batch_id, bs):
         b = C.c_int64(0)

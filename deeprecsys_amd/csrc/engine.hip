@@ -844,6 +844,15 @@ int32_t drs_kernel_time(drs_handle e, int32_t kernel, double* sum_ms, int64_t* l
   return DRS_OK;
 }
 
+int32_t drs_debug_gather_stamps(drs_handle e, int32_t slot, uint64_t* out, int64_t cap, int64_t* n_blocks) {
+  if (!e || slot < 0 || slot >= e->n_slots || !out || !n_blocks) return DRS_ERR_BAD_ARG;
+  Slot& s = e->slots[slot];
+  const int64_t n = s.ts_blocks < cap / 2 ? s.ts_blocks : cap / 2;
+  memcpy(out, s.h_ts.data(), sizeof(uint64_t) * 2 * (size_t)n);
+  *n_blocks = n;
+  return DRS_OK;
+}
+
 int32_t drs_reset_kernel_time(drs_handle e) {
   if (!e) return DRS_ERR_BAD_ARG;
   for (int i = 0; i < DRS_KERNEL_COUNT; ++i) { e->k_ms[i] = 0; e->k_n[i] = 0; }

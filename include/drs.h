@@ -200,6 +200,10 @@ int32_t drs_set_profiling(drs_handle h, int32_t enabled);
 int32_t drs_kernel_time(drs_handle h, int32_t kernel /*DRS_KERNEL_*/,
                         double* sum_ms, int64_t* launches);
 int32_t drs_reset_kernel_time(drs_handle h);
+/* per-workgroup [start, end] device clock ticks (100 MHz) of the last profiled gather
+ * launch on `slot`; out holds 2*n_blocks words.  Tuning aid (tools/gather_timeline.py) */
+int32_t drs_debug_gather_stamps(drs_handle h, int32_t slot, uint64_t* out, int64_t cap,
+                                int64_t* n_blocks);
 /* algorithmic bytes of the gather for a query of `bs` samples of `batch_id`:
  * sum over bags of len*D*4 + len*4 + 4 + D*4  (SURVEY.md 8d / BASELINE.md 2)   */
 int32_t drs_gather_bytes(drs_handle h, int32_t batch_id, int32_t bs, int64_t* bytes);
