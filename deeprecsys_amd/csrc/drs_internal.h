@@ -28,6 +28,7 @@ struct SlsArgs {
   int32_t T;
   int32_t D;
   int32_t n_samples;          // bs
+  int32_t uniform_len;        // >= 0: every bag has exactly this many indices (off[] is not read)
   int32_t* err;               // device error word: bit0 = index out of range
   uint64_t* ts;               // optional [2 * gridDim.x] start/end wall_clock64() per workgroup
 };

@@ -51,6 +51,7 @@ struct Batch {
   int32_t* idx = nullptr;
   int32_t* off = nullptr;
   int32_t n_samples = 0;
+  int32_t uniform_len = -1;    // all bags of all tables have this length, else -1
   std::vector<int32_t> h_off;  // [T][max_batch+1] host copy (gather_bytes, validation)
   bool staged = false;
 };
@@ -103,7 +104,7 @@ struct drs_engine {
   // op-level scratch
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
-  int sls_exact = 1, mlp_split = 1, zero_copy = 1;
+  int sls_exact = 1, mlp_split = 1, zero_copy = 1, sls_uniform = 1;
   // profiling
   bool profiling = false;
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -264,6 +265,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, const Batch& bt, int32_t bs) {
   a.idx = bt.idx; a.off = bt.off; a.idx_stride = e->cap; a.off_stride = e->max_batch + 1;
   a.out = s.T; a.ld_out = e->ldT; a.col0 = e->kind == DRS_MODEL_NCF ? 0 : e->w0;
   a.T = e->T; a.D = e->D; a.n_samples = bs; a.err = reinterpret_cast<int32_t*>(s.d_err);
+  a.uniform_len = e->sls_uniform ? bt.uniform_len : -1;
   a.ts = prof ? s.d_ts : nullptr;
   s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)bs * e->T, e->sls_exact) : 0;
   HIP_TRY(e, launch_sls(a, e->sls_exact, s.stream));
@@ -652,6 +654,15 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
   if (!pinned) HIP_TRY(e, hipStreamSynchronize(stream));
   b.n_samples = n;
   b.staged = true;
+  b.uniform_len = -1;
+  if (n > 0) {
+    const int32_t L = h_len[0][0];
+    bool same = true;
+    for (int t = 0; t < e->T && same; ++t)
+      for (int i = 0; i < n; ++i)
+        if (h_len[t][i] != L) { same = false; break; }
+    if (same) b.uniform_len = L;
+  }
   return DRS_OK;
 }
 
@@ -780,7 +791,7 @@ int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const i
     SlsArgs a;
     a.tables = d_W; a.tab_off = e->d_op_tab; a.tab_rows = e->d_op_tab + 1;
     a.idx = d_idx; a.off = d_off; a.idx_stride = 0; a.off_stride = 0;
-    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.n_samples = (int32_t)n_bags; a.err = d_err; a.ts = nullptr;
+    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.n_samples = (int32_t)n_bags; a.err = d_err; a.ts = nullptr; a.uniform_len = -1;
     r = launch_sls(a, exact_order, s.stream);
   }
   if (r == hipSuccess) r = hipStreamSynchronize(s.stream);
@@ -825,6 +836,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_u") && (value == 4 || value == 8 || value == 16 || value == 20)) g_sls_u = (int)value;
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
+  else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;

@@ -105,9 +105,17 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   const int b = bag_ok ? (int)(bag / a.T) : 0;
   const int t = bag_ok ? (int)(bag - (int64_t)b * a.T) : 0;
 
-  const int32_t* __restrict__ offp = a.off + (int64_t)t * a.off_stride;
-  const int beg = bag_ok ? offp[b] : 0;
-  const int end = bag_ok ? offp[b + 1] : 0;
+  // fixed-length bags (every shipped reference config: num_indices_per_lookup_fixed) need
+  // no offsets: one dependent HBM round trip less before the first row load can issue
+  int beg, end;
+  if (a.uniform_len >= 0) {
+    beg = bag_ok ? b * a.uniform_len : 0;
+    end = bag_ok ? beg + a.uniform_len : 0;
+  } else {
+    const int32_t* __restrict__ offp = a.off + (int64_t)t * a.off_stride;
+    beg = bag_ok ? offp[b] : 0;
+    end = bag_ok ? offp[b + 1] : 0;
+  }
   const int32_t* __restrict__ ip = a.idx + (int64_t)t * a.idx_stride;
   const float* __restrict__ W = a.tables + a.tab_off[t] + col;
   const uint32_t rows = (uint32_t)a.tab_rows[t];

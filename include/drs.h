@@ -186,6 +186,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_exact"  1 (default) sequential-order gather | 0 wave-split gather
  *   "sls_u"      row loads kept in flight per lane: 4 | 8 | 16 (default) | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
+ *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
+ *                read (bag b starts at b*L) | 0 always read the staged prefix sums
  *   "mlp_split"  1 (default) first wide top/bottom layer as its own 2-D launch | 0
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
