@@ -203,23 +203,15 @@ def main():
     mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
     gbytes = eng.gather_bytes(0, bs)
 
-    lat_ms = np.array(lat) * 1e3
-    hist_edges = np.concatenate([[0], np.logspace(-3, 3, 4095)])   # ms
-    hist = np.histogram(lat_ms, bins=hist_edges)[0].astype(np.int64)
+    from deeprecsys_amd import stats
+    hist = stats.latency_histogram(lat)
     tot_elapsed, tot_queries = elapsed, opt.steps
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tot_elapsed = float(t.item())
-        h = torch.from_numpy(hist).cuda()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM)      # the single data collective: 32 KB over xGMI
-        hist = h.cpu().numpy()
-        tot_queries = opt.steps * world
-    cdf = np.cumsum(hist) / max(hist.sum(), 1)
-    p99 = float(hist_edges[1:][np.searchsorted(cdf, 0.99)])
-    p95 = float(hist_edges[1:][np.searchsorted(cdf, 0.95)])
-    p50 = float(hist_edges[1:][np.searchsorted(cdf, 0.50)])
+        # the single collective of the run: MAX(elapsed), SUM(count, latency histogram) -- 32 KB
+        tot_elapsed, tot_queries, hist = stats.allreduce_run_stats(dist, elapsed, opt.steps, hist,
+                                                                   device=torch.device("cuda", local))
+    p50, p95, p99 = (stats.percentile_from_histogram(hist, q) for q in (50, 95, 99))
 
     if rank == 0:
         w = WORKLOADS[opt.workload]

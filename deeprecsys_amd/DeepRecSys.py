@@ -1,0 +1,119 @@
+"""Orchestrator: spawns the load generator and the inference engines, reassembles
+responses, feeds the running tail latency back to the scheduler, reports
+latency-bounded throughput.
+
+Mirror of the reference's DeepRecSys.py:21-185 (same queues, same process layout, same
+printed summary lines) with the extension of SURVEY.md 8(e): `--num_accels k` spawns k
+accelerator engines, one per GPU, all consuming the shared accelRequestQueue
+(the reference hard-wires one, DeepRecSys.py:38-39,63).
+
+This package ships no CPU engine: the CPU forward lives in oracle/ as test
+infrastructure.  Callers that want CPU engines in the mix (bench.py's cpu baseline
+does) pass `cpu_engine=<callable with the inferenceEngine signature>`.
+"""
+import os
+import sys
+from multiprocessing import Process, Queue
+
+import numpy as np
+
+from .accelInferenceEngine import accelInferenceEngine
+from .loadGenerator import accel_engine_count, loadGenerator
+from .stats import ResponseAggregator
+from .utils.utils import cli
+
+
+def DeepRecSys(args=None, cpu_engine=None, quiet=False):
+    say = (lambda *a: None) if quiet else print
+    say("Running DeepRecSys")
+    if args is None:
+        args = cli()
+    say("============================================================")
+    say("DeepRecSys configuration")
+    for key in vars(args):
+        say(key, getattr(args, key))
+    say("============================================================")
+    if not args.queue:
+        sys.exit("ERROR: this build serves through the queue harness only (--queue); for a "
+                 "stand-alone timing run use bench.py")
+
+    n_accel = accel_engine_count(args)
+    n_cpu = int(args.inference_engines)
+    if n_cpu > 0 and cpu_engine is None:
+        sys.exit("ERROR: --inference_engines %d CPU engines requested, but deeprecsys_amd has no "
+                 "CPU forward (by design); use --inference_engines 0 --model_accel" % n_cpu)
+    if n_cpu + n_accel == 0:
+        sys.exit("ERROR: no inference engines configured")
+    args.inference_engines = n_cpu + n_accel        # reference: += 1 when model_accel (:38-39)
+    args.accel_first_engine_id = n_cpu              # engines [n_cpu, n_cpu + n_accel) are accelerators
+    say("[DeepRecSys] total inference engine ", args.inference_engines)
+
+    requestQueue = Queue(maxsize=1024)
+    accelRequestQueue = Queue(maxsize=32 * max(n_accel, 1))
+    pidQueue = Queue()
+    inferenceEngineReadyQueue = Queue()
+    loadGeneratorReturnQueue = Queue()
+    responseQueues = [Queue() for _ in range(args.inference_engines)]
+
+    load_gen = Process(target=loadGenerator,
+                       args=(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineReadyQueue,
+                             pidQueue, accelRequestQueue))
+    engines = []
+    for i in range(args.inference_engines):
+        if i >= n_cpu:
+            p = Process(target=accelInferenceEngine,
+                        args=(args, accelRequestQueue, i, responseQueues[i], inferenceEngineReadyQueue))
+        else:
+            p = Process(target=cpu_engine,
+                        args=(args, requestQueue, i, responseQueues[i], inferenceEngineReadyQueue))
+        p.daemon = True
+        engines.append(p)
+    for p in engines:
+        p.start()
+    load_gen.start()
+
+    agg = ResponseAggregator(args.req_granularity)
+    finished = 0
+    while finished != args.inference_engines:
+        for q in responseQueues:
+            if q.qsize():
+                response = q.get()
+                if response is None:
+                    finished += 1
+                    say("Joined ", finished, " inference engines")
+                    sys.stdout.flush()
+                    continue
+                _latency, running_p95 = agg.add(response)
+                if running_p95 is not None:
+                    say("Running latency: ", running_p95)
+                    sys.stdout.flush()
+                    pidQueue.put(running_p95)
+    say("Finished runing over the inference engines")
+
+    log_dir = os.path.dirname(args.log_file)
+    if log_dir and not os.path.exists(log_dir):
+        os.makedirs(log_dir)
+    with open(args.log_file, "w") as f:
+        for r in agg.responses_list:
+            f.write(str(r) + "\n")
+
+    load_gen.join()
+    cpu_sub_requests, cpu_requests, accel_requests = loadGeneratorReturnQueue.get()
+    agg_requests = cpu_sub_requests + accel_requests
+    say("Exiting DeepRecSys after printing ", len(agg.responses_list), "/", agg_requests)
+    say("CPU sub requests ", cpu_sub_requests, "/", agg_requests)
+    say("CPU requests ", cpu_requests)
+    say("Accel requests ", accel_requests, "/", agg_requests)
+    s = agg.summary()
+    say("Measured QPS: ", s["qps"])
+    say("Measured p95 tail-latency: ", s["p95_ms"], " ms")
+    say("Measured p99 tail-latency: ", s["p99_ms"], " ms")
+    sys.stdout.flush()
+    for p in engines:
+        p.terminate()
+    s.update(cpu_sub_requests=cpu_sub_requests, cpu_requests=cpu_requests, accel_requests=accel_requests)
+    return s
+
+
+if __name__ == "__main__":
+    DeepRecSys()

@@ -104,7 +104,7 @@ struct drs_engine {
   // op-level scratch
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
-  int sls_exact = 1, mlp_split = 1, zero_copy = 1, sls_uniform = 1;
+  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1;
   // profiling
   bool profiling = false;
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -833,7 +833,7 @@ int32_t drs_interact_dot(drs_handle e, const float* d_T, int64_t B, int32_t F, i
 int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   if (!e || !key) return DRS_ERR_BAD_ARG;
   if (!strcmp(key, "sls_exact")) e->sls_exact = value ? 1 : 0;
-  else if (!strcmp(key, "sls_u") && (value == 4 || value == 8 || value == 16 || value == 20)) g_sls_u = (int)value;
+  else if (!strcmp(key, "sls_u") && (value == 0 || value == 4 || value == 8 || value == 16 || value == 20)) g_sls_u = (int)value;
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;

@@ -249,9 +249,11 @@ hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s) {
 
 }  // namespace
 
-// Tunables (set through drs_set_option): rows in flight per lane and the lane
-// width used for D == 32 (8 lanes x 16 B or 16 lanes x 8 B).
-int g_sls_u = 16;
+// Tunables (set through drs_set_option): rows in flight per lane (0 = measured best:
+// 16 for the sequential variant, 4 for the wave-split one, whose 8 waves per CU already
+// provide the memory-level parallelism) and the lane width used for D == 32
+// (8 lanes x 16 B or 16 lanes x 8 B).
+int g_sls_u = 0;
 int g_sls_v_d32 = 4;
 
 int64_t sls_grid_blocks(int D, int64_t n_bags, int exact) {
@@ -265,7 +267,7 @@ int64_t sls_grid_blocks(int D, int64_t n_bags, int exact) {
 hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s) {
   const int D = a.D;
   if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
-  const int u = g_sls_u;
+  const int u = g_sls_u ? g_sls_u : (exact ? 16 : 4);
   if (D == 32 && g_sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s);
   if (D <= 8) return launch_u<2, 4>(a, exact, u, s);
   if (D <= 16) return launch_u<4, 4>(a, exact, u, s);

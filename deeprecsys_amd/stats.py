@@ -1,0 +1,92 @@
+"""Response reassembly and the throughput / tail-latency formulae of the orchestrator
+(reference DeepRecSys.py:89-135 and :168-175), as pure functions so they can be unit
+tested and reused by bench.py.
+
+A query cut into sub-batches is complete when all `total_sub_batches` responses with
+the same (epoch, batch_id, exp_packet) key have arrived; its latency is
+max(inference_end_time) - min(arrival_time) over them.  Measured QPS counts the
+non-experimental responses with sub_id == 0 between the first and the last
+inference_end_time.
+"""
+import numpy as np
+
+
+class ResponseAggregator(object):
+    def __init__(self, request_granularity=64):
+        self.request_granularity = int(request_granularity)
+        self.response_sets = {}
+        self.response_latencies = []         # every completed query (feeds the scheduler)
+        self.final_response_latencies = []   # completed non-experimental queries
+        self.responses_list = []             # per-response dicts, arrival order
+
+    def add(self, response):
+        """-> (latency_seconds or None, running_p95_ms or None).  The running p95 over the
+        last `request_granularity` completed queries is what goes to pidQueue."""
+        key = (response.epoch, response.batch_id, response.exp_packet)
+        if key in self.response_sets:
+            arr0, inf0, remain0 = self.response_sets[key]
+            arr, inf, remain = (min(arr0, response.arrival_time),
+                                max(inf0, response.inference_end_time), remain0 - 1)
+        else:
+            arr, inf, remain = (response.arrival_time, response.inference_end_time,
+                                response.total_sub_batches - 1)
+        self.response_sets[key] = (arr, inf, remain)
+        latency = running = None
+        if remain == 0:
+            latency = inf - arr
+            self.response_latencies.append(latency)
+            if not response.exp_packet:
+                self.final_response_latencies.append(latency)
+            if len(self.response_latencies) % self.request_granularity == 0:
+                running = float(np.percentile(self.response_latencies[-self.request_granularity:], 95)
+                                * 1000.)
+        self.responses_list.append(response.as_dict() if hasattr(response, "as_dict")
+                                   else dict(response.__dict__))
+        return latency, running
+
+    def summary(self):
+        return summarize(self.responses_list, self.final_response_latencies)
+
+
+def summarize(responses_list, final_response_latencies):
+    meas = [r for r in responses_list if (not r["exp_packet"]) and r["sub_id"] == 0]
+    out = {"responses": len(responses_list), "measured_queries": len(meas), "qps": None,
+           "p95_ms": None, "p99_ms": None}
+    if len(meas) >= 2 and meas[-1]["inference_end_time"] > meas[0]["inference_end_time"]:
+        out["qps"] = len(meas) / (meas[-1]["inference_end_time"] - meas[0]["inference_end_time"])
+    if len(final_response_latencies):
+        out["p95_ms"] = float(np.percentile(final_response_latencies, 95) * 1000.)
+        out["p99_ms"] = float(np.percentile(final_response_latencies, 99) * 1000.)
+    return out
+
+
+LAT_BINS_MS = np.concatenate([[0.0], np.logspace(-3, 4, 4095)])   # 4096 edges, 1 us .. 10 s
+
+
+def latency_histogram(latencies_s):
+    """Fixed-bin histogram (int64[4095]) that ranks can sum with one all-reduce."""
+    return np.histogram(np.asarray(latencies_s, dtype=np.float64) * 1e3, bins=LAT_BINS_MS)[0].astype(np.int64)
+
+
+def percentile_from_histogram(hist, q):
+    total = hist.sum()
+    if total == 0:
+        return None
+    cdf = np.cumsum(hist) / total
+    return float(LAT_BINS_MS[1:][np.searchsorted(cdf, q / 100.0)])
+
+
+def allreduce_run_stats(dist, elapsed_s, n_queries, hist, device=None):
+    """The one collective of a multi-GPU run (RCCL over xGMI when the process group is
+    "nccl"; gloo in the CPU tests): MAX of the per-rank elapsed time, SUM of the query
+    counts and of the fixed-bin latency histograms (32 KB).  Returns
+    (max_elapsed_s, total_queries, summed_hist)."""
+    import torch
+    kw = {} if device is None else {"device": device}
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, **kw)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    h = torch.cat([torch.tensor([int(n_queries)], dtype=torch.int64),
+                   torch.as_tensor(np.asarray(hist, dtype=np.int64))]).to(t.device)
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    h = h.cpu().numpy()
+    return float(t.item()), int(h[0]), h[1:]

@@ -183,8 +183,12 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
 
 /* ---- tuning ------------------------------------------------------------------
  * integer knobs, for A/B measurements inside one process (bench.py --sweep):
- *   "sls_exact"  1 (default) sequential-order gather | 0 wave-split gather
- *   "sls_u"      row loads kept in flight per lane: 4 | 8 | 16 (default) | 20
+ *   "sls_exact"  0 (default) wave-split gather: a wave per bag, rows spread over its lane
+ *                groups, wave-wide butterfly at the end (fp32 sum order differs from the
+ *                reference: compare with a tolerance) | 1 sequential-order gather,
+ *                bit-identical to the Caffe2 CPU SparseLengthsSum (about 15% slower)
+ *   "sls_u"      row loads kept in flight per lane: 0 (default: 16 sequential / 4 split)
+ *                | 4 | 8 | 16 | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums

@@ -43,16 +43,23 @@ def test_forward_matches_oracle_and_golden(case):
     try:
         net.stage_batches(None if args.model_type == "ncf" else lX, lS_l, lS_i)
         n = len(lS_l[0][0])
-        for bid in range(len(lS_l)):
-            for bs in sorted({n, 1, max(1, n // 2)}):
-                got = net.run_staged(bid, bs)
-                R = net.engine.fetch_interaction(bs)
-                dense = None if args.model_type == "ncf" else lX[bid]
-                exp, R_exp = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, want_R=True)
-                # pooled embeddings + concat layout + (dot) tril order + bottom MLP: bitwise
-                assert np.array_equal(R, R_exp), (case, bid, bs, np.abs(R - R_exp).max())
-                # outputs: identical chains up to the last expf -> a few ulp
-                assert H.close(got, exp, rtol=1e-6, atol=1e-7), np.abs(got - exp).max()
+        for exact in (1, 0):
+            net.engine.set_option("sls_exact", exact)
+            for bid in range(len(lS_l)):
+                for bs in sorted({n, 1, max(1, n // 2)}):
+                    got = net.run_staged(bid, bs)
+                    R = net.engine.fetch_interaction(bs)
+                    dense = None if args.model_type == "ncf" else lX[bid]
+                    exp, R_exp = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, want_R=True)
+                    if exact:
+                        # pooled embeddings + concat layout + (dot) tril order + bottom MLP: bitwise;
+                        # outputs: identical fma chains up to the last expf -> a few ulp
+                        assert np.array_equal(R, R_exp), (case, bid, bs, np.abs(R - R_exp).max())
+                        assert H.close(got, exp, rtol=1e-6, atol=1e-7), np.abs(got - exp).max()
+                    else:
+                        # wave-split pooling: same rows, different fp32 summation order
+                        assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (case, bid, bs)
+                        assert H.close(got, exp, rtol=H.RTOL_OUT)
         full = net.run_staged(0, n)
         assert H.close(full, z["expected/prob_click"], rtol=H.RTOL_OUT)
         # non-staged inputs (run_queues signature) give the same bits as the staged path
@@ -99,7 +106,7 @@ def test_sls_exact_is_bitwise_and_split_is_close(op_engine, D, L):
     exp = orc.sls(W, idx, lengths)
     dW, di, dl = (torch.from_numpy(a).cuda() for a in (W, idx, lengths))
     out = torch.full((bags, D), float("nan"), device="cuda")
-    for u in (4, 8, 16, 20):
+    for u in (0, 4, 8, 16, 20):
         op_engine.set_option("sls_u", u)
         out.fill_(float("nan"))
         op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
@@ -109,7 +116,7 @@ def test_sls_exact_is_bitwise_and_split_is_close(op_engine, D, L):
         op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
                       out.data_ptr(), exact_order=False)
         assert H.close(out.cpu().numpy(), exp, rtol=1e-5, atol_scale=1e-6), (D, L, u)
-    op_engine.set_option("sls_u", 16)
+    op_engine.set_option("sls_u", 0)
     if D == 32:
         op_engine.set_option("sls_v_d32", 2)
         out.fill_(float("nan"))
@@ -200,6 +207,7 @@ def test_full_size_rmc1_baseline_shape_matches_oracle():
     net.create(lX[0], lS_l[0], lS_i[0], None)
     try:
         net.stage_batches(lX, lS_l, lS_i)
+        net.engine.set_option("sls_exact", 1)
         lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
         tables = [orc.fill_table_uniform(rows, D, t, lo, hi, args.numpy_rand_seed, nthreads=0)
                   for t in range(T)]
@@ -231,6 +239,7 @@ def test_split_variant_within_tolerance_full_size():
     net.create(lX[0], lS_l[0], lS_i[0], None)
     try:
         net.stage_batches(lX, lS_l, lS_i)
+        net.engine.set_option("sls_exact", 1)
         exact = net.run_staged(0, B)
         R_exact = net.engine.fetch_interaction(B)
         net.engine.set_option("sls_exact", 0)
@@ -238,5 +247,53 @@ def test_split_variant_within_tolerance_full_size():
         R_split = net.engine.fetch_interaction(B)
         assert H.close(R_split, R_exact, rtol=1e-5, atol_scale=2e-6)
         assert H.close(split, exact, rtol=H.RTOL_OUT)
+    finally:
+        net.engine.close()
+
+
+def test_engine_ragged_bags_and_device_error_path():
+    """Variable bag lengths (incl. empty bags) through the staged path (prefix-sum
+    offsets), for both gather variants; and Caffe2's ENFORCEs at the ABI."""
+    rng = np.random.RandomState(5)
+    rows, D, T, B, Lmax = [300, 200, 100], 16, 3, 37, 9
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_bot="12-16", arch_mlp_top="8-1", arch_interaction_op="dot",
+                       num_indices_per_lookup=Lmax, num_batches=1, max_mini_batch_size=B,
+                       mini_batch_size=B, numpy_rand_seed=3, model_type="dlrm")
+    np.random.seed(3)
+    net = H.M.DLRM_Net(args)
+    om = H.oracle_model(net)
+    lens = [rng.randint(0, Lmax + 1, size=B).astype(np.int32) for _ in range(T)]
+    lens[0][:4] = 0
+    idx = [rng.randint(0, rows[t], size=int(lens[t].sum())).astype(np.int64) for t in range(T)]
+    X = rng.rand(B, 12).astype(np.float32)
+    net.create(X, lens, idx, None)
+    try:
+        net.engine.stage_batch(0, X, idx, lens)
+        for exact in (1, 0):
+            net.engine.set_option("sls_exact", exact)
+            for bs in (B, 20, 1):
+                got = net.run_staged(0, bs)
+                R = net.engine.fetch_interaction(bs)
+                exp, R_exp = om.forward(X, idx, lens, bs=bs, want_R=True)
+                if exact:
+                    assert np.array_equal(R, R_exp)
+                else:
+                    assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6)
+                assert H.close(got, exp, rtol=H.RTOL_OUT)
+        bad = [i.copy() for i in idx]
+        bad[1][3] = rows[1]
+        with pytest.raises(N.DrsError) as e:
+            net.engine.stage_batch(0, X, bad, lens)
+        assert e.value.code == N.ERR_INDEX_RANGE
+        with pytest.raises(N.DrsError) as e:
+            net.engine.stage_batch(0, X, [i[:-1] for i in idx], lens)
+        assert e.value.code == N.ERR_LENGTHS_SUM
+        with pytest.raises(N.DrsError) as e:
+            net.engine.forward(0, B + 1)
+        assert e.value.code == N.ERR_BAD_ARG
+        # engine still healthy afterwards
+        net.engine.stage_batch(0, X, idx, lens)
+        assert net.run_staged(0, B).shape == (B, 1)
     finally:
         net.engine.close()

@@ -1,0 +1,113 @@
+"""Process-level tests of the serving harness (orchestrator + load generator + engines)
+and of the multi-rank statistics collective.  CPU only unless marked gpu."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from deeprecsys_amd import latency_table, stats
+from deeprecsys_amd.DeepRecSys import DeepRecSys
+from deeprecsys_amd.utils.utils import cli
+
+
+def _args(tmp_path, **kw):
+    a = cli(["--queue", "--model_accel", "--inference_engines", "0", "--num_batches", "8",
+             "--nepochs", "2", "--avg_arrival_rate", "1", "--batch_size_distribution", "normal",
+             "--avg_mini_batch_size", "20", "--var_mini_batch_size", "4", "--max_mini_batch_size", "32",
+             "--req_granularity", "4", "--log_file", str(tmp_path / "log" / "out.log")])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _write_sim_tables(root):
+    d = os.path.join(root, "nvidia_gtx_1080_ti", "raw_data")
+    os.makedirs(d)
+    for m in latency_table.MODELS:
+        rows = [(0.1, 0.01, 0.2, 0.02, 0.3, 0.2 * (i + 1)) for i in range(6)]   # 0.2 .. 1.2 ms
+        latency_table.write_results(os.path.join(d, "results_%s.txt" % m), rows)
+
+
+def test_harness_with_two_simulated_accelerators(tmp_path):
+    """Queue protocol end to end on CPU: ready tokens, whole-query routing to the shared
+    accelerator queue, per-engine sentinels, response reassembly, QPS/p95/p99 summary --
+    with the reference's latency-table engine behaviour (--accel_backend sim) on two
+    accelerator engines."""
+    root = str(tmp_path / "accel") + "/"
+    os.makedirs(root)
+    _write_sim_tables(root)
+    a = _args(tmp_path, accel_backend="sim", num_accels=2, accel_root_dir=root, model_name="rm1")
+    s = DeepRecSys(a, quiet=True)
+    assert s["accel_requests"] == 16 and s["cpu_requests"] == 0 and s["cpu_sub_requests"] == 0
+    assert s["responses"] == 16 and s["measured_queries"] == 16
+    assert s["qps"] > 0 and 0.1 < s["p99_ms"] < 1000
+    lines = open(a.log_file).read().strip().splitlines()
+    assert len(lines) == 16
+    consumers = {eval(l)["consumer_id"] for l in lines}
+    assert consumers <= {0, 1} and len(consumers) >= 1
+
+
+def test_harness_rejects_cpu_engines_without_a_cpu_forward(tmp_path):
+    a = _args(tmp_path, inference_engines=2)
+    with pytest.raises(SystemExit):
+        DeepRecSys(a, quiet=True)
+
+
+def test_accel_engine_startup_failure_still_sends_sentinel(tmp_path):
+    """A dying engine must not hang the orchestrator's join loop (DeepRecSys.py:89)."""
+    a = _args(tmp_path, accel_backend="sim", num_accels=1, accel_root_dir=str(tmp_path / "missing") + "/",
+              model_name="rm1")
+    s = DeepRecSys(a, quiet=True)
+    assert s["responses"] == 0 and s["qps"] is None
+
+
+# ---- the statistics collective, world_size 2 over gloo -----------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(rank)
+    lat = rng.uniform(1e-4, 3e-3, size=500 + 100 * rank)
+    elapsed = 1.0 + rank
+    el, n, h = stats.allreduce_run_stats(dist, elapsed, lat.size, stats.latency_histogram(lat))
+    if rank == 0:
+        out.put((el, n, int(h.sum()), stats.percentile_from_histogram(h, 99)))
+    dist.destroy_process_group()
+
+
+def test_multi_rank_stats_allreduce_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    el, n, total, p99 = out.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    lat = np.concatenate([np.random.RandomState(r).uniform(1e-4, 3e-3, size=500 + 100 * r) for r in range(2)])
+    assert el == 2.0 and n == 1100 and total == 1100
+    assert p99 == pytest.approx(np.percentile(lat, 99, method="higher") * 1e3, rel=0.01)
+
+
+# ---- the real thing ------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_harness_with_a_real_accelerator_engine(tmp_path):
+    a = _args(tmp_path, accel_backend="hip", num_accels=1, arch_sparse_feature_size=16,
+              arch_embedding_size="2000-3000-1000", arch_mlp_bot="13-32-16", arch_mlp_top="32-1",
+              arch_interaction_op="dot", num_indices_per_lookup=10, model_type="dlrm")
+    s = DeepRecSys(a, quiet=True)
+    assert s["accel_requests"] == 16 and s["responses"] == 16
+    lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
+    assert all(l["out_batch_size"] == l["batch_size"] for l in lines)
+    assert s["qps"] > 0 and s["p99_ms"] < 1000

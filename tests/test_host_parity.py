@@ -1,0 +1,246 @@
+"""CPU suite for the host side: the mirrors of the reference's Python surface against
+values captured by running the reference itself (tests/golden/harness.json and the
+per-model fixtures; tools/gen_golden.py)."""
+import json
+import os
+import types
+from unittest import mock
+
+import numpy as np
+import pytest
+
+from deeprecsys_amd import latency_table, loadGenerator, scheduler, stats
+from deeprecsys_amd.utils import packets
+from deeprecsys_amd.utils.utils import EXTRA_FLAGS, cli
+from tests import helpers as H
+
+with open(os.path.join(H.GOLDEN, "harness.json")) as _f:
+    HARNESS = json.load(_f)
+
+
+# ---- cli ------------------------------------------------------------------------------
+def _strip_extra(d):
+    return {k: v for k, v in d.items() if k not in {n for n, _, _ in EXTRA_FLAGS}}
+
+
+def test_cli_defaults_match_reference():
+    assert _strip_extra(vars(cli([]))) == HARNESS["cli"]["defaults"]
+
+
+@pytest.mark.parametrize("cfg", [k for k in HARNESS["cli"] if k.endswith(".json")])
+def test_cli_config_file_overrides_like_reference(cfg, tmp_path):
+    p = tmp_path / cfg
+    p.write_text(json.dumps(HARNESS["cli"][cfg + ":json"]))
+    got = _strip_extra(vars(cli(["--config_file", str(p)])))
+    exp = dict(HARNESS["cli"][cfg])
+    got.pop("config_file"), exp.pop("config_file")
+    assert got == exp
+
+
+def test_cli_run_deeprecsys_bundle(tmp_path):
+    p = tmp_path / "dlrm_rm1.json"
+    p.write_text(json.dumps(HARNESS["cli"]["dlrm_rm1.json:json"]))
+    got = _strip_extra(vars(cli(HARNESS["cli"]["run_DeepRecSys.sh:argv"] + ["--config_file", str(p)])))
+    exp = dict(HARNESS["cli"]["run_DeepRecSys.sh"])
+    got.pop("config_file"), exp.pop("config_file")
+    assert got == exp
+
+
+def test_cli_config_beats_command_line(tmp_path):
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps({"arch_embedding_size": "7-7", "num_indices_per_lookup_fixed": True}))
+    a = cli(["--arch_embedding_size", "9-9-9", "--config_file", str(p)])
+    assert a.arch_embedding_size == "7-7" and a.num_indices_per_lookup_fixed is True
+
+
+# ---- load generator --------------------------------------------------------------------
+@pytest.mark.parametrize("rec", HARNESS["partition_requests"])
+def test_partition_requests(rec):
+    a = types.SimpleNamespace(sub_task_batch_size=rec["sub_task_batch_size"])
+    assert [int(x) for x in loadGenerator.partition_requests(a, rec["batch_size"])] == rec["chunks"]
+
+
+@pytest.mark.parametrize("rec", HARNESS["batch_size_distribution"], ids=lambda r: "%s-%s" % (r["kind"], r["avg"]))
+def test_batch_size_distribution_and_arrivals(rec):
+    a = types.SimpleNamespace(batch_size_distribution=rec["kind"], avg_mini_batch_size=rec["avg"],
+                              var_mini_batch_size=rec["var"], num_batches=32, max_mini_batch_size=1024,
+                              nepochs=2, avg_arrival_rate=10)
+    np.random.seed(rec["seed"])
+    assert [int(x) for x in loadGenerator.model_batch_size_distribution(a)] == rec["sizes"]
+    np.random.seed(rec["seed"])
+    assert [int(x) for x in loadGenerator.model_arrival_times(a)] == rec["arrival_delays"]
+
+
+# ---- scheduler ---------------------------------------------------------------------------
+class _FakeQ(object):
+    def __init__(self, n=0):
+        self.n = n
+
+    def qsize(self):
+        return self.n
+
+    def get(self, *a):
+        self.n -= 1
+        return 0
+
+
+@pytest.mark.parametrize("rec", HARNESS["scheduler"], ids=lambda r: "%s-%s" % (r["mode"], r["script"]))
+def test_scheduler_trajectories_match_reference(rec):
+    a = types.SimpleNamespace(min_arr_range=1, max_arr_range=20, arr_steps=50, avg_arrival_rate=10.0,
+                              batch_configs="512-256-128", accel_configs="96-128-192-256-384-512",
+                              target_latency=25.0, stable_region=0.10, sched_timeout=16,
+                              sub_task_batch_size=512, accel_request_size_thres=1024)
+    with mock.patch("builtins.print"), mock.patch("time.sleep"):
+        s = scheduler.Scheduler(a, _FakeQ(3), _FakeQ(2), _FakeQ(1), mode=rec["mode"])
+        assert [float(v) for v in s.possible_arrival_rates] == rec["possible_arrival_rates"]
+        for lat, exp in zip(rec["latencies"], rec["steps"]):
+            args_o, rate, tuning = s.run(lat)
+            got = {"arr_id": int(s.arr_id), "arrival_rate": float(rate), "tuning": bool(tuning),
+                   "sub_task_batch_size": int(args_o.sub_task_batch_size),
+                   "accel_request_size_thres": int(args_o.accel_request_size_thres)}
+            assert got == exp
+
+
+# ---- latency table (accelerator/) ------------------------------------------------------------
+def test_predict_time_and_table_format(tmp_path):
+    rec = HARNESS["predict_time"]
+    gd = types.SimpleNamespace()
+    for m in latency_table.MODELS:
+        setattr(gd, m + "_exec_time", np.array(rec["table"]) * (1 + 0.1 * len(m)))
+    for pt in rec["points"]:
+        assert float(latency_table.predict_time(pt["model"], pt["batch_size"], gd)) == pytest.approx(pt["ms"], rel=1e-12)
+    p = tmp_path / "results_probe.txt"
+    p.write_text("\n".join(HARNESS["parse_gpu"]["lines"]) + "\n")
+    assert latency_table.parse_results(str(p)) == HARNESS["parse_gpu"]["tuples"]
+    # what we write, the reference's parser (restated) reads back
+    q = tmp_path / "out.txt"
+    latency_table.write_results(str(q), HARNESS["parse_gpu"]["tuples"])
+    assert latency_table.parse_results(str(q)) == HARNESS["parse_gpu"]["tuples"]
+
+
+# ---- packets -------------------------------------------------------------------------------
+def test_packet_fields_are_the_wire_contract():
+    r = packets.ServiceRequest(batch_id=3, epoch=1, arrival_time=2.5, batch_size=7, sub_id=0,
+                               total_sub_batches=2, exp_packet=False)
+    assert (r.batch_id, r.batch_size, r.epoch, r.arrival_time, r.total_sub_batches, r.sub_id, r.exp_packet) \
+        == (3, 7, 1, 2.5, 2, 0, False)
+    s = packets.ServiceResponse(consumer_id=4, epoch=1, batch_id=3, batch_size=7, arrival_time=2.5,
+                                process_start_time=3.0, queue_end_time=3.5, inference_end_time=4.0,
+                                out_batch_size=7, sub_id=0, total_sub_batches=2, exp_packet=False)
+    assert s.queue_start_time == 3.0          # reference stores process_start_time under this name
+    assert set(s.as_dict()) == {"consumer_id", "epoch", "batch_id", "batch_size", "arrival_time",
+                                "queue_start_time", "queue_end_time", "inference_end_time",
+                                "out_batch_size", "total_sub_batches", "exp_packet", "sub_id"}
+    import pickle
+    assert pickle.loads(pickle.dumps(s)).as_dict() == s.as_dict()
+    str(r), str(s)
+
+
+# ---- inputs + weights: RNG consumption order ---------------------------------------------------
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_inputs_and_weights_bitexact_vs_reference(case):
+    meta, z = H.load_fixture(case)
+    dg = meta["digests"]
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    for j in range(meta["nbatches"]):
+        assert H.sha(lX[j]) == dg["lX/%d" % j]["sha256"]
+        assert H.sha(lT[j]) == dg["lT/%d" % j]["sha256"]
+        assert H.sha(np.array(lS_l[j], dtype=np.int32)) == dg["lS_l/%d" % j]["sha256"]
+        for t in range(len(lS_i[j])):
+            assert H.sha(lS_i[j][t]) == dg["lS_i/%d/%d" % (j, t)]["sha256"]
+    if args.model_type == "ncf":
+        tabs = ["blob/emb:::mf_sls0_w", "blob/emb:::mf_sls1_w", "blob/emb:::mlp_sls0_w", "blob/emb:::mlp_sls1_w"]
+    else:
+        tabs = ["blob/emb:::sls%d_w" % t for t in range(len(net.emb_w))]
+    for t, k in enumerate(tabs):
+        assert H.sha(net.emb_w[t]) == dg[k]["sha256"]
+        assert dg[k]["dtype"] == "float32"
+    if args.model_type == "dlrm":
+        for i, (W, b) in enumerate(net.bot_w):
+            assert H.sha(W) == dg["blob/bot:::fc%d_w" % (i + 1)]["sha256"]
+            assert H.sha(b) == dg["blob/bot:::fc%d_b" % (i + 1)]["sha256"]
+        assert np.array_equal(net.tril_indices(), z["blob/interaction_tril_indices"])
+        assert list(net.ln_top) == [z["blob/top:::fc1_w"].shape[1] if "blob/top:::fc1_w" in z.files
+                                    else dg["blob/top:::fc1_w"]["shape"][1]] + \
+            [int(x) for x in args.arch_mlp_top.split("-")]
+    pre = "mlpfc" if args.model_type == "ncf" else "top"
+    for i, (W, b) in enumerate(net.top_w):
+        assert H.sha(W) == dg["blob/%s:::fc%d_w" % (pre, i + 1)]["sha256"]
+        assert H.sha(b) == dg["blob/%s:::fc%d_b" % (pre, i + 1)]["sha256"]
+    if args.model_type == "ncf":
+        assert H.sha(net.final_w[0][0]) == dg["blob/final:::fc1_w"]["sha256"]
+        assert H.sha(net.final_w[0][1]) == dg["blob/final:::fc1_b"]["sha256"]
+
+
+def test_reference_graph_is_what_the_engine_wires():
+    """The op list recorded from the reference builder is exactly the fused pipeline:
+    T x SparseLengthsSum -> bottom FC/Relu chain -> (dot ops | Concat) -> top chain -> Sigmoid."""
+    meta, _ = H.load_fixture("dlrm_dot_small")
+    kinds = [op["type"] for op in meta["ops"]]
+    assert kinds == ["SparseLengthsSum"] * 3 + ["FC", "Relu"] * 2 + \
+        ["Concat", "BatchMatMul", "Flatten", "BatchGather", "Concat"] + ["FC", "Relu"] * 2 + ["FC", "Sigmoid"]
+    meta, _ = H.load_fixture("dlrm_cat_queue_small")
+    kinds = [op["type"] for op in meta["ops"]]
+    assert kinds[:4] == ["DequeueBlobs", "Cast", "DequeueBlobs", "SparseLengthsSum"]
+    assert meta["feed_dtypes"]["emb:::sls0_i"] == "int64" and meta["feed_dtypes"]["emb:::sls0_l"] == "int32"
+    assert meta["ops"][-1]["outputs"] == ["prob_click"]
+
+
+def test_model_shape_checks_exit_like_reference():
+    a = H.args_from({}, arch_sparse_feature_size=8, arch_embedding_size="10-10", arch_mlp_bot="4-6",
+                    arch_mlp_top="4-1", arch_interaction_op="dot")
+    with pytest.raises(SystemExit):
+        H.M.DLRM_Net(a)          # m_spa != ln_bot[-1]
+    a.arch_mlp_bot = "4-8"
+    a.arch_interaction_op = "sum"
+    with pytest.raises(SystemExit):
+        H.M.DLRM_Net(a)          # unknown interaction op
+
+
+# ---- response reassembly + QPS / tail latency formulae -------------------------------------------
+def test_response_aggregator_matches_reference_formulae():
+    rng = np.random.RandomState(0)
+    agg = stats.ResponseAggregator(request_granularity=8)
+    sent = []
+    t = 100.0
+    expect_lat, expect_final = [], []
+    pid = []
+    for q in range(40):
+        exp_packet = q < 10
+        pieces = int(rng.randint(1, 4))
+        arr = t
+        ends = []
+        for sub in range(pieces):
+            end = arr + 0.001 * rng.randint(1, 30)
+            ends.append(end)
+            r = packets.ServiceResponse(consumer_id=sub, epoch=0, batch_id=q, batch_size=8, arrival_time=arr + 1e-6 * sub,
+                                        process_start_time=arr, queue_end_time=end, inference_end_time=end,
+                                        out_batch_size=8, sub_id=sub, total_sub_batches=pieces, exp_packet=exp_packet)
+            sent.append(r)
+        t += 0.01
+    order = rng.permutation(len(sent))
+    # a query's pieces may arrive interleaved with other queries'
+    for i in order:
+        lat, running = agg.add(sent[i])
+        if running is not None:
+            pid.append(running)
+    # restate: per key, latency = max(end) - min(arrival)
+    by = {}
+    for r in sent:
+        k = (r.epoch, r.batch_id, r.exp_packet)
+        a0, e0 = by.get(k, (np.inf, -np.inf))
+        by[k] = (min(a0, r.arrival_time), max(e0, r.inference_end_time))
+    assert sorted(agg.response_latencies) == pytest.approx(sorted(e - a for a, e in by.values()))
+    finals = [e - a for (ep, b, x), (a, e) in by.items() if not x]
+    assert sorted(agg.final_response_latencies) == pytest.approx(sorted(finals))
+    assert len(pid) == 40 // 8
+    s = agg.summary()
+    meas = [r for r in agg.responses_list if not r["exp_packet"] and r["sub_id"] == 0]
+    assert s["qps"] == pytest.approx(len(meas) / (meas[-1]["inference_end_time"] - meas[0]["inference_end_time"]))
+    assert s["p99_ms"] == pytest.approx(np.percentile(finals, 99) * 1000.)
+    # histogram route used by the multi-GPU bench agrees with the exact percentile
+    h = stats.latency_histogram(finals)
+    # (a histogram percentile is the upper edge of the bin holding the "higher" order statistic)
+    assert stats.percentile_from_histogram(h, 99) == pytest.approx(
+        np.percentile(finals, 99, method="higher") * 1e3, rel=0.01)
