@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
     ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--coalesce", type=int, default=4,
+                    help="queries per launch set (the engine coalesces requests that are already queued)")
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -93,27 +95,36 @@ def make_model(opt, device):
     return args, net, (lX, lS_l, lS_i)
 
 
-def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0):
-    """Closed loop with `slots` queries in flight.  Returns elapsed seconds."""
+def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1):
+    """Closed loop: exactly n queries, `coalesce` of them per launch set, `slots` launch
+    sets in flight.  Every query's latency runs from the submit of its launch set to the
+    moment the set's results are observed on the host.  Returns elapsed seconds."""
     t_submit = [0.0] * slots
-    busy = [False] * slots
+    in_slot = [0] * slots
     t0 = time.perf_counter()
-    for i in range(n):
-        s = i % slots
-        if busy[s]:
+    i = g = 0
+    while i < n:
+        c = min(coalesce, n - i)
+        s = g % slots
+        if in_slot[s]:
             eng.wait(s)
             if lat is not None:
-                lat.append(time.perf_counter() - t_submit[s])
+                lat.extend([time.perf_counter() - t_submit[s]] * in_slot[s])
         t_submit[s] = time.perf_counter()
-        eng.forward_async(s, (start_id + i) % nb, bs)
-        busy[s] = True
+        if c == 1:
+            eng.forward_async(s, (start_id + i) % nb, bs)
+        else:
+            eng.forward_multi_async(s, [(start_id + i + k) % nb for k in range(c)], [bs] * c)
+        in_slot[s] = c
+        i += c
+        g += 1
     for k in range(slots):
-        s = (n + k) % slots
-        if busy[s]:
+        s = (g + k) % slots
+        if in_slot[s]:
             eng.wait(s)
             if lat is not None:
-                lat.append(time.perf_counter() - t_submit[s])
-            busy[s] = False
+                lat.extend([time.perf_counter() - t_submit[s]] * in_slot[s])
+            in_slot[s] = 0
     return time.perf_counter() - t0
 
 
@@ -174,7 +185,7 @@ def main():
     for kv in opt.set:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    bs, nb, slots = opt.batch, opt.num_batches, opt.slots
+    bs, nb, slots, co = opt.batch, opt.num_batches, opt.slots, opt.coalesce
 
     def barrier():
         eng.sync()
@@ -184,11 +195,11 @@ def main():
             torch.cuda.synchronize()
 
     # warmup
-    run_queries(eng, opt.warmup, bs, nb, slots)
+    run_queries(eng, opt.warmup, bs, nb, slots, coalesce=co)
     # timed region: exactly K steps per rank, barrier + sync on both sides
     lat = []
     barrier()
-    elapsed = run_queries(eng, opt.steps, bs, nb, slots, lat)
+    elapsed = run_queries(eng, opt.steps, bs, nb, slots, lat, coalesce=co)
     barrier()
 
     # roofline leg: the same K steps with HIP events recorded around the gather launch on the
@@ -196,12 +207,12 @@ def main():
     # packets perturb the stream
     eng.reset_kernel_time()
     eng.set_profiling(True)
-    run_queries(eng, opt.steps, bs, nb, slots)
+    run_queries(eng, opt.steps, bs, nb, slots, coalesce=co)
     eng.set_profiling(False)
     ev_ms, ev_n = eng.kernel_time(N.KERNEL_SLS)          # HIP events around the launch
     sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)  # device clock stamps inside the launch
     mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
-    gbytes = eng.gather_bytes(0, bs)
+    gbytes = eng.gather_bytes(0, bs) * co          # algorithmic bytes of one gather launch
 
     from deeprecsys_amd import stats
     hist = stats.latency_histogram(lat)
@@ -229,7 +240,8 @@ def main():
                                    % (opt.workload.upper(), w["T"], w["rows"], w["D"], w["L"], w["bot"],
                                       w["top"], w["op"], bs, nb),
                        "parallelism": "dp%d (model replicated, independent queries)" % world,
-                       "slots_in_flight": slots, "inputs": "device-resident (pre-staged)"},
+                       "queries_per_launch": co, "launch_sets_in_flight": slots,
+                       "inputs": "device-resident (pre-staged)"},
             "latency_ms": {"p50": round(p50, 4), "p95": round(p95, 4), "p99": round(p99, 4),
                            "sla": SLA_MS, "sla_met": bool(p99 <= SLA_MS)},
             "roofline": {"bound": "hbm", "kernel": "sls_kernel (multi-table SparseLengthsSum)",
@@ -254,11 +266,11 @@ def main():
             for u in (4, 8, 16, 20):
                 eng.set_option("sls_exact", exact)
                 eng.set_option("sls_u", u)
-                run_queries(eng, 200, bs, nb, slots)
+                run_queries(eng, 200, bs, nb, slots, coalesce=co)
                 eng.reset_kernel_time()
-                el = run_queries(eng, 2000, bs, nb, slots)
+                el = run_queries(eng, 2000, bs, nb, slots, coalesce=co)
                 eng.set_profiling(True)
-                run_queries(eng, 1000, bs, nb, slots)
+                run_queries(eng, 1000, bs, nb, slots, coalesce=co)
                 eng.set_profiling(False)
                 ms, n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
                 results.append({"exact": exact, "u": u, "qps": round(2000 / el, 1),

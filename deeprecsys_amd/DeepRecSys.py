@@ -13,7 +13,7 @@ does) pass `cpu_engine=<callable with the inferenceEngine signature>`.
 """
 import os
 import sys
-from multiprocessing import Process, Queue
+import multiprocessing
 
 import numpy as np
 
@@ -48,6 +48,10 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
     args.accel_first_engine_id = n_cpu              # engines [n_cpu, n_cpu + n_accel) are accelerators
     say("[DeepRecSys] total inference engine ", args.inference_engines)
 
+    # "spawn", not the reference's implicit fork: a forked child of a process that has
+    # already touched the HIP runtime (a test runner, a notebook) hangs in its first HIP call
+    ctx = multiprocessing.get_context(getattr(args, "mp_start_method", "spawn"))
+    Process, Queue = ctx.Process, ctx.Queue
     requestQueue = Queue(maxsize=1024)
     accelRequestQueue = Queue(maxsize=32 * max(n_accel, 1))
     pidQueue = Queue()

@@ -39,6 +39,7 @@ SYMBOLS = [
                                     C.POINTER(_i32p)]),
     ("drs_forward", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
     ("drs_forward_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    ("drs_forward_multi_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p]),
     ("drs_wait", C.c_int32, [C.c_void_p, C.c_int32, _f32p]),
     ("drs_sync", C.c_int32, [C.c_void_p]),
     ("drs_forward_inputs", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
@@ -206,6 +207,14 @@ class Engine(object):
 
     def forward_async(self, slot, batch_id, bs):
         self._check(lib().drs_forward_async(self._h, slot, batch_id, bs), "drs_forward_async")
+
+    def forward_multi_async(self, slot, batch_ids, bss):
+        """Coalesce several queries into one set of launches; wait(slot, sum(bss)) returns
+        their outputs back to back."""
+        ids = np.ascontiguousarray(batch_ids, dtype=np.int32)
+        bs = np.ascontiguousarray(bss, dtype=np.int32)
+        self._check(lib().drs_forward_multi_async(self._h, slot, ids.size, ids.ctypes.data_as(_i32p),
+                                                  bs.ctypes.data_as(_i32p)), "drs_forward_multi_async")
 
     def wait(self, slot, bs=None):
         if bs is None:

@@ -8,6 +8,17 @@
 
 namespace drs {
 
+// Up to this many queries can be coalesced into one set of launches.  A query q owns the
+// virtual rows [vstart[q], vstart[q] + bs[q]) of the slot's activation buffers; vstart[]
+// is kept a multiple of 16 so a 16-row MLP slab never straddles two queries.
+#define DRS_MAX_COALESCE 8
+struct QTable {
+  int32_t n_q;
+  int32_t vstart[DRS_MAX_COALESCE + 1];   // virtual first row per query; [n_q] = total virtual rows
+  int32_t cum[DRS_MAX_COALESCE + 1];      // prefix sums of bs (valid samples before query q)
+  int32_t bs[DRS_MAX_COALESCE];
+};
+
 // One launch of the multi-table gather-reduce (SparseLengthsSum x T tables).
 // Bags are numbered sample-major: bag = b * T + t, so the T pooled vectors of a
 // sample land next to each other in the interaction buffer
@@ -18,17 +29,17 @@ struct SlsArgs {
   const float* tables;        // base of the table arena
   const int64_t* tab_off;     // [T] element offset of table t in the arena
   const int64_t* tab_rows;    // [T]
-  const int32_t* idx;         // [T][idx_stride] int32 indices (already narrowed = Cast op)
-  const int32_t* off;         // [T][off_stride] exclusive prefix sums of the lengths, off[t][b]
+  QTable q;                   // which query a bag belongs to
+  const int32_t* idx[DRS_MAX_COALESCE];   // per query: [T][idx_stride] int32 indices (Cast op done)
+  const int32_t* off[DRS_MAX_COALESCE];   // per query: [T][off_stride] exclusive prefix sums of lengths
+  int32_t uniform_len[DRS_MAX_COALESCE];  // per query: >= 0 -> every bag has this many indices
   int64_t idx_stride;
   int64_t off_stride;
   float* out;
-  int64_t ld_out;             // floats between consecutive samples
+  int64_t ld_out;             // floats between consecutive (virtual) samples
   int32_t col0;               // first output column of table 0
   int32_t T;
   int32_t D;
-  int32_t n_samples;          // bs
-  int32_t uniform_len;        // >= 0: every bag has exactly this many indices (off[] is not read)
   int32_t* err;               // device error word: bit0 = index out of range
   uint64_t* ts;               // optional [2 * gridDim.x] start/end wall_clock64() per workgroup
 };
@@ -50,9 +61,16 @@ struct Done {
 };
 
 // y[M, N] (ld = ldy) = act(x[M, K] (ld = ldx) . W[N, K]^T + b), k-ordered fp32 MFMA chain
+// Optional per-query sources of the FIRST layer's input rows (dense features live in the
+// staged batches, one array per query); rows of y are always virtual rows.
+struct XSrc {
+  QTable q;
+  const float* x[DRS_MAX_COALESCE];
+};
+
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                     hipStream_t stream, const Done* done = nullptr);
+                     hipStream_t stream, const Done* done = nullptr, const XSrc* xs = nullptr);
 
 // Fused chain of up to DRS_MAX_CHAIN FC layers on 16-row slabs; intermediate
 // activations never leave LDS.
@@ -69,7 +87,8 @@ struct ChainArgs {
   float* y;
   int64_t ldy;
 };
-hipError_t launch_chain(const ChainArgs& a, hipStream_t stream, const Done* done = nullptr);
+hipError_t launch_chain(const ChainArgs& a, hipStream_t stream, const Done* done = nullptr,
+                        const XSrc* xs = nullptr);
 size_t chain_lds_bytes(const ChainArgs& a);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot

@@ -77,7 +77,10 @@ struct Slot {
   size_t h_stage_bytes = 0;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool ev_pending = false;
-  int32_t last_bs = 0;
+  int32_t last_bs = 0;       // total valid samples of the job in flight
+  int32_t last_n = 0;        // queries coalesced into it
+  int32_t q_bs[DRS_MAX_COALESCE] = {0};
+  int32_t q_vstart[DRS_MAX_COALESCE] = {0};
   bool busy = false;
   bool polled = false;       // completion arrives through the host flag
 };
@@ -99,6 +102,7 @@ struct drs_engine {
   int32_t m_den = 0, w0 = 0;     // dense input width, dense_out width
   int32_t num_int = 0, n_out = 0;
   int64_t ldT = 0, ldR = 0, ldH = 0, cap = 0;
+  int64_t max_rows = 0;          // virtual rows of a slot's activation buffers
   std::vector<Batch> batches;
   std::vector<Slot> slots;
   // op-level scratch
@@ -201,7 +205,7 @@ int32_t mlp_ready(drs_engine* e, const Mlp& m, const char* name) {
 // workgroups); runs of narrow layers are fused into one LDS-resident chain.
 // Segment outputs that are not the final one ping-pong between s.H and s.Hb.
 int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ldx, int64_t M,
-                float* y, int64_t ldy, const Done* done = nullptr) {
+                float* y, int64_t ldy, const Done* done = nullptr, const XSrc* xs = nullptr) {
   const int n_layers = (int)m.layers.size();
   auto act_of = [&](int l) { return (l + 1 == m.sigmoid_layer) ? DRS_ACT_SIGMOID : DRS_ACT_RELU; };
   auto is_wide = [&](int l) {
@@ -236,77 +240,117 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
     const int64_t ldo = last ? ldy : e->ldH;
     if (standalone || chain_lds_bytes(c) > 150 * 1024) {
       HIP_TRY(e, launch_fc(in, ldin, M, m.ln[l0], m.layers[l0].W, m.layers[l0].b, m.ln[l0 + 1],
-                           act_of(l0), out, ldo, s.stream, last ? done : nullptr));
+                           act_of(l0), out, ldo, s.stream, last ? done : nullptr,
+                           l0 == 0 ? xs : nullptr));
     } else {
       c.y = out; c.ldy = ldo;
-      HIP_TRY(e, launch_chain(c, s.stream, last ? done : nullptr));
+      HIP_TRY(e, launch_chain(c, s.stream, last ? done : nullptr, l0 == 0 ? xs : nullptr));
     }
     in = out; ldin = ldo; l0 += cnt;
   }
   return DRS_OK;
 }
 
-int32_t enqueue_forward(drs_engine* e, Slot& s, const Batch& bt, int32_t bs) {
-  if (bs < 0 || bs > bt.n_samples) return fail(e, DRS_ERR_BAD_ARG, "bs=%d outside [0, %d]", bs, bt.n_samples);
+// Enqueue n >= 1 coalesced queries (query i = first bs[i] samples of *bts[i]) as ONE set of
+// launches on the slot's stream.
+int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_t* bss) {
+  if (n < 1 || n > DRS_MAX_COALESCE) return fail(e, DRS_ERR_BAD_ARG, "1..%d queries per launch, got %d", DRS_MAX_COALESCE, n);
   for (int t = 0; t < e->T; ++t)
     if (!e->table_set[t]) return fail(e, DRS_ERR_STATE, "table %d has no data", t);
   int32_t rc;
   if ((rc = mlp_ready(e, e->bot, "bottom")) || (rc = mlp_ready(e, e->top, "top")) ||
       (rc = mlp_ready(e, e->fin, "final")))
     return rc;
-  s.last_bs = bs;
+  // layout of the job: zero-sized queries take no rows
+  QTable q;
+  memset(&q, 0, sizeof q);
+  const Batch* qb[DRS_MAX_COALESCE];
+  int32_t v = 0, c = 0;
+  for (int i = 0; i < n; ++i) {
+    if (bss[i] < 0 || bss[i] > bts[i]->n_samples)
+      return fail(e, DRS_ERR_BAD_ARG, "bs=%d outside [0, %d]", bss[i], bts[i]->n_samples);
+    s.q_bs[i] = bss[i];
+    s.q_vstart[i] = v;
+    if (bss[i] == 0) continue;
+    qb[q.n_q] = bts[i];
+    q.vstart[q.n_q] = v;
+    q.cum[q.n_q] = c;
+    q.bs[q.n_q] = bss[i];
+    q.n_q++;
+    v += (bss[i] + 15) / 16 * 16;
+    c += bss[i];
+  }
+  q.vstart[q.n_q] = v;
+  q.cum[q.n_q] = c;
+  if (v > e->max_rows) return fail(e, DRS_ERR_BAD_ARG, "%d coalesced rows exceed the slot capacity %lld", v, (long long)e->max_rows);
+  s.last_n = n;
+  s.last_bs = c;
   s.busy = true;
-  if (bs == 0) return DRS_OK;
+  s.polled = false;
+  if (c == 0) return DRS_OK;
+  const int64_t Mv = v;
   const bool prof = e->profiling;
   if (prof) HIP_TRY(e, hipEventRecord(s.ev[0], s.stream));
 
   SlsArgs a;
+  memset(&a, 0, sizeof a);
   a.tables = e->tables; a.tab_off = e->d_tab_off; a.tab_rows = e->d_tab_rows;
-  a.idx = bt.idx; a.off = bt.off; a.idx_stride = e->cap; a.off_stride = e->max_batch + 1;
+  a.q = q;
+  for (int i = 0; i < q.n_q; ++i) {
+    a.idx[i] = qb[i]->idx;
+    a.off[i] = qb[i]->off;
+    a.uniform_len[i] = e->sls_uniform ? qb[i]->uniform_len : -1;
+  }
+  a.idx_stride = e->cap; a.off_stride = e->max_batch + 1;
   a.out = s.T; a.ld_out = e->ldT; a.col0 = e->kind == DRS_MODEL_NCF ? 0 : e->w0;
-  a.T = e->T; a.D = e->D; a.n_samples = bs; a.err = reinterpret_cast<int32_t*>(s.d_err);
-  a.uniform_len = e->sls_uniform ? bt.uniform_len : -1;
+  a.T = e->T; a.D = e->D; a.err = reinterpret_cast<int32_t*>(s.d_err);
   a.ts = prof ? s.d_ts : nullptr;
-  s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)bs * e->T, e->sls_exact) : 0;
+  s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, e->sls_exact) : 0;
   HIP_TRY(e, launch_sls(a, e->sls_exact, s.stream));
   if (prof) HIP_TRY(e, hipEventRecord(s.ev[1], s.stream));
 
-  // last kernel of the query: outputs either go straight to host-mapped pinned memory
+  // last kernel of the job: outputs either go straight to host-mapped pinned memory
   // followed by a flag store (zero copy, no stream sync), or to a device buffer + memcpy
   s.seq += 1;
   if (s.seq == 0) s.seq = 1;
   Done done = {s.d_counter, s.dm_out, s.dm_out + 1, s.d_err, s.seq};
   const Done* dp = e->zero_copy ? &done : nullptr;
   float* out = e->zero_copy ? reinterpret_cast<float*>(s.dm_out + 2) : s.d_out;
+  XSrc xs;
+  memset(&xs, 0, sizeof xs);
+  xs.q = q;
+  for (int i = 0; i < q.n_q; ++i) xs.x[i] = qb[i]->dense;
   if (e->kind == DRS_MODEL_NCF) {
     // mf = Sum(sls0, sls1); mlp = Concat(sls2, sls3) -> MLP; Concat(mf, mlp_out) -> FC+Relu
     const int D = e->D;
     const int wl = e->top.ln.back();
     const int64_t ldc = D + wl;
-    HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, bs, D, s.stream));
-    if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, bs, s.H2 + D, ldc))) return rc;
-    if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, bs, out, e->n_out, dp))) return rc;
+    HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, Mv, D, s.stream));
+    if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
+    if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
   } else {
     if (e->bot.layers.empty()) {
-      HIP_TRY(e, launch_copy_rows(bt.dense, e->m_den, s.T, e->ldT, bs, e->w0, s.stream));
+      for (int i = 0; i < q.n_q; ++i)
+        HIP_TRY(e, launch_copy_rows(qb[i]->dense, e->m_den, s.T + (int64_t)q.vstart[i] * e->ldT, e->ldT,
+                                    q.bs[i], e->w0, s.stream));
     } else {
-      if ((rc = run_mlp(e, s, e->bot, bt.dense, e->m_den, bs, s.T, e->ldT))) return rc;
+      if ((rc = run_mlp(e, s, e->bot, nullptr, e->m_den, Mv, s.T, e->ldT, nullptr, &xs))) return rc;
     }
     const float* top_in = s.T;
     int64_t ld_top = e->ldT;
     if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
-      HIP_TRY(e, launch_interact_dot(s.T, e->ldT, bs, e->T + 1, e->D, e->itself, s.R, e->ldR, s.stream));
+      HIP_TRY(e, launch_interact_dot(s.T, e->ldT, Mv, e->T + 1, e->D, e->itself, s.R, e->ldR, s.stream));
       top_in = s.R;
       ld_top = e->ldR;
     }
-    if ((rc = run_mlp(e, s, e->top, top_in, ld_top, bs, out, e->n_out, dp))) return rc;
+    if ((rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
   }
   if (prof) {
     HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
     s.ev_pending = true;
   }
   if (!e->zero_copy) {
-    HIP_TRY(e, hipMemcpyAsync(s.h_out + 2, s.d_out, sizeof(float) * (size_t)bs * e->n_out,
+    HIP_TRY(e, hipMemcpyAsync(s.h_out + 2, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
                               hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(e, hipMemcpyAsync(s.h_out + 1, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   }
@@ -360,8 +404,15 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
     HIP_TRY(e, hipStreamSynchronize(s.stream));
     return fail(e, DRS_ERR_INDEX_RANGE, "an embedding index was out of range on the device");
   }
-  if (h_out && s.last_bs > 0)
-    memcpy(h_out, s.h_out + 2, sizeof(float) * (size_t)s.last_bs * e->n_out);
+  if (h_out && s.last_bs > 0) {
+    // queries sit at 16-row aligned virtual offsets: pack them back to back
+    const float* src = reinterpret_cast<const float*>(s.h_out + 2);
+    size_t o = 0;
+    for (int i = 0; i < s.last_n; ++i) {
+      memcpy(h_out + o, src + (size_t)s.q_vstart[i] * e->n_out, sizeof(float) * (size_t)s.q_bs[i] * e->n_out);
+      o += (size_t)s.q_bs[i] * e->n_out;
+    }
+  }
   return DRS_OK;
 }
 
@@ -494,6 +545,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   CREATE_TRY(hipMemcpy(e->d_tab_rows, e->rows.data(), sizeof(int64_t) * T, hipMemcpyHostToDevice));
 
   e->cap = (int64_t)e->max_batch * e->max_lookups;
+  e->max_rows = (int64_t)DRS_MAX_COALESCE * ((e->max_batch + 15) / 16 * 16);
   e->ldT = e->kind == DRS_MODEL_NCF ? 4 * D : e->w0 + (int64_t)T * D;
   e->ldR = round_up(e->num_int, 4);
   int maxw = 4;
@@ -507,14 +559,14 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   const int n_out_cap = e->kind == DRS_MODEL_NCF ? 1024 : e->n_out;
   for (auto& s : e->slots) {
     CREATE_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    CREATE_TRY(hipMalloc(&s.T, sizeof(float) * (size_t)e->max_batch * e->ldT));
-    CREATE_TRY(hipMemset(s.T, 0, sizeof(float) * (size_t)e->max_batch * e->ldT));
-    CREATE_TRY(hipMalloc(&s.R, sizeof(float) * (size_t)e->max_batch * e->ldR));
-    CREATE_TRY(hipMemset(s.R, 0, sizeof(float) * (size_t)e->max_batch * e->ldR));
-    CREATE_TRY(hipMalloc(&s.H, sizeof(float) * (size_t)e->max_batch * e->ldH));
-    CREATE_TRY(hipMalloc(&s.Hb, sizeof(float) * (size_t)e->max_batch * e->ldH));
-    CREATE_TRY(hipMalloc(&s.H2, sizeof(float) * (size_t)e->max_batch * (e->num_int + 4)));
-    const size_t out_words = 2 + (size_t)e->max_batch * n_out_cap;
+    CREATE_TRY(hipMalloc(&s.T, sizeof(float) * (size_t)e->max_rows * e->ldT));
+    CREATE_TRY(hipMemset(s.T, 0, sizeof(float) * (size_t)e->max_rows * e->ldT));
+    CREATE_TRY(hipMalloc(&s.R, sizeof(float) * (size_t)e->max_rows * e->ldR));
+    CREATE_TRY(hipMemset(s.R, 0, sizeof(float) * (size_t)e->max_rows * e->ldR));
+    CREATE_TRY(hipMalloc(&s.H, sizeof(float) * (size_t)e->max_rows * e->ldH));
+    CREATE_TRY(hipMalloc(&s.Hb, sizeof(float) * (size_t)e->max_rows * e->ldH));
+    CREATE_TRY(hipMalloc(&s.H2, sizeof(float) * (size_t)e->max_rows * (e->num_int + 4)));
+    const size_t out_words = 2 + (size_t)e->max_rows * n_out_cap;
     CREATE_TRY(hipMalloc(&s.d_out, sizeof(float) * out_words));
     CREATE_TRY(hipMalloc(&s.d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&s.d_counter, sizeof(uint32_t)));
@@ -524,8 +576,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipHostMalloc(&s.h_out, sizeof(uint32_t) * out_words, hipHostMallocMapped | hipHostMallocCoherent));
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_out), s.h_out, 0));
-    CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_batch * T));
-    s.h_ts.resize(2 * (size_t)e->max_batch * T);
+    CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_rows * T));
+    s.h_ts.resize(2 * (size_t)e->max_rows * T);
     for (auto& ev : s.ev) CREATE_TRY(hipEventCreate(&ev));
     if (alloc_batch(e, s.scratch)) return bail(DRS_ERR_OOM, e->err.c_str());
     s.scratch.n_samples = 0;
@@ -685,7 +737,25 @@ int32_t drs_forward_async(drs_handle e, int32_t slot, int32_t batch_id, int32_t 
     return fail(e, DRS_ERR_STATE, "batch %d is not staged", batch_id);
   Slot& s = e->slots[slot];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
-  return enqueue_forward(e, s, e->batches[batch_id], bs);
+  const Batch* bt = &e->batches[batch_id];
+  return enqueue_forward(e, s, 1, &bt, &bs);
+}
+
+int32_t drs_forward_multi_async(drs_handle e, int32_t slot, int32_t n, const int32_t* batch_ids,
+                                const int32_t* bs) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  if (!batch_ids || !bs || n < 1 || n > DRS_MAX_COALESCE) return fail(e, DRS_ERR_BAD_ARG, "1..%d queries per launch", DRS_MAX_COALESCE);
+  const Batch* bts[DRS_MAX_COALESCE];
+  for (int i = 0; i < n; ++i) {
+    if (batch_ids[i] < 0 || batch_ids[i] >= e->n_batches || !e->batches[batch_ids[i]].staged)
+      return fail(e, DRS_ERR_STATE, "batch %d is not staged", batch_ids[i]);
+    bts[i] = &e->batches[batch_ids[i]];
+  }
+  Slot& s = e->slots[slot];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  return enqueue_forward(e, s, n, bts, bs);
 }
 
 int32_t drs_wait(drs_handle e, int32_t slot, float* h_out) {
@@ -721,7 +791,8 @@ int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* 
   Slot& s = e->slots[slot];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
   if ((rc = stage_into(e, s.scratch, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage))) return rc;
-  if ((rc = enqueue_forward(e, s, s.scratch, bs))) return rc;
+  const Batch* bt = &s.scratch;
+  if ((rc = enqueue_forward(e, s, 1, &bt, &bs))) return rc;
   return wait_slot(e, s, h_out);
 }
 
@@ -789,9 +860,11 @@ int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const i
   if (r == hipSuccess) r = hipMemset(d_err, 0, sizeof(int32_t));
   if (r == hipSuccess) {
     SlsArgs a;
+    memset(&a, 0, sizeof a);
     a.tables = d_W; a.tab_off = e->d_op_tab; a.tab_rows = e->d_op_tab + 1;
-    a.idx = d_idx; a.off = d_off; a.idx_stride = 0; a.off_stride = 0;
-    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.n_samples = (int32_t)n_bags; a.err = d_err; a.ts = nullptr; a.uniform_len = -1;
+    a.q.n_q = 1; a.q.vstart[1] = (int32_t)n_bags; a.q.cum[1] = (int32_t)n_bags; a.q.bs[0] = (int32_t)n_bags;
+    a.idx[0] = d_idx; a.off[0] = d_off; a.uniform_len[0] = -1;
+    a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.err = d_err; a.ts = nullptr;
     r = launch_sls(a, exact_order, s.stream);
   }
   if (r == hipSuccess) r = hipStreamSynchronize(s.stream);

@@ -16,6 +16,8 @@
 // double-buffered; rows are padded to 68 floats so the staging ds_write_b128 and
 // the per-lane ds_read_b32 operand fetches stay (almost) conflict free.  In the
 // chained form the activations of a slab never leave LDS between layers.
+#include <string.h>
+
 #include "drs_internal.h"
 
 namespace drs {
@@ -84,6 +86,8 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks) {
 struct LayerIo {
   const float* a_glb;   // A operand in global memory (first layer) or nullptr
   int64_t lda_glb;
+  int64_t a_row0;       // first row of this slab inside a_glb ...
+  int64_t a_rows;       // ... which has this many valid rows
   const float* a_lds;   // A operand: activation slab in LDS (later layers) or nullptr
   int lda_lds;
   float* o_glb;         // output to global (last layer) or nullptr
@@ -118,7 +122,7 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int idx = tid + i * 256;
-        if (!A_LDS) ra[i] = load4_raw<VEC>(io.a_glb, io.lda_glb, m0 + idx / QPR, M, kc + (idx % QPR) * 4, K);
+        if (!A_LDS) ra[i] = load4_raw<VEC>(io.a_glb, io.lda_glb, io.a_row0 + idx / QPR, io.a_rows, kc + (idx % QPR) * 4, K);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -199,17 +203,37 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
   }
 }
 
+// Where do the 16 input rows of the slab starting at virtual row m0 come from?  With
+// coalesced queries the first layer reads each query's own staged dense array.
+__device__ __forceinline__ void resolve_src(const XSrc& xs, const float* x, int64_t M, int64_t m0,
+                                            const float** base, int64_t* row0, int64_t* rows) {
+  *base = x; *row0 = m0; *rows = M;
+  if (xs.q.n_q > 0) {
+    const float* p = xs.x[0];
+    int lo = xs.q.vstart[0], n = xs.q.bs[0];
+#pragma unroll
+    for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < xs.q.n_q && m0 >= xs.q.vstart[i];
+      p = in ? xs.x[i] : p;
+      lo = in ? xs.q.vstart[i] : lo;
+      n = in ? xs.q.bs[i] : n;
+    }
+    *base = p; *row0 = m0 - lo; *rows = n;
+  }
+}
+
 // Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64-column group.
 template <bool VEC, int KC>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
                                                  float* __restrict__ y, int64_t ldy, int nbuf,
-                                                 Done done) {
+                                                 Done done, XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                              // [nbuf][16][KC+4]
   float* sB = sA + nbuf * BM * (KC + 4);         // [nbuf][64][KC+4]
-  LayerIo io = {x, ldx, nullptr, 0, y, ldy, nullptr, 0};
+  LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0};
+  resolve_src(xs, x, M, (int64_t)blockIdx.x * BM, &io.a_glb, &io.a_row0, &io.a_rows);
   const int n0 = blockIdx.y * BN;
   layer_pass<false, false, VEC, KC>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0,
                                     min(n0 + BN, N), act, nbuf, sA, sB);
@@ -218,7 +242,8 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, in
 
 // Chain of layers on a 16-row slab; activations ping-pong between two LDS slabs.
 template <bool VEC, int KC>
-__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, int nbuf, Done done) {
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, int nbuf, Done done,
+                                                    XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                              // [nbuf][16][KC+4]
   float* sB = sA + nbuf * BM * (KC + 4);         // [nbuf][64][KC+4]
@@ -237,7 +262,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, in
     const bool first = l == 0, last = l == a.n_layers - 1;
     float* nxt = (l & 1) ? slab1 : slab0;
     LayerIo io;
-    io.a_glb = first ? a.x : nullptr;
+    io.a_glb = nullptr;
+    io.a_row0 = io.a_rows = 0;
+    if (first) resolve_src(xs, a.x, a.M, m0, &io.a_glb, &io.a_row0, &io.a_rows);
     io.lda_glb = a.ldx;
     io.a_lds = first ? nullptr : cur;
     io.lda_lds = slab_ld;
@@ -370,25 +397,29 @@ static hipError_t init_mlp_kernels() {
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                     hipStream_t s, const Done* done) {
+                     hipStream_t s, const Done* done, const XSrc* xsrc) {
   if (M <= 0) return hipSuccess;
   Done d = {nullptr, nullptr, nullptr, nullptr, 0};
   if (done) d = *done;
+  XSrc xs;
+  memset(&xs, 0, sizeof xs);
+  if (xsrc) xs = *xsrc;
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
   int kc = 64, nbuf = 2;
   if (!pick_kc(K, 0, &kc, &nbuf)) return hipErrorInvalidValue;
   const size_t lds = stage_bytes(kc, nbuf);
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-  const bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
+  bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
+  for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
     if (vec)                                                                                      \
       hipLaunchKernelGGL((fc_kernel<true, KC_>), grid, dim3(256), lds, s, x, ldx, M, K, W,        \
-                         (int64_t)K, b, N, act, y, ldy, nbuf, d);                                 \
+                         (int64_t)K, b, N, act, y, ldy, nbuf, d, xs);                             \
     else                                                                                          \
       hipLaunchKernelGGL((fc_kernel<false, KC_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
-                         (int64_t)K, b, N, act, y, ldy, nbuf, d);                                 \
+                         (int64_t)K, b, N, act, y, ldy, nbuf, d, xs);                             \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
@@ -416,10 +447,13 @@ size_t chain_lds_bytes(const ChainArgs& a) {
   return chain_plan(a, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
 }
 
-hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done) {
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
   if (a.M <= 0) return hipSuccess;
   Done d = {nullptr, nullptr, nullptr, nullptr, 0};
   if (done) d = *done;
+  XSrc xs;
+  memset(&xs, 0, sizeof xs);
+  if (xsrc) xs = *xsrc;
   if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN) return hipErrorInvalidValue;
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
@@ -428,15 +462,16 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done) {
   if (!chain_plan(a, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
   bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
+  for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
   const dim3 grid((unsigned)((a.M + BM - 1) / BM));
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
     if (vec)                                                                                      \
       hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, chain_slab_ld(a), \
-                         nbuf, d);                                                                \
+                         nbuf, d, xs);                                                                \
     else                                                                                          \
       hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a,                  \
-                         chain_slab_ld(a), nbuf, d);                                              \
+                         chain_slab_ld(a), nbuf, d, xs);                                              \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH

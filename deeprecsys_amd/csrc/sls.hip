@@ -99,24 +99,38 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   const int col = min(gl * V, a.D - V);       // clamp idle lanes onto valid columns
   const bool col_ok = gl * V < a.D;
 
-  const int64_t n_bags = (int64_t)a.n_samples * a.T;
+  const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
   const int64_t bag = (int64_t)blockIdx.x * BAGS + (EXACT ? g : 0);
   const bool bag_ok = bag < n_bags;
-  const int b = bag_ok ? (int)(bag / a.T) : 0;
-  const int t = bag_ok ? (int)(bag - (int64_t)b * a.T) : 0;
+  const int smp = bag_ok ? (int)(bag / a.T) : 0;            // valid-sample number over all queries
+  const int t = bag_ok ? (int)(bag - (int64_t)smp * a.T) : 0;
+  // which coalesced query owns this sample: select chain over <= 8 entries (no dynamic
+  // indexing of the kernel-argument arrays)
+  int b = smp, vrow = a.q.vstart[0] + smp, ulen = a.uniform_len[0];
+  const int32_t* qidx = a.idx[0];
+  const int32_t* qoff = a.off[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    ulen = in ? a.uniform_len[i] : ulen;
+    qidx = in ? a.idx[i] : qidx;
+    qoff = in ? a.off[i] : qoff;
+  }
 
   // fixed-length bags (every shipped reference config: num_indices_per_lookup_fixed) need
   // no offsets: one dependent HBM round trip less before the first row load can issue
   int beg, end;
-  if (a.uniform_len >= 0) {
-    beg = bag_ok ? b * a.uniform_len : 0;
-    end = bag_ok ? beg + a.uniform_len : 0;
+  if (ulen >= 0) {
+    beg = bag_ok ? b * ulen : 0;
+    end = bag_ok ? beg + ulen : 0;
   } else {
-    const int32_t* __restrict__ offp = a.off + (int64_t)t * a.off_stride;
+    const int32_t* __restrict__ offp = qoff + (int64_t)t * a.off_stride;
     beg = bag_ok ? offp[b] : 0;
     end = bag_ok ? offp[b + 1] : 0;
   }
-  const int32_t* __restrict__ ip = a.idx + (int64_t)t * a.idx_stride;
+  const int32_t* __restrict__ ip = qidx + (int64_t)t * a.idx_stride;
   const float* __restrict__ W = a.tables + a.tab_off[t] + col;
   const uint32_t rows = (uint32_t)a.tab_rows[t];
   const int64_t D = a.D;
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   }
   if (bad) atomicOr(a.err, 1);
   if (bag_ok && col_ok && (EXACT || g == 0)) {
-    float* o = a.out + (int64_t)b * a.ld_out + a.col0 + (int64_t)t * D + col;
+    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)t * D + col;
     *reinterpret_cast<vec*>(o) = acc;
   }
   if (a.ts) {
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
 
 template <int G, int V, int U>
 hipError_t launch_variant(const SlsArgs& a, int exact, hipStream_t s) {
-  const int64_t n_bags = (int64_t)a.n_samples * a.T;
+  const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
   if (n_bags == 0) return hipSuccess;
   if (exact) {
     constexpr int BAGS = 64 / G;

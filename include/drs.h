@@ -145,6 +145,14 @@ int32_t drs_forward(drs_handle h, int32_t batch_id, int32_t bs, float* h_out);
  * pinned buffer; drs_wait blocks for that slot and copies to h_out (may be NULL
  * to only wait).  Slots are independent HIP streams and may overlap.           */
 int32_t drs_forward_async(drs_handle h, int32_t slot, int32_t batch_id, int32_t bs);
+/* Query coalescing: n (1..8) queries -- query i = first bs[i] samples of staged batch
+ * batch_ids[i] -- run as ONE set of launches (one gather over all their bags, one MLP
+ * pass over all their rows).  This is what the engine does when several requests are
+ * already waiting in its queue; drs_wait then returns the n results back to back,
+ * [sum(bs), n_out].  drs_forward_async is the n == 1 case.                         */
+#define DRS_MAX_COALESCE 8
+int32_t drs_forward_multi_async(drs_handle h, int32_t slot, int32_t n, const int32_t* batch_ids,
+                                const int32_t* bs);
 int32_t drs_wait(drs_handle h, int32_t slot, float* h_out);
 int32_t drs_sync(drs_handle h);
 /* non-staged inputs (the run_queues(ids, lengths, fc, bs) signature,

@@ -297,3 +297,30 @@ def test_engine_ragged_bags_and_device_error_path():
         assert net.run_staged(0, B).shape == (B, 1)
     finally:
         net.engine.close()
+
+
+@pytest.mark.parametrize("kind", ["dlrm_dot", "wnd", "ncf"])
+def test_coalesced_queries_equal_individual_queries(kind):
+    """drs_forward_multi_async: several queries in one set of launches return exactly the
+    bits of the same queries run one by one (rows never mix)."""
+    case = {"dlrm_dot": "dlrm_rm1_mini", "wnd": "wnd_mini", "ncf": "ncf_mini"}[kind]
+    meta, z = H.load_fixture(case)
+    over = dict(arch_interaction_op="dot", arch_mlp_top="128-1") if kind == "dlrm_dot" else {}
+    args = H.args_from(meta["args"], num_batches=2 if kind == "dlrm_dot" else 1, accel_slots=2, **over)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    try:
+        net.stage_batches(None if kind == "ncf" else lX, lS_l, lS_i)
+        eng = net.engine
+        n, nb = len(lS_l[0][0]), len(lS_l)
+        for exact in (1, 0):
+            eng.set_option("sls_exact", exact)
+            jobs = [(0, n), (nb - 1, 1), (0, 0), (nb - 1, n - 3), (0, 5), (nb - 1, n), (0, 2), (0, n)]
+            singles = [eng.forward(b, bs) for b, bs in jobs]
+            eng.forward_multi_async(1, [b for b, _ in jobs], [bs for _, bs in jobs])
+            got = eng.wait(1, sum(bs for _, bs in jobs))
+            assert np.array_equal(got, np.concatenate(singles, axis=0))
+        with pytest.raises(N.DrsError):
+            eng.forward_multi_async(0, [0] * 9, [1] * 9)
+    finally:
+        net.engine.close()
