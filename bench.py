@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
-    ap.add_argument("--slots", type=int, default=4)
-    ap.add_argument("--coalesce", type=int, default=4,
+    ap.add_argument("--slots", type=int, default=2)
+    ap.add_argument("--coalesce", type=int, default=8,
                     help="queries per launch set (the engine coalesces requests that are already queued)")
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
@@ -213,6 +213,12 @@ def main():
     sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)  # device clock stamps inside the launch
     mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
     gbytes = eng.gather_bytes(0, bs) * co          # algorithmic bytes of one gather launch
+    # reference point: the same gather serving ONE query per launch, nothing else in flight
+    eng.reset_kernel_time()
+    eng.set_profiling(True)
+    run_queries(eng, 300, bs, nb, 1, coalesce=1)
+    eng.set_profiling(False)
+    one_ms, one_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
 
     from deeprecsys_amd import stats
     hist = stats.latency_histogram(lat)
@@ -254,7 +260,10 @@ def main():
                          "timer": "device wall clock stamps of the launch's own workgroups "
                                   "(max end - min start); hip-event bracket for comparison",
                          "hip_event_avg_us": None if not ev_n else round(ev_ms / ev_n * 1e3, 3),
-                         "rest_of_query_event_us": None if not mlp_n else round(mlp_ms / mlp_n * 1e3, 3)},
+                         "rest_of_launch_set_event_us": None if not mlp_n else round(mlp_ms / mlp_n * 1e3, 3),
+                         "single_query_launch": None if not one_n else {
+                             "bytes": gbytes // co, "avg_launch_us": round(one_ms / one_n * 1e3, 3),
+                             "frac": round(gbytes / co / (one_ms / one_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
         }
         if not opt.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt, net, data, opt.cpu_seconds)

@@ -124,6 +124,17 @@ class _HipNet(object):
         self._out = self.engine.forward(int(batch_id), int(batch_size))
         return self._out
 
+    def run_staged_multi(self, batch_ids, batch_sizes, slot=0):
+        """Several queued queries in one set of launches (drs_forward_multi_async); returns
+        the list of their [bs_i, n_out] outputs."""
+        sizes = [int(b) for b in batch_sizes]
+        self.engine.forward_multi_async(slot, [int(b) for b in batch_ids], sizes)
+        out = self.engine.wait(slot, sum(sizes))
+        cuts = np.cumsum(sizes)[:-1]
+        outs = np.split(out, cuts, axis=0)
+        self._out = outs[-1]
+        return outs
+
     def fetch_output(self):
         """FetchBlob("prob_click") counterpart: [bs, n_out] float32 of the last run."""
         return self._out
