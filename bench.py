@@ -196,28 +196,33 @@ def main():
 
     # warmup
     run_queries(eng, opt.warmup, bs, nb, slots, coalesce=co)
-    # timed region: exactly K steps per rank, barrier + sync on both sides
+    # timed region: exactly K steps per rank, barrier + sync on both sides.  Profiling level 1
+    # (device clock stamps of the gather launch, handed over with the results: no copy, no
+    # sync, no extra launch) stays on inside it, so the roofline figure is taken over the
+    # timed region itself.
     lat = []
+    eng.reset_kernel_time()
+    eng.set_profiling(1)
     barrier()
     elapsed = run_queries(eng, opt.steps, bs, nb, slots, lat, coalesce=co)
     barrier()
-
-    # roofline leg: the same K steps with HIP events recorded around the gather launch on the
-    # stream it is launched on (drs_set_profiling); kept out of `value` because the event
-    # packets perturb the stream
-    eng.reset_kernel_time()
-    eng.set_profiling(True)
-    run_queries(eng, opt.steps, bs, nb, slots, coalesce=co)
-    eng.set_profiling(False)
-    ev_ms, ev_n = eng.kernel_time(N.KERNEL_SLS)          # HIP events around the launch
-    sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)  # device clock stamps inside the launch
-    mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
+    eng.set_profiling(0)
+    sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
     gbytes = eng.gather_bytes(0, bs) * co          # algorithmic bytes of one gather launch
+
+    # cross-check leg (not part of `value`): HIP events recorded around the gather launch on the
+    # stream it is launched on; they bracket several us of packet processing as well
+    eng.reset_kernel_time()
+    eng.set_profiling(2)
+    run_queries(eng, min(opt.steps, 1000), bs, nb, slots, coalesce=co)
+    eng.set_profiling(0)
+    ev_ms, ev_n = eng.kernel_time(N.KERNEL_SLS)
+    mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
     # reference point: the same gather serving ONE query per launch, nothing else in flight
     eng.reset_kernel_time()
-    eng.set_profiling(True)
+    eng.set_profiling(1)
     run_queries(eng, 300, bs, nb, 1, coalesce=1)
-    eng.set_profiling(False)
+    eng.set_profiling(0)
     one_ms, one_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
 
     from deeprecsys_amd import stats
@@ -278,9 +283,9 @@ def main():
                 run_queries(eng, 200, bs, nb, slots, coalesce=co)
                 eng.reset_kernel_time()
                 el = run_queries(eng, 2000, bs, nb, slots, coalesce=co)
-                eng.set_profiling(True)
+                eng.set_profiling(1)
                 run_queries(eng, 1000, bs, nb, slots, coalesce=co)
-                eng.set_profiling(False)
+                eng.set_profiling(0)
                 ms, n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
                 results.append({"exact": exact, "u": u, "qps": round(2000 / el, 1),
                                 "sls_us": round(ms / n * 1e3, 3),

@@ -260,8 +260,9 @@ class Engine(object):
     def set_option(self, key, value):
         self._check(lib().drs_set_option(self._h, key.encode(), int(value)), "drs_set_option")
 
-    def set_profiling(self, enabled):
-        self._check(lib().drs_set_profiling(self._h, int(bool(enabled))), "drs_set_profiling")
+    def set_profiling(self, level):
+        """0 off | 1 device clock stamps of the gather launch (free) | 2 also HIP events."""
+        self._check(lib().drs_set_profiling(self._h, int(level)), "drs_set_profiling")
 
     def kernel_time(self, kernel):
         ms, n = C.c_double(0), C.c_int64(0)

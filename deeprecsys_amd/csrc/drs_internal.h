@@ -10,7 +10,7 @@ namespace drs {
 
 // Up to this many queries can be coalesced into one set of launches.  A query q owns the
 // virtual rows [vstart[q], vstart[q] + bs[q]) of the slot's activation buffers; vstart[]
-// is kept a multiple of 16 so a 16-row MLP slab never straddles two queries.
+// is kept a multiple of 64 so a 16- or 64-row MLP block never straddles two queries.
 #define DRS_MAX_COALESCE 8
 struct QTable {
   int32_t n_q;
@@ -58,6 +58,12 @@ struct Done {
   uint32_t* host_err;       // host-mapped: receives *dev_err
   const uint32_t* dev_err;  // device error word written by earlier kernels of the query
   uint32_t seq;
+  // live timing of the gather launch: its per-workgroup [start, end] clock stamps are
+  // reduced to (min start, max end) by the same last-arriving workgroup and stored in
+  // host-mapped memory, so profiling adds no copy, no sync and no extra launch
+  const uint64_t* ts;       // [2 * ts_blocks] or nullptr
+  uint32_t ts_blocks;
+  uint64_t* host_span;      // host-mapped [2]
 };
 
 // y[M, N] (ld = ldy) = act(x[M, K] (ld = ldx) . W[N, K]^T + b), k-ordered fp32 MFMA chain

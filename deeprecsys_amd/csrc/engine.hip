@@ -23,6 +23,7 @@
 namespace drs {
 extern int g_sls_u;
 extern int g_sls_v_d32;
+extern int g_mlp_rs_rows;
 }  // namespace drs
 
 using namespace drs;
@@ -71,7 +72,9 @@ struct Slot {
   uint32_t seq = 0;          // sequence number of the query in flight on this slot
   uint64_t* d_ts = nullptr;  // [2 * max gather workgroups] device clock stamps (profiling)
   std::vector<uint64_t> h_ts;
-  int64_t ts_blocks = 0;
+  int64_t ts_blocks = 0, ts_blocks_done = 0;
+  uint64_t* h_span = nullptr;  // pinned [2]: (min start, max end) of the gather launch
+  uint64_t* dm_span = nullptr;
   Batch scratch;             // drs_forward_inputs staging
   void* h_stage = nullptr;   // pinned host staging for forward_inputs
   size_t h_stage_bytes = 0;
@@ -110,7 +113,7 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1;
   // profiling
-  bool profiling = false;
+  int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
   int64_t k_n[DRS_KERNEL_COUNT] = {0, 0, 0};
   double wall_clock_khz = 100000.0;
@@ -277,7 +280,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     q.cum[q.n_q] = c;
     q.bs[q.n_q] = bss[i];
     q.n_q++;
-    v += (bss[i] + 15) / 16 * 16;
+    v += (bss[i] + 63) / 64 * 64;   // whole 64-row MLP blocks per query
     c += bss[i];
   }
   q.vstart[q.n_q] = v;
@@ -289,8 +292,9 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   s.polled = false;
   if (c == 0) return DRS_OK;
   const int64_t Mv = v;
-  const bool prof = e->profiling;
-  if (prof) HIP_TRY(e, hipEventRecord(s.ev[0], s.stream));
+  const bool prof = e->profiling >= 1;
+  const bool evts = e->profiling >= 2;
+  if (evts) HIP_TRY(e, hipEventRecord(s.ev[0], s.stream));
 
   SlsArgs a;
   memset(&a, 0, sizeof a);
@@ -307,13 +311,17 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   a.ts = prof ? s.d_ts : nullptr;
   s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, e->sls_exact) : 0;
   HIP_TRY(e, launch_sls(a, e->sls_exact, s.stream));
-  if (prof) HIP_TRY(e, hipEventRecord(s.ev[1], s.stream));
+  if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.stream));
 
   // last kernel of the job: outputs either go straight to host-mapped pinned memory
   // followed by a flag store (zero copy, no stream sync), or to a device buffer + memcpy
   s.seq += 1;
   if (s.seq == 0) s.seq = 1;
-  Done done = {s.d_counter, s.dm_out, s.dm_out + 1, s.d_err, s.seq};
+  Done done;
+  memset(&done, 0, sizeof done);
+  done.counter = s.d_counter; done.host_flag = s.dm_out; done.host_err = s.dm_out + 1;
+  done.dev_err = s.d_err; done.seq = s.seq;
+  if (prof && e->zero_copy) { done.ts = s.d_ts; done.ts_blocks = (uint32_t)s.ts_blocks; done.host_span = s.dm_span; }
   const Done* dp = e->zero_copy ? &done : nullptr;
   float* out = e->zero_copy ? reinterpret_cast<float*>(s.dm_out + 2) : s.d_out;
   XSrc xs;
@@ -345,7 +353,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     }
     if ((rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
   }
-  if (prof) {
+  if (evts) {
     HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
     s.ev_pending = true;
   }
@@ -387,16 +395,24 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
     if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) { e->k_ms[DRS_KERNEL_SLS] += ms; e->k_n[DRS_KERNEL_SLS]++; }
     if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) { e->k_ms[DRS_KERNEL_MLP] += ms; e->k_n[DRS_KERNEL_MLP]++; }
     s.ev_pending = false;
-    if (s.ts_blocks > 0) {
+  }
+  if (s.ts_blocks > 0) {
+    uint64_t lo = ~0ull, hi = 0;
+    if (s.polled) {
+      lo = s.h_span[0]; hi = s.h_span[1];       // reduced on the device, see Done
+    } else {
       HIP_TRY(e, hipMemcpy(s.h_ts.data(), s.d_ts, sizeof(uint64_t) * 2 * (size_t)s.ts_blocks, hipMemcpyDeviceToHost));
-      uint64_t lo = ~0ull, hi = 0;
       for (int64_t i = 0; i < s.ts_blocks; ++i) {
         lo = s.h_ts[2 * i] < lo ? s.h_ts[2 * i] : lo;
         hi = s.h_ts[2 * i + 1] > hi ? s.h_ts[2 * i + 1] : hi;
       }
+    }
+    if (hi > lo) {
       e->k_ms[DRS_KERNEL_SLS_CLOCK] += (double)(hi - lo) / e->wall_clock_khz;
       e->k_n[DRS_KERNEL_SLS_CLOCK]++;
     }
+    s.ts_blocks_done = s.ts_blocks;
+    s.ts_blocks = 0;
   }
   if (s.last_bs > 0 && s.h_out[1] != 0) {
     s.h_out[1] = 0;
@@ -545,7 +561,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   CREATE_TRY(hipMemcpy(e->d_tab_rows, e->rows.data(), sizeof(int64_t) * T, hipMemcpyHostToDevice));
 
   e->cap = (int64_t)e->max_batch * e->max_lookups;
-  e->max_rows = (int64_t)DRS_MAX_COALESCE * ((e->max_batch + 15) / 16 * 16);
+  e->max_rows = (int64_t)DRS_MAX_COALESCE * ((e->max_batch + 63) / 64 * 64);
   e->ldT = e->kind == DRS_MODEL_NCF ? 4 * D : e->w0 + (int64_t)T * D;
   e->ldR = round_up(e->num_int, 4);
   int maxw = 4;
@@ -577,6 +593,9 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_out), s.h_out, 0));
     CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_rows * T));
+    CREATE_TRY(hipHostMalloc(&s.h_span, sizeof(uint64_t) * 2, hipHostMallocMapped | hipHostMallocCoherent));
+    s.h_span[0] = s.h_span[1] = 0;
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_span), s.h_span, 0));
     s.h_ts.resize(2 * (size_t)e->max_rows * T);
     for (auto& ev : s.ev) CREATE_TRY(hipEventCreate(&ev));
     if (alloc_batch(e, s.scratch)) return bail(DRS_ERR_OOM, e->err.c_str());
@@ -604,6 +623,7 @@ int32_t drs_destroy(drs_handle e) {
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.d_err) (void)hipFree(s.d_err);
     if (s.d_ts) (void)hipFree(s.d_ts);
+    if (s.h_span) (void)hipHostFree(s.h_span);
     if (s.d_counter) (void)hipFree(s.d_counter);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_stage) (void)hipHostFree(s.h_stage);
@@ -910,6 +930,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_rs_rows") && value >= 0) g_mlp_rs_rows = value == 0 ? (1 << 30) : (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;
@@ -918,7 +939,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
 int32_t drs_set_profiling(drs_handle e, int32_t enabled) {
   if (!e) return DRS_ERR_BAD_ARG;
   int32_t rc = drs_sync(e);
-  e->profiling = enabled != 0;
+  e->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
   return rc;
 }
 
@@ -932,7 +953,10 @@ int32_t drs_kernel_time(drs_handle e, int32_t kernel, double* sum_ms, int64_t* l
 int32_t drs_debug_gather_stamps(drs_handle e, int32_t slot, uint64_t* out, int64_t cap, int64_t* n_blocks) {
   if (!e || slot < 0 || slot >= e->n_slots || !out || !n_blocks) return DRS_ERR_BAD_ARG;
   Slot& s = e->slots[slot];
-  const int64_t n = s.ts_blocks < cap / 2 ? s.ts_blocks : cap / 2;
+  if (hipSetDevice(e->device) != hipSuccess) return DRS_ERR_HIP;
+  const int64_t n = s.ts_blocks_done < cap / 2 ? s.ts_blocks_done : cap / 2;
+  if (n > 0 && hipMemcpy(s.h_ts.data(), s.d_ts, sizeof(uint64_t) * 2 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    return DRS_ERR_HIP;
   memcpy(out, s.h_ts.data(), sizeof(uint64_t) * 2 * (size_t)n);
   *n_blocks = n;
   return DRS_OK;

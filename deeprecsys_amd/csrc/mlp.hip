@@ -25,7 +25,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 16;         // rows per slab
 constexpr int BN = 64;         // columns per pass (4 waves x 16)
 // K chunk staged per step is a template parameter KC in {64, 128, 192, 256}: a dependent
 // global-load round costs ~1 us on this chip (Infinity-Cache latency; per-XCD L2s start
@@ -68,18 +67,51 @@ __device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
 // see Done in drs_internal.h.  Every thread fences its own output stores at system
 // scope, the workgroup joins, then one lane takes a ticket; the workgroup that draws
 // the last ticket knows all outputs are visible and publishes the flag.
-__device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks) {
+__device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, void* lds_scratch) {
   if (!d.counter) return;
+  unsigned* s_u = reinterpret_cast<unsigned*>(lds_scratch);   // dynamic LDS is free by now
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == n_blocks - 1) {
-      __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_u[0] = old == n_blocks - 1;
+  }
+  __syncthreads();
+  if (!s_u[0]) return;
+  // last workgroup of the launch: everything the query produced is visible
+  unsigned long long lo = ~0ull, hi = 0ull;
+  if (d.ts) {
+    for (unsigned i = threadIdx.x; i < d.ts_blocks; i += blockDim.x) {
+      const unsigned long long a = d.ts[2 * i], b = d.ts[2 * i + 1];
+      lo = a < lo ? a : lo;
+      hi = b > hi ? b : hi;
     }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const unsigned long long lo2 = __shfl_xor(lo, m), hi2 = __shfl_xor(hi, m);
+      lo = lo2 < lo ? lo2 : lo;
+      hi = hi2 > hi ? hi2 : hi;
+    }
+    unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (unsigned w = 1; w < blockDim.x / 64; ++w) {
+        lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
+        hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d.ts) {
+      __hip_atomic_store(d.host_span, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(d.host_span + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -96,27 +128,40 @@ struct LayerIo {
   int ldo_lds;
 };
 
-// One layer for the slab rows [m0, m0+16) and the columns [n_begin, n_end).
-// sA: [nbuf][16][KC+4] (used only when A comes from global), sB: [nbuf][64][KC+4];
+// One layer for the block's rows [m0, m0+BMK) and the columns [n_begin, n_end).
+//   RS = false ("column split", few rows in flight, e.g. one query): BMK = 16 rows, the 4
+//        waves take 16 columns each of a 64-column pass -> 1 accumulator per wave, many
+//        workgroups even at M = 256.
+//   RS = true ("row split", coalesced queries, M >= ~1000): BMK = 64 rows, wave w owns
+//        rows [16w, 16w+16) and all 64 columns of the pass -> 4 independent accumulators
+//        per wave (MFMA issue-bound instead of dependent-latency-bound) and every staged
+//        W tile is shared by 4x more rows (4x less W traffic through L2 / Infinity Cache).
+// Either way every output element is one k-ordered fma chain.
+// sA: [nbuf][BMK][KC+4] (used only when A comes from global), sB: [nbuf][64][KC+4];
 // nbuf = 2 (double buffered) when the layer needs more than one K chunk, else 1.
-template <bool A_LDS, bool O_LDS, bool VEC, int KC>
+template <bool A_LDS, bool O_LDS, bool VEC, int KC, bool RS>
 __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K,
                                            const float* __restrict__ W, int64_t ldw,
                                            const float* __restrict__ bias, int N, int n_begin,
                                            int n_end, int act, int nbuf, float* sA, float* sB) {
+  constexpr int BMK = RS ? 64 : 16;
+  constexpr int NT = RS ? 4 : 1;         // accumulators (16-column tiles) per wave
   constexpr int LD = KC + 4;
-  constexpr int QPR = KC / 4;          // float4 per staged row
-  constexpr int NA = KC / 64;          // float4 of A per thread per chunk
-  constexpr int NB = KC / 16;          // float4 of W per thread per chunk
+  constexpr int QPR = KC / 4;            // float4 per staged row
+  constexpr int NA = BMK * KC / 1024;    // float4 of A per thread per chunk
+  constexpr int NB = KC / 16;            // float4 of W per thread per chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int r = lane & 15;   // row of A / column of the tile
   const int g = lane >> 4;   // k within an MFMA step
+  const int arow = RS ? 16 * wave + r : r;          // this lane's A row inside the block
   const int n_chunks = (K + KC - 1) / KC;
 
   for (int n0 = n_begin; n0 < n_end; n0 += BN) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 ra[NA], rb[NB];
     auto fetch = [&](int kc) {
 #pragma unroll
@@ -135,7 +180,7 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       for (int i = 0; i < NA; ++i) {
         const int idx = tid + i * 256;
         if (!A_LDS)
-          *reinterpret_cast<float4*>(sA + (buf * BM + idx / QPR) * LD + (idx % QPR) * 4) =
+          *reinterpret_cast<float4*>(sA + (buf * BMK + idx / QPR) * LD + (idx % QPR) * 4) =
               mask4(ra[i], kc + (idx % QPR) * 4, K);
       }
 #pragma unroll
@@ -154,29 +199,33 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       const bool more = c + 1 < n_chunks;
       if (more) fetch((c + 1) * KC);   // next chunk's global loads fly during the MFMAs
 
-      const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
-                              : sA + (buf * BM + r) * LD + g;
-      const float* pb = sB + (buf * BN + wave * 16 + r) * LD + g;
+      const float* pa = A_LDS ? io.a_lds + arow * io.lda_lds + c * KC + g
+                              : sA + (buf * BMK + arow) * LD + g;
+      const float* pb = sB + (buf * BN + (RS ? 0 : wave * 16) + r) * LD + g;
       const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
+      constexpr int SG = RS ? 4 : 16;                   // steps whose operands are read together
 #pragma unroll
-      for (int sg = 0; sg < KC / 64; ++sg) {
-        if (16 * sg < ksteps) {                         // uniform
-          // 32 unconditional operand reads (one lgkmcnt wait); staged chunks are zero
+      for (int sg = 0; sg < KC / 4 / SG; ++sg) {
+        if (SG * sg < ksteps) {                         // uniform
+          // unconditional operand reads (one lgkmcnt wait per group); staged chunks are zero
           // filled past K, an LDS activation slab may hold stale columns there -> select
-          float av[16], bv[16];
+          float av[SG], bv[NT][SG];
 #pragma unroll
-          for (int s = 0; s < 16; ++s) {
-            av[s] = pa[4 * (16 * sg + s)];
-            bv[s] = pb[4 * (16 * sg + s)];
-            if (A_LDS) av[s] = (c * KC + 4 * (16 * sg + s) + g < K) ? av[s] : 0.f;
+          for (int s = 0; s < SG; ++s) {
+            av[s] = pa[4 * (SG * sg + s)];
+            if (A_LDS) av[s] = (c * KC + 4 * (SG * sg + s) + g < K) ? av[s] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j][s] = pb[j * 16 * LD + 4 * (SG * sg + s)];
           }
           // fma(0, 0, acc) == acc, so a padded step is exact; skip groups of 4 uniformly
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (16 * sg + 4 * q < ksteps) {
+          for (int q = 0; q < SG / 4; ++q) {
+            if (SG * sg + 4 * q < ksteps) {
 #pragma unroll
               for (int s = 4 * q; s < 4 * q + 4; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                  acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[j][s], acc[j], 0, 0, 0);
             }
           }
         }
@@ -185,18 +234,21 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       __syncthreads();
     }
 
-    // epilogue: bias + activation; lane holds rows g*4+i, column r
-    const int col = n0 + wave * 16 + r;
-    if (col < N) {
-      const float bcol = bias ? bias[col] : 0.f;
+    // epilogue: bias + activation; lane holds rows g*4+i of its tile, column r
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = g * 4 + i;
-        const float v = act_apply(acc[i] + bcol, act);
-        if (O_LDS) {
-          io.o_lds[row * io.ldo_lds + col] = v;
-        } else if (m0 + row < M) {
-          io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + (RS ? j * 16 : wave * 16) + r;
+      if (col < N) {
+        const float bcol = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (RS ? 16 * wave : 0) + g * 4 + i;
+          const float v = act_apply(acc[j][i] + bcol, act);
+          if (O_LDS) {
+            io.o_lds[row * io.ldo_lds + col] = v;
+          } else if (m0 + row < M) {
+            io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
+          }
         }
       }
     }
@@ -222,38 +274,40 @@ __device__ __forceinline__ void resolve_src(const XSrc& xs, const float* x, int6
   }
 }
 
-// Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64-column group.
-template <bool VEC, int KC>
+// Single layer, 2-D grid: blockIdx.x = row block (16 or 64 rows), blockIdx.y = 64-column group.
+template <bool VEC, int KC, bool RS>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
                                                  float* __restrict__ y, int64_t ldy, int nbuf,
                                                  Done done, XSrc xs) {
+  constexpr int BMK = RS ? 64 : 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                              // [nbuf][16][KC+4]
-  float* sB = sA + nbuf * BM * (KC + 4);         // [nbuf][64][KC+4]
+  float* sA = smem;                              // [nbuf][BMK][KC+4]
+  float* sB = sA + nbuf * BMK * (KC + 4);        // [nbuf][64][KC+4]
   LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0};
-  resolve_src(xs, x, M, (int64_t)blockIdx.x * BM, &io.a_glb, &io.a_row0, &io.a_rows);
+  resolve_src(xs, x, M, (int64_t)blockIdx.x * BMK, &io.a_glb, &io.a_row0, &io.a_rows);
   const int n0 = blockIdx.y * BN;
-  layer_pass<false, false, VEC, KC>(io, (int64_t)blockIdx.x * BM, M, K, W, ldw, b, N, n0,
-                                    min(n0 + BN, N), act, nbuf, sA, sB);
-  signal_done(done, gridDim.x * gridDim.y);
+  layer_pass<false, false, VEC, KC, RS>(io, (int64_t)blockIdx.x * BMK, M, K, W, ldw, b, N, n0,
+                                        min(n0 + BN, N), act, nbuf, sA, sB);
+  signal_done(done, gridDim.x * gridDim.y, smem);
 }
 
-// Chain of layers on a 16-row slab; activations ping-pong between two LDS slabs.
-template <bool VEC, int KC>
+// Chain of layers on one row block; activations ping-pong between two LDS slabs.
+template <bool VEC, int KC, bool RS>
 __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, int nbuf, Done done,
                                                     XSrc xs) {
+  constexpr int BMK = RS ? 64 : 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                              // [nbuf][16][KC+4]
-  float* sB = sA + nbuf * BM * (KC + 4);         // [nbuf][64][KC+4]
-  float* slab0 = sB + nbuf * BN * (KC + 4);      // [16][slab_ld]
-  float* slab1 = slab0 + BM * slab_ld;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  float* sA = smem;                              // [nbuf][BMK][KC+4]
+  float* sB = sA + nbuf * BMK * (KC + 4);        // [nbuf][64][KC+4]
+  float* slab0 = sB + nbuf * BN * (KC + 4);      // [BMK][slab_ld]
+  float* slab1 = slab0 + BMK * slab_ld;
+  const int64_t m0 = (int64_t)blockIdx.x * BMK;
 
   // zero both slabs once: padded K tails of later layers must read finite values
   if (a.n_layers > 1) {
-    for (int i = threadIdx.x; i < 2 * BM * slab_ld; i += blockDim.x) slab0[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * BMK * slab_ld; i += blockDim.x) slab0[i] = 0.f;
     __syncthreads();
   }
 
@@ -274,17 +328,17 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, in
     io.ldo_lds = slab_ld;
     const int K = a.width[l], N = a.width[l + 1];
     if (first && last)
-      layer_pass<false, false, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
+      layer_pass<false, false, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     else if (first)
-      layer_pass<false, true, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
+      layer_pass<false, true, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     else if (last)
-      layer_pass<true, false, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
+      layer_pass<true, false, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     else
-      layer_pass<true, true, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
+      layer_pass<true, true, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
     __syncthreads();
     cur = nxt;
   }
-  signal_done(done, gridDim.x);
+  signal_done(done, gridDim.x, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -353,16 +407,19 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 constexpr size_t kLdsBudget = 150 * 1024;
 
-static size_t stage_bytes(int kc, int nbuf) { return sizeof(float) * (size_t)nbuf * (BM + BN) * (kc + 4); }
+static size_t stage_bytes(int kc, int nbuf, int bmk) {
+  return sizeof(float) * (size_t)nbuf * (bmk + BN) * (kc + 4);
+}
 
 // Fewest K rounds that fit the LDS budget next to `extra` bytes of slabs.
-static bool pick_kc(int maxK, size_t extra, int* kc_out, int* nbuf_out) {
+static bool pick_kc(int maxK, size_t extra, int bmk, int* kc_out, int* nbuf_out) {
   const int cands[4] = {256, 192, 128, 64};
   int best_kc = 0, best_nbuf = 0, best_rounds = 1 << 30;
   for (int kc : cands) {
+    if (bmk * kc / 1024 < 1) continue;
     const int rounds = (maxK + kc - 1) / kc;
     const int nbuf = rounds > 1 ? 2 : 1;
-    if (stage_bytes(kc, nbuf) + extra > kLdsBudget) continue;
+    if (stage_bytes(kc, nbuf, bmk) + extra > kLdsBudget) continue;
     if (rounds < best_rounds || (rounds == best_rounds && kc < best_kc)) {
       best_rounds = rounds; best_kc = kc; best_nbuf = nbuf;
     }
@@ -384,22 +441,30 @@ static hipError_t init_mlp_kernels() {
   static bool done = false;
   if (done) return hipSuccess;
   hipError_t e = hipSuccess;
-#define SET_ATTR(KC_)                                                        \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_>);                \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_>);               \
-  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_>);             \
-  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
+#define SET_ATTR(KC_)                                                               \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, false>);                \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, false>);               \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, true>);                 \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, true>);                \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_, false>);             \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_, false>);            \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_, true>);              \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_, true>);
   DRS_FOR_EACH_KC(SET_ATTR)
 #undef SET_ATTR
   if (e == hipSuccess) done = true;
   return e;
 }
 
+// rows at or above which the row-split tiling is used (drs_set_option "mlp_rs_rows")
+int g_mlp_rs_rows = 1024;
+
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
                      hipStream_t s, const Done* done, const XSrc* xsrc) {
   if (M <= 0) return hipSuccess;
-  Done d = {nullptr, nullptr, nullptr, nullptr, 0};
+  Done d;
+  memset(&d, 0, sizeof d);
   if (done) d = *done;
   XSrc xs;
   memset(&xs, 0, sizeof xs);
@@ -407,22 +472,27 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
   int kc = 64, nbuf = 2;
-  if (!pick_kc(K, 0, &kc, &nbuf)) return hipErrorInvalidValue;
-  const size_t lds = stage_bytes(kc, nbuf);
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+  bool rs = M >= g_mlp_rs_rows;
+  if (rs && !pick_kc(K, 0, 64, &kc, &nbuf)) rs = false;
+  if (!rs && !pick_kc(K, 0, 16, &kc, &nbuf)) return hipErrorInvalidValue;
+  const int bmk = rs ? 64 : 16;
+  const size_t lds = stage_bytes(kc, nbuf, bmk);
+  dim3 grid((unsigned)((M + bmk - 1) / bmk), (unsigned)((N + BN - 1) / BN));
   bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
+#define LAUNCH2(KC_, VEC_, RS_)                                                                   \
+  hipLaunchKernelGGL((fc_kernel<VEC_, KC_, RS_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
+                     (int64_t)K, b, N, act, y, ldy, nbuf, d, xs)
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
-    if (vec)                                                                                      \
-      hipLaunchKernelGGL((fc_kernel<true, KC_>), grid, dim3(256), lds, s, x, ldx, M, K, W,        \
-                         (int64_t)K, b, N, act, y, ldy, nbuf, d, xs);                             \
-    else                                                                                          \
-      hipLaunchKernelGGL((fc_kernel<false, KC_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
-                         (int64_t)K, b, N, act, y, ldy, nbuf, d, xs);                             \
+    if (vec && rs) LAUNCH2(KC_, true, true);                                                      \
+    else if (vec) LAUNCH2(KC_, true, false);                                                      \
+    else if (rs) LAUNCH2(KC_, false, true);                                                       \
+    else LAUNCH2(KC_, false, false);                                                              \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH2
   return hipGetLastError();
 }
 
@@ -432,24 +502,25 @@ static int chain_slab_ld(const ChainArgs& a) {
   return (w + 3) / 4 * 4 + 4;
 }
 
-static bool chain_plan(const ChainArgs& a, int* kc, int* nbuf, size_t* lds) {
+static bool chain_plan(const ChainArgs& a, int bmk, int* kc, int* nbuf, size_t* lds) {
   int maxK = 1;
   for (int l = 0; l < a.n_layers; ++l) maxK = a.width[l] > maxK ? a.width[l] : maxK;
-  const size_t slabs = a.n_layers > 1 ? sizeof(float) * (size_t)2 * BM * chain_slab_ld(a) : 0;
-  if (!pick_kc(maxK, slabs, kc, nbuf)) return false;
-  *lds = stage_bytes(*kc, *nbuf) + slabs;
+  const size_t slabs = a.n_layers > 1 ? sizeof(float) * (size_t)2 * bmk * chain_slab_ld(a) : 0;
+  if (!pick_kc(maxK, slabs, bmk, kc, nbuf)) return false;
+  *lds = stage_bytes(*kc, *nbuf, bmk) + slabs;
   return true;
 }
 
 size_t chain_lds_bytes(const ChainArgs& a) {
   int kc, nbuf;
   size_t lds;
-  return chain_plan(a, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
+  return chain_plan(a, 16, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
   if (a.M <= 0) return hipSuccess;
-  Done d = {nullptr, nullptr, nullptr, nullptr, 0};
+  Done d;
+  memset(&d, 0, sizeof d);
   if (done) d = *done;
   XSrc xs;
   memset(&xs, 0, sizeof xs);
@@ -459,22 +530,27 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, con
   if (e != hipSuccess) return e;
   int kc = 64, nbuf = 2;
   size_t lds = 0;
-  if (!chain_plan(a, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
+  bool rs = a.M >= g_mlp_rs_rows;
+  if (rs && !chain_plan(a, 64, &kc, &nbuf, &lds)) rs = false;
+  if (!rs && !chain_plan(a, 16, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
+  const int bmk = rs ? 64 : 16;
   bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
-  const dim3 grid((unsigned)((a.M + BM - 1) / BM));
+  const dim3 grid((unsigned)((a.M + bmk - 1) / bmk));
+  const int sld = chain_slab_ld(a);
+#define LAUNCH2(KC_, VEC_, RS_)                                                                   \
+  hipLaunchKernelGGL((chain_kernel<VEC_, KC_, RS_>), grid, dim3(256), lds, s, a, sld, nbuf, d, xs)
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
-    if (vec)                                                                                      \
-      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, chain_slab_ld(a), \
-                         nbuf, d, xs);                                                                \
-    else                                                                                          \
-      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a,                  \
-                         chain_slab_ld(a), nbuf, d, xs);                                              \
+    if (vec && rs) LAUNCH2(KC_, true, true);                                                      \
+    else if (vec) LAUNCH2(KC_, true, false);                                                      \
+    else if (rs) LAUNCH2(KC_, false, true);                                                       \
+    else LAUNCH2(KC_, false, false);                                                              \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
+#undef LAUNCH2
   return hipGetLastError();
 }
 

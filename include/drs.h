@@ -201,16 +201,26 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums
  *   "mlp_split"  1 (default) first wide top/bottom layer as its own 2-D launch | 0
+ *   "mlp_rs_rows" rows of a launch set from which the MLP kernels tile 64 rows x 64
+ *                columns per workgroup with 4 accumulators per wave (default 1024;
+ *                0 = never): coalesced queries | below: 16 rows x 64 columns
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG                                               */
 int32_t drs_set_option(drs_handle h, const char* key, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------
- * Live HIP-event timing of the engine's own launches (bench.py roofline leg).
- * When enabled, every forward brackets its kernels with hipEvents recorded on
- * the stream they are launched on.                                             */
-int32_t drs_set_profiling(drs_handle h, int32_t enabled);
+ * Live timing of the engine's own launches (bench.py roofline leg).
+ *   level 1: every workgroup of the gather stamps the device's constant-rate clock at
+ *            entry and exit; the query's last kernel reduces the stamps to (min start,
+ *            max end) and hands them to the host with the results -- no copy, no sync,
+ *            no extra launch, so it can stay on inside a timed region
+ *            (DRS_KERNEL_SLS_CLOCK).
+ *   level 2: additionally brackets the gather and the rest of the launch set with
+ *            hipEvents recorded on the stream they are launched on (DRS_KERNEL_SLS,
+ *            DRS_KERNEL_MLP); the event packets perturb a ~10-60 us launch by several
+ *            us, which is why level 1 exists.                                      */
+int32_t drs_set_profiling(drs_handle h, int32_t level);
 int32_t drs_kernel_time(drs_handle h, int32_t kernel /*DRS_KERNEL_*/,
                         double* sum_ms, int64_t* launches);
 int32_t drs_reset_kernel_time(drs_handle h);

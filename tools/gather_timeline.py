@@ -20,7 +20,7 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     bench.run_queries(eng, 200, opt.batch, opt.num_batches, 1)
-    eng.set_profiling(True)
+    eng.set_profiling(1)
     spans = []
     for i in range(20):
         eng.forward(i % opt.num_batches, opt.batch)
@@ -35,7 +35,7 @@ def main():
             print("launch %d: blocks=%d span=%.2f us | start[p0,p10,p50,p90,p100]= %s | dur= %s | end= %s"
                   % (i, len(st), end.max(), q(start), q(dur), q(end)))
     print("mean span %.2f us" % np.mean(spans))
-    eng.set_profiling(False)
+    eng.set_profiling(0)
     eng.close()
 
 
