@@ -73,6 +73,7 @@ struct Slot {
   uint64_t* d_ts = nullptr;  // [2 * max gather workgroups] device clock stamps (profiling)
   std::vector<uint64_t> h_ts;
   int64_t ts_blocks = 0, ts_blocks_done = 0;
+  uint64_t* d_span_acc = nullptr;  // device [2]: running (min, max) of the stamps
   uint64_t* h_span = nullptr;  // pinned [2]: (min start, max end) of the gather launch
   uint64_t* dm_span = nullptr;
   Batch scratch;             // drs_forward_inputs staging
@@ -321,7 +322,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   memset(&done, 0, sizeof done);
   done.counter = s.d_counter; done.host_flag = s.dm_out; done.host_err = s.dm_out + 1;
   done.dev_err = s.d_err; done.seq = s.seq;
-  if (prof && e->zero_copy) { done.ts = s.d_ts; done.ts_blocks = (uint32_t)s.ts_blocks; done.host_span = s.dm_span; }
+  if (prof && e->zero_copy) { done.ts = s.d_ts; done.ts_blocks = (uint32_t)s.ts_blocks; done.span_acc = s.d_span_acc; done.host_span = s.dm_span; }
   const Done* dp = e->zero_copy ? &done : nullptr;
   float* out = e->zero_copy ? reinterpret_cast<float*>(s.dm_out + 2) : s.d_out;
   XSrc xs;
@@ -593,6 +594,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_out), s.h_out, 0));
     CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_rows * T));
+    CREATE_TRY(hipMalloc(&s.d_span_acc, sizeof(uint64_t) * 2));
+    { const uint64_t init[2] = {~0ull, 0ull}; CREATE_TRY(hipMemcpy(s.d_span_acc, init, sizeof init, hipMemcpyHostToDevice)); }
     CREATE_TRY(hipHostMalloc(&s.h_span, sizeof(uint64_t) * 2, hipHostMallocMapped | hipHostMallocCoherent));
     s.h_span[0] = s.h_span[1] = 0;
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_span), s.h_span, 0));
@@ -624,6 +627,7 @@ int32_t drs_destroy(drs_handle e) {
     if (s.d_err) (void)hipFree(s.d_err);
     if (s.d_ts) (void)hipFree(s.d_ts);
     if (s.h_span) (void)hipHostFree(s.h_span);
+    if (s.d_span_acc) (void)hipFree(s.d_span_acc);
     if (s.d_counter) (void)hipFree(s.d_counter);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_stage) (void)hipHostFree(s.h_stage);

@@ -70,18 +70,13 @@ __device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
 __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, void* lds_scratch) {
   if (!d.counter) return;
   unsigned* s_u = reinterpret_cast<unsigned*>(lds_scratch);   // dynamic LDS is free by now
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_u[0] = old == n_blocks - 1;
-  }
-  __syncthreads();
-  if (!s_u[0]) return;
-  // last workgroup of the launch: everything the query produced is visible
-  unsigned long long lo = ~0ull, hi = 0ull;
   if (d.ts) {
-    for (unsigned i = threadIdx.x; i < d.ts_blocks; i += blockDim.x) {
+    // every workgroup folds its slice of the gather's clock stamps into (min start, max end)
+    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned per = (d.ts_blocks + n_blocks - 1) / n_blocks;
+    const unsigned end = min(d.ts_blocks, (bid + 1) * per);
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (unsigned i = bid * per + threadIdx.x; i < end; i += blockDim.x) {
       const unsigned long long a = d.ts[2 * i], b = d.ts[2 * i + 1];
       lo = a < lo ? a : lo;
       hi = b > hi ? b : hi;
@@ -92,27 +87,33 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
       lo = lo2 < lo ? lo2 : lo;
       hi = hi2 > hi ? hi2 : hi;
     }
-    unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (unsigned w = 1; w < blockDim.x / 64; ++w) {
-        lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
-        hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
-      }
+    if ((threadIdx.x & 63) == 0 && hi != 0ull) {
+      atomicMin(reinterpret_cast<unsigned long long*>(d.span_acc), lo);
+      atomicMax(reinterpret_cast<unsigned long long*>(d.span_acc) + 1, hi);
     }
   }
+  __threadfence_system();
+  __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d.ts) {
-      __hip_atomic_store(d.host_span, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(d.host_span + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == n_blocks - 1) {
+      // last workgroup of the launch: everything the query produced is visible
+      __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d.ts) {
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
+        const unsigned long long lo = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(acc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(acc, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  (void)s_u;
 }
 
 struct LayerIo {
@@ -457,7 +458,7 @@ static hipError_t init_mlp_kernels() {
 }
 
 // rows at or above which the row-split tiling is used (drs_set_option "mlp_rs_rows")
-int g_mlp_rs_rows = 1024;
+int g_mlp_rs_rows = 1 << 30;   // measured: not yet a win over the column split
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,

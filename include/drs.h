@@ -202,8 +202,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums
  *   "mlp_split"  1 (default) first wide top/bottom layer as its own 2-D launch | 0
  *   "mlp_rs_rows" rows of a launch set from which the MLP kernels tile 64 rows x 64
- *                columns per workgroup with 4 accumulators per wave (default 1024;
- *                0 = never): coalesced queries | below: 16 rows x 64 columns
+ *                columns per workgroup with 4 accumulators per wave (0 = never, the
+ *                default: not yet faster than the 16-row x 64-column split)
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG                                               */

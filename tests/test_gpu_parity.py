@@ -317,9 +317,13 @@ def test_coalesced_queries_equal_individual_queries(kind):
             eng.set_option("sls_exact", exact)
             jobs = [(0, n), (nb - 1, 1), (0, 0), (nb - 1, n - 3), (0, 5), (nb - 1, n), (0, 2), (0, n)]
             singles = [eng.forward(b, bs) for b, bs in jobs]
-            eng.forward_multi_async(1, [b for b, _ in jobs], [bs for _, bs in jobs])
-            got = eng.wait(1, sum(bs for _, bs in jobs))
-            assert np.array_equal(got, np.concatenate(singles, axis=0))
+            for rs_rows in (0, 64):      # 16-row column-split tiles | 64-row row-split tiles
+                eng.set_option("mlp_rs_rows", rs_rows)
+                eng.forward_multi_async(1, [b for b, _ in jobs], [bs for _, bs in jobs])
+                got = eng.wait(1, sum(bs for _, bs in jobs))
+                # same k-ordered chains whatever the tiling: bit-identical
+                assert np.array_equal(got, np.concatenate(singles, axis=0)), (exact, rs_rows)
+            eng.set_option("mlp_rs_rows", 0)
         with pytest.raises(N.DrsError):
             eng.forward_multi_async(0, [0] * 9, [1] * 9)
     finally:
