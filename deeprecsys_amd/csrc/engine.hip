@@ -58,7 +58,8 @@ struct Batch {
 };
 
 struct Slot {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // the stream this slot launches on (shared or own)
+  hipStream_t own_stream = nullptr;
   float* T = nullptr;        // [max_batch, ldT]  concat buffer: dense_out | emb_0 | ...
   float* R = nullptr;        // [max_batch, ldR]  dot-interaction output (dot only)
   float* H = nullptr;        // [max_batch, ldH]  inter-segment MLP scratch (ping)
@@ -112,7 +113,7 @@ struct drs_engine {
   // op-level scratch
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
-  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1;
+  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1;
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -575,7 +576,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   e->slots.resize(e->n_slots);
   const int n_out_cap = e->kind == DRS_MODEL_NCF ? 1024 : e->n_out;
   for (auto& s : e->slots) {
-    CREATE_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
+    s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
     CREATE_TRY(hipMalloc(&s.T, sizeof(float) * (size_t)e->max_rows * e->ldT));
     CREATE_TRY(hipMemset(s.T, 0, sizeof(float) * (size_t)e->max_rows * e->ldT));
     CREATE_TRY(hipMalloc(&s.R, sizeof(float) * (size_t)e->max_rows * e->ldR));
@@ -617,7 +619,7 @@ int32_t drs_destroy(drs_handle e) {
   if (!e) return DRS_OK;
   (void)hipSetDevice(e->device);
   for (auto& s : e->slots) {
-    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); }
+    if (s.own_stream) { (void)hipStreamSynchronize(s.own_stream); (void)hipStreamDestroy(s.own_stream); }
     if (s.T) (void)hipFree(s.T);
     if (s.R) (void)hipFree(s.R);
     if (s.H) (void)hipFree(s.H);
@@ -934,6 +936,12 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
+  else if (!strcmp(key, "shared_stream")) {
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    e->shared_stream = value ? 1 : 0;
+    for (auto& s : e->slots) s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
+  }
   else if (!strcmp(key, "mlp_rs_rows") && value >= 0) g_mlp_rs_rows = value == 0 ? (1 << 30) : (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);

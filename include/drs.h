@@ -204,6 +204,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_rs_rows" rows of a launch set from which the MLP kernels tile 64 rows x 64
  *                columns per workgroup with 4 accumulators per wave (0 = never, the
  *                default: not yet faster than the 16-row x 64-column split)
+ *   "shared_stream" 1 (default) all slots enqueue on one HIP stream: launch sets run back
+ *                to back (each kernel has the chip to itself) while the host is already
+ *                enqueueing the next set | 0 one stream per slot: sets overlap on the GPU
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG                                               */
