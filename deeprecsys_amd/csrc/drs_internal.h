@@ -97,6 +97,11 @@ struct ChainArgs {
 hipError_t launch_chain(const ChainArgs& a, hipStream_t stream, const Done* done = nullptr,
                         const XSrc* xs = nullptr);
 size_t chain_lds_bytes(const ChainArgs& a);
+// two chains on the same rows in one launch (bottom MLP, then the top MLP that reads the
+// buffer the first one wrote its last layer into)
+hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t stream,
+                         const Done* done = nullptr, const XSrc* xs = nullptr);
+size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot
 hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F, int32_t D,

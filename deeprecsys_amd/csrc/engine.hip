@@ -23,7 +23,6 @@
 namespace drs {
 extern int g_sls_u;
 extern int g_sls_v_d32;
-extern int g_mlp_rs_rows;
 }  // namespace drs
 
 using namespace drs;
@@ -113,7 +112,7 @@ struct drs_engine {
   // op-level scratch
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
-  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1;
+  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1, mlp_fuse = 1;
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -206,16 +205,34 @@ int32_t mlp_ready(drs_engine* e, const Mlp& m, const char* name) {
   return DRS_OK;
 }
 
-// Run all layers of `m` on x -> y.  A wide layer runs as its own 2-D launch (more
-// workgroups); runs of narrow layers are fused into one LDS-resident chain.
-// Segment outputs that are not the final one ping-pong between s.H and s.Hb.
+int act_of(const Mlp& m, int l) { return (l + 1 == m.sigmoid_layer) ? DRS_ACT_SIGMOID : DRS_ACT_RELU; }
+
+// A layer big enough to deserve its own 2-D launch (many workgroups, W streamed once per
+// 16-row slab would be too much traffic): RM3's 2560x1024.  RM1's 576x256 is not.
+bool is_wide(const drs_engine* e, const Mlp& m, int l) {
+  return e->mlp_split && (int64_t)m.ln[l] * m.ln[l + 1] >= 512 * 1024;
+}
+
+void fill_chain(ChainArgs& c, const Mlp& m, int l0, int cnt, const float* x, int64_t ldx, int64_t M,
+                float* y, int64_t ldy) {
+  memset(&c, 0, sizeof c);
+  c.x = x; c.ldx = ldx; c.M = M; c.n_layers = cnt; c.y = y; c.ldy = ldy;
+  for (int i = 0; i <= cnt; ++i) c.width[i] = m.ln[l0 + i];
+  for (int i = 0; i < cnt; ++i) {
+    c.W[i] = m.layers[l0 + i].W;
+    c.b[i] = m.layers[l0 + i].b;
+    c.act[i] = act_of(m, l0 + i);
+  }
+}
+
+constexpr size_t kChainLds = 150 * 1024;
+
+// Run all layers of `m` on x -> y.  A huge layer runs as its own 2-D launch; runs of
+// ordinary layers are fused into one LDS-resident chain.  Segment outputs that are not
+// the final one ping-pong between s.H and s.Hb.
 int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ldx, int64_t M,
                 float* y, int64_t ldy, const Done* done = nullptr, const XSrc* xs = nullptr) {
   const int n_layers = (int)m.layers.size();
-  auto act_of = [&](int l) { return (l + 1 == m.sigmoid_layer) ? DRS_ACT_SIGMOID : DRS_ACT_RELU; };
-  auto is_wide = [&](int l) {
-    return e->mlp_split && (int64_t)m.ln[l] * m.ln[l + 1] >= 64 * 1024 && m.ln[l + 1] > 64;
-  };
   int l0 = 0;
   const float* in = x;
   int64_t ldin = ldx;
@@ -223,29 +240,23 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
     int cnt = 1;
     ChainArgs c;
     memset(&c, 0, sizeof c);
-    const bool standalone = is_wide(l0);
+    bool standalone = is_wide(e, m, l0);
     if (!standalone) {
-      // longest run of narrow layers that fits LDS
       cnt = 0;
-      while (l0 + cnt < n_layers && cnt < DRS_MAX_CHAIN && !is_wide(l0 + cnt)) ++cnt;
+      while (l0 + cnt < n_layers && cnt < DRS_MAX_CHAIN && !is_wide(e, m, l0 + cnt)) ++cnt;
       for (;;) {
-        c.x = in; c.ldx = ldin; c.M = M; c.n_layers = cnt;
-        for (int i = 0; i <= cnt; ++i) c.width[i] = m.ln[l0 + i];
-        for (int i = 0; i < cnt; ++i) {
-          c.W[i] = m.layers[l0 + i].W;
-          c.b[i] = m.layers[l0 + i].b;
-          c.act[i] = act_of(l0 + i);
-        }
-        if (chain_lds_bytes(c) <= 150 * 1024 || cnt == 1) break;
+        fill_chain(c, m, l0, cnt, in, ldin, M, nullptr, 0);
+        if (chain_lds_bytes(c) <= kChainLds) break;
+        if (cnt == 1) { standalone = true; break; }
         --cnt;
       }
     }
     const bool last = l0 + cnt == n_layers;
     float* out = last ? y : (in == s.H ? s.Hb : s.H);
     const int64_t ldo = last ? ldy : e->ldH;
-    if (standalone || chain_lds_bytes(c) > 150 * 1024) {
+    if (standalone) {
       HIP_TRY(e, launch_fc(in, ldin, M, m.ln[l0], m.layers[l0].W, m.layers[l0].b, m.ln[l0 + 1],
-                           act_of(l0), out, ldo, s.stream, last ? done : nullptr,
+                           act_of(m, l0), out, ldo, s.stream, last ? done : nullptr,
                            l0 == 0 ? xs : nullptr));
     } else {
       c.y = out; c.ldy = ldo;
@@ -254,6 +265,25 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
     in = out; ldin = ldo; l0 += cnt;
   }
   return DRS_OK;
+}
+
+// DLRM with the "cat" interaction: bottom MLP and top MLP of a 16-row slab in ONE launch
+// (the slab's dense_out never waits for a kernel boundary).  false = not applicable.
+bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const Done* dp,
+                          const XSrc* xs, int32_t* rc) {
+  *rc = DRS_OK;
+  if (!e->mlp_fuse || e->kind != DRS_MODEL_DLRM || e->interaction_op != DRS_INTERACT_CAT) return false;
+  const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
+  if (nb < 1 || nt < 1 || nb > DRS_MAX_CHAIN || nt > DRS_MAX_CHAIN) return false;
+  for (int l = 0; l < nb; ++l) if (is_wide(e, e->bot, l)) return false;
+  for (int l = 0; l < nt; ++l) if (is_wide(e, e->top, l)) return false;
+  ChainArgs a, b;
+  fill_chain(a, e->bot, 0, nb, nullptr, e->m_den, Mv, s.T, e->ldT);
+  fill_chain(b, e->top, 0, nt, s.T, e->ldT, Mv, out, e->n_out);
+  if (chain2_lds_bytes(a, b) > kChainLds) return false;
+  hipError_t r = launch_chain2(a, &b, s.stream, dp, xs);
+  if (r != hipSuccess) *rc = fail(e, DRS_ERR_HIP, "launch_chain2: %s", hipGetErrorString(r));
+  return true;
 }
 
 // Enqueue n >= 1 coalesced queries (query i = first bs[i] samples of *bts[i]) as ONE set of
@@ -339,7 +369,14 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
     if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
   } else {
-    if (e->bot.layers.empty()) {
+    bool fused = false;
+    if (!e->bot.layers.empty()) {
+      fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
+      if (rc) return rc;
+    }
+    if (fused) {
+      // nothing else to launch
+    } else if (e->bot.layers.empty()) {
       for (int i = 0; i < q.n_q; ++i)
         HIP_TRY(e, launch_copy_rows(qb[i]->dense, e->m_den, s.T + (int64_t)q.vstart[i] * e->ldT, e->ldT,
                                     q.bs[i], e->w0, s.stream));
@@ -353,7 +390,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       top_in = s.R;
       ld_top = e->ldR;
     }
-    if ((rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
+    if (!fused && (rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
   }
   if (evts) {
     HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
@@ -942,7 +979,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     e->shared_stream = value ? 1 : 0;
     for (auto& s : e->slots) s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
   }
-  else if (!strcmp(key, "mlp_rs_rows") && value >= 0) g_mlp_rs_rows = value == 0 ? (1 << 30) : (int)value;
+  else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;

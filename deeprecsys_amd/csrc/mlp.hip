@@ -129,37 +129,34 @@ struct LayerIo {
   int ldo_lds;
 };
 
-// One layer for the block's rows [m0, m0+BMK) and the columns [n_begin, n_end).
-//   RS = false ("column split", few rows in flight, e.g. one query): BMK = 16 rows, the 4
-//        waves take 16 columns each of a 64-column pass -> 1 accumulator per wave, many
-//        workgroups even at M = 256.
-//   RS = true ("row split", coalesced queries, M >= ~1000): BMK = 64 rows, wave w owns
-//        rows [16w, 16w+16) and all 64 columns of the pass -> 4 independent accumulators
-//        per wave (MFMA issue-bound instead of dependent-latency-bound) and every staged
-//        W tile is shared by 4x more rows (4x less W traffic through L2 / Infinity Cache).
-// Either way every output element is one k-ordered fma chain.
-// sA: [nbuf][BMK][KC+4] (used only when A comes from global), sB: [nbuf][64][KC+4];
+// One layer for the block's 16 rows [m0, m0+16) and the columns [n_begin, n_end).
+// A pass covers 64*NT columns: wave w owns the NT 16-column tiles starting at column
+// n0 + 16*NT*w.  NT = 1 keeps every wave busy on narrow layers (N <= 64); NT = 2 gives
+// each wave two independent accumulators, which is enough to issue an MFMA every 32
+// cycles instead of waiting out the 40-cycle dependent latency, and halves the number
+// of passes (and re-stagings of A) on wide layers.  Every output element is one
+// k-ordered fma chain either way.
+// sA: [nbuf][16][KC+4] (used only when A comes from global), sB: [nbuf][64*NT][KC+4];
 // nbuf = 2 (double buffered) when the layer needs more than one K chunk, else 1.
-template <bool A_LDS, bool O_LDS, bool VEC, int KC, bool RS>
+template <bool A_LDS, bool O_LDS, bool VEC, int KC, int NT>
 __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K,
                                            const float* __restrict__ W, int64_t ldw,
                                            const float* __restrict__ bias, int N, int n_begin,
                                            int n_end, int act, int nbuf, float* sA, float* sB) {
-  constexpr int BMK = RS ? 64 : 16;
-  constexpr int NT = RS ? 4 : 1;         // accumulators (16-column tiles) per wave
+  constexpr int BMK = 16;
+  constexpr int PN = BN * NT;            // columns per pass
   constexpr int LD = KC + 4;
   constexpr int QPR = KC / 4;            // float4 per staged row
-  constexpr int NA = BMK * KC / 1024;    // float4 of A per thread per chunk
-  constexpr int NB = KC / 16;            // float4 of W per thread per chunk
+  constexpr int NA = KC / 64;            // float4 of A per thread per chunk
+  constexpr int NB = NT * KC / 16;       // float4 of W per thread per chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int r = lane & 15;   // row of A / column of the tile
   const int g = lane >> 4;   // k within an MFMA step
-  const int arow = RS ? 16 * wave + r : r;          // this lane's A row inside the block
   const int n_chunks = (K + KC - 1) / KC;
 
-  for (int n0 = n_begin; n0 < n_end; n0 += BN) {
+  for (int n0 = n_begin; n0 < n_end; n0 += PN) {
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -187,7 +184,7 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = tid + i * 256;
-        *reinterpret_cast<float4*>(sB + (buf * BN + idx / QPR) * LD + (idx % QPR) * 4) =
+        *reinterpret_cast<float4*>(sB + (buf * PN + idx / QPR) * LD + (idx % QPR) * 4) =
             mask4(rb[i], kc + (idx % QPR) * 4, K);
       }
     };
@@ -200,11 +197,11 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       const bool more = c + 1 < n_chunks;
       if (more) fetch((c + 1) * KC);   // next chunk's global loads fly during the MFMAs
 
-      const float* pa = A_LDS ? io.a_lds + arow * io.lda_lds + c * KC + g
-                              : sA + (buf * BMK + arow) * LD + g;
-      const float* pb = sB + (buf * BN + (RS ? 0 : wave * 16) + r) * LD + g;
+      const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
+                              : sA + (buf * BMK + r) * LD + g;
+      const float* pb = sB + (buf * PN + wave * 16 * NT + r) * LD + g;
       const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
-      constexpr int SG = RS ? 4 : 16;                   // steps whose operands are read together
+      constexpr int SG = 16 / NT;                       // steps whose operands are read together
 #pragma unroll
       for (int sg = 0; sg < KC / 4 / SG; ++sg) {
         if (SG * sg < ksteps) {                         // uniform
@@ -238,12 +235,12 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
     // epilogue: bias + activation; lane holds rows g*4+i of its tile, column r
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int col = n0 + (RS ? j * 16 : wave * 16) + r;
+      const int col = n0 + (wave * NT + j) * 16 + r;
       if (col < N) {
         const float bcol = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int row = (RS ? 16 * wave : 0) + g * 4 + i;
+          const int row = g * 4 + i;
           const float v = act_apply(acc[j][i] + bcol, act);
           if (O_LDS) {
             io.o_lds[row * io.ldo_lds + col] = v;
@@ -275,43 +272,29 @@ __device__ __forceinline__ void resolve_src(const XSrc& xs, const float* x, int6
   }
 }
 
-// Single layer, 2-D grid: blockIdx.x = row block (16 or 64 rows), blockIdx.y = 64-column group.
-template <bool VEC, int KC, bool RS>
+// Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64*NT-column group.
+template <bool VEC, int KC, int NT>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
                                                  float* __restrict__ y, int64_t ldy, int nbuf,
                                                  Done done, XSrc xs) {
-  constexpr int BMK = RS ? 64 : 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                              // [nbuf][BMK][KC+4]
-  float* sB = sA + nbuf * BMK * (KC + 4);        // [nbuf][64][KC+4]
+  float* sA = smem;                              // [nbuf][16][KC+4]
+  float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][64*NT][KC+4]
   LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0};
-  resolve_src(xs, x, M, (int64_t)blockIdx.x * BMK, &io.a_glb, &io.a_row0, &io.a_rows);
-  const int n0 = blockIdx.y * BN;
-  layer_pass<false, false, VEC, KC, RS>(io, (int64_t)blockIdx.x * BMK, M, K, W, ldw, b, N, n0,
-                                        min(n0 + BN, N), act, nbuf, sA, sB);
+  resolve_src(xs, x, M, (int64_t)blockIdx.x * 16, &io.a_glb, &io.a_row0, &io.a_rows);
+  const int n0 = blockIdx.y * BN * NT;
+  layer_pass<false, false, VEC, KC, NT>(io, (int64_t)blockIdx.x * 16, M, K, W, ldw, b, N, n0,
+                                        min(n0 + BN * NT, N), act, nbuf, sA, sB);
   signal_done(done, gridDim.x * gridDim.y, smem);
 }
 
-// Chain of layers on one row block; activations ping-pong between two LDS slabs.
-template <bool VEC, int KC, bool RS>
-__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, int nbuf, Done done,
-                                                    XSrc xs) {
-  constexpr int BMK = RS ? 64 : 16;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                              // [nbuf][BMK][KC+4]
-  float* sB = sA + nbuf * BMK * (KC + 4);        // [nbuf][64][KC+4]
-  float* slab0 = sB + nbuf * BN * (KC + 4);      // [BMK][slab_ld]
-  float* slab1 = slab0 + BMK * slab_ld;
-  const int64_t m0 = (int64_t)blockIdx.x * BMK;
-
-  // zero both slabs once: padded K tails of later layers must read finite values
-  if (a.n_layers > 1) {
-    for (int i = threadIdx.x; i < 2 * BMK * slab_ld; i += blockDim.x) slab0[i] = 0.f;
-    __syncthreads();
-  }
-
+// One chain of layers on the block's 16 rows; activations ping-pong between two LDS slabs.
+// Layers wider than 64 columns run with two tiles per wave (NT = 2).
+template <bool VEC, int KC>
+__device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, int64_t m0, int slab_ld,
+                                          int nbuf, float* sA, float* sB, float* slab0, float* slab1) {
   float* cur = nullptr;
   for (int l = 0; l < a.n_layers; ++l) {
     const bool first = l == 0, last = l == a.n_layers - 1;
@@ -328,16 +311,46 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a, int slab_ld, in
     io.o_lds = last ? nullptr : nxt;
     io.ldo_lds = slab_ld;
     const int K = a.width[l], N = a.width[l + 1];
-    if (first && last)
-      layer_pass<false, false, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
-    else if (first)
-      layer_pass<false, true, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
-    else if (last)
-      layer_pass<true, false, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
-    else
-      layer_pass<true, true, VEC, KC, RS>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB);
+#define DRS_PASS(AL, OL)                                                                          \
+  if (N > BN)                                                                                     \
+    layer_pass<AL, OL, VEC, KC, 2>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB); \
+  else                                                                                            \
+    layer_pass<AL, OL, VEC, KC, 1>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB)
+    if (first && last) { DRS_PASS(false, false); }
+    else if (first) { DRS_PASS(false, true); }
+    else if (last) { DRS_PASS(true, false); }
+    else { DRS_PASS(true, true); }
+#undef DRS_PASS
     __syncthreads();
     cur = nxt;
+  }
+}
+
+// Up to two chains back to back in ONE launch on the same 16 rows: the bottom MLP
+// (dense features -> dense_out slot of the interaction buffer) and, for the "cat"
+// interaction, the top MLP that reads that buffer.  The second chain re-reads rows this
+// very workgroup wrote: a workgroup-scope fence + barrier orders that.
+template <bool VEC, int KC>
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, int slab_ld, int nbuf,
+                                                    Done done, XSrc xs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                              // [nbuf][16][KC+4]
+  float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][128][KC+4]
+  float* slab0 = sB + nbuf * 2 * BN * (KC + 4);  // [16][slab_ld]
+  float* slab1 = slab0 + 16 * slab_ld;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+
+  // zero both slabs once: padded K tails of later layers must read finite values
+  for (int i = threadIdx.x; i < 2 * 16 * slab_ld; i += blockDim.x) slab0[i] = 0.f;
+  __syncthreads();
+
+  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1);
+  if (a1.n_layers > 0) {
+    __threadfence_block();
+    __syncthreads();
+    XSrc none;
+    none.q.n_q = 0;
+    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1);
   }
   signal_done(done, gridDim.x, smem);
 }
@@ -408,19 +421,18 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 constexpr size_t kLdsBudget = 150 * 1024;
 
-static size_t stage_bytes(int kc, int nbuf, int bmk) {
-  return sizeof(float) * (size_t)nbuf * (bmk + BN) * (kc + 4);
+static size_t stage_bytes(int kc, int nbuf, int nt) {
+  return sizeof(float) * (size_t)nbuf * (16 + BN * nt) * (kc + 4);
 }
 
 // Fewest K rounds that fit the LDS budget next to `extra` bytes of slabs.
-static bool pick_kc(int maxK, size_t extra, int bmk, int* kc_out, int* nbuf_out) {
+static bool pick_kc(int maxK, size_t extra, int nt, int* kc_out, int* nbuf_out) {
   const int cands[4] = {256, 192, 128, 64};
   int best_kc = 0, best_nbuf = 0, best_rounds = 1 << 30;
   for (int kc : cands) {
-    if (bmk * kc / 1024 < 1) continue;
     const int rounds = (maxK + kc - 1) / kc;
     const int nbuf = rounds > 1 ? 2 : 1;
-    if (stage_bytes(kc, nbuf, bmk) + extra > kLdsBudget) continue;
+    if (stage_bytes(kc, nbuf, nt) + extra > kLdsBudget) continue;
     if (rounds < best_rounds || (rounds == best_rounds && kc < best_kc)) {
       best_rounds = rounds; best_kc = kc; best_nbuf = nbuf;
     }
@@ -443,22 +455,17 @@ static hipError_t init_mlp_kernels() {
   if (done) return hipSuccess;
   hipError_t e = hipSuccess;
 #define SET_ATTR(KC_)                                                               \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, false>);                \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, false>);               \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, true>);                 \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, true>);                \
-  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_, false>);             \
-  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_, false>);            \
-  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_, true>);              \
-  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_, true>);
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, 1>);                    \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, 1>);                   \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, 2>);                    \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, 2>);                   \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_>);                    \
+  if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
   DRS_FOR_EACH_KC(SET_ATTR)
 #undef SET_ATTR
   if (e == hipSuccess) done = true;
   return e;
 }
-
-// rows at or above which the row-split tiling is used (drs_set_option "mlp_rs_rows")
-int g_mlp_rs_rows = 1 << 30;   // measured: not yet a win over the column split
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
@@ -473,23 +480,22 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
   int kc = 64, nbuf = 2;
-  bool rs = M >= g_mlp_rs_rows;
-  if (rs && !pick_kc(K, 0, 64, &kc, &nbuf)) rs = false;
-  if (!rs && !pick_kc(K, 0, 16, &kc, &nbuf)) return hipErrorInvalidValue;
-  const int bmk = rs ? 64 : 16;
-  const size_t lds = stage_bytes(kc, nbuf, bmk);
-  dim3 grid((unsigned)((M + bmk - 1) / bmk), (unsigned)((N + BN - 1) / BN));
+  // two tiles per wave once that still leaves >= 256 workgroups
+  int nt = (N > BN && ((M + 15) / 16) * ((N + 2 * BN - 1) / (2 * BN)) >= 256) ? 2 : 1;
+  if (!pick_kc(K, 0, nt, &kc, &nbuf)) return hipErrorInvalidValue;
+  const size_t lds = stage_bytes(kc, nbuf, nt);
+  dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + BN * nt - 1) / (BN * nt)));
   bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
-#define LAUNCH2(KC_, VEC_, RS_)                                                                   \
-  hipLaunchKernelGGL((fc_kernel<VEC_, KC_, RS_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
+#define LAUNCH2(KC_, VEC_, NT_)                                                                   \
+  hipLaunchKernelGGL((fc_kernel<VEC_, KC_, NT_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
                      (int64_t)K, b, N, act, y, ldy, nbuf, d, xs)
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
-    if (vec && rs) LAUNCH2(KC_, true, true);                                                      \
-    else if (vec) LAUNCH2(KC_, true, false);                                                      \
-    else if (rs) LAUNCH2(KC_, false, true);                                                       \
-    else LAUNCH2(KC_, false, false);                                                              \
+    if (vec && nt == 2) LAUNCH2(KC_, true, 2);                                                    \
+    else if (vec) LAUNCH2(KC_, true, 1);                                                          \
+    else if (nt == 2) LAUNCH2(KC_, false, 2);                                                     \
+    else LAUNCH2(KC_, false, 1);                                                                  \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
@@ -497,28 +503,37 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   return hipGetLastError();
 }
 
-static int chain_slab_ld(const ChainArgs& a) {
+static int chain_slab_ld2(const ChainArgs& a, const ChainArgs* b) {
   int w = 4;
   for (int l = 1; l < a.n_layers; ++l) w = a.width[l] > w ? a.width[l] : w;  // slabs hold layer outputs
+  if (b) for (int l = 1; l < b->n_layers; ++l) w = b->width[l] > w ? b->width[l] : w;
   return (w + 3) / 4 * 4 + 4;
 }
 
-static bool chain_plan(const ChainArgs& a, int bmk, int* kc, int* nbuf, size_t* lds) {
+static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbuf, size_t* lds) {
   int maxK = 1;
   for (int l = 0; l < a.n_layers; ++l) maxK = a.width[l] > maxK ? a.width[l] : maxK;
-  const size_t slabs = a.n_layers > 1 ? sizeof(float) * (size_t)2 * bmk * chain_slab_ld(a) : 0;
-  if (!pick_kc(maxK, slabs, bmk, kc, nbuf)) return false;
-  *lds = stage_bytes(*kc, *nbuf, bmk) + slabs;
+  if (b) for (int l = 0; l < b->n_layers; ++l) maxK = b->width[l] > maxK ? b->width[l] : maxK;
+  const size_t slabs = sizeof(float) * (size_t)2 * 16 * chain_slab_ld2(a, b);
+  if (!pick_kc(maxK, slabs, 2, kc, nbuf)) return false;
+  *lds = stage_bytes(*kc, *nbuf, 2) + slabs;
   return true;
 }
 
 size_t chain_lds_bytes(const ChainArgs& a) {
   int kc, nbuf;
   size_t lds;
-  return chain_plan(a, 16, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
+  return chain_plan(a, nullptr, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
 }
 
-hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
+size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b) {
+  int kc, nbuf;
+  size_t lds;
+  return chain_plan(a, &b, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
+}
+
+hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, const Done* done,
+                         const XSrc* xsrc) {
   if (a.M <= 0) return hipSuccess;
   Done d;
   memset(&d, 0, sizeof d);
@@ -526,33 +541,39 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, con
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   if (xsrc) xs = *xsrc;
-  if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN) return hipErrorInvalidValue;
+  if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN || (b && (b->n_layers < 1 || b->n_layers > DRS_MAX_CHAIN)))
+    return hipErrorInvalidValue;
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
   int kc = 64, nbuf = 2;
   size_t lds = 0;
-  bool rs = a.M >= g_mlp_rs_rows;
-  if (rs && !chain_plan(a, 64, &kc, &nbuf, &lds)) rs = false;
-  if (!rs && !chain_plan(a, 16, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
-  const int bmk = rs ? 64 : 16;
+  if (!chain_plan(a, b, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
   bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
+  if (b) {
+    vec = vec && aligned16(b->x) && (b->ldx & 3) == 0;
+    for (int l = 0; l < b->n_layers; ++l) vec = vec && aligned16(b->W[l]) && (b->width[l] & 3) == 0;
+  }
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
-  const dim3 grid((unsigned)((a.M + bmk - 1) / bmk));
-  const int sld = chain_slab_ld(a);
-#define LAUNCH2(KC_, VEC_, RS_)                                                                   \
-  hipLaunchKernelGGL((chain_kernel<VEC_, KC_, RS_>), grid, dim3(256), lds, s, a, sld, nbuf, d, xs)
+  ChainArgs second;
+  memset(&second, 0, sizeof second);
+  if (b) second = *b;
+  const dim3 grid((unsigned)((a.M + 15) / 16));
+  const int sld = chain_slab_ld2(a, b);
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
-    if (vec && rs) LAUNCH2(KC_, true, true);                                                      \
-    else if (vec) LAUNCH2(KC_, true, false);                                                      \
-    else if (rs) LAUNCH2(KC_, false, true);                                                       \
-    else LAUNCH2(KC_, false, false);                                                              \
+    if (vec)                                                                                      \
+      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, d, xs);  \
+    else                                                                                          \
+      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, d, xs); \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
-#undef LAUNCH2
   return hipGetLastError();
+}
+
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
+  return launch_chain2(a, nullptr, s, done, xsrc);
 }
 
 hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F, int32_t D,

@@ -200,10 +200,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums
- *   "mlp_split"  1 (default) first wide top/bottom layer as its own 2-D launch | 0
- *   "mlp_rs_rows" rows of a launch set from which the MLP kernels tile 64 rows x 64
- *                columns per workgroup with 4 accumulators per wave (0 = never, the
- *                default: not yet faster than the 16-row x 64-column split)
+ *   "mlp_split"  1 (default) a layer with K*N >= 512K weights (RM3's 2560x1024) runs as
+ *                its own 2-D launch | 0 chain everything that fits LDS
+ *   "mlp_fuse"   1 (default) DLRM/"cat": bottom and top MLP of a 16-row slab in ONE launch
+ *                | 0 one launch per MLP
  *   "shared_stream" 1 (default) all slots enqueue on one HIP stream: launch sets run back
  *                to back (each kernel has the chip to itself) while the host is already
  *                enqueueing the next set | 0 one stream per slot: sets overlap on the GPU

@@ -317,13 +317,15 @@ def test_coalesced_queries_equal_individual_queries(kind):
             eng.set_option("sls_exact", exact)
             jobs = [(0, n), (nb - 1, 1), (0, 0), (nb - 1, n - 3), (0, 5), (nb - 1, n), (0, 2), (0, n)]
             singles = [eng.forward(b, bs) for b, bs in jobs]
-            for rs_rows in (0, 64):      # 16-row column-split tiles | 64-row row-split tiles
-                eng.set_option("mlp_rs_rows", rs_rows)
+            for fuse, split in ((1, 1), (0, 1), (0, 0)):   # launch structure must not change a bit
+                eng.set_option("mlp_fuse", fuse)
+                eng.set_option("mlp_split", split)
                 eng.forward_multi_async(1, [b for b, _ in jobs], [bs for _, bs in jobs])
                 got = eng.wait(1, sum(bs for _, bs in jobs))
                 # same k-ordered chains whatever the tiling: bit-identical
-                assert np.array_equal(got, np.concatenate(singles, axis=0)), (exact, rs_rows)
-            eng.set_option("mlp_rs_rows", 0)
+                assert np.array_equal(got, np.concatenate(singles, axis=0)), (exact, fuse, split)
+            eng.set_option("mlp_fuse", 1)
+            eng.set_option("mlp_split", 1)
         with pytest.raises(N.DrsError):
             eng.forward_multi_async(0, [0] * 9, [1] * 9)
     finally:
