@@ -340,6 +340,30 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, 
   float* slab1 = slab0 + 16 * slab_ld;
   const int64_t m0 = (int64_t)blockIdx.x * 16;
 
+  // L2 warm-up.  All workgroups walk the same weights in lock step, so without help every
+  // K chunk is a compulsory miss in each XCD's L2 (the gather before us has flushed it) and
+  // every staging round pays a full Infinity-Cache/HBM latency (~2 us, measured: waves 53%
+  // in s_waitcnt).  Here each workgroup touches ONE slice of all the weights, one load per
+  // 128-B line, fire-and-forget: the XCD's 16 or so resident workgroups together pull the
+  // whole set into their L2 during the first layer's prologue.  Purely a hint: a different
+  // workgroup->XCD placement changes speed, not results.
+  float warm[2 * DRS_MAX_CHAIN];   // consumed only at the very end: never waited for early
+  {
+    const unsigned part = (blockIdx.x >> 3) & 15;          // my rank among the XCD's workgroups
+    auto touch = [&](const ChainArgs& c, int l) -> float {
+      if (l >= c.n_layers) return 0.f;
+      const int64_t lines = ((int64_t)c.width[l] * c.width[l + 1] + 31) / 32;   // 128-B lines
+      // 16 parts x 256 threads x 1 line: covers 512 KB per layer (all of RM1/RM2's layers)
+      const int64_t i = min(lines - 1, (int64_t)part * 256 + threadIdx.x + (int64_t)(blockIdx.x >> 7) * 4096);
+      return c.W[l][i * 32];
+    };
+#pragma unroll
+    for (int l = 0; l < DRS_MAX_CHAIN; ++l) {
+      warm[l] = touch(a0, l);
+      warm[DRS_MAX_CHAIN + l] = touch(a1, l);
+    }
+  }
+
   // zero both slabs once: padded K tails of later layers must read finite values
   for (int i = threadIdx.x; i < 2 * 16 * slab_ld; i += blockDim.x) slab0[i] = 0.f;
   __syncthreads();
@@ -352,6 +376,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, 
     none.q.n_q = 0;
     run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1);
   }
+#pragma unroll
+  for (int l = 0; l < 2 * DRS_MAX_CHAIN; ++l) asm volatile("" ::"v"(warm[l]));
   signal_done(done, gridDim.x, smem);
 }
 
