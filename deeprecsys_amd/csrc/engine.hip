@@ -225,7 +225,7 @@ void fill_chain(ChainArgs& c, const Mlp& m, int l0, int cnt, const float* x, int
   }
 }
 
-constexpr size_t kChainLds = 150 * 1024;
+constexpr size_t kChainLds = 156 * 1024;
 
 // Run all layers of `m` on x -> y.  A huge layer runs as its own 2-D launch; runs of
 // ordinary layers are fused into one LDS-resident chain.  Segment outputs that are not

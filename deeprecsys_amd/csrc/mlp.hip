@@ -292,20 +292,50 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, in
 
 // One chain of layers on the block's 16 rows; activations ping-pong between two LDS slabs.
 // Layers wider than 64 columns run with two tiles per wave (NT = 2).
+//
+// The chain's input rows are streamed exactly once by exactly one workgroup, so every
+// chunk of them is a compulsory miss all the way to HBM / Infinity Cache (~2 us) that a
+// one-chunk-ahead prefetch cannot hide.  When they fit (slabA != nullptr) all 16 x K0
+// inputs are therefore pulled into LDS with ONE round of loads up front and the first
+// layer reads its A operand from LDS like every later layer; only the weights (shared by
+// all workgroups, L2 resident after the warm-up) keep streaming per K chunk.
 template <bool VEC, int KC>
 __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, int64_t m0, int slab_ld,
-                                          int nbuf, float* sA, float* sB, float* slab0, float* slab1) {
+                                          int nbuf, float* sA, float* sB, float* slab0, float* slab1,
+                                          float* slabA, int ldA) {
   float* cur = nullptr;
+  const int K0 = a.width[0];
+  const bool pre = slabA != nullptr && K0 <= 640;
+  if (pre) {
+    const float* base; int64_t row0, rows;
+    resolve_src(xs, a.x, a.M, m0, &base, &row0, &rows);
+    const int qpr = (K0 + 3) / 4;                 // float4 per row
+    const int total = 16 * qpr;
+    float4 v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int idx = min((int)threadIdx.x + i * 256, total - 1);
+      v[i] = load4_raw<VEC>(base, a.ldx, row0 + idx / qpr, rows, (idx % qpr) * 4, K0);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      if (idx < total)
+        *reinterpret_cast<float4*>(slabA + (idx / qpr) * ldA + (idx % qpr) * 4) = mask4(v[i], (idx % qpr) * 4, K0);
+    }
+    __syncthreads();
+  }
   for (int l = 0; l < a.n_layers; ++l) {
     const bool first = l == 0, last = l == a.n_layers - 1;
+    const bool a_lds = !first || pre;
     float* nxt = (l & 1) ? slab1 : slab0;
     LayerIo io;
     io.a_glb = nullptr;
     io.a_row0 = io.a_rows = 0;
-    if (first) resolve_src(xs, a.x, a.M, m0, &io.a_glb, &io.a_row0, &io.a_rows);
+    if (first && !pre) resolve_src(xs, a.x, a.M, m0, &io.a_glb, &io.a_row0, &io.a_rows);
     io.lda_glb = a.ldx;
-    io.a_lds = first ? nullptr : cur;
-    io.lda_lds = slab_ld;
+    io.a_lds = first ? (pre ? slabA : nullptr) : cur;
+    io.lda_lds = first ? ldA : slab_ld;
     io.o_glb = last ? a.y : nullptr;
     io.ldo_glb = a.ldy;
     io.o_lds = last ? nullptr : nxt;
@@ -316,8 +346,8 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
     layer_pass<AL, OL, VEC, KC, 2>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB); \
   else                                                                                            \
     layer_pass<AL, OL, VEC, KC, 1>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB)
-    if (first && last) { DRS_PASS(false, false); }
-    else if (first) { DRS_PASS(false, true); }
+    if (!a_lds && last) { DRS_PASS(false, false); }
+    else if (!a_lds) { DRS_PASS(false, true); }
     else if (last) { DRS_PASS(true, false); }
     else { DRS_PASS(true, true); }
 #undef DRS_PASS
@@ -332,12 +362,13 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
 // very workgroup wrote: a workgroup-scope fence + barrier orders that.
 template <bool VEC, int KC>
 __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, int slab_ld, int nbuf,
-                                                    Done done, XSrc xs) {
+                                                    int ldA, Done done, XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                              // [nbuf][16][KC+4]
   float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][128][KC+4]
   float* slab0 = sB + nbuf * 2 * BN * (KC + 4);  // [16][slab_ld]
   float* slab1 = slab0 + 16 * slab_ld;
+  float* slabA = ldA > 0 ? slab1 + 16 * slab_ld : nullptr;   // [16][ldA] preloaded chain input
   const int64_t m0 = (int64_t)blockIdx.x * 16;
 
   // L2 warm-up.  All workgroups walk the same weights in lock step, so without help every
@@ -368,13 +399,13 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, 
   for (int i = threadIdx.x; i < 2 * 16 * slab_ld; i += blockDim.x) slab0[i] = 0.f;
   __syncthreads();
 
-  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1);
+  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA);
   if (a1.n_layers > 0) {
     __threadfence_block();
     __syncthreads();
     XSrc none;
     none.q.n_q = 0;
-    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1);
+    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA);
   }
 #pragma unroll
   for (int l = 0; l < 2 * DRS_MAX_CHAIN; ++l) asm volatile("" ::"v"(warm[l]));
@@ -445,7 +476,7 @@ __global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const 
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-constexpr size_t kLdsBudget = 150 * 1024;
+constexpr size_t kLdsBudget = 156 * 1024;
 
 static size_t stage_bytes(int kc, int nbuf, int nt) {
   return sizeof(float) * (size_t)nbuf * (16 + BN * nt) * (kc + 4);
@@ -536,26 +567,39 @@ static int chain_slab_ld2(const ChainArgs& a, const ChainArgs* b) {
   return (w + 3) / 4 * 4 + 4;
 }
 
-static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbuf, size_t* lds) {
-  int maxK = 1;
+// ldA > 0: the chains' input slab (16 x K0) is preloaded into LDS (see run_chain)
+static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbuf, size_t* lds,
+                       int* ldA) {
+  int maxK = 1, k0 = a.width[0];
   for (int l = 0; l < a.n_layers; ++l) maxK = a.width[l] > maxK ? a.width[l] : maxK;
-  if (b) for (int l = 0; l < b->n_layers; ++l) maxK = b->width[l] > maxK ? b->width[l] : maxK;
+  if (b) {
+    for (int l = 0; l < b->n_layers; ++l) maxK = b->width[l] > maxK ? b->width[l] : maxK;
+    k0 = b->width[0] > k0 ? b->width[0] : k0;
+  }
   const size_t slabs = sizeof(float) * (size_t)2 * 16 * chain_slab_ld2(a, b);
+  const int lda = (k0 + 3) / 4 * 4 + 4;
+  const size_t pre = k0 <= 640 ? sizeof(float) * (size_t)16 * lda : 0;
+  if (pre && pick_kc(maxK, slabs + pre, 2, kc, nbuf)) {
+    *lds = stage_bytes(*kc, *nbuf, 2) + slabs + pre;
+    *ldA = lda;
+    return true;
+  }
   if (!pick_kc(maxK, slabs, 2, kc, nbuf)) return false;
   *lds = stage_bytes(*kc, *nbuf, 2) + slabs;
+  *ldA = 0;
   return true;
 }
 
 size_t chain_lds_bytes(const ChainArgs& a) {
-  int kc, nbuf;
+  int kc, nbuf, lda;
   size_t lds;
-  return chain_plan(a, nullptr, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
+  return chain_plan(a, nullptr, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
 }
 
 size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b) {
-  int kc, nbuf;
+  int kc, nbuf, lda;
   size_t lds;
-  return chain_plan(a, &b, &kc, &nbuf, &lds) ? lds : (size_t)1 << 30;
+  return chain_plan(a, &b, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
 }
 
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, const Done* done,
@@ -571,9 +615,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
     return hipErrorInvalidValue;
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
-  int kc = 64, nbuf = 2;
+  int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
-  if (!chain_plan(a, b, &kc, &nbuf, &lds)) return hipErrorInvalidValue;
+  if (!chain_plan(a, b, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;
   bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
   if (b) {
@@ -589,9 +633,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
     if (vec)                                                                                      \
-      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, d, xs);  \
+      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, lda, d, xs);  \
     else                                                                                          \
-      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, d, xs); \
+      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, lda, d, xs); \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
