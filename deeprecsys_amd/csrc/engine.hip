@@ -23,6 +23,7 @@
 namespace drs {
 extern int g_sls_u;
 extern int g_sls_v_d32;
+extern int g_mlp_preload;
 }  // namespace drs
 
 using namespace drs;
@@ -980,6 +981,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     for (auto& s : e->slots) s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;

@@ -202,18 +202,35 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       const float* pb = sB + (buf * PN + wave * 16 * NT + r) * LD + g;
       const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
       constexpr int SG = 16 / NT;                       // steps whose operands are read together
+      constexpr int NG = KC / 4 / SG;                   // operand groups per chunk
+      // Only the last chunk of an LDS activation slab can hold stale columns past K (staged
+      // chunks are zero filled there): keep the select out of the steady state.
+      const bool a_tail = A_LDS && (c + 1) * KC > K;
+      // Operand reads are software pipelined by hand over two register sets: the
+      // ds_reads of group sg+1 are issued BEFORE the MFMAs of group sg (the scheduling
+      // barriers pin that order), so LDS latency hides under 16 MFMAs instead of being
+      // paid in front of every pair (what the compiler's own schedule did).
+      float av[2][SG], bv[2][NT][SG];
+      auto read_group = [&](int sg, int set) {
 #pragma unroll
-      for (int sg = 0; sg < KC / 4 / SG; ++sg) {
+        for (int s = 0; s < SG; ++s) {
+          av[set][s] = pa[4 * (SG * sg + s)];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bv[set][j][s] = pb[j * 16 * LD + 4 * (SG * sg + s)];
+        }
+      };
+      read_group(0, 0);
+#pragma unroll
+      for (int sg = 0; sg < NG; ++sg) {
+        const int set = sg & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (sg + 1 < NG) read_group(sg + 1, set ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (SG * sg < ksteps) {                         // uniform
-          // unconditional operand reads (one lgkmcnt wait per group); staged chunks are zero
-          // filled past K, an LDS activation slab may hold stale columns there -> select
-          float av[SG], bv[NT][SG];
+          if (a_tail) {
 #pragma unroll
-          for (int s = 0; s < SG; ++s) {
-            av[s] = pa[4 * (SG * sg + s)];
-            if (A_LDS) av[s] = (c * KC + 4 * (SG * sg + s) + g < K) ? av[s] : 0.f;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j][s] = pb[j * 16 * LD + 4 * (SG * sg + s)];
+            for (int s = 0; s < SG; ++s)
+              av[set][s] = (c * KC + 4 * (SG * sg + s) + g < K) ? av[set][s] : 0.f;
           }
           // fma(0, 0, acc) == acc, so a padded step is exact; skip groups of 4 uniformly
 #pragma unroll
@@ -223,7 +240,7 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
               for (int s = 4 * q; s < 4 * q + 4; ++s)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                  acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[j][s], acc[j], 0, 0, 0);
+                  acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][s], bv[set][j][s], acc[j], 0, 0, 0);
             }
           }
         }
@@ -567,6 +584,8 @@ static int chain_slab_ld2(const ChainArgs& a, const ChainArgs* b) {
   return (w + 3) / 4 * 4 + 4;
 }
 
+int g_mlp_preload = 0;   // drs_set_option "mlp_preload"
+
 // ldA > 0: the chains' input slab (16 x K0) is preloaded into LDS (see run_chain)
 static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbuf, size_t* lds,
                        int* ldA) {
@@ -578,7 +597,7 @@ static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbu
   }
   const size_t slabs = sizeof(float) * (size_t)2 * 16 * chain_slab_ld2(a, b);
   const int lda = (k0 + 3) / 4 * 4 + 4;
-  const size_t pre = k0 <= 640 ? sizeof(float) * (size_t)16 * lda : 0;
+  const size_t pre = (g_mlp_preload && k0 <= 640) ? sizeof(float) * (size_t)16 * lda : 0;
   if (pre && pick_kc(maxK, slabs + pre, 2, kc, nbuf)) {
     *lds = stage_bytes(*kc, *nbuf, 2) + slabs + pre;
     *ldA = lda;

@@ -204,6 +204,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                its own 2-D launch | 0 chain everything that fits LDS
  *   "mlp_fuse"   1 (default) DLRM/"cat": bottom and top MLP of a 16-row slab in ONE launch
  *                | 0 one launch per MLP
+ *   "mlp_preload" 0 (default) | 1 pull a chain's 16 x K0 input slab into LDS in one round
+ *                before its first layer instead of streaming it per K chunk
  *   "shared_stream" 1 (default) all slots enqueue on one HIP stream: launch sets run back
  *                to back (each kernel has the chip to itself) while the host is already
  *                enqueueing the next set | 0 one stream per slot: sets overlap on the GPU
