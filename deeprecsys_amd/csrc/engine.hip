@@ -102,6 +102,9 @@ struct drs_engine {
   int64_t* d_tab_rows = nullptr;
   std::vector<bool> table_set;
   Mlp bot, top, fin;
+  float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the
+  size_t w_arena_floats = 0;     // MLP kernels' per-CU TLBs then hold every weight page)
+  size_t w_arena_used = 0;
   int32_t interaction_op = DRS_INTERACT_CAT, itself = 0;
   int32_t max_batch = 0, max_lookups = 0, n_batches = 0, n_slots = 0;
   int32_t m_den = 0, w0 = 0;     // dense input width, dense_out width
@@ -676,7 +679,8 @@ int32_t drs_destroy(drs_handle e) {
   }
   for (auto& b : e->batches) free_batch(b);
   for (Mlp* m : {&e->bot, &e->top, &e->fin})
-    for (auto& l : m->layers) { if (l.W) (void)hipFree(l.W); if (l.b) (void)hipFree(l.b); }
+    for (auto& l : m->layers) { l.W = l.b = nullptr; }
+  if (e->w_arena) (void)hipFree(e->w_arena);
   if (e->tables) (void)hipFree(e->tables);
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
   if (e->d_tab_rows) (void)hipFree(e->d_tab_rows);
@@ -720,8 +724,24 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (n != M->ln[layer] || m != M->ln[layer + 1])
     return fail(e, DRS_ERR_BAD_ARG, "layer %d expects W[%d,%d], got [%d,%d]", layer, M->ln[layer + 1], M->ln[layer], m, n);
   Layer& L = M->layers[layer];
-  if (!L.W) HIP_TRY(e, hipMalloc(&L.W, sizeof(float) * (size_t)m * n));
-  if (!L.b) HIP_TRY(e, hipMalloc(&L.b, sizeof(float) * (size_t)m));
+  if (!L.W) {
+    if (!e->w_arena) {
+      // sized for every layer of the three MLPs (the final predictor's width is at most 1024)
+      size_t need = 0;
+      for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
+        for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
+          const size_t out = mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024;
+          need += ((size_t)mm->ln[i] * out + 63) / 64 * 64 + (out + 63) / 64 * 64;
+        }
+      e->w_arena_floats = need < (1u << 20) ? (1u << 20) : need;   // >= 4 MiB
+      HIP_TRY(e, hipMalloc(&e->w_arena, sizeof(float) * e->w_arena_floats));
+    }
+    const size_t wsz = ((size_t)m * n + 63) / 64 * 64, bsz = ((size_t)m + 63) / 64 * 64;
+    if (e->w_arena_used + wsz + bsz > e->w_arena_floats) return fail(e, DRS_ERR_OOM, "weight arena exhausted");
+    L.W = e->w_arena + e->w_arena_used;
+    L.b = L.W + wsz;
+    e->w_arena_used += wsz + bsz;
+  }
   HIP_TRY(e, hipMemcpy(L.W, h_W, sizeof(float) * (size_t)m * n, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(L.b, h_b, sizeof(float) * (size_t)m, hipMemcpyHostToDevice));
   L.m = m; L.n = n; L.set = true;
