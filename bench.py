@@ -51,8 +51,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=16000)
+    ap.add_argument("--warmup", type=int, default=1600)
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
