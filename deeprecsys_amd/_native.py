@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrs_hip.so")
+LIB_PATH = os.environ.get("DRS_HIP_LIB") or os.path.join(_HERE, "libdrs_hip.so")
 
 # status codes (include/drs.h)
 OK, ERR_BAD_ARG, ERR_OOM, ERR_HIP, ERR_INDEX_RANGE, ERR_LENGTHS_SUM, ERR_STATE, ERR_UNSUPPORTED = \

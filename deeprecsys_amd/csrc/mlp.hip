@@ -25,6 +25,23 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Optional in-kernel timeline (tools/mlp_timeline.py, built with -DDRS_TIMELINE into a
+// separate library): wave 0 of workgroup 0 stamps the shader clock at the phase
+// boundaries of every K-chunk round.  Compiled out of the product build.
+#ifdef DRS_TIMELINE
+__device__ unsigned long long g_tl[16384];
+__device__ unsigned g_tl_n;
+#define TL(tag)                                                                         \
+  do {                                                                                  \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                       \
+      const unsigned i_ = g_tl_n++;                                                     \
+      if (i_ < 16384) g_tl[i_] = ((unsigned long long)(tag) << 48) | (clock64() & 0xffffffffffffull); \
+    }                                                                                   \
+  } while (0)
+#else
+#define TL(tag)
+#endif
+
 constexpr int BN = 64;         // columns per pass (4 waves x 16)
 // K chunk staged per step is a template parameter KC in {64, 128, 192, 256}: a dependent
 // global-load round costs ~1 us on this chip (Infinity-Cache latency; per-XCD L2s start
@@ -188,14 +205,20 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
             mask4(rb[i], kc + (idx % QPR) * 4, K);
       }
     };
+    TL(1);
     fetch(0);
+    TL(2);
     stash(0, 0);
+    TL(3);
     __syncthreads();
+    TL(4);
 
     for (int c = 0; c < n_chunks; ++c) {
       const int buf = c & (nbuf - 1);
       const bool more = c + 1 < n_chunks;
+      TL(10);
       if (more) fetch((c + 1) * KC);   // next chunk's global loads fly during the MFMAs
+      TL(11);
 
       const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
                               : sA + (buf * BMK + r) * LD + g;
@@ -245,8 +268,11 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
           }
         }
       }
+      TL(12);
       if (more) stash(buf ^ 1, (c + 1) * KC);
+      TL(13);
       __syncthreads();
+      TL(14);
     }
 
     // epilogue: bias + activation; lane holds rows g*4+i of its tile, column r
@@ -664,6 +690,18 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
   return launch_chain2(a, nullptr, s, done, xsrc);
 }
+
+#ifdef DRS_TIMELINE
+extern "C" int drs_debug_timeline(unsigned long long* out, int cap, int reset) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_n), sizeof n) != hipSuccess) return -1;
+  if (n > 16384) n = 16384;
+  if ((int)n > cap) n = cap;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+  if (reset) { unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_n), &z, sizeof z); }
+  return (int)n;
+}
+#endif
 
 hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F, int32_t D,
                                int32_t itself, float* R, int64_t ldr, hipStream_t s) {
