@@ -31,15 +31,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef DRS_TIMELINE
 __device__ unsigned long long g_tl[16384];
 __device__ unsigned g_tl_n;
-#define TL(tag)                                                                         \
-  do {                                                                                  \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                       \
-      const unsigned i_ = g_tl_n++;                                                     \
-      if (i_ < 16384) g_tl[i_] = ((unsigned long long)(tag) << 48) | (clock64() & 0xffffffffffffull); \
-    }                                                                                   \
-  } while (0)
+// stamps go to a spare 8 KB at the very end of the dynamic LDS (no global traffic while the
+// kernel runs); thread 0 of workgroup 0 flushes them at the end
+#define TL_SLOTS 1000
+__device__ __forceinline__ void tl_stamp(unsigned long long* tl, unsigned tag) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned i = (unsigned)tl[0];
+    if (i + 1 < TL_SLOTS) {
+      tl[i + 1] = ((unsigned long long)tag << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull);
+      tl[0] = i + 1;
+    }
+  }
+}
+#define TL(tag) tl_stamp(g_tl_lds, tag)
+#define TL_DECL unsigned long long* g_tl_lds
+#define TL_ARG , g_tl_lds
+#define TL_PARAM , unsigned long long* g_tl_lds
 #else
 #define TL(tag)
+#define TL_ARG
+#define TL_PARAM
 #endif
 
 constexpr int BN = 64;         // columns per pass (4 waves x 16)
@@ -159,7 +170,7 @@ template <bool A_LDS, bool O_LDS, bool VEC, int KC, int NT>
 __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K,
                                            const float* __restrict__ W, int64_t ldw,
                                            const float* __restrict__ bias, int N, int n_begin,
-                                           int n_end, int act, int nbuf, float* sA, float* sB) {
+                                           int n_end, int act, int nbuf, float* sA, float* sB TL_PARAM) {
   constexpr int BMK = 16;
   constexpr int PN = BN * NT;            // columns per pass
   constexpr int LD = KC + 4;
@@ -325,11 +336,23 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, in
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                              // [nbuf][16][KC+4]
   float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][64*NT][KC+4]
+#ifdef DRS_TIMELINE
+  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(sB + nbuf * BN * NT * (KC + 4));
+  if (threadIdx.x == 0) g_tl_lds[0] = 0;
+#endif
   LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0};
   resolve_src(xs, x, M, (int64_t)blockIdx.x * 16, &io.a_glb, &io.a_row0, &io.a_rows);
   const int n0 = blockIdx.y * BN * NT;
   layer_pass<false, false, VEC, KC, NT>(io, (int64_t)blockIdx.x * 16, M, K, W, ldw, b, N, n0,
-                                        min(n0 + BN * NT, N), act, nbuf, sA, sB);
+                                        min(n0 + BN * NT, N), act, nbuf, sA, sB TL_ARG);
+#ifdef DRS_TIMELINE
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned n = (unsigned)g_tl_lds[0];
+    unsigned base = g_tl_n;
+    for (unsigned i = 0; i < n && base + i < 16384; ++i) g_tl[base + i] = g_tl_lds[i + 1];
+    g_tl_n = base + n;
+  }
+#endif
   signal_done(done, gridDim.x * gridDim.y, smem);
 }
 
@@ -345,7 +368,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, in
 template <bool VEC, int KC>
 __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, int64_t m0, int slab_ld,
                                           int nbuf, float* sA, float* sB, float* slab0, float* slab1,
-                                          float* slabA, int ldA) {
+                                          float* slabA, int ldA TL_PARAM) {
   float* cur = nullptr;
   const int K0 = a.width[0];
   const bool pre = slabA != nullptr && K0 <= 640;
@@ -386,9 +409,9 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
     const int K = a.width[l], N = a.width[l + 1];
 #define DRS_PASS(AL, OL)                                                                          \
   if (N > BN)                                                                                     \
-    layer_pass<AL, OL, VEC, KC, 2>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB); \
+    layer_pass<AL, OL, VEC, KC, 2>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB TL_ARG); \
   else                                                                                            \
-    layer_pass<AL, OL, VEC, KC, 1>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB)
+    layer_pass<AL, OL, VEC, KC, 1>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB TL_ARG)
     if (!a_lds && last) { DRS_PASS(false, false); }
     else if (!a_lds) { DRS_PASS(false, true); }
     else if (last) { DRS_PASS(true, false); }
@@ -412,6 +435,10 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, 
   float* slab0 = sB + nbuf * 2 * BN * (KC + 4);  // [16][slab_ld]
   float* slab1 = slab0 + 16 * slab_ld;
   float* slabA = ldA > 0 ? slab1 + 16 * slab_ld : nullptr;   // [16][ldA] preloaded chain input
+#ifdef DRS_TIMELINE
+  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(slab1 + 16 * slab_ld + (ldA > 0 ? 16 * ldA : 0));
+  if (threadIdx.x == 0) g_tl_lds[0] = 0;
+#endif
   const int64_t m0 = (int64_t)blockIdx.x * 16;
 
   // L2 warm-up.  All workgroups walk the same weights in lock step, so without help every
@@ -442,16 +469,24 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, 
   for (int i = threadIdx.x; i < 2 * 16 * slab_ld; i += blockDim.x) slab0[i] = 0.f;
   __syncthreads();
 
-  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA);
+  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA TL_ARG);
   if (a1.n_layers > 0) {
     __threadfence_block();
     __syncthreads();
     XSrc none;
     none.q.n_q = 0;
-    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA);
+    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA TL_ARG);
   }
 #pragma unroll
   for (int l = 0; l < 2 * DRS_MAX_CHAIN; ++l) asm volatile("" ::"v"(warm[l]));
+#ifdef DRS_TIMELINE
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned n = (unsigned)g_tl_lds[0];
+    unsigned base = g_tl_n;
+    for (unsigned i = 0; i < n && base + i < 16384; ++i) g_tl[base + i] = g_tl_lds[i + 1];
+    g_tl_n = base + n;
+  }
+#endif
   signal_done(done, gridDim.x, smem);
 }
 
@@ -583,7 +618,11 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   // two tiles per wave once that still leaves >= 256 workgroups
   int nt = (N > BN && ((M + 15) / 16) * ((N + 2 * BN - 1) / (2 * BN)) >= 256) ? 2 : 1;
   if (!pick_kc(K, 0, nt, &kc, &nbuf)) return hipErrorInvalidValue;
+#ifdef DRS_TIMELINE
+  const size_t lds = stage_bytes(kc, nbuf, nt) + 8192;
+#else
   const size_t lds = stage_bytes(kc, nbuf, nt);
+#endif
   dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + BN * nt - 1) / (BN * nt)));
   bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
@@ -663,6 +702,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
   int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
   if (!chain_plan(a, b, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;
+#ifdef DRS_TIMELINE
+  lds += 8192;
+#endif
   bool vec = aligned16(a.x) && (a.ldx & 3) == 0;
   for (int l = 0; l < a.n_layers; ++l) vec = vec && aligned16(a.W[l]) && (a.width[l] & 3) == 0;
   if (b) {
