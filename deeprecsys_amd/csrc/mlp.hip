@@ -87,6 +87,17 @@ __device__ __forceinline__ float4 load4_raw(const float* __restrict__ p, int64_t
 }
 // zero the k >= K tail; applied when the value is written to LDS (i.e. after the MFMA
 // block of the previous chunk), so the loads stay in flight across that block
+// LDS bank swizzle.  Operand reads are ds_read_b32 at float address row*LD + 4s + g with
+// LD = KC+4 (== 4 mod 32), so rows r and r+8 of a 16-row tile hit the same banks (2-way
+// conflict on every read; measured: 46 % of all LDS cycles).  Storing element k of rows
+// 8..15 at column k^2 instead moves them onto the two banks rows 0..7 leave free.  Bit 1
+// of k never leaves its 16-byte slot, so the staging writes stay one ds_write_b128 with
+// the halves of the float4 swapped.
+__device__ __forceinline__ float4 swz4(const float4 v, int row) {
+  return (row & 8) ? make_float4(v.z, v.w, v.x, v.y) : v;
+}
+__device__ __forceinline__ int swz(int col, int row) { return col ^ ((row & 8) >> 2); }
+
 __device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
   return make_float4(k + 0 < K ? v.x : 0.f, k + 1 < K ? v.y : 0.f, k + 2 < K ? v.z : 0.f,
                      k + 3 < K ? v.w : 0.f);
@@ -202,18 +213,21 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       }
     };
     auto stash = [&](int buf, int kc) {
+      const bool tail = kc + KC > K;              // uniform: only the last chunk needs the k mask
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int idx = tid + i * 256;
+        const int row = idx / QPR, k = (idx % QPR) * 4;
         if (!A_LDS)
-          *reinterpret_cast<float4*>(sA + (buf * BMK + idx / QPR) * LD + (idx % QPR) * 4) =
-              mask4(ra[i], kc + (idx % QPR) * 4, K);
+          *reinterpret_cast<float4*>(sA + (buf * BMK + row) * LD + k) =
+              swz4(tail ? mask4(ra[i], kc + k, K) : ra[i], row);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = tid + i * 256;
-        *reinterpret_cast<float4*>(sB + (buf * PN + idx / QPR) * LD + (idx % QPR) * 4) =
-            mask4(rb[i], kc + (idx % QPR) * 4, K);
+        const int row = idx / QPR, k = (idx % QPR) * 4;
+        *reinterpret_cast<float4*>(sB + (buf * PN + row) * LD + k) =
+            swz4(tail ? mask4(rb[i], kc + k, K) : rb[i], row);
       }
     };
     TL(1);
@@ -231,9 +245,10 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       if (more) fetch((c + 1) * KC);   // next chunk's global loads fly during the MFMAs
       TL(11);
 
-      const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + g
-                              : sA + (buf * BMK + r) * LD + g;
-      const float* pb = sB + (buf * PN + wave * 16 * NT + r) * LD + g;
+      const int gs = swz(g, r);                         // see swz4: rows 8..15 live at k^2
+      const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + gs
+                              : sA + (buf * BMK + r) * LD + gs;
+      const float* pb = sB + (buf * PN + wave * 16 * NT + r) * LD + gs;
       const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
       constexpr int SG = 16 / NT;                       // steps whose operands are read together
       constexpr int NG = KC / 4 / SG;                   // operand groups per chunk
@@ -297,7 +312,7 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
           const int row = g * 4 + i;
           const float v = act_apply(acc[j][i] + bcol, act);
           if (O_LDS) {
-            io.o_lds[row * io.ldo_lds + col] = v;
+            io.o_lds[row * io.ldo_lds + swz(col, row)] = v;
           } else if (m0 + row < M) {
             io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
           }
@@ -387,7 +402,8 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
     for (int i = 0; i < 10; ++i) {
       const int idx = threadIdx.x + i * 256;
       if (idx < total)
-        *reinterpret_cast<float4*>(slabA + (idx / qpr) * ldA + (idx % qpr) * 4) = mask4(v[i], (idx % qpr) * 4, K0);
+        *reinterpret_cast<float4*>(slabA + (idx / qpr) * ldA + (idx % qpr) * 4) =
+            swz4(mask4(v[i], (idx % qpr) * 4, K0), idx / qpr);
     }
     __syncthreads();
   }
