@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""End-to-end serving run through the queue harness (GPU box): load generator ->
+accelRequestQueue -> k accelerator engine processes -> orchestrator, i.e. the reference's
+run_DeepRecSys.sh flow with real accelerator engines.  Prints the orchestrator summary."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from deeprecsys_amd.DeepRecSys import DeepRecSys
+from deeprecsys_amd.utils.utils import cli
+
+if __name__ == "__main__":
+    # defaults = run_DeepRecSys.sh's query-size distribution on DLRM-RMC1 (BASELINE shape)
+    base = ["--queue", "--model_accel", "--inference_engines", "0", "--num_accels", "1",
+            "--model_type", "dlrm", "--arch_sparse_feature_size", "64",
+            "--arch_embedding_size", "-".join(["1000000"] * 8), "--arch_mlp_bot", "128-64-64",
+            "--arch_mlp_top", "256-64-1", "--arch_interaction_op", "cat",
+            "--num_indices_per_lookup", "80", "--num_indices_per_lookup_fixed", "1",
+            "--accel_table_init", "device", "--num_batches", "32", "--nepochs", "64",
+            "--batch_size_distribution", "normal", "--avg_mini_batch_size", "165",
+            "--var_mini_batch_size", "16", "--max_mini_batch_size", "256",
+            "--avg_arrival_rate", "0.05", "--req_granularity", "64", "--log_file", "/tmp/drs_log/out.log"]
+    args = cli(base + sys.argv[1:])
+    s = DeepRecSys(args, quiet=True)
+    print(json.dumps(s))
