@@ -24,6 +24,7 @@ namespace drs {
 extern int g_sls_u;
 extern int g_sls_v_d32;
 extern int g_mlp_preload;
+extern int g_mlp_kc;
 }  // namespace drs
 
 using namespace drs;
@@ -1002,6 +1003,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
   else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) g_mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;

@@ -577,10 +577,13 @@ static size_t stage_bytes(int kc, int nbuf, int nt) {
 }
 
 // Fewest K rounds that fit the LDS budget next to `extra` bytes of slabs.
+int g_mlp_kc = 0;   // drs_set_option "mlp_kc": force the K chunk (0 = fewest rounds that fit)
+
 static bool pick_kc(int maxK, size_t extra, int nt, int* kc_out, int* nbuf_out) {
   const int cands[4] = {256, 192, 128, 64};
   int best_kc = 0, best_nbuf = 0, best_rounds = 1 << 30;
   for (int kc : cands) {
+    if (g_mlp_kc && kc != g_mlp_kc) continue;
     const int rounds = (maxK + kc - 1) / kc;
     const int nbuf = rounds > 1 ? 2 : 1;
     if (stage_bytes(kc, nbuf, nt) + extra > kLdsBudget) continue;
