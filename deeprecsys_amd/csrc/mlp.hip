@@ -53,7 +53,6 @@ __device__ __forceinline__ void tl_stamp(unsigned long long* tl, unsigned tag) {
 #define TL_PARAM
 #endif
 
-constexpr int BN = 64;         // columns per pass (4 waves x 16)
 // K chunk staged per step is a template parameter KC in {64, 128, 192, 256}: a dependent
 // global-load round costs ~1 us on this chip (Infinity-Cache latency; per-XCD L2s start
 // cold every launch), far more than the MFMAs it feeds, so layers are cut into as few
@@ -169,25 +168,29 @@ struct LayerIo {
 };
 
 // One layer for the block's 16 rows [m0, m0+16) and the columns [n_begin, n_end).
-// A pass covers 64*NT columns: wave w owns the NT 16-column tiles starting at column
-// n0 + 16*NT*w.  NT = 1 keeps every wave busy on narrow layers (N <= 64); NT = 2 gives
-// each wave two independent accumulators, which is enough to issue an MFMA every 32
-// cycles instead of waiting out the 40-cycle dependent latency, and halves the number
-// of passes (and re-stagings of A) on wide layers.  Every output element is one
-// k-ordered fma chain either way.
-// sA: [nbuf][16][KC+4] (used only when A comes from global), sB: [nbuf][64*NT][KC+4];
+// The workgroup is 8 waves (512 threads): a pass covers 128 columns, wave w owns the
+// 16-column tile at n0 + 16w (on layers narrower than 128 the upper waves only help with
+// the staging).  Two waves per SIMD is the point: with one wave per SIMD the ~390
+// instructions of a K-chunk round (address math, selects, LDS traffic around only 32
+// MFMAs) issue back to back with nothing to hide their latencies -- the in-kernel
+// timeline showed 3.6 k cycles per round against 1 k cycles of MFMA.  Eight waves split the
+// same round into streams half as long that interleave on each SIMD.
+// Every output element is one k-ordered fma chain.
+// sA: [nbuf][16][KC+4] (used only when A comes from global), sB: [nbuf][128][KC+4];
 // nbuf = 2 (double buffered) when the layer needs more than one K chunk, else 1.
-template <bool A_LDS, bool O_LDS, bool VEC, int KC, int NT>
+constexpr int kThreads = 512;
+constexpr int PN = 128;                  // columns per pass (8 waves x 16)
+
+template <bool A_LDS, bool O_LDS, bool VEC, int KC>
 __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t M, int K,
                                            const float* __restrict__ W, int64_t ldw,
                                            const float* __restrict__ bias, int N, int n_begin,
                                            int n_end, int act, int nbuf, float* sA, float* sB TL_PARAM) {
   constexpr int BMK = 16;
-  constexpr int PN = BN * NT;            // columns per pass
   constexpr int LD = KC + 4;
-  constexpr int QPR = KC / 4;            // float4 per staged row
-  constexpr int NA = KC / 64;            // float4 of A per thread per chunk
-  constexpr int NB = NT * KC / 16;       // float4 of W per thread per chunk
+  constexpr int QPR = KC / 4;                       // float4 per staged row
+  constexpr int NA = (16 * QPR + kThreads - 1) / kThreads;   // float4 of A per thread per chunk (KC=64: half the threads)
+  constexpr int NB = PN * QPR / kThreads;           // float4 of W per thread per chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -196,19 +199,18 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
   const int n_chunks = (K + KC - 1) / KC;
 
   for (int n0 = n_begin; n0 < n_end; n0 += PN) {
-    f32x4 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool my_tile = n0 + wave * 16 < n_end;    // wave-uniform: is there a tile for me?
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float4 ra[NA], rb[NB];
     auto fetch = [&](int kc) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = min(tid + i * kThreads, 16 * QPR - 1);
         if (!A_LDS) ra[i] = load4_raw<VEC>(io.a_glb, io.lda_glb, io.a_row0 + idx / QPR, io.a_rows, kc + (idx % QPR) * 4, K);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * kThreads;
         rb[i] = load4_raw<VEC>(W, ldw, n0 + idx / QPR, N, kc + (idx % QPR) * 4, K);
       }
     };
@@ -216,15 +218,15 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       const bool tail = kc + KC > K;              // uniform: only the last chunk needs the k mask
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * kThreads;
         const int row = idx / QPR, k = (idx % QPR) * 4;
-        if (!A_LDS)
+        if (!A_LDS && idx < 16 * QPR)
           *reinterpret_cast<float4*>(sA + (buf * BMK + row) * LD + k) =
               swz4(tail ? mask4(ra[i], kc + k, K) : ra[i], row);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * kThreads;
         const int row = idx / QPR, k = (idx % QPR) * 4;
         *reinterpret_cast<float4*>(sB + (buf * PN + row) * LD + k) =
             swz4(tail ? mask4(rb[i], kc + k, K) : rb[i], row);
@@ -245,51 +247,38 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
       if (more) fetch((c + 1) * KC);   // next chunk's global loads fly during the MFMAs
       TL(11);
 
-      const int gs = swz(g, r);                         // see swz4: rows 8..15 live at k^2
-      const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + gs
-                              : sA + (buf * BMK + r) * LD + gs;
-      const float* pb = sB + (buf * PN + wave * 16 * NT + r) * LD + gs;
-      const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
-      constexpr int SG = 16 / NT;                       // steps whose operands are read together
-      constexpr int NG = KC / 4 / SG;                   // operand groups per chunk
-      // Only the last chunk of an LDS activation slab can hold stale columns past K (staged
-      // chunks are zero filled there): keep the select out of the steady state.
-      const bool a_tail = A_LDS && (c + 1) * KC > K;
-      // Operand reads are software pipelined by hand over two register sets: the
-      // ds_reads of group sg+1 are issued BEFORE the MFMAs of group sg (the scheduling
-      // barriers pin that order), so LDS latency hides under 16 MFMAs instead of being
-      // paid in front of every pair (what the compiler's own schedule did).
-      float av[2][SG], bv[2][NT][SG];
-      auto read_group = [&](int sg, int set) {
+      if (my_tile) {
+        const int gs = swz(g, r);                         // see swz4: rows 8..15 live at k^2
+        const float* pa = A_LDS ? io.a_lds + r * io.lda_lds + c * KC + gs
+                                : sA + (buf * BMK + r) * LD + gs;
+        const float* pb = sB + (buf * PN + wave * 16 + r) * LD + gs;
+        const int ksteps = min(KC, K - c * KC + 3) / 4;   // steps that carry real k
+        // Only the last chunk of an LDS activation slab can hold stale columns past K (staged
+        // chunks are zero filled there): keep the select out of the steady state.
+        const bool a_tail = A_LDS && (c + 1) * KC > K;
+        // operands of 16 steps (64 k) are read together (one counted lgkmcnt stream), then
+        // their 16 MFMAs; the SIMD's second wave covers the LDS latency in between
 #pragma unroll
-        for (int s = 0; s < SG; ++s) {
-          av[set][s] = pa[4 * (SG * sg + s)];
+        for (int sg = 0; sg < KC / 64; ++sg) {
+          if (16 * sg < ksteps) {                           // uniform
+            float av[16], bv[16];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) bv[set][j][s] = pb[j * 16 * LD + 4 * (SG * sg + s)];
-        }
-      };
-      read_group(0, 0);
+            for (int s = 0; s < 16; ++s) {
+              av[s] = pa[4 * (16 * sg + s)];
+              bv[s] = pb[4 * (16 * sg + s)];
+            }
+            if (a_tail) {
 #pragma unroll
-      for (int sg = 0; sg < NG; ++sg) {
-        const int set = sg & 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (sg + 1 < NG) read_group(sg + 1, set ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SG * sg < ksteps) {                         // uniform
-          if (a_tail) {
+              for (int s = 0; s < 16; ++s) av[s] = (c * KC + 4 * (16 * sg + s) + g < K) ? av[s] : 0.f;
+            }
+            // fma(0, 0, acc) == acc, so a padded step is exact; skip groups of 4 uniformly
 #pragma unroll
-            for (int s = 0; s < SG; ++s)
-              av[set][s] = (c * KC + 4 * (SG * sg + s) + g < K) ? av[set][s] : 0.f;
-          }
-          // fma(0, 0, acc) == acc, so a padded step is exact; skip groups of 4 uniformly
+            for (int q = 0; q < 4; ++q) {
+              if (16 * sg + 4 * q < ksteps) {
 #pragma unroll
-          for (int q = 0; q < SG / 4; ++q) {
-            if (SG * sg + 4 * q < ksteps) {
-#pragma unroll
-              for (int s = 4 * q; s < 4 * q + 4; ++s)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                  acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][s], bv[set][j][s], acc[j], 0, 0, 0);
+                for (int s = 4 * q; s < 4 * q + 4; ++s)
+                  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+              }
             }
           }
         }
@@ -302,20 +291,17 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
     }
 
     // epilogue: bias + activation; lane holds rows g*4+i of its tile, column r
+    const int col = n0 + wave * 16 + r;
+    if (my_tile && col < N) {
+      const float bcol = bias ? bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + (wave * NT + j) * 16 + r;
-      if (col < N) {
-        const float bcol = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = g * 4 + i;
-          const float v = act_apply(acc[j][i] + bcol, act);
-          if (O_LDS) {
-            io.o_lds[row * io.ldo_lds + swz(col, row)] = v;
-          } else if (m0 + row < M) {
-            io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
-          }
+      for (int i = 0; i < 4; ++i) {
+        const int row = g * 4 + i;
+        const float v = act_apply(acc[i] + bcol, act);
+        if (O_LDS) {
+          io.o_lds[row * io.ldo_lds + swz(col, row)] = v;
+        } else if (m0 + row < M) {
+          io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
         }
       }
     }
@@ -341,25 +327,25 @@ __device__ __forceinline__ void resolve_src(const XSrc& xs, const float* x, int6
   }
 }
 
-// Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 64*NT-column group.
-template <bool VEC, int KC, int NT>
-__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
+// Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 128-column group.
+template <bool VEC, int KC>
+__global__ __launch_bounds__(512) void fc_kernel(const float* __restrict__ x, int64_t ldx, int64_t M,
                                                  int K, const float* __restrict__ W, int64_t ldw,
                                                  const float* __restrict__ b, int N, int act,
                                                  float* __restrict__ y, int64_t ldy, int nbuf,
                                                  Done done, XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                              // [nbuf][16][KC+4]
-  float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][64*NT][KC+4]
+  float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][128][KC+4]
 #ifdef DRS_TIMELINE
-  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(sB + nbuf * BN * NT * (KC + 4));
+  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(sB + nbuf * PN * (KC + 4));
   if (threadIdx.x == 0) g_tl_lds[0] = 0;
 #endif
   LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0};
   resolve_src(xs, x, M, (int64_t)blockIdx.x * 16, &io.a_glb, &io.a_row0, &io.a_rows);
-  const int n0 = blockIdx.y * BN * NT;
-  layer_pass<false, false, VEC, KC, NT>(io, (int64_t)blockIdx.x * 16, M, K, W, ldw, b, N, n0,
-                                        min(n0 + BN * NT, N), act, nbuf, sA, sB TL_ARG);
+  const int n0 = blockIdx.y * PN;
+  layer_pass<false, false, VEC, KC>(io, (int64_t)blockIdx.x * 16, M, K, W, ldw, b, N, n0,
+                                    min(n0 + PN, N), act, nbuf, sA, sB TL_ARG);
 #ifdef DRS_TIMELINE
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     const unsigned n = (unsigned)g_tl_lds[0];
@@ -372,7 +358,6 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, in
 }
 
 // One chain of layers on the block's 16 rows; activations ping-pong between two LDS slabs.
-// Layers wider than 64 columns run with two tiles per wave (NT = 2).
 //
 // The chain's input rows are streamed exactly once by exactly one workgroup, so every
 // chunk of them is a compulsory miss all the way to HBM / Infinity Cache (~2 us) that a
@@ -392,15 +377,15 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
     resolve_src(xs, a.x, a.M, m0, &base, &row0, &rows);
     const int qpr = (K0 + 3) / 4;                 // float4 per row
     const int total = 16 * qpr;
-    float4 v[10];
+    float4 v[5];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int idx = min((int)threadIdx.x + i * 256, total - 1);
+    for (int i = 0; i < 5; ++i) {
+      const int idx = min((int)threadIdx.x + i * kThreads, total - 1);
       v[i] = load4_raw<VEC>(base, a.ldx, row0 + idx / qpr, rows, (idx % qpr) * 4, K0);
     }
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int idx = threadIdx.x + i * 256;
+    for (int i = 0; i < 5; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
       if (idx < total)
         *reinterpret_cast<float4*>(slabA + (idx / qpr) * ldA + (idx % qpr) * 4) =
             swz4(mask4(v[i], (idx % qpr) * 4, K0), idx / qpr);
@@ -424,10 +409,7 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
     io.ldo_lds = slab_ld;
     const int K = a.width[l], N = a.width[l + 1];
 #define DRS_PASS(AL, OL)                                                                          \
-  if (N > BN)                                                                                     \
-    layer_pass<AL, OL, VEC, KC, 2>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB TL_ARG); \
-  else                                                                                            \
-    layer_pass<AL, OL, VEC, KC, 1>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB TL_ARG)
+  layer_pass<AL, OL, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB TL_ARG)
     if (!a_lds && last) { DRS_PASS(false, false); }
     else if (!a_lds) { DRS_PASS(false, true); }
     else if (last) { DRS_PASS(true, false); }
@@ -443,12 +425,12 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
 // interaction, the top MLP that reads that buffer.  The second chain re-reads rows this
 // very workgroup wrote: a workgroup-scope fence + barrier orders that.
 template <bool VEC, int KC>
-__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, int slab_ld, int nbuf,
+__global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, int slab_ld, int nbuf,
                                                     int ldA, Done done, XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                              // [nbuf][16][KC+4]
   float* sB = sA + nbuf * 16 * (KC + 4);         // [nbuf][128][KC+4]
-  float* slab0 = sB + nbuf * 2 * BN * (KC + 4);  // [16][slab_ld]
+  float* slab0 = sB + nbuf * PN * (KC + 4);      // [16][slab_ld]
   float* slab1 = slab0 + 16 * slab_ld;
   float* slabA = ldA > 0 ? slab1 + 16 * slab_ld : nullptr;   // [16][ldA] preloaded chain input
 #ifdef DRS_TIMELINE
@@ -470,8 +452,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a0, ChainArgs a1, 
     auto touch = [&](const ChainArgs& c, int l) -> float {
       if (l >= c.n_layers) return 0.f;
       const int64_t lines = ((int64_t)c.width[l] * c.width[l + 1] + 31) / 32;   // 128-B lines
-      // 16 parts x 256 threads x 1 line: covers 512 KB per layer (all of RM1/RM2's layers)
-      const int64_t i = min(lines - 1, (int64_t)part * 256 + threadIdx.x + (int64_t)(blockIdx.x >> 7) * 4096);
+      // 16 parts x 512 threads x 1 line: covers 1 MB per layer (all of RM1/RM2's layers)
+      const int64_t i = min(lines - 1, (int64_t)part * kThreads + threadIdx.x + (int64_t)(blockIdx.x >> 7) * 16 * kThreads);
       return c.W[l][i * 32];
     };
 #pragma unroll
@@ -572,8 +554,8 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 constexpr size_t kLdsBudget = 156 * 1024;
 
-static size_t stage_bytes(int kc, int nbuf, int nt) {
-  return sizeof(float) * (size_t)nbuf * (16 + BN * nt) * (kc + 4);
+static size_t stage_bytes(int kc, int nbuf, int) {
+  return sizeof(float) * (size_t)nbuf * (16 + PN) * (kc + 4);
 }
 
 // Fewest K rounds that fit the LDS budget next to `extra` bytes of slabs.
@@ -609,10 +591,8 @@ static hipError_t init_mlp_kernels() {
   if (done) return hipSuccess;
   hipError_t e = hipSuccess;
 #define SET_ATTR(KC_)                                                               \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, 1>);                    \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, 1>);                   \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_, 2>);                    \
-  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_, 2>);                   \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_>);                       \
+  if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_>);                      \
   if (e == hipSuccess) e = set_max_lds(chain_kernel<true, KC_>);                    \
   if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
   DRS_FOR_EACH_KC(SET_ATTR)
@@ -634,30 +614,26 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
   int kc = 64, nbuf = 2;
-  // two tiles per wave once that still leaves >= 256 workgroups
-  int nt = (N > BN && ((M + 15) / 16) * ((N + 2 * BN - 1) / (2 * BN)) >= 256) ? 2 : 1;
-  if (!pick_kc(K, 0, nt, &kc, &nbuf)) return hipErrorInvalidValue;
+  if (!pick_kc(K, 0, 2, &kc, &nbuf)) return hipErrorInvalidValue;
 #ifdef DRS_TIMELINE
-  const size_t lds = stage_bytes(kc, nbuf, nt) + 8192;
+  const size_t lds = stage_bytes(kc, nbuf, 2) + 8192;
 #else
-  const size_t lds = stage_bytes(kc, nbuf, nt);
+  const size_t lds = stage_bytes(kc, nbuf, 2);
 #endif
-  dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + BN * nt - 1) / (BN * nt)));
+  dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + PN - 1) / PN));
   bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
-#define LAUNCH2(KC_, VEC_, NT_)                                                                   \
-  hipLaunchKernelGGL((fc_kernel<VEC_, KC_, NT_>), grid, dim3(256), lds, s, x, ldx, M, K, W,       \
-                     (int64_t)K, b, N, act, y, ldy, nbuf, d, xs)
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
-    if (vec && nt == 2) LAUNCH2(KC_, true, 2);                                                    \
-    else if (vec) LAUNCH2(KC_, true, 1);                                                          \
-    else if (nt == 2) LAUNCH2(KC_, false, 2);                                                     \
-    else LAUNCH2(KC_, false, 1);                                                                  \
+    if (vec)                                                                                      \
+      hipLaunchKernelGGL((fc_kernel<true, KC_>), grid, dim3(kThreads), lds, s, x, ldx, M, K, W,   \
+                         (int64_t)K, b, N, act, y, ldy, nbuf, d, xs);                             \
+    else                                                                                          \
+      hipLaunchKernelGGL((fc_kernel<false, KC_>), grid, dim3(kThreads), lds, s, x, ldx, M, K, W,  \
+                         (int64_t)K, b, N, act, y, ldy, nbuf, d, xs);                             \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
-#undef LAUNCH2
   return hipGetLastError();
 }
 
@@ -739,9 +715,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
     if (vec)                                                                                      \
-      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, lda, d, xs);  \
+      hipLaunchKernelGGL((chain_kernel<true, KC_>), grid, dim3(kThreads), lds, s, a, second, sld, nbuf, lda, d, xs);  \
     else                                                                                          \
-      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(256), lds, s, a, second, sld, nbuf, lda, d, xs); \
+      hipLaunchKernelGGL((chain_kernel<false, KC_>), grid, dim3(kThreads), lds, s, a, second, sld, nbuf, lda, d, xs); \
   }
   DRS_FOR_EACH_KC(LAUNCH)
 #undef LAUNCH
