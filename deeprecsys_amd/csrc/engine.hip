@@ -360,7 +360,9 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   done.dev_err = s.d_err; done.seq = s.seq;
   if (prof && e->zero_copy) { done.ts = s.d_ts; done.ts_blocks = (uint32_t)s.ts_blocks; done.span_acc = s.d_span_acc; done.host_span = s.dm_span; }
   const Done* dp = e->zero_copy ? &done : nullptr;
-  float* out = e->zero_copy ? reinterpret_cast<float*>(s.dm_out + 2) : s.d_out;
+  float* out = s.d_out;          // kernels store to the device buffer; see Done::host_out
+  done.dev_out = s.d_out; done.host_out = reinterpret_cast<float*>(s.dm_out + 2);
+  done.out_words = (uint32_t)(Mv * e->n_out);
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   xs.q = q;

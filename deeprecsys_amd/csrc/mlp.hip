@@ -130,28 +130,42 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
       atomicMax(reinterpret_cast<unsigned long long*>(d.span_acc) + 1, hi);
     }
   }
-  __threadfence_system();
+  // publish this workgroup's (device-memory) outputs: every wave drains its stores, ONE
+  // lane releases at agent scope, then takes a ticket (cdna guide, G16 counter form)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == n_blocks - 1) {
-      // last workgroup of the launch: everything the query produced is visible
-      __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d.ts) {
-        unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
-        const unsigned long long lo = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(acc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(acc, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_u[0] = old == n_blocks - 1;
+    if (s_u[0]) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  (void)s_u;
+  __syncthreads();
+  if (!s_u[0]) return;
+  // last workgroup of the launch: everything the query produced is visible to it.  Stream
+  // the outputs to host-mapped pinned memory, then ONE system-scope release and the flag.
+  for (unsigned i = threadIdx.x; i < d.out_words; i += blockDim.x)
+    d.host_out[i] = __builtin_nontemporal_load(d.dev_out + i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d.ts) {
+      unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
+      const unsigned long long lo = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long hi = __hip_atomic_load(acc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(acc, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: outputs before the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 struct LayerIo {
