@@ -130,23 +130,21 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
       atomicMax(reinterpret_cast<unsigned long long*>(d.span_acc) + 1, hi);
     }
   }
-  // publish this workgroup's (device-memory) outputs: every wave drains its stores, ONE
-  // lane releases at agent scope, then takes a ticket (cdna guide, G16 counter form)
+  // publish this workgroup's outputs (device memory, stored write-through = sc1, see
+  // LayerIo::o_sc1): every wave drains its stores, then ONE lane takes a ticket; no L2
+  // write-back fence is needed for write-through data (cdna guide G16, form R1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_u[0] = old == n_blocks - 1;
-    if (s_u[0]) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (!s_u[0]) return;
   // last workgroup of the launch: everything the query produced is visible to it.  Stream
   // the outputs to host-mapped pinned memory, then ONE system-scope release and the flag.
   for (unsigned i = threadIdx.x; i < d.out_words; i += blockDim.x)
-    d.host_out[i] = __builtin_nontemporal_load(d.dev_out + i);
+    d.host_out[i] = __hip_atomic_load(d.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: bypasses my L1
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -179,6 +177,8 @@ struct LayerIo {
   int64_t ldo_glb;
   float* o_lds;         // output slab in LDS or nullptr
   int ldo_lds;
+  bool o_sc1;           // outputs of the query's LAST layer: write-through (agent-scope) stores,
+                        // so publishing them to the last-arriving workgroup needs no L2 write-back fence
 };
 
 // One layer for the block's 16 rows [m0, m0+16) and the columns [n_begin, n_end).
@@ -315,7 +315,9 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
         if (O_LDS) {
           io.o_lds[row * io.ldo_lds + swz(col, row)] = v;
         } else if (m0 + row < M) {
-          io.o_glb[(m0 + row) * io.ldo_glb + col] = v;
+          float* dst = io.o_glb + (m0 + row) * io.ldo_glb + col;
+          if (io.o_sc1) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = v;
         }
       }
     }
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512) void fc_kernel(const float* __restrict__ x, in
   unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(sB + nbuf * PN * (KC + 4));
   if (threadIdx.x == 0) g_tl_lds[0] = 0;
 #endif
-  LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0};
+  LayerIo io = {x, ldx, 0, 0, nullptr, 0, y, ldy, nullptr, 0, done.counter != nullptr};
   resolve_src(xs, x, M, (int64_t)blockIdx.x * 16, &io.a_glb, &io.a_row0, &io.a_rows);
   const int n0 = blockIdx.y * PN;
   layer_pass<false, false, VEC, KC>(io, (int64_t)blockIdx.x * 16, M, K, W, ldw, b, N, n0,
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(512) void fc_kernel(const float* __restrict__ x, in
 template <bool VEC, int KC>
 __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, int64_t m0, int slab_ld,
                                           int nbuf, float* sA, float* sB, float* slab0, float* slab1,
-                                          float* slabA, int ldA TL_PARAM) {
+                                          float* slabA, int ldA, bool publish TL_PARAM) {
   float* cur = nullptr;
   const int K0 = a.width[0];
   const bool pre = slabA != nullptr && K0 <= 640;
@@ -421,6 +423,7 @@ __device__ __forceinline__ void run_chain(const ChainArgs& a, const XSrc& xs, in
     io.ldo_glb = a.ldy;
     io.o_lds = last ? nullptr : nxt;
     io.ldo_lds = slab_ld;
+    io.o_sc1 = last && publish;
     const int K = a.width[l], N = a.width[l + 1];
 #define DRS_PASS(AL, OL)                                                                          \
   layer_pass<AL, OL, VEC, KC>(io, m0, a.M, K, a.W[l], K, a.b[l], N, 0, N, a.act[l], nbuf, sA, sB TL_ARG)
@@ -481,13 +484,15 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
   for (int i = threadIdx.x; i < 2 * 16 * slab_ld; i += blockDim.x) slab0[i] = 0.f;
   __syncthreads();
 
-  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA TL_ARG);
+  run_chain<VEC, KC>(a0, xs, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA,
+                     done.counter != nullptr && a1.n_layers == 0 TL_ARG);
   if (a1.n_layers > 0) {
     __threadfence_block();
     __syncthreads();
     XSrc none;
     none.q.n_q = 0;
-    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA TL_ARG);
+    run_chain<VEC, KC>(a1, none, m0, slab_ld, nbuf, sA, sB, slab0, slab1, slabA, ldA,
+                       done.counter != nullptr TL_ARG);
   }
 #pragma unroll
   for (int l = 0; l < 2 * DRS_MAX_CHAIN; ++l) asm volatile("" ::"v"(warm[l]));
