@@ -63,7 +63,7 @@ struct Done {
   // host-mapped memory, so profiling adds no copy, no sync and no extra launch
   const uint64_t* ts;       // [2 * ts_blocks] or nullptr
   uint32_t ts_blocks;
-  uint64_t* span_acc;       // device [2]: running (min, max), reset by the last arriver
+  uint64_t* span_acc;       // device [2 * workgroups of the last kernel]: per-workgroup (min, max)
   uint64_t* host_span;      // host-mapped [2]
   // the outputs themselves: every workgroup stores to the DEVICE buffer; only the last
   // arriver streams them to host-mapped memory (8 KB for 2048 rows) behind ONE system-scope

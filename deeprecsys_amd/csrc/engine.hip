@@ -640,8 +640,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_out), s.h_out, 0));
     CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_rows * T));
-    CREATE_TRY(hipMalloc(&s.d_span_acc, sizeof(uint64_t) * 2));
-    { const uint64_t init[2] = {~0ull, 0ull}; CREATE_TRY(hipMemcpy(s.d_span_acc, init, sizeof init, hipMemcpyHostToDevice)); }
+    CREATE_TRY(hipMalloc(&s.d_span_acc, sizeof(uint64_t) * 2 * 65536));
     CREATE_TRY(hipHostMalloc(&s.h_span, sizeof(uint64_t) * 2, hipHostMallocMapped | hipHostMallocCoherent));
     s.h_span[0] = s.h_span[1] = 0;
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_span), s.h_span, 0));

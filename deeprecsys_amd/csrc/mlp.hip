@@ -125,9 +125,21 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
       lo = lo2 < lo ? lo2 : lo;
       hi = hi2 > hi ? hi2 : hi;
     }
-    if ((threadIdx.x & 63) == 0 && hi != 0ull) {
-      atomicMin(reinterpret_cast<unsigned long long*>(d.span_acc), lo);
-      atomicMax(reinterpret_cast<unsigned long long*>(d.span_acc) + 1, hi);
+    // one (min, max) pair per workgroup, stored write-through; the last arriver folds them.
+    // (Atomics on one address from every wave serialise at ~12 ns each: 2048 of them cost
+    // more than the whole MLP.)
+    unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (unsigned w = 1; w < blockDim.x / 64; ++w) {
+        lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
+        hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
+      }
+      unsigned long long* part = reinterpret_cast<unsigned long long*>(d.span_acc) + 2 * bid;
+      __hip_atomic_store(part, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(part + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   // publish this workgroup's outputs (device memory, stored write-through = sc1, see
@@ -144,25 +156,47 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
   // last workgroup of the launch: everything the query produced is visible to it.  Stream
   // the outputs to host-mapped pinned memory, then ONE system-scope release and the flag.
   for (unsigned i = threadIdx.x; i < d.out_words; i += blockDim.x)
-    d.host_out[i] = __hip_atomic_load(d.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: bypasses my L1
+    __hip_atomic_store(d.host_out + i,
+                       __hip_atomic_load(d.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc1 load (bypasses my L1) -> write-through store
+  unsigned long long lo = ~0ull, hi = 0ull;
+  if (d.ts) {
+    // fold the per-workgroup (min start, max end) pairs: all threads, then waves, then one lane
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
+    for (unsigned b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+      const unsigned long long a = __hip_atomic_load(acc + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long z = __hip_atomic_load(acc + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lo = a < lo ? a : lo;
+      hi = z > hi ? z : hi;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const unsigned long long lo2 = __shfl_xor(lo, m), hi2 = __shfl_xor(hi, m);
+      lo = lo2 < lo ? lo2 : lo;
+      hi = hi2 > hi ? hi2 : hi;
+    }
+    unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
+    if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d.ts) {
-      unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
-      const unsigned long long lo = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long hi = __hip_atomic_load(acc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(acc, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(acc + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
+      for (unsigned w = 1; w < blockDim.x / 64; ++w) {
+        lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
+        hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
+      }
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: outputs before the flag
+    // every payload store above is a write-through system-scope store that has been waited
+    // for (vmcnt(0) + barrier): the flag can follow without an L2 write-back fence (G16 R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
