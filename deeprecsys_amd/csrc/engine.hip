@@ -118,6 +118,8 @@ struct drs_engine {
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1, mlp_fuse = 1;
+  int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
+  int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -215,7 +217,7 @@ int act_of(const Mlp& m, int l) { return (l + 1 == m.sigmoid_layer) ? DRS_ACT_SI
 // A layer big enough to deserve its own 2-D launch (many workgroups, W streamed once per
 // 16-row slab would be too much traffic): RM3's 2560x1024.  RM1's 576x256 is not.
 bool is_wide(const drs_engine* e, const Mlp& m, int l) {
-  return e->mlp_split && (int64_t)m.ln[l] * m.ln[l + 1] >= 512 * 1024;
+  return e->mlp_split && (int64_t)m.ln[l] * m.ln[l + 1] >= e->mlp_wide_kn;
 }
 
 void fill_chain(ChainArgs& c, const Mlp& m, int l0, int cnt, const float* x, int64_t ldx, int64_t M,
@@ -277,7 +279,7 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
 bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const Done* dp,
                           const XSrc* xs, int32_t* rc) {
   *rc = DRS_OK;
-  if (!e->mlp_fuse || e->kind != DRS_MODEL_DLRM || e->interaction_op != DRS_INTERACT_CAT) return false;
+  if (!e->mlp_fuse || Mv < e->mlp_fuse_rows || e->kind != DRS_MODEL_DLRM || e->interaction_op != DRS_INTERACT_CAT) return false;
   const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
   if (nb < 1 || nt < 1 || nb > DRS_MAX_CHAIN || nt > DRS_MAX_CHAIN) return false;
   for (int l = 0; l < nb; ++l) if (is_wide(e, e->bot, l)) return false;
@@ -1003,6 +1005,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     for (auto& s : e->slots) s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
+  else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) g_mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
