@@ -25,6 +25,8 @@ extern int g_sls_u;
 extern int g_sls_v_d32;
 extern int g_mlp_preload;
 extern int g_mlp_kc;
+extern int g_mlp_stream;
+extern int g_mlp_debug;
 }  // namespace drs
 
 using namespace drs;
@@ -118,7 +120,7 @@ struct drs_engine {
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1, mlp_fuse = 1;
-  int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
+  int64_t mlp_wide_kn = 64 * 1024;   // K*N from which a layer gets its own 2-D launch
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
@@ -730,21 +732,32 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   Layer& L = M->layers[layer];
   if (!L.W) {
     if (!e->w_arena) {
-      // sized for every layer of the three MLPs (the final predictor's width is at most 1024)
-      size_t need = 0;
-      for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
+      // sized for every layer of the three MLPs (the final predictor's width is at most 1024).
+      // All biases sit in front, back to back in layer order (each padded to 4 floats), so a
+      // fused MLP launch can pull every bias it needs into LDS with one flat copy.
+      size_t need = 0, nbias = 0;
+      for (Mlp* mm : {&e->bot, &e->top, &e->fin})
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
           const size_t out = mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024;
-          need += ((size_t)mm->ln[i] * out + 63) / 64 * 64 + (out + 63) / 64 * 64;
+          need += ((size_t)mm->ln[i] * out + 63) / 64 * 64;
+          nbias += (out + 3) / 4 * 4;
         }
+      nbias = (nbias + 63) / 64 * 64;
+      need += nbias;
       e->w_arena_floats = need < (1u << 20) ? (1u << 20) : need;   // >= 4 MiB
       HIP_TRY(e, hipMalloc(&e->w_arena, sizeof(float) * e->w_arena_floats));
+      size_t boff = 0;
+      for (Mlp* mm : {&e->bot, &e->top, &e->fin})
+        for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
+          mm->layers[i].b = e->w_arena + boff;
+          boff += ((mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024) + 3) / 4 * 4;
+        }
+      e->w_arena_used = nbias;
     }
-    const size_t wsz = ((size_t)m * n + 63) / 64 * 64, bsz = ((size_t)m + 63) / 64 * 64;
-    if (e->w_arena_used + wsz + bsz > e->w_arena_floats) return fail(e, DRS_ERR_OOM, "weight arena exhausted");
+    const size_t wsz = ((size_t)m * n + 63) / 64 * 64;
+    if (e->w_arena_used + wsz > e->w_arena_floats) return fail(e, DRS_ERR_OOM, "weight arena exhausted");
     L.W = e->w_arena + e->w_arena_used;
-    L.b = L.W + wsz;
-    e->w_arena_used += wsz + bsz;
+    e->w_arena_used += wsz;
   }
   HIP_TRY(e, hipMemcpy(L.W, h_W, sizeof(float) * (size_t)m * n, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(L.b, h_b, sizeof(float) * (size_t)m, hipMemcpyHostToDevice));
@@ -1008,6 +1021,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_stream")) g_mlp_stream = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_debug")) g_mlp_debug = (int)value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) g_mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);

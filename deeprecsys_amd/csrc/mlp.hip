@@ -542,6 +542,262 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
 }
 
 // ---------------------------------------------------------------------------
+// Stream kernel: the same chain(s) of layers as chain_kernel, organised around ONE flat
+// stream of weight tiles instead of per-layer passes.
+//
+// chain_kernel's K-chunk round is fetch -> MFMA -> stash -> barrier with every phase
+// exposed (in-kernel timeline: ~1.0 k cycles of MFMA in a 2.2 k cycle round) and every
+// pass of every layer starts with a cold fetch (6 x ~2.3 k cycles on RM1).  Weights do not
+// depend on activations, so here the tiles W[n0:n0+128, c*64:(c+1)*64] of ALL layers form
+// one sequence that is fetched two tiles ahead of its use, across pass and layer
+// boundaries:
+//     round i:  issue global loads of tile i+2          (registers, set i&1)
+//               MFMAs of tile i from LDS buffer i&1, interleaved with
+//               the LDS stash of tile i+1 (set (i+1)&1 -> buffer (i+1)&1)
+//               [epilogue of the pass: bias + activation -> next layer's LDS slab]
+//               barrier
+// so a round is bounded by the MFMA pipe (16 dependent MFMAs x 2 waves per SIMD), the
+// loads have two rounds to land and the only cold start is the kernel's first tile.
+// All layer inputs live in LDS slabs: the chains' global inputs (dense features; the
+// pooled-embedding columns of the interaction buffer) are pulled in once at kernel start,
+// every later activation is written there by the previous layer's epilogue.  Slab columns
+// between K and the next multiple of 64 are kept zero, weight tiles read zeros beyond K,
+// so the MFMA body has no selects and no branches.
+// Requires K % 4 == 0 and 16-B aligned operands on every layer and the slabs to fit in
+// LDS; launch_chain2 falls back to chain_kernel otherwise.
+struct SLayer {
+  const float* W;          // [N, K] row-major
+  const float* b;          // [N] or nullptr
+  int32_t K, N, act;
+  int32_t in_off, in_ld;   // input slab: float offset in LDS, leading dimension
+  int32_t out_off, out_ld; // output slab (out_off < 0: none)
+  int32_t out_pad;         // columns [N, out_pad) of the output slab are zero filled
+  int32_t b_off;           // LDS copy of the bias (zeros when b == nullptr), N floats
+  float* g_out;            // global output or nullptr
+  int64_t g_ld;
+  int32_t g_sc1;           // write-through stores (final outputs handed over by signal_done)
+};
+struct SInput {            // 16 x cols block of a global matrix -> LDS slab, zero padded to cols_pad
+  const float* src;
+  int64_t ld;
+  int32_t col0, cols, cols_pad;
+  int32_t lds_off, lds_ld, lds_col0;
+  int32_t use_xs, pad_;
+};
+#define DRS_MAX_STREAM_LAYERS (2 * DRS_MAX_CHAIN)
+struct SArgs {
+  int32_t n_layers, n_tiles, sB_off, n_inputs;
+  int32_t dbg, lds_floats;
+  int32_t n_bias, bias_off; // all biases: n_bias floats at `bias` -> LDS float offset bias_off
+  const float* bias;
+  int64_t M;
+  const float* zero;       // 16 B of zeros in device memory: source of every out-of-range float4 load
+                           // (an address select keeps the load unconditional; a value select would
+                           // put it under divergent control flow and serialise the tile's loads)
+  SLayer L[DRS_MAX_STREAM_LAYERS];
+  SInput in[2];
+};
+
+
+__global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LD = 68;                       // staged W rows: 64 k + 4 pad
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int gs = swz(g, r);
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  float* sB = smem + a.sB_off;
+#ifdef DRS_TIMELINE
+  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(smem + a.lds_floats);
+  if (threadIdx.x == 0) g_tl_lds[0] = 0;
+#endif
+  TL(1);
+  const float* zero = a.zero;
+  // staging role of this thread: row frow (+32 j) of the tile, floats fk..fk+3 of the chunk
+  const int frow = tid >> 4, fk = (tid & 15) * 4;
+  const int st_lo = (frow & 8) ? 2 : 0, st_hi = 2 - st_lo;   // swz4 of my rows (same for all j)
+  float* const st_base = sB + frow * LD + fk;
+
+  // ---- fetch iterator: two tiles ahead --------------------------------------------------
+  int f_l = 0, f_n0 = 0, f_c = 0, f_K = a.L[0].K, f_N = a.L[0].N;
+  const float* f_W = a.L[0].W;
+  int64_t f_zoff = zero - f_W;                 // the zero page, as an element offset from f_W
+  auto fetch = [&](float4 (&rb)[4]) {
+    const int k = f_c * 64 + fk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = min(f_n0 + frow + 32 * j, f_N - 1);
+      // out-of-range k reads the zero page: an OFFSET select off one base pointer (a select of
+      // two pointers is turned into two predicated loads, i.e. divergent control flow + waits)
+      int64_t off = (int64_t)row * f_K + k;
+      if (a.dbg & 1) off = (int64_t)min(frow + 32 * j, f_N - 1) * f_K + fk;   // timing experiment: hot tile
+      off = k < f_K ? off : f_zoff;
+      asm("" : "+v"(off));
+      rb[j] = *reinterpret_cast<const float4*>(f_W + off);
+    }
+    // advance (uniform)
+    ++f_c;
+    if (f_c * 64 >= f_K) {
+      f_c = 0;
+      f_n0 += 128;
+      if (f_n0 >= f_N) {
+        f_n0 = 0;
+        if (f_l + 1 < a.n_layers) {
+          ++f_l;
+          f_K = a.L[f_l].K; f_N = a.L[f_l].N; f_W = a.L[f_l].W;
+          f_zoff = zero - f_W;
+        }
+      }
+    }
+  };
+  // swz4 by address instead of by value: the halves of a float4 go to swapped 8-B slots
+  // on rows 8..15 (two ds_write_b64, no selects)
+  auto stash = [&](int buf, const float4 (&rb)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* q = st_base + (buf * 128 + 32 * j) * LD;
+      *reinterpret_cast<float2*>(q + st_lo) = make_float2(rb[j].x, rb[j].y);
+      *reinterpret_cast<float2*>(q + st_hi) = make_float2(rb[j].z, rb[j].w);
+    }
+  };
+
+  auto stash_part = [&](int buf, const float4 (&rb)[4], int q) {
+    float* p = st_base + (buf * 128 + 32 * (q >> 1)) * LD;
+    if (q & 1) *reinterpret_cast<float2*>(p + st_hi) = make_float2(rb[q >> 1].z, rb[q >> 1].w);
+    else *reinterpret_cast<float2*>(p + st_lo) = make_float2(rb[q >> 1].x, rb[q >> 1].y);
+  };
+
+  float4 rb0[4], rb1[4];
+  fetch(rb0);                                   // tile 0
+  fetch(rb1);                                   // tile 1 (a repeat of the last tile if there is none)
+  TL(2);
+
+  // ---- chain inputs -> LDS slabs ---------------------------------------------------------
+  for (int q = 0; q < a.n_inputs; ++q) {
+    const SInput& in = a.in[q];
+    const float* base = in.src;
+    int64_t row0 = m0, rows = a.M;
+    if (in.use_xs) resolve_src(xs, in.src, a.M, m0, &base, &row0, &rows);
+    const int qpr = in.cols_pad >> 2, total = 16 * qpr;
+    float* dst = smem + in.lds_off + in.lds_col0;
+    for (int i0 = 0; i0 < total; i0 += 4 * kThreads) {
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = min(i0 + tid + j * kThreads, total - 1);
+        const int row = idx / qpr, k = (idx - row * qpr) * 4;
+        const int64_t grow = min(row0 + row, rows - 1);
+        int64_t off = grow * in.ld + in.col0 + k;
+        off = k < in.cols ? off : (int64_t)(zero - base);
+        asm("" : "+v"(off));
+        v[j] = *reinterpret_cast<const float4*>(base + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = i0 + tid + j * kThreads;
+        const int row = idx / qpr, k = (idx - row * qpr) * 4;
+        if (idx < total) *reinterpret_cast<float4*>(dst + row * in.lds_ld + k) = swz4(v[j], row);
+      }
+    }
+  }
+  // biases -> LDS: a global load in the epilogue would put a vmcnt(0) (= the full latency of
+  // the weight tiles just requested) at the end of every pass
+  // (the engine keeps the chains' biases back to back, padded to 4 floats: one flat copy)
+  for (int i0 = 0; i0 < a.n_bias; i0 += 4 * kThreads) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = a.bias[min(i0 + tid + j * kThreads, a.n_bias - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + tid + j * kThreads < a.n_bias) smem[a.bias_off + i0 + tid + j * kThreads] = v[j];
+  }
+  TL(3);
+  stash(0, rb0);
+  __syncthreads();
+  TL(4);
+
+  // ---- consume iterator ------------------------------------------------------------------
+  int c_l = 0, c_n0 = 0, c_c = 0;
+  SLayer cl = a.L[0];
+  int c_nch = (cl.K + 63) >> 6;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+#define DRS_ROUND(BUF, RB_FETCH, RB_STASH)                                                        \
+  {                                                                                               \
+    TL(10);                                                                                       \
+    fetch(RB_FETCH);                                                                              \
+    TL(11);                                                                                       \
+    const int col = c_n0 + wave * 16 + r;                                                         \
+    if (c_n0 + wave * 16 < cl.N) {                                                                \
+      const float* pa = smem + cl.in_off + r * cl.in_ld + c_c * 64 + gs;                          \
+      const float* pb = sB + ((BUF) * 128 + wave * 16 + r) * LD + gs;                             \
+      float av[16], bv[16];                                                                       \
+      _Pragma("unroll") for (int s = 0; s < 16; ++s) { av[s] = pa[4 * s]; bv[s] = pb[4 * s]; }    \
+      /* issue order, pinned: all operand reads; then the dependent MFMA chain with one LDS    */ \
+      /* write of the stash in the shadow of every second MFMA                                 */ \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                             \
+        if (!(a.dbg & 2)) {                                                                       \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * q], bv[2 * q], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * q + 1], bv[2 * q + 1], acc, 0, 0, 0);   \
+        }                                                                                         \
+        stash_part((BUF) ^ 1, RB_STASH, q);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+      }                                                                                           \
+    } else {                                                                                      \
+      stash((BUF) ^ 1, RB_STASH);                                                                 \
+    }                                                                                             \
+    TL(12);                                                                                       \
+    if (c_c == c_nch - 1) {                                                                       \
+      if (col < (cl.out_off >= 0 ? cl.out_pad : cl.N)) {                                          \
+        const float bias_v = smem[cl.b_off + min(col, cl.N - 1)];                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+          const int row = g * 4 + i;                                                              \
+          const float v = col < cl.N ? act_apply(acc[i] + bias_v, cl.act) : 0.f;                  \
+          if (cl.out_off >= 0) smem[cl.out_off + row * cl.out_ld + swz(col, row)] = v;            \
+          if (cl.g_out && col < cl.N && m0 + row < a.M) {                                         \
+            float* dstg = cl.g_out + (m0 + row) * cl.g_ld + col;                                  \
+            if (cl.g_sc1) __hip_atomic_store(dstg, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\
+            else *dstg = v;                                                                       \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
+      c_c = 0;                                                                                    \
+      c_n0 += 128;                                                                                \
+      if (c_n0 >= cl.N) {                                                                         \
+        c_n0 = 0;                                                                                 \
+        if (c_l + 1 < a.n_layers) { ++c_l; cl = a.L[c_l]; c_nch = (cl.K + 63) >> 6; }             \
+      }                                                                                           \
+    } else {                                                                                      \
+      ++c_c;                                                                                      \
+    }                                                                                             \
+    TL(13);                                                                                       \
+    __syncthreads();                                                                              \
+    TL(14);                                                                                       \
+  }
+
+  for (int i = 0; i < a.n_tiles; i += 2) {
+    DRS_ROUND(0, rb0, rb1)
+    if (i + 1 >= a.n_tiles) break;
+    DRS_ROUND(1, rb1, rb0)
+  }
+#undef DRS_ROUND
+  TL(20);
+  signal_done(done, gridDim.x, smem);
+#ifdef DRS_TIMELINE
+  TL(21);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned n = (unsigned)g_tl_lds[0];
+    unsigned base = g_tl_n;
+    for (unsigned i = 0; i < n && base + i < 16384; ++i) g_tl[base + i] = g_tl_lds[i + 1];
+    g_tl_n = base + n;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // dot interaction: one wave per sample.  T[b] is [F, D]; Z = T T^T is computed
 // in 16x16 MFMA tiles (A and B operands are the same register: B[k][j] = T[j][k]),
 // the strictly-lower (or lower, with `itself`) triangle is scattered in the
@@ -639,10 +895,17 @@ static hipError_t set_max_lds(F kernel) {
 
 #define DRS_FOR_EACH_KC(X) X(64) X(128) X(192) X(256)
 
+static float* g_zero_dev = nullptr;
+
 static hipError_t init_mlp_kernels() {
   static bool done = false;
   if (done) return hipSuccess;
   hipError_t e = hipSuccess;
+  if (!g_zero_dev) {
+    e = hipMalloc(reinterpret_cast<void**>(&g_zero_dev), 256);
+    if (e == hipSuccess) e = hipMemset(g_zero_dev, 0, 256);
+    if (e != hipSuccess) return e;
+  }
 #define SET_ATTR(KC_)                                                               \
   if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_>);                       \
   if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_>);                      \
@@ -650,6 +913,7 @@ static hipError_t init_mlp_kernels() {
   if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
   DRS_FOR_EACH_KC(SET_ATTR)
 #undef SET_ATTR
+  if (e == hipSuccess) e = set_max_lds(stream_kernel);
   if (e == hipSuccess) done = true;
   return e;
 }
@@ -734,6 +998,107 @@ size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b) {
   return chain_plan(a, &b, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
 }
 
+int g_mlp_debug = 0;
+int g_mlp_stream = 1;   // drs_set_option "mlp_stream": use stream_kernel where it applies
+
+static inline int pad64(int n) { return (n + 63) & ~63; }
+
+// Lay the chain(s) out for stream_kernel.  false = not applicable (caller uses chain_kernel).
+static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, bool publish,
+                        SArgs* out, size_t* lds_bytes) {
+  SArgs& p = *out;
+  memset(&p, 0, sizeof p);
+  const int na = a.n_layers, nb = b ? b->n_layers : 0;
+  if (na + nb > DRS_MAX_STREAM_LAYERS) return false;
+  // second chain must read the buffer the first one writes (dense_out slot in front)
+  const int d_out = a.width[na];
+  if (b && (b->x != a.y || b->ldx != a.ldy || d_out > b->width[0] || (d_out & 3))) return false;
+  auto ok_ptr = [](const void* q) { return aligned16(q); };
+  if (!ok_ptr(a.x) || (a.ldx & 3)) return false;
+  for (int i = 0; i < xs.q.n_q; ++i) if (!ok_ptr(xs.x[i])) return false;
+  for (int l = 0; l < na; ++l) if (!ok_ptr(a.W[l]) || (a.width[l] & 3)) return false;
+  if (b) {
+    if (!ok_ptr(b->x) || (b->ldx & 3)) return false;
+    for (int l = 0; l < nb; ++l) if (!ok_ptr(b->W[l]) || (b->width[l] & 3)) return false;
+  }
+  // biases back to back, each padded to 4 floats (how the engine's arena lays them out)
+  {
+    const float* expect = a.b[0];
+    if (!expect) return false;
+    for (int l = 0; l < na; ++l) { if (a.b[l] != expect) return false; expect += (a.width[l + 1] + 3) & ~3; }
+    for (int l = 0; l < nb; ++l) { if (b->b[l] != expect) return false; expect += (b->width[l + 1] + 3) & ~3; }
+  }
+  // LDS layout (floats): [sB 2x128x68][X0][RS][P][Q][biases]
+  int off = 0;
+  p.sB_off = off; off += 2 * 128 * 68;
+  const int x0_ld = pad64(a.width[0]) + 4;
+  const int x0_off = off; off += 16 * x0_ld;
+  int rs_off = -1, rs_ld = 0;
+  if (b) { rs_ld = pad64(b->width[0]) + 4; rs_off = off; off += 16 * rs_ld; }
+  // ping-pong widths
+  int wP = 0, wQ = 0;
+  {
+    int which = 0;   // next ping-pong slab to write: 0 = P, 1 = Q
+    auto note = [&](int n) { int& w = which ? wQ : wP; w = pad64(n) > w ? pad64(n) : w; which ^= 1; };
+    for (int l = 0; l < na; ++l) if (!(l == na - 1)) note(a.width[l + 1]);
+    for (int l = 0; l < nb; ++l) if (!(l == nb - 1)) note(b->width[l + 1]);
+  }
+  const int p_ld = wP + 4, q_ld = wQ + 4;
+  const int p_off = off; off += wP ? 16 * p_ld : 0;
+  const int q_off = off; off += wQ ? 16 * q_ld : 0;
+  const int bias_off = off;
+  for (int l = 0; l < na; ++l) off += (a.width[l + 1] + 3) & ~3;
+  for (int l = 0; l < nb; ++l) off += (b->width[l + 1] + 3) & ~3;
+  if (sizeof(float) * (size_t)off > kLdsBudget) return false;
+  *lds_bytes = sizeof(float) * (size_t)off;
+  p.lds_floats = off;
+
+  int which = 0, cur_off = x0_off, cur_ld = x0_ld, n = 0, tiles = 0, boff = bias_off;
+  auto add = [&](const ChainArgs& c, int l, bool last_of_chain, bool last_of_all) {
+    SLayer& L = p.L[n++];
+    L.W = c.W[l]; L.b = c.b[l]; L.K = c.width[l]; L.N = c.width[l + 1]; L.act = c.act[l];
+    L.in_off = cur_off; L.in_ld = cur_ld;
+    L.out_off = -1; L.out_ld = 0; L.out_pad = L.N;
+    L.g_out = nullptr; L.g_ld = 0; L.g_sc1 = 0;
+    L.b_off = boff; boff += (L.N + 3) & ~3;
+    if (last_of_chain) {
+      L.g_out = c.y; L.g_ld = c.ldy;
+      L.g_sc1 = last_of_all && publish;
+      if (!last_of_all) {           // dense_out slot of the second chain's input slab
+        L.out_off = rs_off; L.out_ld = rs_ld; L.out_pad = L.N;
+        cur_off = rs_off; cur_ld = rs_ld;
+      }
+    } else {
+      L.out_off = which ? q_off : p_off; L.out_ld = which ? q_ld : p_ld; L.out_pad = pad64(L.N);
+      cur_off = L.out_off; cur_ld = L.out_ld;
+      which ^= 1;
+    }
+    tiles += ((L.N + 127) / 128) * ((L.K + 63) / 64);
+  };
+  for (int l = 0; l < na; ++l) add(a, l, l == na - 1, l == na - 1 && !b);
+  for (int l = 0; l < nb; ++l) add(*b, l, l == nb - 1, l == nb - 1);
+  p.n_layers = n;
+  p.n_tiles = tiles;
+  p.n_bias = boff - bias_off;
+  p.bias_off = bias_off;
+  p.bias = a.b[0];
+  p.M = a.M;
+  p.zero = g_zero_dev;
+  p.dbg = g_mlp_debug;
+  SInput& i0 = p.in[0];
+  i0.src = a.x; i0.ld = a.ldx; i0.col0 = 0; i0.cols = a.width[0]; i0.cols_pad = pad64(a.width[0]);
+  i0.lds_off = x0_off; i0.lds_ld = x0_ld; i0.lds_col0 = 0; i0.use_xs = xs.q.n_q > 0;
+  p.n_inputs = 1;
+  if (b) {
+    SInput& i1 = p.in[1];
+    i1.src = b->x; i1.ld = b->ldx; i1.col0 = d_out; i1.cols = b->width[0] - d_out;
+    i1.cols_pad = pad64(b->width[0]) - d_out;
+    i1.lds_off = rs_off; i1.lds_ld = rs_ld; i1.lds_col0 = d_out; i1.use_xs = 0;
+    p.n_inputs = 2;
+  }
+  return true;
+}
+
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, const Done* done,
                          const XSrc* xsrc) {
   if (a.M <= 0) return hipSuccess;
@@ -747,6 +1112,17 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
     return hipErrorInvalidValue;
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
+  if (g_mlp_stream) {
+    SArgs sp;
+    size_t slds = 0;
+    if (stream_plan(a, b, xs, d.counter != nullptr, &sp, &slds)) {
+#ifdef DRS_TIMELINE
+      slds += 8192;
+#endif
+      hipLaunchKernelGGL(stream_kernel, dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
+      return hipGetLastError();
+    }
+  }
   int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
   if (!chain_plan(a, b, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;

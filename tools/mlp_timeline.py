@@ -12,7 +12,7 @@ import numpy as np
 import bench
 
 NAMES = {1: "pass start", 2: "fetch0 issued", 3: "stash0 done", 4: "barrier0", 10: "round start",
-         11: "fetch issued", 12: "mfma done", 13: "stash done", 14: "barrier"}
+         11: "fetch issued", 12: "mfma done", 13: "stash done", 14: "barrier", 20: "loop end", 21: "signal done"}
 
 
 def main():
