@@ -63,6 +63,9 @@ struct Batch {
 struct Slot {
   hipStream_t stream = nullptr;   // the stream this slot launches on (shared or own)
   hipStream_t own_stream = nullptr;
+  hipStream_t gather_stream = nullptr;   // where the gather is launched (== stream unless pipelined)
+  hipEvent_t ev_sls = nullptr;           // pipelined mode: gather done -> the MLP stream may go on
+  hipEvent_t ev_in = nullptr;            // pipelined mode: per-call inputs copied -> the gather may start
   float* T = nullptr;        // [max_batch, ldT]  concat buffer: dense_out | emb_0 | ...
   float* R = nullptr;        // [max_batch, ldR]  dot-interaction output (dot only)
   float* H = nullptr;        // [max_batch, ldH]  inter-segment MLP scratch (ping)
@@ -120,7 +123,8 @@ struct drs_engine {
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1, mlp_fuse = 1;
-  int64_t mlp_wide_kn = 64 * 1024;   // K*N from which a layer gets its own 2-D launch
+  hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+  int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
@@ -278,21 +282,39 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
 
 // DLRM with the "cat" interaction: bottom MLP and top MLP of a 16-row slab in ONE launch
 // (the slab's dense_out never waits for a kernel boundary).  false = not applicable.
-bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const Done* dp,
-                          const XSrc* xs, int32_t* rc) {
-  *rc = DRS_OK;
+bool fused_applicable(const drs_engine* e, int64_t Mv) {
   if (!e->mlp_fuse || Mv < e->mlp_fuse_rows || e->kind != DRS_MODEL_DLRM || e->interaction_op != DRS_INTERACT_CAT) return false;
   const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
   if (nb < 1 || nt < 1 || nb > DRS_MAX_CHAIN || nt > DRS_MAX_CHAIN) return false;
   for (int l = 0; l < nb; ++l) if (is_wide(e, e->bot, l)) return false;
   for (int l = 0; l < nt; ++l) if (is_wide(e, e->top, l)) return false;
   ChainArgs a, b;
+  fill_chain(a, e->bot, 0, nb, nullptr, e->m_den, Mv, nullptr, 0);
+  fill_chain(b, e->top, 0, nt, nullptr, 0, Mv, nullptr, 0);
+  return chain2_lds_bytes(a, b) <= kChainLds;
+}
+
+bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const Done* dp,
+                          const XSrc* xs, int32_t* rc) {
+  *rc = DRS_OK;
+  if (!fused_applicable(e, Mv)) return false;
+  const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
+  ChainArgs a, b;
   fill_chain(a, e->bot, 0, nb, nullptr, e->m_den, Mv, s.T, e->ldT);
   fill_chain(b, e->top, 0, nt, s.T, e->ldT, Mv, out, e->n_out);
-  if (chain2_lds_bytes(a, b) > kChainLds) return false;
   hipError_t r = launch_chain2(a, &b, s.stream, dp, xs);
   if (r != hipSuccess) *rc = fail(e, DRS_ERR_HIP, "launch_chain2: %s", hipGetErrorString(r));
   return true;
+}
+
+// shared_stream: 1 = one stream for everything (launch sets strictly back to back);
+// 0 = one stream per slot; 2 = pipelined: every gather on stream_g, everything else on the
+// first slot's stream behind an event, so the HBM-bound gather of set i+1 runs under the
+// latency-bound MLP of set i and the gathers themselves never overlap each other.
+void apply_stream_mode(drs_engine* e) {
+  for (auto& s : e->slots) {
+    s.gather_stream = e->shared_stream == 2 ? e->stream_g : s.stream;
+  }
 }
 
 // Enqueue n >= 1 coalesced queries (query i = first bs[i] samples of *bts[i]) as ONE set of
@@ -335,7 +357,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   const int64_t Mv = v;
   const bool prof = e->profiling >= 1;
   const bool evts = e->profiling >= 2;
-  if (evts) HIP_TRY(e, hipEventRecord(s.ev[0], s.stream));
+  const bool piped = s.gather_stream != s.stream;
+  if (evts) HIP_TRY(e, hipEventRecord(s.ev[0], s.gather_stream));
 
   SlsArgs a;
   memset(&a, 0, sizeof a);
@@ -351,8 +374,15 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   a.T = e->T; a.D = e->D; a.err = reinterpret_cast<int32_t*>(s.d_err);
   a.ts = prof ? s.d_ts : nullptr;
   s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, e->sls_exact) : 0;
-  HIP_TRY(e, launch_sls(a, e->sls_exact, s.stream));
-  if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.stream));
+  HIP_TRY(e, launch_sls(a, e->sls_exact, s.gather_stream));
+  if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.gather_stream));
+  if (piped) HIP_TRY(e, hipEventRecord(s.ev_sls, s.gather_stream));
+  bool joined = !piped;   // has s.stream been made to wait for the gather yet?
+  auto join = [&]() -> hipError_t {
+    if (joined) return hipSuccess;
+    joined = true;
+    return hipStreamWaitEvent(s.stream, s.ev_sls, 0);
+  };
 
   // last kernel of the job: outputs either go straight to host-mapped pinned memory
   // followed by a flag store (zero copy, no stream sync), or to a device buffer + memcpy
@@ -376,12 +406,14 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     const int D = e->D;
     const int wl = e->top.ln.back();
     const int64_t ldc = D + wl;
+    HIP_TRY(e, join());
     HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, Mv, D, s.stream));
     if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
     if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
   } else {
     bool fused = false;
     if (!e->bot.layers.empty()) {
+      if (fused_applicable(e, Mv)) HIP_TRY(e, join());
       fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
       if (rc) return rc;
     }
@@ -394,6 +426,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     } else {
       if ((rc = run_mlp(e, s, e->bot, nullptr, e->m_den, Mv, s.T, e->ldT, nullptr, &xs))) return rc;
     }
+    HIP_TRY(e, join());   // (the bottom MLP above ran beside the gather)
     const float* top_in = s.T;
     int64_t ld_top = e->ldT;
     if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
@@ -625,7 +658,6 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   const int n_out_cap = e->kind == DRS_MODEL_NCF ? 1024 : e->n_out;
   for (auto& s : e->slots) {
     CREATE_TRY(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
-    s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
     CREATE_TRY(hipMalloc(&s.T, sizeof(float) * (size_t)e->max_rows * e->ldT));
     CREATE_TRY(hipMemset(s.T, 0, sizeof(float) * (size_t)e->max_rows * e->ldT));
     CREATE_TRY(hipMalloc(&s.R, sizeof(float) * (size_t)e->max_rows * e->ldR));
@@ -650,6 +682,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_span), s.h_span, 0));
     s.h_ts.resize(2 * (size_t)e->max_rows * T);
     for (auto& ev : s.ev) CREATE_TRY(hipEventCreate(&ev));
+    CREATE_TRY(hipEventCreateWithFlags(&s.ev_sls, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
     if (alloc_batch(e, s.scratch)) return bail(DRS_ERR_OOM, e->err.c_str());
     s.scratch.n_samples = 0;
     s.h_stage_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1) +
@@ -657,6 +691,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
                       sizeof(int32_t) * (size_t)T * (e->max_batch + 1);
     CREATE_TRY(hipHostMalloc(&s.h_stage, s.h_stage_bytes, hipHostMallocDefault));
   }
+  CREATE_TRY(hipStreamCreateWithFlags(&e->stream_g, hipStreamNonBlocking));
+  apply_stream_mode(e);
 #undef CREATE_TRY
   *out = e;
   return DRS_OK;
@@ -665,8 +701,11 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
 int32_t drs_destroy(drs_handle e) {
   if (!e) return DRS_OK;
   (void)hipSetDevice(e->device);
+  if (e->stream_g) { (void)hipStreamSynchronize(e->stream_g); (void)hipStreamDestroy(e->stream_g); }
   for (auto& s : e->slots) {
     if (s.own_stream) { (void)hipStreamSynchronize(s.own_stream); (void)hipStreamDestroy(s.own_stream); }
+    if (s.ev_sls) (void)hipEventDestroy(s.ev_sls);
+    if (s.ev_in) (void)hipEventDestroy(s.ev_in);
     if (s.T) (void)hipFree(s.T);
     if (s.R) (void)hipFree(s.R);
     if (s.H) (void)hipFree(s.H);
@@ -892,6 +931,10 @@ int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* 
   Slot& s = e->slots[slot];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
   if ((rc = stage_into(e, s.scratch, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage))) return rc;
+  if (s.gather_stream != s.stream) {   // the gather runs on another stream: order it behind the copies
+    HIP_TRY(e, hipEventRecord(s.ev_in, s.stream));
+    HIP_TRY(e, hipStreamWaitEvent(s.gather_stream, s.ev_in, 0));
+  }
   const Batch* bt = &s.scratch;
   if ((rc = enqueue_forward(e, s, 1, &bt, &bs))) return rc;
   return wait_slot(e, s, h_out);
@@ -1014,8 +1057,9 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "shared_stream")) {
     int32_t rc = drs_sync(e);
     if (rc) return rc;
-    e->shared_stream = value ? 1 : 0;
-    for (auto& s : e->slots) s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
+    if (value < 0 || value > 2) return fail(e, DRS_ERR_BAD_ARG, "shared_stream is 0, 1 or 2");
+    e->shared_stream = (int)value;
+    apply_stream_mode(e);
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;

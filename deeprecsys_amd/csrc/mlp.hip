@@ -549,15 +549,15 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
 // exposed (in-kernel timeline: ~1.0 k cycles of MFMA in a 2.2 k cycle round) and every
 // pass of every layer starts with a cold fetch (6 x ~2.3 k cycles on RM1).  Weights do not
 // depend on activations, so here the tiles W[n0:n0+128, c*64:(c+1)*64] of ALL layers form
-// one sequence that is fetched two tiles ahead of its use, across pass and layer
-// boundaries:
-//     round i:  issue global loads of tile i+2          (registers, set i&1)
+// one sequence that is requested SIX tiles ahead of its use, across pass and layer
+// boundaries (a ring of six register sets per thread, 16 VGPRs each):
+//     round i:  issue global loads of tile i+6          (register set i%6)
 //               MFMAs of tile i from LDS buffer i&1, interleaved with
-//               the LDS stash of tile i+1 (set (i+1)&1 -> buffer (i+1)&1)
+//               the LDS stash of tile i+1 (set (i+1)%6 -> buffer (i+1)&1)
 //               [epilogue of the pass: bias + activation -> next layer's LDS slab]
 //               barrier
 // so a round is bounded by the MFMA pipe (16 dependent MFMAs x 2 waves per SIMD), the
-// loads have two rounds to land and the only cold start is the kernel's first tile.
+// loads have five rounds to land and the only cold start is the kernel's first tile.
 // All layer inputs live in LDS slabs: the chains' global inputs (dense features; the
 // pooled-embedding columns of the interaction buffer) are pulled in once at kernel start,
 // every later activation is written there by the previous layer's epilogue.  Slab columns
@@ -623,18 +623,22 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   int f_l = 0, f_n0 = 0, f_c = 0, f_K = a.L[0].K, f_N = a.L[0].N;
   const float* f_W = a.L[0].W;
   int64_t f_zoff = zero - f_W;                 // the zero page, as an element offset from f_W
-  auto fetch = [&](float4 (&rb)[4]) {
+  // The tile loads are issued through inline asm and waited for with an explicit
+  // s_waitcnt (DRS_WAIT_TILE): the compiler's own counter model drains the whole ring at
+  // the loop header (vmcnt(0) once per trip), which costs a full miss latency every six
+  // rounds.  vmcnt retires in order, so waiting for "at most 20 newer" is exact for the
+  // set requested five rounds (5 x 4 loads) ago no matter how many stores came in between.
+  auto fetch = [&](f32x4 (&rb)[4]) {
     const int k = f_c * 64 + fk;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = min(f_n0 + frow + 32 * j, f_N - 1);
-      // out-of-range k reads the zero page: an OFFSET select off one base pointer (a select of
-      // two pointers is turned into two predicated loads, i.e. divergent control flow + waits)
+      // out-of-range k reads the zero page
       int64_t off = (int64_t)row * f_K + k;
       if (a.dbg & 1) off = (int64_t)min(frow + 32 * j, f_N - 1) * f_K + fk;   // timing experiment: hot tile
       off = k < f_K ? off : f_zoff;
-      asm("" : "+v"(off));
-      rb[j] = *reinterpret_cast<const float4*>(f_W + off);
+      const float* p = f_W + off;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[j]) : "v"(p));
     }
     // advance (uniform)
     ++f_c;
@@ -653,26 +657,29 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   };
   // swz4 by address instead of by value: the halves of a float4 go to swapped 8-B slots
   // on rows 8..15 (two ds_write_b64, no selects)
-  auto stash = [&](int buf, const float4 (&rb)[4]) {
+  auto stash = [&](int buf, const f32x4 (&rb)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float* q = st_base + (buf * 128 + 32 * j) * LD;
-      *reinterpret_cast<float2*>(q + st_lo) = make_float2(rb[j].x, rb[j].y);
-      *reinterpret_cast<float2*>(q + st_hi) = make_float2(rb[j].z, rb[j].w);
+      *reinterpret_cast<float2*>(q + st_lo) = make_float2(rb[j][0], rb[j][1]);
+      *reinterpret_cast<float2*>(q + st_hi) = make_float2(rb[j][2], rb[j][3]);
     }
   };
+#define DRS_WAIT_TILE(RB, N) \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3]))
 
-  auto stash_part = [&](int buf, const float4 (&rb)[4], int q) {
+  auto stash_part = [&](int buf, const f32x4 (&rb)[4], int q) {
     float* p = st_base + (buf * 128 + 32 * (q >> 1)) * LD;
-    if (q & 1) *reinterpret_cast<float2*>(p + st_hi) = make_float2(rb[q >> 1].z, rb[q >> 1].w);
-    else *reinterpret_cast<float2*>(p + st_lo) = make_float2(rb[q >> 1].x, rb[q >> 1].y);
+    if (q & 1) *reinterpret_cast<float2*>(p + st_hi) = make_float2(rb[q >> 1][2], rb[q >> 1][3]);
+    else *reinterpret_cast<float2*>(p + st_lo) = make_float2(rb[q >> 1][0], rb[q >> 1][1]);
   };
 
-  float4 rb0[4], rb1[4];
-  fetch(rb0);                                   // tile 0
-  fetch(rb1);                                   // tile 1 (a repeat of the last tile if there is none)
+  // ring of 6 register sets: tile i+6 is requested in round i and stashed in round i+5, so a
+  // weight tile has five rounds to arrive (the gather of the next launch set runs beside this
+  // kernel and pushes L2 misses to several microseconds)
+  f32x4 rb0[4], rb1[4], rb2[4], rb3[4], rb4[4], rb5[4];
+  fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3); fetch(rb4); fetch(rb5);   // tiles 0..5 (repeats past the end)
   TL(2);
-
   // ---- chain inputs -> LDS slabs ---------------------------------------------------------
   for (int q = 0; q < a.n_inputs; ++q) {
     const SInput& in = a.in[q];
@@ -713,6 +720,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       if (i0 + tid + j * kThreads < a.n_bias) smem[a.bias_off + i0 + tid + j * kThreads] = v[j];
   }
   TL(3);
+  DRS_WAIT_TILE(rb0, 0);
   stash(0, rb0);
   __syncthreads();
   TL(4);
@@ -736,6 +744,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       _Pragma("unroll") for (int s = 0; s < 16; ++s) { av[s] = pa[4 * s]; bv[s] = pb[4 * s]; }    \
       /* issue order, pinned: all operand reads; then the dependent MFMA chain with one LDS    */ \
       /* write of the stash in the shadow of every second MFMA                                 */ \
+      DRS_WAIT_TILE(RB_STASH, 20);                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                             \
         if (!(a.dbg & 2)) {                                                                       \
@@ -746,6 +755,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         __builtin_amdgcn_sched_barrier(0);                                                        \
       }                                                                                           \
     } else {                                                                                      \
+      DRS_WAIT_TILE(RB_STASH, 20);                                                                \
       stash((BUF) ^ 1, RB_STASH);                                                                 \
     }                                                                                             \
     TL(12);                                                                                       \
@@ -778,12 +788,22 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     TL(14);                                                                                       \
   }
 
-  for (int i = 0; i < a.n_tiles; i += 2) {
+  for (int i = 0; i < a.n_tiles; i += 6) {
     DRS_ROUND(0, rb0, rb1)
     if (i + 1 >= a.n_tiles) break;
-    DRS_ROUND(1, rb1, rb0)
+    DRS_ROUND(1, rb1, rb2)
+    if (i + 2 >= a.n_tiles) break;
+    DRS_ROUND(0, rb2, rb3)
+    if (i + 3 >= a.n_tiles) break;
+    DRS_ROUND(1, rb3, rb4)
+    if (i + 4 >= a.n_tiles) break;
+    DRS_ROUND(0, rb4, rb5)
+    if (i + 5 >= a.n_tiles) break;
+    DRS_ROUND(1, rb5, rb0)
   }
 #undef DRS_ROUND
+#undef DRS_WAIT_TILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing requests
   TL(20);
   signal_done(done, gridDim.x, smem);
 #ifdef DRS_TIMELINE

@@ -330,3 +330,53 @@ def test_coalesced_queries_equal_individual_queries(kind):
             eng.forward_multi_async(0, [0] * 9, [1] * 9)
     finally:
         net.engine.close()
+
+
+# ------------------------------------------------------------------------------------
+# MLP launch structures: weight-tile stream kernel vs per-layer chain kernel vs one launch
+# per MLP, single stream vs pipelined gather/MLP streams -- every one the same k-ordered
+# fma chains, so the same bits
+@pytest.mark.parametrize("D,T,bot,top", [
+    (8, 3, "20-36-8", "100-200-1"),        # K tails (20, 36, 100), N not a multiple of 16, 2 passes (200)
+    (64, 8, "128-64-64", "256-64-1"),      # BASELINE RMC1 widths
+    (32, 8, "128-64-32", "256-64-1"),      # reference dlrm_rm1.json widths
+    (16, 2, "64-16", "300-4-1"),           # 3 passes, a 4-wide layer, fewer tiles than the prefetch ring
+    (4, 1, "4-4", "4-1"),                  # smallest legal widths: 3 tiles in total
+])
+def test_mlp_launch_structures_are_bit_identical(D, T, bot, top):
+    rows, L, B = 5000, 3, 100
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, bot, top, B, nb=2, seed=7)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        eng = net.engine
+        eng.set_option("sls_exact", 1)
+        lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
+        net.emb_w = [orc.fill_table_uniform(rows, D, t, lo, hi, args.numpy_rand_seed, nthreads=0)
+                     for t in range(T)]
+        om = H.oracle_model(net)
+        jobs = [(0, B), (1, 1), (0, 37), (1, 64), (0, 17)]      # row tails: 100, 1, 37, 17
+        exp = np.concatenate([om.forward(lX[b], lS_i[b], lS_l[b], bs=bs, nthreads=0) for b, bs in jobs])
+        results = {}
+        for name, opts in {
+            "stream": dict(mlp_stream=1, mlp_fuse=1, shared_stream=1),
+            "chain": dict(mlp_stream=0, mlp_fuse=1, shared_stream=1),
+            "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
+            "unfused_chain": dict(mlp_stream=0, mlp_fuse=0, shared_stream=1),
+            "standalone_layers": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1, mlp_wide_kn=1),
+            "pipelined": dict(mlp_stream=1, mlp_fuse=1, shared_stream=2),
+            "per_slot_streams": dict(mlp_stream=1, mlp_fuse=1, shared_stream=0),
+        }.items():
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            for slot in (0, 1, 2):      # keep several launch sets in flight
+                eng.forward_multi_async(slot, [b for b, _ in jobs], [bs for _, bs in jobs])
+            outs = [eng.wait(slot, sum(bs for _, bs in jobs)) for slot in (0, 1, 2)]
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), name
+            results[name] = outs[0]
+            eng.set_option("mlp_wide_kn", 512 * 1024)
+        for name, got in results.items():
+            assert np.array_equal(got, results["stream"]), name
+        assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
+    finally:
+        net.engine.close()
