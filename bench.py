@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
-    ap.add_argument("--slots", type=int, default=2)
+    ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--coalesce", type=int, default=8,
                     help="queries per launch set (the engine coalesces requests that are already queued)")
     ap.add_argument("--seed", type=int, default=123)
@@ -186,6 +186,9 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     bs, nb, slots, co = opt.batch, opt.num_batches, opt.slots, opt.coalesce
+    stream_mode = {"2": "pipelined (gathers back to back on one stream, MLP launches on a second)",
+                   "1": "single stream", "0": "one stream per launch set"}[
+        dict(kv.split("=") for kv in opt.set).get("shared_stream", "2")]
 
     def barrier():
         eng.sync()
@@ -237,6 +240,17 @@ def main():
 
     if rank == 0:
         w = WORKLOADS[opt.workload]
+        # HBM bytes per gather launch cannot be counted from inside this process: they come from
+        # separate rocprofv3 --pmc passes over this same command (profiles/README.md), committed
+        # as profiles/traffic.json and reported here only when they were taken on this workload
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("workload") == opt.workload and tj.get("batch") == bs and tj.get("queries_per_launch") == co:
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         ach = gbytes / (sls_ms / max(sls_n, 1) * 1e-3) / 1e9 if sls_n else None
         out = {
             "metric": "queries/sec under p99 latency SLA, DLRM-RMC1 synthetic",
@@ -252,20 +266,26 @@ def main():
                                       w["top"], w["op"], bs, nb),
                        "parallelism": "dp%d (model replicated, independent queries)" % world,
                        "queries_per_launch": co, "launch_sets_in_flight": slots,
+                       "streams": stream_mode,
                        "inputs": "device-resident (pre-staged)"},
             "latency_ms": {"p50": round(p50, 4), "p95": round(p95, 4), "p99": round(p99, 4),
                            "sla": SLA_MS, "sla_met": bool(p99 <= SLA_MS)},
             "roofline": {"bound": "hbm", "kernel": "sls_kernel (multi-table SparseLengthsSum)",
                          "achieved": None if ach is None else round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": gbytes,
                          "avg_launch_us": None if not sls_n else round(sls_ms / sls_n * 1e3, 3),
                          "launches_timed": sls_n,
                          "timer": "device wall clock stamps of the launch's own workgroups "
                                   "(max end - min start); hip-event bracket for comparison",
                          "hip_event_avg_us": None if not ev_n else round(ev_ms / ev_n * 1e3, 3),
-                         "rest_of_launch_set_event_us": None if not mlp_n else round(mlp_ms / mlp_n * 1e3, 3),
+                         "gather_end_to_set_end_event_us": None if not mlp_n else round(mlp_ms / mlp_n * 1e3, 3),
+                         # all gather launches of the timed region over its wall time: how busy
+                         # the launch structure keeps HBM, gaps and MLP phases included
+                         "sustained_over_timed_region": {
+                             "GBps": round(gbytes * (opt.steps / co) / elapsed / 1e9, 1),
+                             "frac": round(gbytes * (opt.steps / co) / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
                          "single_query_launch": None if not one_n else {
                              "bytes": gbytes // co, "avg_launch_us": round(one_ms / one_n * 1e3, 3),
                              "frac": round(gbytes / co / (one_ms / one_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},

@@ -122,7 +122,7 @@ struct drs_engine {
   // op-level scratch
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
-  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 1, mlp_fuse = 1;
+  int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
   int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on

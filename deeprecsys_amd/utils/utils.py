@@ -68,7 +68,7 @@ EXTRA_FLAGS = [
     ("accel_backend", _S, "hip"),     # "hip": real forward on the GPU | "sim": latency table
     ("accel_device_offset", _I, 0),   # first GPU ordinal used by the accel engines
     ("accel_table_init", _S, "numpy"),  # "numpy": reference RNG stream | "device": counter-based fill
-    ("accel_slots", _I, 2),           # in-flight queries per accel engine
+    ("accel_slots", _I, 3),           # launch sets in flight per accel engine (gather | MLP | enqueue)
     ("accel_coalesce", _I, 8),        # queued requests an accel engine may serve per launch set
     ("mp_start_method", _S, "spawn"),  # engine/loadgen processes: spawn (HIP-safe) | fork
 ]

@@ -200,15 +200,26 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums
- *   "mlp_split"  1 (default) a layer with K*N >= 512K weights (RM3's 2560x1024) runs as
- *                its own 2-D launch | 0 chain everything that fits LDS
+ *   "mlp_split"  1 (default) a layer with K*N >= "mlp_wide_kn" weights (RM3's 2560x1024)
+ *                runs as its own 2-D launch | 0 chain everything that fits LDS
+ *   "mlp_wide_kn" that threshold (default 512K weights)
  *   "mlp_fuse"   1 (default) DLRM/"cat": bottom and top MLP of a 16-row slab in ONE launch
- *                | 0 one launch per MLP
- *   "mlp_preload" 0 (default) | 1 pull a chain's 16 x K0 input slab into LDS in one round
- *                before its first layer instead of streaming it per K chunk
- *   "shared_stream" 1 (default) all slots enqueue on one HIP stream: launch sets run back
- *                to back (each kernel has the chip to itself) while the host is already
- *                enqueueing the next set | 0 one stream per slot: sets overlap on the GPU
+ *                | 0 one launch per MLP;  "mlp_fuse_rows": fuse only from this many rows on
+ *   "mlp_stream" 1 (default) chains run as the weight-tile stream kernel (tiles of all layers
+ *                requested six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and
+ *                the slabs fit | 0 always the per-layer chain kernel.  Same bits either way.
+ *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
+ *                LDS in one round instead of streaming it per K chunk
+ *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)
+ *   "mlp_debug"  timing experiments on the stream kernel (bit 0: always fetch the first
+ *                tile, bit 1: skip the MFMAs).  Results are garbage while set.
+ *   "shared_stream" how the launch sets of the slots are put on HIP streams:
+ *                2 (default) pipelined: every gather on one stream, back to back; the rest of
+ *                  each set (MLPs, interaction, completion) behind an event on a second
+ *                  stream, so the HBM-bound gather of set i+1 runs beside the latency-bound
+ *                  MLP of set i and gathers never overlap each other
+ *                1 one stream: sets strictly back to back, each kernel has the chip to itself
+ *                0 one stream per slot: whole sets overlap freely
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG                                               */
