@@ -15,8 +15,11 @@ sets resident in HBM, runs the query through libdrs_hip.so and stamps
 inference_end_time when the result is on the host.  Requests that are already waiting
 in the queue when the engine comes back for work (up to --accel_coalesce, max 8) are
 served by ONE set of launches (drs_forward_multi_async): the gather then runs long
-enough to amortise its start-up and tail, which is worth ~15% HBM efficiency.  `--accel_backend sim` keeps the
-reference behaviour (latency_table.py) for runs without a GPU.
+enough to amortise its start-up and tail, which is worth ~15% HBM efficiency.  Up to
+--accel_slots (default 3) such sets are in flight at a time: the library runs the gather
+of one beside the MLP of the previous one while this loop is already pulling the next
+requests off the queue.  `--accel_backend sim` keeps the reference behaviour
+(latency_table.py) for runs without a GPU.
 
 Failure policy: any error is printed, the None sentinel is still sent so the
 orchestrator's join loop (DeepRecSys.py:89) cannot hang, and the process exits 1.
@@ -88,40 +91,69 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
 
     inferenceEngineReadyQueue.put(True)
     coalesce = max(1, min(int(getattr(args, "accel_coalesce", 8)), 8)) if model is not None else 1
+    n_slots = model.net.engine.num_slots if model is not None else 1
+    free = list(range(n_slots))          # launch-set slots with nothing in flight
+    inflight = []                        # [(slot, requests, start_time)], oldest first
     shutdown = False
-    while not shutdown:
-        debugPrint(args, "Accel", "Trying to pull request")
-        requests = [requestQueue.get()]
-        # requests that are ALREADY waiting ride along in the same set of launches
-        while requests[-1] is not None and len(requests) < coalesce:
+
+    def fail(requests, e):
+        print("[Accel %s] request(s) %s failed: %r" % (
+            engine_id, [(r.batch_id, r.batch_size) for r in requests], e))
+        sys.stdout.flush()
+        if not shutdown:
+            _drain_until_sentinel(requestQueue)
+        responseQueue.put(None)
+        sys.exit(1)
+
+    def finish_oldest():
+        slot, requests, start_time = inflight.pop(0)
+        try:
+            outs = model.net.collect_staged_multi([r.batch_size for r in requests], slot)
+        except Exception as e:
+            fail(requests, e)
+        end_time = time.time()
+        free.append(slot)
+        for r, o in zip(requests, outs):
+            responseQueue.put(_respond(r, engine_id, start_time, end_time, o.shape[0]))
+
+    while not shutdown or inflight:
+        requests = []
+        if not shutdown and free:
+            debugPrint(args, "Accel", "Trying to pull request")
+            # block only when the GPU has nothing to do; otherwise take what is already there
             try:
-                requests.append(requestQueue.get_nowait())
+                requests.append(requestQueue.get() if not inflight else requestQueue.get_nowait())
             except pyqueue.Empty:
-                break
-        if requests[-1] is None:
-            shutdown = True
-            requests.pop()
+                pass
+            # requests that are ALREADY waiting ride along in the same set of launches
+            while requests and requests[-1] is not None and len(requests) < coalesce:
+                try:
+                    requests.append(requestQueue.get_nowait())
+                except pyqueue.Empty:
+                    break
+            if requests and requests[-1] is None:
+                shutdown = True
+                requests.pop()
         if requests:
             start_time = time.time()
-            try:
-                if model is not None:
-                    outs = model.net.run_staged_multi([r.batch_id for r in requests],
-                                                      [r.batch_size for r in requests])
-                    sizes = [o.shape[0] for o in outs]
-                else:
+            if model is not None:
+                slot = free.pop()
+                try:
+                    model.net.submit_staged_multi([r.batch_id for r in requests],
+                                                  [r.batch_size for r in requests], slot)
+                except Exception as e:
+                    fail(requests, e)
+                inflight.append((slot, requests, start_time))
+            else:
+                # reference behaviour: one request, one table lookup, one sleep
+                try:
                     time.sleep(predict_time(args.model_name, requests[0].batch_size, accel_data) / 1000.)
-                    sizes = [requests[0].batch_size]
-            except Exception as e:
-                print("[Accel %s] request(s) %s failed: %r" % (
-                    engine_id, [(r.batch_id, r.batch_size) for r in requests], e))
-                sys.stdout.flush()
-                if not shutdown:
-                    _drain_until_sentinel(requestQueue)
-                responseQueue.put(None)
-                sys.exit(1)
-            end_time = time.time()
-            for r, n_out_rows in zip(requests, sizes):
-                responseQueue.put(_respond(r, engine_id, start_time, end_time, n_out_rows))
+                except Exception as e:
+                    fail(requests, e)
+                end_time = time.time()
+                responseQueue.put(_respond(requests[0], engine_id, start_time, end_time, requests[0].batch_size))
+        elif inflight:
+            finish_oldest()              # nothing new (or every slot busy): retire the oldest set
     debugPrint(args, "Accel", "Sending final done signal")
     responseQueue.put(None)
     if model is not None:

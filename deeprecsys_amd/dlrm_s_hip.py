@@ -79,7 +79,7 @@ class _HipNet(object):
                        sigmoid_top=sigmoid_top, max_batch=max_batch,
                        max_lookups=max(int(a.num_indices_per_lookup), 1),
                        num_staged_batches=n_stage,
-                       num_slots=max(int(getattr(a, "accel_slots", 1)), 1), device=self._device)
+                       num_slots=max(int(getattr(a, "accel_slots", 3)), 1), device=self._device)
         seed = int(getattr(a, "numpy_rand_seed", 0))
         for t, W in enumerate(self.emb_w):
             if W is None:
@@ -132,6 +132,20 @@ class _HipNet(object):
         out = self.engine.wait(slot, sum(sizes))
         cuts = np.cumsum(sizes)[:-1]
         outs = np.split(out, cuts, axis=0)
+        self._out = outs[-1]
+        return outs
+
+    def submit_staged_multi(self, batch_ids, batch_sizes, slot):
+        """Enqueue one set of launches on `slot` and return at once; collect_staged_multi(slot,
+        batch_sizes) hands the outputs over.  With several slots the engine process keeps the
+        gather of one set, the MLP of the previous one and the host work of the next in flight
+        at the same time."""
+        self.engine.forward_multi_async(slot, [int(b) for b in batch_ids], [int(b) for b in batch_sizes])
+
+    def collect_staged_multi(self, batch_sizes, slot):
+        sizes = [int(b) for b in batch_sizes]
+        out = self.engine.wait(slot, sum(sizes))
+        outs = np.split(out, np.cumsum(sizes)[:-1], axis=0)
         self._out = outs[-1]
         return outs
 
