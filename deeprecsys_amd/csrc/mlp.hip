@@ -635,7 +635,9 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       const int row = min(f_n0 + frow + 32 * j, f_N - 1);
       // out-of-range k reads the zero page
       int64_t off = (int64_t)row * f_K + k;
+#ifdef DRS_TIMELINE
       if (a.dbg & 1) off = (int64_t)min(frow + 32 * j, f_N - 1) * f_K + fk;   // timing experiment: hot tile
+#endif
       off = k < f_K ? off : f_zoff;
       const float* p = f_W + off;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[j]) : "v"(p));
@@ -731,6 +733,12 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   int c_nch = (cl.K + 63) >> 6;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
+// timing experiments ("mlp_debug") exist only in the timeline build
+#ifdef DRS_TIMELINE
+#define DRS_DBG_MFMA_ON (!(a.dbg & 2))
+#else
+#define DRS_DBG_MFMA_ON true
+#endif
 #define DRS_ROUND(BUF, RB_FETCH, RB_STASH)                                                        \
   {                                                                                               \
     TL(10);                                                                                       \
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       DRS_WAIT_TILE(RB_STASH, 20);                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                             \
-        if (!(a.dbg & 2)) {                                                                       \
+        if (DRS_DBG_MFMA_ON) {                                                                    \
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * q], bv[2 * q], acc, 0, 0, 0);           \
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * q + 1], bv[2 * q + 1], acc, 0, 0, 0);   \
         }                                                                                         \

@@ -211,8 +211,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
  *                LDS in one round instead of streaming it per K chunk
  *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)
- *   "mlp_debug"  timing experiments on the stream kernel (bit 0: always fetch the first
- *                tile, bit 1: skip the MFMAs).  Results are garbage while set.
+ *   "mlp_debug"  timing experiments on the stream kernel, honoured by the `make timeline`
+ *                build only (bit 0: always fetch the first tile, bit 1: skip the MFMAs;
+ *                results are garbage while set)
  *   "shared_stream" how the launch sets of the slots are put on HIP streams:
  *                2 (default) pipelined: every gather on one stream, back to back; the rest of
  *                  each set (MLPs, interaction, completion) behind an event on a second
