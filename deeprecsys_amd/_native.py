@@ -42,6 +42,8 @@ SYMBOLS = [
     ("drs_forward_multi_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p]),
     ("drs_wait", C.c_int32, [C.c_void_p, C.c_int32, _f32p]),
     ("drs_sync", C.c_int32, [C.c_void_p]),
+    ("drs_forward_inputs_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
+                                             C.POINTER(_i32p)]),
     ("drs_forward_inputs", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
                                        C.POINTER(_i32p), _f32p]),
     ("drs_fetch_interaction", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
@@ -237,6 +239,17 @@ class Engine(object):
         self._check(lib().drs_forward_inputs(self._h, slot, bs, dp, ip, n_idx.ctypes.data_as(_i64p), lp,
                                              out.ctypes.data_as(_f32p)), "drs_forward_inputs")
         return out
+
+    def forward_inputs_async(self, dense, idx, lengths, bs, slot=0):
+        """Enqueue only; wait(slot, bs) returns the result.  The arrays are consumed (converted
+        into the slot's pinned block) before this returns."""
+        idx, lengths, n_idx, ip, lp = self._pack_sparse(idx, lengths)
+        dp = None
+        if dense is not None:
+            dense = _f32(dense)
+            dp = dense.ctypes.data_as(_f32p)
+        self._check(lib().drs_forward_inputs_async(self._h, slot, bs, dp, ip, n_idx.ctypes.data_as(_i64p), lp),
+                    "drs_forward_inputs_async")
 
     def fetch_interaction(self, bs, slot=0):
         R = np.empty((bs, self.num_int), dtype=np.float32)

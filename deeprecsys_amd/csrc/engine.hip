@@ -66,6 +66,7 @@ struct Slot {
   hipStream_t gather_stream = nullptr;   // where the gather is launched (== stream unless pipelined)
   hipEvent_t ev_sls = nullptr;           // pipelined mode: gather done -> the MLP stream may go on
   hipEvent_t ev_in = nullptr;            // pipelined mode: per-call inputs copied -> the gather may start
+  Batch zc;                              // per-call inputs read in place from host-mapped pinned memory
   float* T = nullptr;        // [max_batch, ldT]  concat buffer: dense_out | emb_0 | ...
   float* R = nullptr;        // [max_batch, ldR]  dot-interaction output (dot only)
   float* H = nullptr;        // [max_batch, ldH]  inter-segment MLP scratch (ping)
@@ -124,6 +125,7 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+  int zero_copy_inputs = 1;         // drs_forward_inputs: kernels read the inputs in place from pinned host memory
   int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   // profiling
@@ -693,7 +695,18 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     s.h_stage_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1) +
                       sizeof(int32_t) * (size_t)T * e->cap +
                       sizeof(int32_t) * (size_t)T * (e->max_batch + 1);
-    CREATE_TRY(hipHostMalloc(&s.h_stage, s.h_stage_bytes, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&s.h_stage, s.h_stage_bytes, hipHostMallocMapped));
+    {
+      // device view of the same block, laid out like a staged batch: [dense | idx | off]
+      char* dm = nullptr;
+      CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&dm), s.h_stage, 0));
+      const size_t dense_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1);
+      const size_t idx_bytes = sizeof(int32_t) * (size_t)T * e->cap;
+      s.zc.dense = reinterpret_cast<float*>(dm);
+      s.zc.idx = reinterpret_cast<int32_t*>(dm + dense_bytes);
+      s.zc.off = reinterpret_cast<int32_t*>(dm + dense_bytes + idx_bytes);
+      s.zc.h_off.assign((size_t)T * (e->max_batch + 1), 0);
+    }
   }
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream_g, hipStreamNonBlocking));
   apply_stream_mode(e);
@@ -810,7 +823,8 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
 
 static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_dense,
                           const int64_t* const* h_idx, const int64_t* n_idx,
-                          const int32_t* const* h_len, hipStream_t stream, void* pinned) {
+                          const int32_t* const* h_len, hipStream_t stream, void* pinned,
+                          bool in_place = false) {
   if (n < 0 || n > e->max_batch) return fail(e, DRS_ERR_BAD_ARG, "n_samples=%d exceeds max_batch=%d", n, e->max_batch);
   if (!h_idx || !n_idx || !h_len) return fail(e, DRS_ERR_BAD_ARG, "null index/length arrays");
   if (e->m_den > 0 && !h_dense && n > 0) return fail(e, DRS_ERR_BAD_ARG, "null dense input");
@@ -833,6 +847,11 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
   int32_t rc = convert_inputs(e, n, h_idx, n_idx, h_len, idx32, off32);
   if (rc) return rc;
   if (pinned) memcpy(b.h_off.data(), off32, off_bytes);
+  if (in_place) {
+    // `b` aliases the pinned block: the converted indices/offsets are already where the
+    // kernels will read them (over PCIe, once); only the dense rows need a host copy
+    if (e->m_den > 0 && n > 0) memcpy(dense_stage, h_dense, sizeof(float) * (size_t)n * e->m_den);
+  } else {
   // copy only what is used of each table's index row
   for (int t = 0; t < e->T; ++t)
     if (n_idx[t] > 0)
@@ -846,6 +865,7 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
       src = dense_stage;
     }
     HIP_TRY(e, hipMemcpyAsync(b.dense, src, sizeof(float) * (size_t)n * e->m_den, hipMemcpyHostToDevice, stream));
+  }
   }
   if (!pinned) HIP_TRY(e, hipStreamSynchronize(stream));
   b.n_samples = n;
@@ -926,22 +946,37 @@ int32_t drs_sync(drs_handle e) {
   return first;
 }
 
-int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
-                           const int64_t* const* h_idx, const int64_t* n_idx,
-                           const int32_t* const* h_len, float* h_out) {
+int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
+                                 const int64_t* const* h_idx, const int64_t* n_idx,
+                                 const int32_t* const* h_len) {
   int32_t rc = check_handle(e);
   if (rc) return rc;
   if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
   Slot& s = e->slots[slot];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
-  if ((rc = stage_into(e, s.scratch, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage))) return rc;
-  if (s.gather_stream != s.stream) {   // the gather runs on another stream: order it behind the copies
-    HIP_TRY(e, hipEventRecord(s.ev_in, s.stream));
-    HIP_TRY(e, hipStreamWaitEvent(s.gather_stream, s.ev_in, 0));
+  const Batch* bt;
+  if (e->zero_copy_inputs) {
+    // no H2D copies at all: convert straight into the slot's host-mapped pinned block and let
+    // the gather / first MLP layer read it in place (795 KB per RMC1 query, read once)
+    if ((rc = stage_into(e, s.zc, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage, true))) return rc;
+    bt = &s.zc;
+  } else {
+    if ((rc = stage_into(e, s.scratch, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage))) return rc;
+    if (s.gather_stream != s.stream) {   // the gather runs on another stream: order it behind the copies
+      HIP_TRY(e, hipEventRecord(s.ev_in, s.stream));
+      HIP_TRY(e, hipStreamWaitEvent(s.gather_stream, s.ev_in, 0));
+    }
+    bt = &s.scratch;
   }
-  const Batch* bt = &s.scratch;
-  if ((rc = enqueue_forward(e, s, 1, &bt, &bs))) return rc;
-  return wait_slot(e, s, h_out);
+  return enqueue_forward(e, s, 1, &bt, &bs);
+}
+
+int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
+                           const int64_t* const* h_idx, const int64_t* n_idx,
+                           const int32_t* const* h_len, float* h_out) {
+  int32_t rc = drs_forward_inputs_async(e, slot, bs, h_dense, h_idx, n_idx, h_len);
+  if (rc) return rc;
+  return wait_slot(e, e->slots[slot], h_out);
 }
 
 int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R) {
@@ -1066,6 +1101,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     apply_stream_mode(e);
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
+  else if (!strcmp(key, "zero_copy_inputs")) e->zero_copy_inputs = value ? 1 : 0;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;

@@ -156,12 +156,18 @@ int32_t drs_forward_multi_async(drs_handle h, int32_t slot, int32_t n, const int
 int32_t drs_wait(drs_handle h, int32_t slot, float* h_out);
 int32_t drs_sync(drs_handle h);
 /* non-staged inputs (the run_queues(ids, lengths, fc, bs) signature,
- * models/dlrm_s_caffe2.py:162-174): H2D through the slot's pinned staging
- * area, then the same forward.                                                 */
+ * models/dlrm_s_caffe2.py:162-174): int64 -> int32 narrowing (the Cast op, :308-309) and the
+ * Caffe2 ENFORCEs on the host, into the slot's pinned staging block, then the same forward.
+ * The caller's arrays are consumed before the call returns.  _async + drs_wait keeps several
+ * slots in flight (the next query's host pass overlaps this query's kernels).        */
 int32_t drs_forward_inputs(drs_handle h, int32_t slot, int32_t bs,
                            const float* h_dense,
                            const int64_t* const* h_idx, const int64_t* n_idx,
                            const int32_t* const* h_len, float* h_out);
+int32_t drs_forward_inputs_async(drs_handle h, int32_t slot, int32_t bs,
+                                 const float* h_dense,
+                                 const int64_t* const* h_idx, const int64_t* n_idx,
+                                 const int32_t* const* h_len);
 /* read back an intermediate activation of the last forward on `slot`
  * (parity tests): which = 0 interaction input R [bs, num_int] ... */
 int32_t drs_fetch_interaction(drs_handle h, int32_t slot, int32_t bs, float* h_R);
@@ -221,6 +227,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                  MLP of set i and gathers never overlap each other
  *                1 one stream: sets strictly back to back, each kernel has the chip to itself
  *                0 one stream per slot: whole sets overlap freely
+ *   "zero_copy_inputs" 1 (default) drs_forward_inputs converts the caller's arrays into the
+ *                slot's host-mapped pinned block and the kernels read them in place over
+ *                PCIe (no H2D copies) | 0 copy them to HBM first
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG                                               */

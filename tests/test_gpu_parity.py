@@ -86,6 +86,11 @@ def test_queue_requests_from_reference_engine(case):
             out = w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)
             assert out.shape == (bs, 1)
             assert H.close(out, z["req/%d/expected/prob_click" % r], rtol=H.RTOL_OUT)
+            # per-call inputs read in place from pinned host memory (default) == copied to HBM
+            net.engine.set_option("zero_copy_inputs", 0)
+            copied = w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)
+            net.engine.set_option("zero_copy_inputs", 1)
+            assert np.array_equal(out, copied)
     finally:
         net.engine.close()
 
