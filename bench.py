@@ -45,6 +45,10 @@ WORKLOADS = {
     "rmc2_ref": dict(rows=500_000, T=32, D=64, L=120, bot="256-128-64", top="128-64-1", op="cat"),
     "rmc3_ref": dict(rows=2_000_000, T=10, D=32, L=20, bot="2560-1024-256-32", top="512-256-1", op="cat"),
     "rmc1_dot": dict(rows=1_000_000, T=8, D=64, L=80, bot="128-64-64", top="256-64-1", op="dot"),
+    # BASELINE config 4's models, the reference's models/configs/{wide_and_deep,ncf}.json
+    "wnd": dict(kind="wnd", rows=1_000_000, T=27, D=32, L=1, bot="512", top="1024-512-256-1", op="cat"),
+    "ncf": dict(kind="ncf", rows=[140_000, 140_000, 28_000, 28_000], T=4, D=64, L=1, bot="512",
+                top="256-256-128-64-64", op="cat"),
 }
 
 
@@ -74,7 +78,8 @@ def make_model(opt, device):
     w = WORKLOADS[opt.workload]
     args = cli([])
     args.arch_sparse_feature_size = w["D"]
-    args.arch_embedding_size = "-".join([str(w["rows"])] * w["T"])
+    rows = w["rows"] if isinstance(w["rows"], list) else [w["rows"]] * w["T"]
+    args.arch_embedding_size = "-".join(str(r) for r in rows)
     args.arch_mlp_bot, args.arch_mlp_top = w["bot"], w["top"]
     args.arch_interaction_op = w["op"]
     args.num_indices_per_lookup = w["L"]
@@ -83,15 +88,16 @@ def make_model(opt, device):
     args.numpy_rand_seed = opt.seed
     args.accel_table_init = "device"          # counter-based fill, bit-identical in oracle/
     args.accel_slots = opt.slots
-    args.model_type = "dlrm"
+    kind = w.get("kind", "dlrm")
+    args.model_type = args.model_name = kind
+    args.num_indices_per_lookup_fixed = True
     args._drs_device = device
     np.random.seed(opt.seed)
-    net = M.DLRM_Net(args)
+    net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF}[kind](args)
     m_den = int(w["bot"].split("-")[0])
-    nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den,
-                                                  [w["rows"]] * w["T"], w["L"], opt.seed)
+    nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
     net.create(lX[0], lS_l[0], lS_i[0], None)
-    net.stage_batches(lX, lS_l, lS_i)
+    net.stage_batches(None if kind == "ncf" else lX, lS_l, lS_i)
     return args, net, (lX, lS_l, lS_i)
 
 
@@ -233,7 +239,8 @@ def main():
     lX, lS_l, lS_i = data
     L = WORKLOADS[opt.workload]["L"]
     host_sets = [([np.ascontiguousarray(t[:bs * L]) for t in lS_i[b]], [np.ascontiguousarray(t[:bs]) for t in lS_l[b]],
-                  np.ascontiguousarray(lX[b][:bs])) for b in range(min(nb, 4))]
+                  None if WORKLOADS[opt.workload].get("kind") == "ncf" else np.ascontiguousarray(lX[b][:bs]))
+                 for b in range(min(nb, 4))]
     def host_leg(n):
         busy = [False] * slots
         t0 = time.perf_counter()
@@ -277,16 +284,17 @@ def main():
             pass
         ach = gbytes / (sls_ms / max(sls_n, 1) * 1e-3) / 1e9 if sls_n else None
         out = {
-            "metric": "queries/sec under p99 latency SLA, DLRM-RMC1 synthetic",
+            "metric": "queries/sec under p99 latency SLA, %s synthetic"
+                      % ("DLRM-RMC1" if opt.workload == "rmc1" else opt.workload),
             "value": round(tot_queries / tot_elapsed, 1),
             "unit": "queries/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": round(tot_elapsed / opt.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DLRM-%s: %d tables x %d rows x %d-dim, %d lookups/bag, "
+            "config": {"workload": "%s-%s: %d tables x %s rows x %d-dim, %d lookups/bag, "
                                    "bot %s, top %s (%s), batch %d, %d resident input sets"
-                                   % (opt.workload.upper(), w["T"], w["rows"], w["D"], w["L"], w["bot"],
+                                   % (w.get("kind", "dlrm").upper(), opt.workload.upper(), w["T"], w["rows"], w["D"], w["L"], w["bot"],
                                       w["top"], w["op"], bs, nb),
                        "parallelism": "dp%d (model replicated, independent queries)" % world,
                        "queries_per_launch": co, "launch_sets_in_flight": slots,

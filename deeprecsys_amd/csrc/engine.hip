@@ -125,6 +125,7 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+  int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used
   int zero_copy_inputs = 1;         // drs_forward_inputs: kernels read the inputs in place from pinned host memory
   int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
@@ -375,8 +376,13 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   a.out = s.T; a.ld_out = e->ldT; a.col0 = e->kind == DRS_MODEL_NCF ? 0 : e->w0;
   a.T = e->T; a.D = e->D; a.err = reinterpret_cast<int32_t*>(s.d_err);
   a.ts = prof ? s.d_ts : nullptr;
-  s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, e->sls_exact) : 0;
-  HIP_TRY(e, launch_sls(a, e->sls_exact, s.gather_stream));
+  // Bags of a few rows (W&D / NCF: one lookup per table) would leave most of a wave idle in the
+  // wave-per-bag variant: a lane group per bag is both faster there and bit-exact.
+  bool short_bags = true;
+  for (int i = 0; i < q.n_q; ++i) short_bags = short_bags && qb[i]->uniform_len >= 0 && qb[i]->uniform_len <= e->sls_short_bag;
+  const int exact_now = e->sls_exact || short_bags;
+  s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, exact_now) : 0;
+  HIP_TRY(e, launch_sls(a, exact_now, s.gather_stream));
   if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.gather_stream));
   static const bool dbg_nojoin = getenv("DRS_DEBUG_NOJOIN") != nullptr;   // timing experiment only
   if (piped && !dbg_nojoin) HIP_TRY(e, hipEventRecord(s.ev_sls, s.gather_stream));
@@ -1102,6 +1108,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
   else if (!strcmp(key, "zero_copy_inputs")) e->zero_copy_inputs = value ? 1 : 0;
+  else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;

@@ -201,6 +201,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                groups, wave-wide butterfly at the end (fp32 sum order differs from the
  *                reference: compare with a tolerance) | 1 sequential-order gather,
  *                bit-identical to the Caffe2 CPU SparseLengthsSum (about 15% slower)
+ *   "sls_short_bag" fixed-length batches with at most this many lookups per bag (default 8;
+ *                W&D and NCF have 1) always take the sequential-order variant: a lane group
+ *                per bag instead of a mostly idle wave per bag | -1 never
  *   "sls_u"      row loads kept in flight per lane: 0 (default: 16 sequential / 4 split)
  *                | 4 | 8 | 16 | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
