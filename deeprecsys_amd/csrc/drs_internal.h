@@ -86,6 +86,12 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
                      hipStream_t stream, const Done* done = nullptr, const XSrc* xs = nullptr);
 
+// Register-blocked GEMM for wide layers (gemm.hip); false = not applicable, use launch_fc's
+// own kernel.  zero_page: 16 B of zeros in device memory.
+bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
+                 int32_t N, int32_t act, float* y, int64_t ldy, const float* zero_page,
+                 hipStream_t stream, const Done& done, const XSrc& xs, hipError_t* err);
+
 // Fused chain of up to DRS_MAX_CHAIN FC layers on 16-row slabs; intermediate
 // activations never leave LDS.
 #define DRS_MAX_CHAIN 6

@@ -19,11 +19,10 @@
 #include <string.h>
 
 #include "drs_internal.h"
+#include "mlp_dev.h"
 
 namespace drs {
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Optional in-kernel timeline (tools/mlp_timeline.py, built with -DDRS_TIMELINE into a
 // separate library): wave 0 of workgroup 0 stamps the shader clock at the phase
@@ -58,147 +57,6 @@ __device__ __forceinline__ void tl_stamp(unsigned long long* tl, unsigned tag) {
 // cold every launch), far more than the MFMAs it feeds, so layers are cut into as few
 // rounds as LDS allows.  Rows of a staged chunk are padded to KC+4 floats.
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == DRS_ACT_RELU) return v > 0.0f ? v : 0.0f;
-  if (act == DRS_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
-  return v;
-}
-
-// 4 consecutive floats of row `row` starting at column k of a [rows, K] matrix with
-// leading dimension ld; zero outside.  Branch-free on purpose: every load is issued
-// unconditionally from a clamped (always valid) address and masked afterwards, so the
-// compiler can keep all of a chunk's loads in flight behind ONE s_waitcnt (a load
-// inside divergent control flow gets its own vmcnt(0) at the join, which serialised
-// the five loads of a chunk and cost ~5x).  VEC: base 16-B aligned, ld % 4 == 0 and
-// K % 4 == 0, so a float4 never straddles the end of a row.
-template <bool VEC>
-__device__ __forceinline__ float4 load4_raw(const float* __restrict__ p, int64_t ld, int64_t row,
-                                            int64_t rows, int k, int K) {
-  // rows past the end are clamped, not masked: they only feed output rows/columns that
-  // are never stored
-  const float* q = p + (row < rows ? row : rows - 1) * ld;
-  if (VEC) {
-    return *reinterpret_cast<const float4*>(q + (k < K ? k : 0));
-  } else {
-    return make_float4(q[min(k + 0, K - 1)], q[min(k + 1, K - 1)], q[min(k + 2, K - 1)],
-                       q[min(k + 3, K - 1)]);
-  }
-}
-// zero the k >= K tail; applied when the value is written to LDS (i.e. after the MFMA
-// block of the previous chunk), so the loads stay in flight across that block
-// LDS bank swizzle.  Operand reads are ds_read_b32 at float address row*LD + 4s + g with
-// LD = KC+4 (== 4 mod 32), so rows r and r+8 of a 16-row tile hit the same banks (2-way
-// conflict on every read; measured: 46 % of all LDS cycles).  Storing element k of rows
-// 8..15 at column k^2 instead moves them onto the two banks rows 0..7 leave free.  Bit 1
-// of k never leaves its 16-byte slot, so the staging writes stay one ds_write_b128 with
-// the halves of the float4 swapped.
-__device__ __forceinline__ float4 swz4(const float4 v, int row) {
-  return (row & 8) ? make_float4(v.z, v.w, v.x, v.y) : v;
-}
-__device__ __forceinline__ int swz(int col, int row) { return col ^ ((row & 8) >> 2); }
-
-__device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
-  return make_float4(k + 0 < K ? v.x : 0.f, k + 1 < K ? v.y : 0.f, k + 2 < K ? v.z : 0.f,
-                     k + 3 < K ? v.w : 0.f);
-}
-
-// see Done in drs_internal.h.  Every thread fences its own output stores at system
-// scope, the workgroup joins, then one lane takes a ticket; the workgroup that draws
-// the last ticket knows all outputs are visible and publishes the flag.
-__device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, void* lds_scratch) {
-  if (!d.counter) return;
-  unsigned* s_u = reinterpret_cast<unsigned*>(lds_scratch);   // dynamic LDS is free by now
-  if (d.ts) {
-    // every workgroup folds its slice of the gather's clock stamps into (min start, max end)
-    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned per = (d.ts_blocks + n_blocks - 1) / n_blocks;
-    const unsigned end = min(d.ts_blocks, (bid + 1) * per);
-    unsigned long long lo = ~0ull, hi = 0ull;
-    for (unsigned i = bid * per + threadIdx.x; i < end; i += blockDim.x) {
-      const unsigned long long a = d.ts[2 * i], b = d.ts[2 * i + 1];
-      lo = a < lo ? a : lo;
-      hi = b > hi ? b : hi;
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      const unsigned long long lo2 = __shfl_xor(lo, m), hi2 = __shfl_xor(hi, m);
-      lo = lo2 < lo ? lo2 : lo;
-      hi = hi2 > hi ? hi2 : hi;
-    }
-    // one (min, max) pair per workgroup, stored write-through; the last arriver folds them.
-    // (Atomics on one address from every wave serialise at ~12 ns each: 2048 of them cost
-    // more than the whole MLP.)
-    unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (unsigned w = 1; w < blockDim.x / 64; ++w) {
-        lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
-        hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
-      }
-      unsigned long long* part = reinterpret_cast<unsigned long long*>(d.span_acc) + 2 * bid;
-      __hip_atomic_store(part, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(part + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  // publish this workgroup's outputs (device memory, stored write-through = sc1, see
-  // LayerIo::o_sc1): every wave drains its stores, then ONE lane takes a ticket; no L2
-  // write-back fence is needed for write-through data (cdna guide G16, form R1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_u[0] = old == n_blocks - 1;
-  }
-  __syncthreads();
-  if (!s_u[0]) return;
-  // last workgroup of the launch: everything the query produced is visible to it.  Stream
-  // the outputs to host-mapped pinned memory, then ONE system-scope release and the flag.
-  for (unsigned i = threadIdx.x; i < d.out_words; i += blockDim.x)
-    __hip_atomic_store(d.host_out + i,
-                       __hip_atomic_load(d.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc1 load (bypasses my L1) -> write-through store
-  unsigned long long lo = ~0ull, hi = 0ull;
-  if (d.ts) {
-    // fold the per-workgroup (min start, max end) pairs: all threads, then waves, then one lane
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
-    for (unsigned b = threadIdx.x; b < n_blocks; b += blockDim.x) {
-      const unsigned long long a = __hip_atomic_load(acc + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long z = __hip_atomic_load(acc + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      lo = a < lo ? a : lo;
-      hi = z > hi ? z : hi;
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      const unsigned long long lo2 = __shfl_xor(lo, m), hi2 = __shfl_xor(hi, m);
-      lo = lo2 < lo ? lo2 : lo;
-      hi = hi2 > hi ? hi2 : hi;
-    }
-    unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
-    if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d.ts) {
-      unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
-      for (unsigned w = 1; w < blockDim.x / 64; ++w) {
-        lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
-        hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
-      }
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // every payload store above is a write-through system-scope store that has been waited
-    // for (vmcnt(0) + barrier): the flag can follow without an L2 write-back fence (G16 R1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
 
 struct LayerIo {
   const float* a_glb;   // A operand in global memory (first layer) or nullptr
@@ -358,24 +216,6 @@ __device__ __forceinline__ void layer_pass(const LayerIo io, int64_t m0, int64_t
   }
 }
 
-// Where do the 16 input rows of the slab starting at virtual row m0 come from?  With
-// coalesced queries the first layer reads each query's own staged dense array.
-__device__ __forceinline__ void resolve_src(const XSrc& xs, const float* x, int64_t M, int64_t m0,
-                                            const float** base, int64_t* row0, int64_t* rows) {
-  *base = x; *row0 = m0; *rows = M;
-  if (xs.q.n_q > 0) {
-    const float* p = xs.x[0];
-    int lo = xs.q.vstart[0], n = xs.q.bs[0];
-#pragma unroll
-    for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
-      const bool in = i < xs.q.n_q && m0 >= xs.q.vstart[i];
-      p = in ? xs.x[i] : p;
-      lo = in ? xs.q.vstart[i] : lo;
-      n = in ? xs.q.bs[i] : n;
-    }
-    *base = p; *row0 = m0 - lo; *rows = n;
-  }
-}
 
 // Single layer, 2-D grid: blockIdx.x = 16-row slab, blockIdx.y = 128-column group.
 template <bool VEC, int KC>
@@ -958,6 +798,10 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   if (xsrc) xs = *xsrc;
   hipError_t e = init_mlp_kernels();
   if (e != hipSuccess) return e;
+  if (N >= 64 && K >= 64) {
+    hipError_t ge = hipSuccess;
+    if (launch_gemm(x, ldx, M, K, W, b, N, act, y, ldy, g_zero_dev, s, d, xs, &ge)) return ge;
+  }
   int kc = 64, nbuf = 2;
   if (!pick_kc(K, 0, 2, &kc, &nbuf)) return hipErrorInvalidValue;
 #ifdef DRS_TIMELINE
