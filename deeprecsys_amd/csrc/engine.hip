@@ -27,6 +27,7 @@ extern int g_mlp_preload;
 extern int g_mlp_kc;
 extern int g_mlp_stream;
 extern int g_mlp_gemm;
+extern int g_gemm_tile;
 extern int g_mlp_debug;
 }  // namespace drs
 
@@ -1115,6 +1116,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "mlp_stream")) g_mlp_stream = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm")) g_mlp_gemm = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11)) g_gemm_tile = (int)value;
   else if (!strcmp(key, "mlp_debug")) g_mlp_debug = (int)value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) g_mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }

@@ -29,7 +29,7 @@ namespace drs {
 namespace {
 
 constexpr int kGThreads = 512;
-constexpr int GBM = 64, GBN = 128, GKC = 64, GLD = 68;   // rows / columns / k per chunk, padded row
+constexpr int GKC = 64, GLD = 68;   // k per chunk, padded LDS row
 
 struct GArgs {
   const float* x;
@@ -43,15 +43,22 @@ struct GArgs {
   int32_t K, N, act, sc1;
 };
 
+// TM x TN MFMA tiles (16 x 16) per wave; the 8 waves sit 2 x 4, so a workgroup owns
+// 32 TM rows x 64 TN columns.  (2,2) is the full-rate shape; the smaller ones exist so a
+// launch with few rows (one query: 256) or few columns still covers the chip.
+template <int TM, int TN>
 __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) {
+  constexpr int GBM = 32 * TM, GBN = 64 * TN;
+  constexpr int NA = TM, NB = 2 * TN;            // float4 per thread per chunk
+  constexpr int NQ = 2 * (NA + NB);              // ds_write_b64 per stashed chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                        // [2][64][68]
-  float* sB = smem + 2 * GBM * GLD;        // [2][128][68]
+  float* sA = smem;                        // [2][GBM][68]
+  float* sB = smem + 2 * GBM * GLD;        // [2][GBN][68]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int gs = swz(g, r);
-  const int wm = wave & 1, wn = wave >> 1;           // my 32 x 32 block inside the 64 x 128 tile
+  const int wm = wave & 1, wn = wave >> 1;           // my (16 TM) x (16 TN) block inside the tile
   const int64_t m0 = (int64_t)blockIdx.x * GBM;
   const int n0 = blockIdx.y * GBN;
   const int K = a.K, N = a.N;
@@ -67,26 +74,26 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
   float* const stB = sB + frow * GLD + fk;
   // per-thread row offsets (elements), clamped once: rows past the end only feed outputs
   // that are never stored
-  int64_t offA[2], offB[4];
+  int64_t offA[NA], offB[NB];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) offA[j] = min(row0 + frow + 32 * j, rows - 1) * a.ldx + fk;
+  for (int j = 0; j < NA; ++j) offA[j] = min(row0 + frow + 32 * j, rows - 1) * a.ldx + fk;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) offB[j] = (int64_t)min(n0 + frow + 32 * j, N - 1) * K + fk;
+  for (int j = 0; j < NB; ++j) offB[j] = (int64_t)min(n0 + frow + 32 * j, N - 1) * K + fk;
   const int64_t zA = a.zero - xb, zB = a.zero - a.W;
 
   int f_c = 0;   // next chunk to request (stays on the last one past the end)
-  auto fetch = [&](f32x4 (&ra)[2], f32x4 (&rb)[4]) {
+  auto fetch = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
     const int k0 = f_c * GKC;
     const bool in = k0 + fk < K;       // K % 4 == 0: a float4 is inside or outside as a whole
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NA; ++j) {
       int64_t off = in ? offA[j] + k0 : zA;
       asm("" : "+v"(off));
       const float* p = xb + off;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[j]) : "v"(p));
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NB; ++j) {
       int64_t off = in ? offB[j] + k0 : zB;
       asm("" : "+v"(off));
       const float* p = a.W + off;
@@ -94,38 +101,49 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
     }
     if (f_c + 1 < nch) ++f_c;
   };
-  // one of the 12 ds_write_b64 of a chunk's stash
-  auto stash_part = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rb)[4], int q) {
-    if (q < 4) {
+  // one of the NQ ds_write_b64 of a chunk's stash
+  auto stash_part = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int q) {
+    if (q < 2 * NA) {
       float* p = stA + (buf * GBM + 32 * (q >> 1)) * GLD;
       if (q & 1) *reinterpret_cast<float2*>(p + st_hi) = make_float2(ra[q >> 1][2], ra[q >> 1][3]);
       else *reinterpret_cast<float2*>(p + st_lo) = make_float2(ra[q >> 1][0], ra[q >> 1][1]);
     } else {
-      const int qq = q - 4;
+      const int qq = q - 2 * NA;
       float* p = stB + (buf * GBN + 32 * (qq >> 1)) * GLD;
       if (qq & 1) *reinterpret_cast<float2*>(p + st_hi) = make_float2(rb[qq >> 1][2], rb[qq >> 1][3]);
       else *reinterpret_cast<float2*>(p + st_lo) = make_float2(rb[qq >> 1][0], rb[qq >> 1][1]);
     }
   };
-#define DRS_GWAIT(RA, RB, N_)                                                                    \
-  asm volatile("s_waitcnt vmcnt(" #N_ ")"                                                        \
-               : "+v"(RA[0]), "+v"(RA[1]), "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3]))
+  // explicit wait for one register set: "at most 3 newer chunks outstanding" (vmcnt retires
+  // in order); the registers are tied to the asm so no use can be scheduled above it
+  auto gwait = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+    constexpr int n = 3 * (NA + NB);
+    if constexpr (NA == 2 && NB == 4)
+      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(n));
+    else if constexpr (NA == 1 && NB == 4)
+      asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(n));
+    else if constexpr (NA == 2 && NB == 2)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]) : "n"(n));
+    else
+      asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(rb[1]) : "n"(n));
+  };
+#define DRS_GWAIT(RA, RB, N_) gwait(RA, RB)
 
-  f32x4 ra0[2], rb0[4], ra1[2], rb1[4], ra2[2], rb2[4], ra3[2], rb3[4];
+  f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB], ra2[NA], rb2[NB], ra3[NA], rb3[NB];
   fetch(ra0, rb0); fetch(ra1, rb1); fetch(ra2, rb2); fetch(ra3, rb3);   // chunks 0..3
   DRS_GWAIT(ra0, rb0, 18);
 #pragma unroll
-  for (int q = 0; q < 12; ++q) stash_part(0, ra0, rb0, q);
+  for (int q = 0; q < NQ; ++q) stash_part(0, ra0, rb0, q);
   __syncthreads();
 
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* const pa0 = sA + (32 * wm + r) * GLD + gs;
-  const float* const pb0 = sB + (32 * wn + r) * GLD + gs;
+  const float* const pa0 = sA + (16 * TM * wm + r) * GLD + gs;
+  const float* const pb0 = sB + (16 * TN * wn + r) * GLD + gs;
 
   // One K chunk: MFMAs on buffer BUF, stash of the NEXT chunk (sets RAS/RBS) into BUF^1,
   // request of chunk +4 into the sets this chunk came from (RAF/RBF).
@@ -134,27 +152,27 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
     fetch(RAF, RBF);                                                                              \
     const float* pa = pa0 + (BUF) * GBM * GLD;                                                    \
     const float* pb = pb0 + (BUF) * GBN * GLD;                                                    \
-    float av[2][2][4], bv[2][2][4];   /* [ping/pong][tile][step of the group] */                  \
+    float av[2][TM][4], bv[2][TN][4];   /* [ping/pong][tile][step of the group] */                \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
-      av[0][0][s] = pa[4 * s]; av[0][1][s] = pa[16 * GLD + 4 * s];                                \
-      bv[0][0][s] = pb[4 * s]; bv[0][1][s] = pb[16 * GLD + 4 * s];                                \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i][s] = pa[16 * i * GLD + 4 * s];      \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j][s] = pb[16 * j * GLD + 4 * s];      \
     }                                                                                             \
     DRS_GWAIT(RAS, RBS, 18);                                                                      \
+    int wq = 0;   /* stash writes issued so far (compile-time after unrolling) */                  \
     _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                            \
       const int cur = gq & 1, nxt = cur ^ 1;                                                      \
       if (gq < 3) {                                                                               \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                           \
-          av[nxt][0][s] = pa[16 * (gq + 1) + 4 * s]; av[nxt][1][s] = pa[16 * GLD + 16 * (gq + 1) + 4 * s]; \
-          bv[nxt][0][s] = pb[16 * (gq + 1) + 4 * s]; bv[nxt][1][s] = pb[16 * GLD + 16 * (gq + 1) + 4 * s]; \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i) av[nxt][i][s] = pa[16 * i * GLD + 16 * (gq + 1) + 4 * s]; \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[nxt][j][s] = pb[16 * j * GLD + 16 * (gq + 1) + 4 * s]; \
         }                                                                                         \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][0][s], bv[cur][0][s], acc[0][0], 0, 0, 0); \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][0][s], bv[cur][1][s], acc[0][1], 0, 0, 0); \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][1][s], bv[cur][0][s], acc[1][0], 0, 0, 0); \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][1][s], bv[cur][1][s], acc[1][1], 0, 0, 0); \
-        if (4 * gq + s < 12) stash_part((BUF) ^ 1, RAS, RBS, 4 * gq + s);                         \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i][s], bv[cur][j][s], acc[i][j], 0, 0, 0); \
+        if (wq < NQ) { stash_part((BUF) ^ 1, RAS, RBS, wq); ++wq; }                               \
         __builtin_amdgcn_sched_barrier(0);                                                        \
       }                                                                                           \
     }                                                                                             \
@@ -176,15 +194,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
 
   // epilogue: bias + activation; lane holds rows 4g+q of each tile, column r
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + 32 * wn + 16 * j + r;
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + 16 * TN * wn + 16 * j + r;
     if (col < N) {
       const float bcol = a.b ? a.b[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int64_t row = m0 + 32 * wm + 16 * i + 4 * g + q;
+          const int64_t row = m0 + 16 * TM * wm + 16 * i + 4 * g + q;
           if (row < a.M) {
             const float v = act_apply(acc[i][j][q] + bcol, a.act);
             float* dst = a.y + row * a.ldy + col;
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
 }  // namespace
 
 int g_mlp_gemm = 1;   // drs_set_option "mlp_gemm": wide layers through gemm_kernel
+int g_gemm_tile = 0;  // "mlp_gemm_tile": force TM*10+TN (22 | 12 | 21 | 11), 0 = by block count
 
 // false = not applicable (caller falls back to fc_kernel)
 bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
@@ -210,19 +229,33 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   if (!g_mlp_gemm || !zero_page || (K & 3) || (ldx & 3) || !al(x) || !al(W)) return false;
   for (int i = 0; i < xs.q.n_q; ++i) if (!al(xs.x[i])) return false;
   static bool attr = false;
-  const size_t lds = sizeof(float) * 2 * (GBM + GBN) * GLD;
   if (!attr) {
-    *err = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (*err != hipSuccess) return true;
+    for (const void* k : {reinterpret_cast<const void*>(gemm_kernel<2, 2>), reinterpret_cast<const void*>(gemm_kernel<1, 2>),
+                          reinterpret_cast<const void*>(gemm_kernel<2, 1>), reinterpret_cast<const void*>(gemm_kernel<1, 1>)}) {
+      *err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (*err != hipSuccess) return true;
+    }
     attr = true;
   }
   GArgs a;
   memset(&a, 0, sizeof a);
   a.x = x; a.ldx = ldx; a.M = M; a.W = W; a.b = b; a.y = y; a.ldy = ldy; a.zero = zero_page;
   a.K = K; a.N = N; a.act = act; a.sc1 = d.counter != nullptr;
-  const dim3 grid((unsigned)((M + GBM - 1) / GBM), (unsigned)((N + GBN - 1) / GBN));
-  hipLaunchKernelGGL(gemm_kernel, grid, dim3(kGThreads), lds, s, a, d, xs);
+  // largest tile that still gives every CU a workgroup (256 CUs); rows are halved first (the
+  // weight panel is the shared operand, re-read once per row block)
+  auto blocks = [&](int tm, int tn) { return ((M + 32 * tm - 1) / (32 * tm)) * (int64_t)((N + 64 * tn - 1) / (64 * tn)); };
+  int tm = 2, tn = 2;
+  if (g_gemm_tile) { tm = g_gemm_tile / 10; tn = g_gemm_tile % 10; }
+  else if (blocks(2, 2) >= 256) { tm = 2; tn = 2; }
+  else if (blocks(1, 2) >= 256) { tm = 1; tn = 2; }
+  else if (blocks(2, 1) >= 256) { tm = 2; tn = 1; }
+  else { tm = 1; tn = 1; }
+  const dim3 grid((unsigned)((M + 32 * tm - 1) / (32 * tm)), (unsigned)((N + 64 * tn - 1) / (64 * tn)));
+  const size_t lds = sizeof(float) * 2 * (32 * tm + 64 * tn) * GLD;
+#define DRS_GLAUNCH(TM_, TN_) \
+  if (tm == TM_ && tn == TN_) hipLaunchKernelGGL((gemm_kernel<TM_, TN_>), grid, dim3(kGThreads), lds, s, a, d, xs);
+  DRS_GLAUNCH(2, 2) DRS_GLAUNCH(1, 2) DRS_GLAUNCH(2, 1) DRS_GLAUNCH(1, 1)
+#undef DRS_GLAUNCH
   *err = hipGetLastError();
   return true;
 }
