@@ -20,7 +20,7 @@ import numpy as np
 from .accelInferenceEngine import accelInferenceEngine
 from .loadGenerator import accel_engine_count, loadGenerator
 from .stats import ResponseAggregator
-from .utils.utils import cli
+from .utils.utils import cli, mix_models
 
 
 def DeepRecSys(args=None, cpu_engine=None, quiet=False):
@@ -76,7 +76,7 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
         p.start()
     load_gen.start()
 
-    agg = ResponseAggregator(args.req_granularity)
+    agg = ResponseAggregator(args.req_granularity, with_model=bool(mix_models(args)))
     finished = 0
     while finished != args.inference_engines:
         for q in responseQueues:

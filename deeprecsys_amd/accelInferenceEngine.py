@@ -31,7 +31,7 @@ import time
 import numpy as np
 
 from .utils.packets import ServiceResponse
-from .utils.utils import debugPrint
+from .utils.utils import debugPrint, mix_models
 
 SIM_MODELS = ("wnd", "rm1", "rm2", "rm3", "ncf", "din", "dien", "mtwnd")   # reference omits "ncf"
 
@@ -42,7 +42,8 @@ def _respond(request, engine_id, start_time, end_time, out_batch_size):
                            process_start_time=start_time, queue_end_time=end_time,
                            inference_end_time=end_time, out_batch_size=out_batch_size,
                            total_sub_batches=request.total_sub_batches,
-                           exp_packet=request.exp_packet, sub_id=request.sub_id)
+                           exp_packet=request.exp_packet, sub_id=request.sub_id,
+                           model_id=getattr(request, "model_id", 0))
 
 
 def _build_hip_model(args, engine_id):
@@ -80,7 +81,14 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
                 raise SystemExit(1)
             accel_data = GPU_Data(root_dir=args.accel_root_dir, hardware="nvidia_gtx_1080_ti")
         else:
-            model = _build_hip_model(args, engine_id)
+            # mixed-model stream: one resident model per --mix_config_files entry, all on this GPU
+            mix = [a for a, _share in mix_models(args)]
+            models = []
+            for a in (mix or [args]):
+                a.accel_first_engine_id = getattr(args, "accel_first_engine_id", engine_id or 0)
+                np.random.seed(args.numpy_rand_seed)      # every model: the stream a lone engine would see
+                models.append(_build_hip_model(a, engine_id))
+            model = models[0]
     except BaseException as e:   # incl. SystemExit from the builders' sys.exit checks
         print("[Accel %s] start-up failed: %r" % (engine_id, e))
         sys.stdout.flush()
@@ -92,8 +100,10 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
     inferenceEngineReadyQueue.put(True)
     coalesce = max(1, min(int(getattr(args, "accel_coalesce", 8)), 8)) if model is not None else 1
     n_slots = model.net.engine.num_slots if model is not None else 1
-    free = list(range(n_slots))          # launch-set slots with nothing in flight
-    inflight = []                        # [(slot, requests, start_time)], oldest first
+    n_models = len(models) if model is not None else 1
+    free = [list(range(n_slots)) for _ in range(n_models)]   # per model: slots with nothing in flight
+    inflight = []                        # [(model_id, slot, requests, start_time)], oldest first
+    backlog = []                         # pulled but not yet submitted (other model's turn / no free slot)
     shutdown = False
 
     def fail(requests, e):
@@ -106,58 +116,75 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
         sys.exit(1)
 
     def finish_oldest():
-        slot, requests, start_time = inflight.pop(0)
+        mid, slot, requests, start_time = inflight.pop(0)
         try:
-            outs = model.net.collect_staged_multi([r.batch_size for r in requests], slot)
+            outs = models[mid].net.collect_staged_multi([r.batch_size for r in requests], slot)
         except Exception as e:
             fail(requests, e)
         end_time = time.time()
-        free.append(slot)
+        free[mid].append(slot)
         for r, o in zip(requests, outs):
             responseQueue.put(_respond(r, engine_id, start_time, end_time, o.shape[0]))
 
-    while not shutdown or inflight:
-        requests = []
-        if not shutdown and free:
+    def model_of(r):
+        mid = int(getattr(r, "model_id", 0) or 0)
+        if not 0 <= mid < n_models:
+            fail([r], ValueError("request for model %d, engine serves %d model(s)" % (mid, n_models)))
+        return mid
+
+    while not shutdown or inflight or backlog:
+        # 1. pull: block only when the GPU has nothing to do; otherwise take what is already there
+        if not shutdown and len(backlog) < coalesce:
             debugPrint(args, "Accel", "Trying to pull request")
-            # block only when the GPU has nothing to do; otherwise take what is already there
             try:
-                requests.append(requestQueue.get() if not inflight else requestQueue.get_nowait())
+                backlog.append(requestQueue.get() if not (inflight or backlog) else requestQueue.get_nowait())
             except pyqueue.Empty:
                 pass
             # requests that are ALREADY waiting ride along in the same set of launches
-            while requests and requests[-1] is not None and len(requests) < coalesce:
+            while backlog and backlog[-1] is not None and len(backlog) < coalesce:
                 try:
-                    requests.append(requestQueue.get_nowait())
+                    backlog.append(requestQueue.get_nowait())
                 except pyqueue.Empty:
                     break
-            if requests and requests[-1] is None:
+            if backlog and backlog[-1] is None:
                 shutdown = True
-                requests.pop()
-        if requests:
-            start_time = time.time()
-            if model is not None:
-                slot = free.pop()
-                try:
-                    model.net.submit_staged_multi([r.batch_id for r in requests],
-                                                  [r.batch_size for r in requests], slot)
-                except Exception as e:
-                    fail(requests, e)
-                inflight.append((slot, requests, start_time))
-            else:
+                backlog.pop()
+        # 2. submit: the oldest waiting request picks the model; same-model requests behind it join
+        submitted = False
+        if backlog:
+            mid = model_of(backlog[0]) if model is not None else 0
+            if model is None:
                 # reference behaviour: one request, one table lookup, one sleep
+                r = backlog.pop(0)
+                start_time = time.time()
                 try:
-                    time.sleep(predict_time(args.model_name, requests[0].batch_size, accel_data) / 1000.)
+                    time.sleep(predict_time(args.model_name, r.batch_size, accel_data) / 1000.)
+                except Exception as e:
+                    fail([r], e)
+                end_time = time.time()
+                responseQueue.put(_respond(r, engine_id, start_time, end_time, r.batch_size))
+                submitted = True
+            elif free[mid]:
+                requests = [r for r in backlog if model_of(r) == mid][:coalesce]
+                for r in requests:
+                    backlog.remove(r)
+                start_time = time.time()
+                slot = free[mid].pop()
+                try:
+                    models[mid].net.submit_staged_multi([r.batch_id for r in requests],
+                                                        [r.batch_size for r in requests], slot)
                 except Exception as e:
                     fail(requests, e)
-                end_time = time.time()
-                responseQueue.put(_respond(requests[0], engine_id, start_time, end_time, requests[0].batch_size))
-        elif inflight:
-            finish_oldest()              # nothing new (or every slot busy): retire the oldest set
+                inflight.append((mid, slot, requests, start_time))
+                submitted = True
+        # 3. nothing new could be started: retire the oldest set in flight
+        if not submitted and inflight:
+            finish_oldest()
     debugPrint(args, "Accel", "Sending final done signal")
     responseQueue.put(None)
     if model is not None:
-        model.net.engine.close()
+        for m in models:
+            m.net.engine.close()
 
 
 def _drain_until_sentinel(q):

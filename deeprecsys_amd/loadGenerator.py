@@ -14,7 +14,7 @@ import numpy as np
 
 from .scheduler import Scheduler
 from .utils.packets import ServiceRequest
-from .utils.utils import debugPrint
+from .utils.utils import debugPrint, mix_models
 
 
 def model_arrival_times(args):
@@ -89,6 +89,11 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
     query_scheduler = Scheduler(args, requestQueue, accelRequestQueue, pidQueue, mode="cpu")
     accel_query_scheduler = Scheduler(args, requestQueue, accelRequestQueue, pidQueue, mode="accel")
 
+    # mixed-model stream: each query is for one of the engine's models, drawn from its own
+    # seeded stream so the reference's RNG consumption (sizes, arrivals) is untouched
+    shares = [share for _a, share in mix_models(args)]
+    mix_rng = np.random.RandomState(args.numpy_rand_seed + 7919) if shares else None
+
     epoch = exp_epochs = 0
     while tuning_batch_qps or (exp_epochs < args.nepochs):
         for batch_id in range(args.num_batches):
@@ -106,12 +111,14 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
                     continue
 
             request_size = int(batch_size_distributions[batch_id])
+            model_id = int(mix_rng.choice(len(shares), p=shares)) if shares else 0
             exploring = bool(tuning_batch_qps or tuning_accel_qps)
             to_accel = n_accel > 0 and (n_cpu == 0 or request_size >= args.accel_request_size_thres)
             if to_accel:
                 # whole query to an accelerator (loadGenerator.py:162-177)
                 request = ServiceRequest(batch_id=batch_id, epoch=epoch, batch_size=request_size,
-                                         sub_id=0, total_sub_batches=1, exp_packet=exploring)
+                                         sub_id=0, total_sub_batches=1, exp_packet=exploring,
+                                         model_id=model_id)
                 accel_requests += 1
                 request.arrival_time = time.time()
                 accelRequestQueue.put(request)

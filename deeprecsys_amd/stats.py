@@ -12,8 +12,9 @@ import numpy as np
 
 
 class ResponseAggregator(object):
-    def __init__(self, request_granularity=64):
+    def __init__(self, request_granularity=64, with_model=False):
         self.request_granularity = int(request_granularity)
+        self.with_model = bool(with_model)       # mixed-model run: log and count per model
         self.response_sets = {}
         self.response_latencies = []         # every completed query (feeds the scheduler)
         self.final_response_latencies = []   # completed non-experimental queries
@@ -40,12 +41,19 @@ class ResponseAggregator(object):
             if len(self.response_latencies) % self.request_granularity == 0:
                 running = float(np.percentile(self.response_latencies[-self.request_granularity:], 95)
                                 * 1000.)
-        self.responses_list.append(response.as_dict() if hasattr(response, "as_dict")
+        self.responses_list.append(response.as_dict(self.with_model) if hasattr(response, "as_dict")
                                    else dict(response.__dict__))
         return latency, running
 
     def summary(self):
-        return summarize(self.responses_list, self.final_response_latencies)
+        out = summarize(self.responses_list, self.final_response_latencies)
+        if self.with_model:
+            per = {}
+            for r in self.responses_list:
+                if not r["exp_packet"] and r["sub_id"] == 0:
+                    per[r.get("model_id", 0)] = per.get(r.get("model_id", 0), 0) + 1
+            out["queries_per_model"] = {str(k): v for k, v in sorted(per.items())}
+        return out
 
 
 def summarize(responses_list, final_response_latencies):

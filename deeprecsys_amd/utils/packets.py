@@ -7,11 +7,14 @@ the reference stores the `process_start_time` argument as `queue_start_time`.
 
 
 class ServiceRequest(object):
+    # model_id is this build's extension for mixed-model streams (which of the engine's models
+    # the query is for); engines read it with getattr(..., 0) so reference packets still work
     __slots__ = ("batch_id", "batch_size", "epoch", "arrival_time", "total_sub_batches", "sub_id",
-                 "exp_packet")
+                 "exp_packet", "model_id")
 
     def __init__(self, batch_id=None, epoch=None, arrival_time=None, batch_size=None, sub_id=None,
-                 total_sub_batches=None, exp_packet=None):
+                 total_sub_batches=None, exp_packet=None, model_id=0):
+        self.model_id = model_id
         self.batch_id = batch_id
         self.batch_size = batch_size
         self.epoch = epoch
@@ -29,12 +32,13 @@ class ServiceRequest(object):
 class ServiceResponse(object):
     __slots__ = ("consumer_id", "epoch", "batch_id", "batch_size", "arrival_time", "queue_start_time",
                  "queue_end_time", "inference_end_time", "out_batch_size", "total_sub_batches",
-                 "exp_packet", "sub_id")
+                 "exp_packet", "sub_id", "model_id")
 
     def __init__(self, consumer_id=None, epoch=None, batch_id=None, batch_size=None,
                  arrival_time=None, process_start_time=None, queue_end_time=None,
                  inference_end_time=None, out_batch_size=None, sub_id=None, total_sub_batches=None,
-                 exp_packet=None):
+                 exp_packet=None, model_id=0):
+        self.model_id = model_id
         self.consumer_id = consumer_id
         self.epoch = epoch
         self.batch_id = batch_id
@@ -48,9 +52,10 @@ class ServiceResponse(object):
         self.exp_packet = exp_packet
         self.sub_id = sub_id
 
-    def as_dict(self):
-        """What the orchestrator logs per response (reference uses response.__dict__)."""
-        return {k: getattr(self, k) for k in self.__slots__}
+    def as_dict(self, with_model=False):
+        """What the orchestrator logs per response (reference uses response.__dict__): the
+        reference's fields; mixed-model runs add model_id."""
+        return {k: getattr(self, k) for k in self.__slots__ if with_model or k != "model_id"}
 
     def __str__(self):
         return "Response[%s] -> arrival %s start %s end %s inference_end %s" % (

@@ -71,6 +71,10 @@ EXTRA_FLAGS = [
     ("accel_slots", _I, 3),           # launch sets in flight per accel engine (gather | MLP | enqueue)
     ("accel_coalesce", _I, 8),        # queued requests an accel engine may serve per launch set
     ("mp_start_method", _S, "spawn"),  # engine/loadgen processes: spawn (HIP-safe) | fork
+    # mixed-model stream (BASELINE config 4: W&D + NCF on the same accelerators): several model
+    # configs served by every accel engine, each query tagged with the model it is for
+    ("mix_config_files", _S, ""),     # comma-separated JSON configs (models/configs/*.json format)
+    ("mix_weights", _S, ""),          # comma-separated shares of the query stream (default: equal)
 ]
 
 
@@ -104,6 +108,27 @@ def apply_config(args, config):
         caster = type(getattr(args, key))
         setattr(args, key, caster(value))
     return args
+
+
+def mix_models(args):
+    """[(args_for_model_i, share_i)] of a mixed-model run, [] when --mix_config_files is unset.
+    Every model's namespace is the run's own with that model's JSON applied on top (the same
+    "JSON is the master" rule as --config_file, utils/utils.py:151-160 in the reference)."""
+    files = [f for f in str(getattr(args, "mix_config_files", "") or "").split(",") if f]
+    if not files:
+        return []
+    w = [float(x) for x in str(getattr(args, "mix_weights", "") or "").split(",") if x]
+    if not w:
+        w = [1.0] * len(files)
+    if len(w) != len(files) or min(w) < 0 or sum(w) <= 0:
+        raise ValueError("--mix_weights needs one non-negative share per --mix_config_files entry")
+    out = []
+    for f, share in zip(files, w):
+        a = argparse.Namespace(**vars(args))
+        with open(f, "r") as fh:
+            apply_config(a, json.load(fh))
+        out.append((a, share / sum(w)))
+    return out
 
 
 def cli(argv=None):

@@ -50,6 +50,46 @@ def test_harness_with_two_simulated_accelerators(tmp_path):
     assert consumers <= {0, 1} and len(consumers) >= 1
 
 
+def _write_mix_configs(tmp_path):
+    """Shrunk models/configs/{wide_and_deep,ncf}.json (same keys, small tables)."""
+    import json
+    wnd = {"arch_mlp_bot": "64", "arch_mlp_top": "128-64-1", "arch_embedding_size": "-".join(["300"] * 5),
+           "arch_sparse_feature_size": 16, "num_indices_per_lookup_fixed": True, "num_indices_per_lookup": 1,
+           "arch_interaction_op": "cat", "model_type": "wnd", "model_name": "wnd"}
+    ncf = {"arch_mlp_bot": "64", "arch_mlp_top": "64-32-16", "arch_embedding_size": "200-200-40-40",
+           "arch_sparse_feature_size": 16, "num_indices_per_lookup_fixed": True, "num_indices_per_lookup": 1,
+           "arch_interaction_op": "cat", "model_type": "ncf", "model_name": "ncf"}
+    files = []
+    for name, cfg in (("wnd", wnd), ("ncf", ncf)):
+        f = str(tmp_path / (name + ".json"))
+        json.dump(cfg, open(f, "w"))
+        files.append(f)
+    return ",".join(files)
+
+
+def test_mixed_model_stream_tags_queries_deterministically(tmp_path):
+    """BASELINE config 4's stream: every query is for one of the engine's models, drawn from
+    its own seeded stream with the configured shares; the log carries model_id."""
+    from deeprecsys_amd.utils.utils import mix_models
+    root = str(tmp_path / "accel") + "/"
+    os.makedirs(root)
+    _write_sim_tables(root)
+    a = _args(tmp_path, accel_backend="sim", num_accels=1, accel_root_dir=root, model_name="wnd",
+              mix_config_files=_write_mix_configs(tmp_path), mix_weights="3,1")
+    mm = mix_models(a)
+    assert [m.model_type for m, _ in mm] == ["wnd", "ncf"] and [w for _, w in mm] == [0.75, 0.25]
+    assert mm[1][0].arch_mlp_top == "64-32-16" and a.model_name == "wnd"       # copies, run args untouched
+    s = DeepRecSys(a, quiet=True)
+    lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
+    got = [l["model_id"] for l in sorted(lines, key=lambda l: (l["epoch"], l["batch_id"]))]
+    rng = np.random.RandomState(a.numpy_rand_seed + 7919)
+    assert got == [int(rng.choice(2, p=[0.75, 0.25])) for _ in range(len(got))]
+    assert s["queries_per_model"] == {str(k): got.count(k) for k in sorted(set(got))}
+    with pytest.raises(ValueError):
+        a.mix_weights = "1"
+        mix_models(a)
+
+
 def test_harness_rejects_cpu_engines_without_a_cpu_forward(tmp_path):
     a = _args(tmp_path, inference_engines=2)
     with pytest.raises(SystemExit):
@@ -111,3 +151,17 @@ def test_harness_with_a_real_accelerator_engine(tmp_path):
     lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
     assert all(l["out_batch_size"] == l["batch_size"] for l in lines)
     assert s["qps"] > 0 and s["p99_ms"] < 1000
+
+
+@pytest.mark.gpu
+def test_mixed_wnd_ncf_stream_on_a_real_accelerator(tmp_path):
+    """W&D and NCF resident on the same GPU, one engine process serving the mixed stream
+    (requests coalesce per model, never across models)."""
+    a = _args(tmp_path, accel_backend="hip", num_accels=1, mix_config_files=_write_mix_configs(tmp_path),
+              mix_weights="1,1", nepochs=4)
+    s = DeepRecSys(a, quiet=True)
+    n = a.nepochs * a.num_batches
+    assert s["accel_requests"] == n and s["responses"] == n
+    lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
+    assert all(l["out_batch_size"] == l["batch_size"] for l in lines)
+    assert set(s["queries_per_model"]) == {"0", "1"} and sum(s["queries_per_model"].values()) == n

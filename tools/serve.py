@@ -22,6 +22,25 @@ if __name__ == "__main__":
             "--batch_size_distribution", "normal", "--avg_mini_batch_size", "165",
             "--var_mini_batch_size", "16", "--max_mini_batch_size", "256",
             "--avg_arrival_rate", "0.05", "--req_granularity", "64", "--log_file", "/tmp/drs_log/out.log"]
-    args = cli(base + sys.argv[1:])
+    argv = sys.argv[1:]
+    if "--mix" in argv:
+        # BASELINE config 4: W&D + NCF mixed stream (reference JSON shapes) on every accel engine
+        argv.remove("--mix")
+        import tempfile
+        d = tempfile.mkdtemp(prefix="drs_mix_")
+        wnd = {"arch_mlp_bot": "512", "arch_mlp_top": "1024-512-256-1",
+               "arch_embedding_size": "-".join(["1000000"] * 27), "arch_sparse_feature_size": 32,
+               "num_indices_per_lookup_fixed": True, "num_indices_per_lookup": 1,
+               "arch_interaction_op": "cat", "model_type": "wnd", "model_name": "wnd"}
+        ncf = {"arch_mlp_bot": "512", "arch_mlp_top": "256-256-128-64-64",
+               "arch_embedding_size": "140000-140000-28000-28000", "arch_sparse_feature_size": 64,
+               "num_indices_per_lookup_fixed": True, "num_indices_per_lookup": 1,
+               "arch_interaction_op": "cat", "model_type": "ncf", "model_name": "ncf"}
+        files = []
+        for name, cfg in (("wide_and_deep", wnd), ("ncf", ncf)):
+            files.append(os.path.join(d, name + ".json"))
+            json.dump(cfg, open(files[-1], "w"))
+        argv = ["--mix_config_files", ",".join(files)] + argv
+    args = cli(base + argv)
     s = DeepRecSys(args, quiet=True)
     print(json.dumps(s))
