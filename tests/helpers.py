@@ -76,3 +76,35 @@ def close(a, b, rtol, atol=0.0, atol_scale=0.0):
 
 # tolerance BASELINE.json's north_star states for fp32 MLP outputs
 RTOL_OUT = 1e-4
+
+
+def oracle_inference_engine(args, requestQueue=None, engine_id=None, responseQueue=None,
+                            inferenceEngineReadyQueue=None):
+    """CPU inference engine for harness tests: the reference's inferenceEngine()
+    (inferenceEngine.py:62-249) with the CPU oracle in place of Caffe2 -- same start-up
+    order (seed, inputs, weights), same ready token, same per-request prefix slicing
+    (:200-215), same response stamping, None sentinel in and out.  TEST INFRASTRUCTURE:
+    DeepRecSys(cpu_engine=oracle_inference_engine) puts real CPU engines beside the
+    accelerator engine, e.g. to run the scheduler against measured latencies."""
+    import time
+
+    from deeprecsys_amd.utils.packets import ServiceResponse
+    net, lX, lS_l, lS_i, lT = materialize(args)
+    om = oracle_model(net)
+    inferenceEngineReadyQueue.put(True)
+    while True:
+        request = requestQueue.get()
+        if request is None:
+            responseQueue.put(None)
+            return
+        start = time.time()
+        bid, bs = request.batch_id, request.batch_size
+        dense = None if args.model_type == "ncf" else lX[bid]
+        out = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, nthreads=1)
+        end = time.time()
+        responseQueue.put(ServiceResponse(consumer_id=engine_id, epoch=request.epoch, batch_id=bid,
+                                          batch_size=bs, arrival_time=request.arrival_time,
+                                          process_start_time=start, queue_end_time=end,
+                                          inference_end_time=end, out_batch_size=out.shape[0],
+                                          total_sub_batches=request.total_sub_batches,
+                                          exp_packet=request.exp_packet, sub_id=request.sub_id))

@@ -165,3 +165,25 @@ def test_mixed_wnd_ncf_stream_on_a_real_accelerator(tmp_path):
     lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
     assert all(l["out_batch_size"] == l["batch_size"] for l in lines)
     assert set(s["queries_per_model"]) == {"0", "1"} and sum(s["queries_per_model"].values()) == n
+
+
+@pytest.mark.gpu
+def test_scheduler_in_the_loop_with_measured_latencies(tmp_path, capsys):
+    """DeepRecSched over REAL engines: two CPU engines (the oracle behind the reference's
+    engine protocol) and one MI355X engine; the scheduler hill-climbs the per-core batch
+    size and then the CPU/accelerator size threshold on measured tail latencies
+    (scheduler.py:104-106,128-130; loadGenerator.py:152-177) and the run terminates with
+    every engine joined."""
+    from tests.helpers import oracle_inference_engine
+    a = _args(tmp_path, accel_backend="hip", num_accels=1, inference_engines=2,
+              arch_sparse_feature_size=16, arch_embedding_size="2000-3000-1000", arch_mlp_bot="13-32-16",
+              arch_mlp_top="32-1", arch_interaction_op="dot", num_indices_per_lookup=10, model_type="dlrm",
+              tune_batch_qps=True, tune_accel_qps=True, batch_configs="16-8", accel_configs="8-16-24",
+              min_arr_range=0.2, max_arr_range=5.0, arr_steps=6, sched_timeout=3, target_latency=50.0,
+              avg_arrival_rate=1.0, nepochs=2)
+    s = DeepRecSys(a, cpu_engine=oracle_inference_engine, quiet=False)
+    out = capsys.readouterr().out
+    assert "Finished batch size scheduler" in out
+    assert "Optimal batch_size configuration" in out and "Optimal accel configuration" in out
+    assert s["responses"] > 0 and s["qps"] > 0
+    assert s["accel_requests"] > 0 and s["cpu_requests"] > 0      # both kinds of engine served queries
