@@ -168,7 +168,7 @@ def test_mixed_wnd_ncf_stream_on_a_real_accelerator(tmp_path):
 
 
 @pytest.mark.gpu
-def test_scheduler_in_the_loop_with_measured_latencies(tmp_path, capsys):
+def test_scheduler_in_the_loop_with_measured_latencies(tmp_path, capfd):
     """DeepRecSched over REAL engines: two CPU engines (the oracle behind the reference's
     engine protocol) and one MI355X engine; the scheduler hill-climbs the per-core batch
     size and then the CPU/accelerator size threshold on measured tail latencies
@@ -182,7 +182,7 @@ def test_scheduler_in_the_loop_with_measured_latencies(tmp_path, capsys):
               min_arr_range=0.2, max_arr_range=5.0, arr_steps=6, sched_timeout=3, target_latency=50.0,
               avg_arrival_rate=1.0, nepochs=2)
     s = DeepRecSys(a, cpu_engine=oracle_inference_engine, quiet=False)
-    out = capsys.readouterr().out
+    out = capfd.readouterr().out          # fd level: the scheduler prints from the load generator process
     assert "Finished batch size scheduler" in out
     assert "Optimal batch_size configuration" in out and "Optimal accel configuration" in out
     assert s["responses"] > 0 and s["qps"] > 0
