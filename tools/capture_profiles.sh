@@ -36,9 +36,16 @@ done
 # 4. other operating points (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 8000 --warmup 800 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 4000 --warmup 400 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
-for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot; do
+for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf; do
   run 300 python bench.py --workload $w --no_cpu_baseline --steps 4000 --warmup 400 > "$OUT/bench_$w.json" 2>/dev/null
 done
+# 4b. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
+for m in rm1 rm2 rm3; do
+  run 300 python tools/characterize.py --model $m --out "$OUT/accelerator_mi355x/" > "$OUT/characterize_$m.txt" 2>&1
+done
+# 4c. the queue harness end to end: one accel engine, RMC1 and the W&D + NCF mixed stream
+run 300 python tools/serve.py --avg_arrival_rate 0.01 2>/dev/null | tail -1 > "$OUT/serve_rmc1.json"
+run 300 python tools/serve.py --mix --avg_arrival_rate 0.01 2>/dev/null | tail -1 > "$OUT/serve_mix_wnd_ncf.json"
 # 5. the driver's multi-GPU launch line, on the one GPU of this box
 run 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 1 --steps 8000 --warmup 800 --no_cpu_baseline > "$OUT/bench_torchrun_n1.json" 2> "$OUT/bench_torchrun_n1.err"

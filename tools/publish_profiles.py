@@ -22,13 +22,21 @@ def main(tag, prefix):
              "kernel_trace_by_grid.txt": "kernel_trace_by_grid.txt", "pmc_summary.txt": "pmc_summary.txt",
              "bench_single_stream.json": "bench_single_stream.json", "bench_coalesce1.json": "bench_coalesce1.json",
              "bench_torchrun_n1.json": "bench_torchrun_n1.json"}
-    for w in ("rmc1_ref", "rmc2_ref", "rmc3_ref", "rmc1_dot"):
+    for w in ("rmc1_ref", "rmc2_ref", "rmc3_ref", "rmc1_dot", "wnd", "ncf"):
         names["bench_%s.json" % w] = "bench_%s.json" % w
+    for f in ("serve_rmc1.json", "serve_mix_wnd_ncf.json"):
+        names[f] = f
     for a, b in names.items():
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(dst, "%s_%s" % (prefix, b)))
             print("profiles/%s_%s" % (prefix, b))
+    acc = os.path.join(src, "accelerator_mi355x")
+    if os.path.isdir(acc):
+        out = os.path.join(dst, "accelerator_mi355x")
+        shutil.rmtree(out, ignore_errors=True)
+        shutil.copytree(acc, out)
+        print("profiles/accelerator_mi355x/")
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     co = bench["config"]["queries_per_launch"]
     # gather launches of the timed region are the biggest sls_kernel grid in the PMC passes
