@@ -127,6 +127,7 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+  int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (2+: no gain measured)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used
   int zero_copy_inputs = 1;         // drs_forward_inputs: kernels read the inputs in place from pinned host memory
   int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
@@ -317,8 +318,16 @@ bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const 
 // first slot's stream behind an event, so the HBM-bound gather of set i+1 runs under the
 // latency-bound MLP of set i and the gathers themselves never overlap each other.
 void apply_stream_mode(drs_engine* e) {
+  // pipelined mode: the MLP launches may alternate between `mlp_streams` streams, so that the
+  // latency-bound tail of one set's MLP launch (completion hand-off: one workgroup active)
+  // overlaps the start of the next set's
+  const int nm = e->mlp_streams < 1 ? 1 : (e->mlp_streams > (int)e->slots.size() ? (int)e->slots.size() : e->mlp_streams);
+  int k = 0;
   for (auto& s : e->slots) {
+    if (e->shared_stream == 2) s.stream = e->slots[k % nm].own_stream;
+    else s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
     s.gather_stream = e->shared_stream == 2 ? e->stream_g : s.stream;
+    ++k;
   }
 }
 
@@ -1110,6 +1119,12 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
   else if (!strcmp(key, "zero_copy_inputs")) e->zero_copy_inputs = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_streams") && value >= 1 && value <= 8) {
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    e->mlp_streams = (int)value;
+    apply_stream_mode(e);
+  }
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;

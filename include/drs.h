@@ -214,6 +214,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_wide_kn" that threshold (default 512K weights)
  *   "mlp_fuse"   1 (default) DLRM/"cat": bottom and top MLP of a 16-row slab in ONE launch
  *                | 0 one launch per MLP;  "mlp_fuse_rows": fuse only from this many rows on
+ *   "mlp_gemm"   1 (default) stand-alone wide layers run as the register-blocked gemm_kernel
+ *                (gemm.hip) | 0 fc_kernel;  "mlp_gemm_tile" 0 (default: by workgroup count)
+ *                | 22 | 12 | 21 | 11 forces the per-wave tile shape
  *   "mlp_stream" 1 (default) chains run as the weight-tile stream kernel (tiles of all layers
  *                requested six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and
  *                the slabs fit | 0 always the per-layer chain kernel.  Same bits either way.
@@ -228,6 +231,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                  each set (MLPs, interaction, completion) behind an event on a second
  *                  stream, so the HBM-bound gather of set i+1 runs beside the latency-bound
  *                  MLP of set i and gathers never overlap each other
+ *                  ("mlp_streams" n: alternate the MLP side over n streams; default 1, more
+ *                  measured no gain)
  *                1 one stream: sets strictly back to back, each kernel has the chip to itself
  *                0 one stream per slot: whole sets overlap freely
  *   "zero_copy_inputs" 1 (default) drs_forward_inputs converts the caller's arrays into the
