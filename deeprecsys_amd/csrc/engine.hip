@@ -1,14 +1,18 @@
 // Host side of libdrs_hip.so: the C ABI of include/drs.h on top of the kernels in
-// sls.hip / mlp.hip.  One engine = one GPU = one process (accelInferenceEngine
+// sls.hip / mlp.hip / gemm.hip.  One engine = one GPU = one process (accelInferenceEngine
 // counterpart, reference accelInferenceEngine.py:18-86).
 //
 // HBM layout (all hipMalloc'ed once in drs_create / first use):
 //   tables   one arena, table t at a 256-B aligned offset, rows*D fp32 row-major
-//   weights  per layer W [N, K] dense row-major + b [N]   (as fed by the reference)
+//   weights  one arena: all biases back to back (layer order, padded to 4 floats), then per
+//            layer W [N, K] dense row-major (as fed by the reference)
 //   batches  per staged batch: dense [max_batch, m_den] f32 | idx [T, cap] i32 |
 //            off [T, max_batch+1] i32 (exclusive prefix sums of the lengths)
-//   slots    per in-flight query: interaction buffer(s), layer scratch,
-//            [err | out] device words + the same in pinned host memory
+//   slots    per in-flight launch set (up to 8 coalesced queries): interaction buffer(s),
+//            layer scratch, device output buffer, [flag | err | out] in host-mapped pinned
+//            memory, and a host-mapped pinned input block for per-call inputs
+// Streams: every gather on stream_g, the rest of each launch set on a second stream behind
+// an event; completion is a flag in pinned memory, not a stream sync.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -395,9 +399,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, exact_now) : 0;
   HIP_TRY(e, launch_sls(a, exact_now, s.gather_stream));
   if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.gather_stream));
-  static const bool dbg_nojoin = getenv("DRS_DEBUG_NOJOIN") != nullptr;   // timing experiment only
-  if (piped && !dbg_nojoin) HIP_TRY(e, hipEventRecord(s.ev_sls, s.gather_stream));
-  bool joined = !piped || dbg_nojoin;   // has s.stream been made to wait for the gather yet?
+  if (piped) HIP_TRY(e, hipEventRecord(s.ev_sls, s.gather_stream));
+  bool joined = !piped;   // has s.stream been made to wait for the gather yet?
   auto join = [&]() -> hipError_t {
     if (joined) return hipSuccess;
     joined = true;

@@ -10,12 +10,17 @@
 // operands are fed so that MFMA step s carries k = 4s .. 4s+3, so GPU and oracle
 // agree bitwise up to the final expf of the sigmoid.
 //
-// Tiling: a workgroup (4 waves) owns a 16-row slab of the batch and 64 output
+// Tiling: a workgroup (8 waves) owns a 16-row slab of the batch and 128 output
 // columns at a time (one 16x16 tile per wave).  W (stored [N, K], K contiguous --
-// already the "B^T" layout MFMA wants) streams through LDS in 64-deep K chunks,
-// double-buffered; rows are padded to 68 floats so the staging ds_write_b128 and
-// the per-lane ds_read_b32 operand fetches stay (almost) conflict free.  In the
-// chained form the activations of a slab never leave LDS between layers.
+// already the "B^T" layout MFMA wants) streams through LDS in 64-deep K chunks; rows
+// are padded to 68 floats and rows 8..15 stored at k^2 so the per-lane ds_read_b32
+// operand fetches are conflict free.  The activations of a slab never leave LDS
+// between layers.  Three kernels share this contract:
+//   stream_kernel  all layers of one or two chains as ONE prefetched sequence of weight
+//                  tiles (the default)
+//   chain_kernel   per-layer passes (fallback: widths not a multiple of 4, inputs too
+//                  wide for an LDS slab)
+//   fc_kernel      one layer on a 2-D grid (fallback of gemm.hip's gemm_kernel)
 #include <string.h>
 
 #include "drs_internal.h"
