@@ -385,3 +385,51 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top):
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
     finally:
         net.engine.close()
+
+
+# ------------------------------------------------------------------------------------
+# BASELINE.json config 3 at full size (12 tables x 10M rows x 32 = 15.36 GB of tables, batch
+# 512, L = 20): no CPU oracle at this size -- size-independent properties instead
+def test_rmc3_baseline_size_counting_property():
+    """Tables filled with ones: every pooled column must equal the bag length EXACTLY (a sum
+    of L ones is exact in any fp32 order), for both gather variants, including bags that
+    touch row 0 and the last row of a 10M-row table; and the Caffe2 index ENFORCE must fire
+    for row N at that size."""
+    T, rows, D, L, B = 12, 10_000_000, 32, 20, 512
+    eng = N.Engine(N.MODEL_DLRM, [rows] * T, D, [64, 32], [D * (T + 1), 16, 1], N.INTERACT_CAT,
+                   sigmoid_top=2, max_batch=B, max_lookups=L, num_staged_batches=1, num_slots=2)
+    try:
+        for t in range(T):
+            eng.fill_table_uniform(t, 1.0, 1.0, 5)
+        rng = np.random.RandomState(3)
+        eng.set_fc(N.MLP_BOT, 0, rng.randn(32, 64).astype(np.float32), rng.randn(32).astype(np.float32))
+        eng.set_fc(N.MLP_TOP, 0, rng.randn(16, D * (T + 1)).astype(np.float32) * 0.01, np.zeros(16, np.float32))
+        eng.set_fc(N.MLP_TOP, 1, rng.randn(1, 16).astype(np.float32), np.zeros(1, np.float32))
+        idx = [np.sort(rng.randint(0, rows, size=(B, L)), axis=1).astype(np.int64) for _ in range(T)]
+        for t in range(T):
+            idx[t][0, 0] = 0
+            idx[t][B - 1, L - 1] = rows - 1          # the very last row of the table
+        lens = [np.full(B, L, dtype=np.int32) for _ in range(T)]
+        dense = rng.rand(B, 64).astype(np.float32)
+        eng.stage_batch(0, dense, [i.reshape(-1) for i in idx], lens)
+        outs = {}
+        for exact in (1, 0):
+            eng.set_option("sls_exact", exact)
+            for bs in (B, 165, 1):
+                out = eng.forward(0, bs)
+                R = eng.fetch_interaction(bs)
+                assert R.shape == (bs, D * (T + 1))
+                assert np.array_equal(R[:, D:], np.full((bs, D * T), float(L), np.float32)), (exact, bs)
+                assert np.all(np.isfinite(out)) and np.all((out > 0) & (out < 1))
+                outs[(exact, bs)] = out
+        # pooled sums identical -> the whole forward identical between the two gather variants
+        for bs in (B, 165, 1):
+            assert np.array_equal(outs[(1, bs)], outs[(0, bs)])
+        assert eng.gather_bytes(0, B) == B * T * (L * D * 4 + L * 4 + 4 + D * 4)
+        bad = [i.copy() for i in idx]
+        bad[T - 1][7, 3] = rows                       # one past the end
+        with pytest.raises(N.DrsError) as ei:
+            eng.forward_inputs(dense, [i.reshape(-1) for i in bad], lens, B)
+        assert ei.value.code == N.ERR_INDEX_RANGE
+    finally:
+        eng.close()
