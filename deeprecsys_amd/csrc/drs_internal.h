@@ -112,8 +112,22 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t stream, const Done* done
 size_t chain_lds_bytes(const ChainArgs& a);
 // two chains on the same rows in one launch (bottom MLP, then the top MLP that reads the
 // buffer the first one wrote its last layer into)
+// Optional dot interaction BETWEEN the two chains of launch_chain2 (DLRM "dot",
+// models/dlrm_s_caffe2.py:334-354): the first chain writes the dense_out slot of T, the
+// interaction turns T [M, F*D] into R [M, D + P], the second chain reads R.
+struct DotArgs {
+  const float* T;   // == a.y: [M, F*D] sample-major (dense_out | emb_0 | ...), ld = ldt
+  int64_t ldt;
+  int32_t F, D, itself;
+  float* R;         // == b->x: interaction output, ld = ldr (also kept for drs_fetch_interaction)
+  int64_t ldr;
+};
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t stream,
-                         const Done* done = nullptr, const XSrc* xs = nullptr);
+                         const Done* done = nullptr, const XSrc* xs = nullptr,
+                         const DotArgs* dot = nullptr);
+// would launch_chain2(a, &b, ..., dot) run as the stream kernel?  (With a dot interaction in
+// between it is the only kernel that can.)
+bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xs, const DotArgs* dot);
 size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot

@@ -290,29 +290,47 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
   return DRS_OK;
 }
 
-// DLRM with the "cat" interaction: bottom MLP and top MLP of a 16-row slab in ONE launch
-// (the slab's dense_out never waits for a kernel boundary).  false = not applicable.
-bool fused_applicable(const drs_engine* e, int64_t Mv) {
-  if (!e->mlp_fuse || Mv < e->mlp_fuse_rows || e->kind != DRS_MODEL_DLRM || e->interaction_op != DRS_INTERACT_CAT) return false;
-  const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
-  if (nb < 1 || nt < 1 || nb > DRS_MAX_CHAIN || nt > DRS_MAX_CHAIN) return false;
-  for (int l = 0; l < nb; ++l) if (is_wide(e, e->bot, l)) return false;
-  for (int l = 0; l < nt; ++l) if (is_wide(e, e->top, l)) return false;
+// DLRM: bottom MLP, interaction and top MLP of a 16-row slab in ONE launch (the slab's
+// dense_out never waits for a kernel boundary).  "cat": the top chain reads the buffer the
+// bottom chain wrote; "dot": the stream kernel computes T.T^T in LDS between the chains.
+struct FusedPlan {
+  bool ok = false;
   ChainArgs a, b;
-  fill_chain(a, e->bot, 0, nb, nullptr, e->m_den, Mv, nullptr, 0);
-  fill_chain(b, e->top, 0, nt, nullptr, 0, Mv, nullptr, 0);
-  return chain2_lds_bytes(a, b) <= kChainLds;
+  DotArgs dot;
+  bool has_dot = false;
+};
+
+FusedPlan fused_plan(const drs_engine* e, const Slot& s, int64_t Mv, float* out, const XSrc* xs) {
+  FusedPlan p;
+  if (!e->mlp_fuse || Mv < e->mlp_fuse_rows || e->kind != DRS_MODEL_DLRM) return p;
+  const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
+  if (nb < 1 || nt < 1 || nb > DRS_MAX_CHAIN || nt > DRS_MAX_CHAIN) return p;
+  for (int l = 0; l < nb; ++l) if (is_wide(e, e->bot, l)) return p;
+  for (int l = 0; l < nt; ++l) if (is_wide(e, e->top, l)) return p;
+  fill_chain(p.a, e->bot, 0, nb, nullptr, e->m_den, Mv, s.T, e->ldT);
+  if (e->interaction_op == DRS_INTERACT_CAT) {
+    fill_chain(p.b, e->top, 0, nt, s.T, e->ldT, Mv, out, e->n_out);
+    p.ok = chain2_lds_bytes(p.a, p.b) <= kChainLds || stream_applicable(p.a, p.b, xs, nullptr);
+  } else {
+    fill_chain(p.b, e->top, 0, nt, s.R, e->ldR, Mv, out, e->n_out);
+    p.dot.T = s.T; p.dot.ldt = e->ldT; p.dot.F = e->T + 1; p.dot.D = e->D; p.dot.itself = e->itself;
+    p.dot.R = s.R; p.dot.ldr = e->ldR;
+    p.has_dot = true;
+    p.ok = stream_applicable(p.a, p.b, xs, &p.dot);   // only the stream kernel has the interaction
+  }
+  return p;
+}
+
+bool fused_applicable(const drs_engine* e, const Slot& s, int64_t Mv, const XSrc* xs) {
+  return fused_plan(e, s, Mv, s.d_out, xs).ok;
 }
 
 bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const Done* dp,
                           const XSrc* xs, int32_t* rc) {
   *rc = DRS_OK;
-  if (!fused_applicable(e, Mv)) return false;
-  const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
-  ChainArgs a, b;
-  fill_chain(a, e->bot, 0, nb, nullptr, e->m_den, Mv, s.T, e->ldT);
-  fill_chain(b, e->top, 0, nt, s.T, e->ldT, Mv, out, e->n_out);
-  hipError_t r = launch_chain2(a, &b, s.stream, dp, xs);
+  FusedPlan p = fused_plan(e, s, Mv, out, xs);
+  if (!p.ok) return false;
+  hipError_t r = launch_chain2(p.a, &p.b, s.stream, dp, xs, p.has_dot ? &p.dot : nullptr);
   if (r != hipSuccess) *rc = fail(e, DRS_ERR_HIP, "launch_chain2: %s", hipGetErrorString(r));
   return true;
 }
@@ -436,7 +454,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   } else {
     bool fused = false;
     if (!e->bot.layers.empty()) {
-      if (fused_applicable(e, Mv)) HIP_TRY(e, join());
+      if (fused_applicable(e, s, Mv, &xs)) HIP_TRY(e, join());
       fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
       if (rc) return rc;
     }
@@ -452,7 +470,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     HIP_TRY(e, join());   // (the bottom MLP above ran beside the gather)
     const float* top_in = s.T;
     int64_t ld_top = e->ldT;
-    if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
+    if (!fused && e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
       HIP_TRY(e, launch_interact_dot(s.T, e->ldT, Mv, e->T + 1, e->D, e->itself, s.R, e->ldR, s.stream));
       top_in = s.R;
       ld_top = e->ldR;

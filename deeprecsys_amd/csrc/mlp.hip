@@ -408,6 +408,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
 // every later activation is written there by the previous layer's epilogue.  Slab columns
 // between K and the next multiple of 64 are kept zero, weight tiles read zeros beyond K,
 // so the MFMA body has no selects and no branches.
+// With a DotArgs the DLRM dot interaction runs between the two chains, in LDS (interact()).
 // Requires K % 4 == 0 and 16-B aligned operands on every layer and the slabs to fit in
 // LDS; launch_chain2 falls back to chain_kernel otherwise.
 struct SLayer {
@@ -433,6 +434,12 @@ struct SInput {            // 16 x cols block of a global matrix -> LDS slab, ze
 struct SArgs {
   int32_t n_layers, n_tiles, sB_off, n_inputs;
   int32_t dbg, lds_floats;
+  // dot interaction between the chains (DotArgs): at tile `inter_tile` the T slab (F x D per
+  // row) becomes the R slab (D + P per row, zero padded to r_pad) the second chain reads
+  int32_t inter_on, inter_tile, F, D, itself, P;
+  int32_t t_off, t_ld, r_off, r_ld, r_pad, pad2_;
+  float* g_R;
+  int64_t g_ldr;
   int32_t n_bias, bias_off; // all biases: n_bias floats at `bias` -> LDS float offset bias_off
   const float* bias;
   int64_t M;
@@ -572,7 +579,35 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   __syncthreads();
   TL(4);
 
+  // ---- dot interaction between the chains (one d-ordered fma chain per pair, like the
+  // oracle and interact_dot_kernel: bit-identical) -------------------------------------------
+  auto interact = [&]() {
+    const float* Ts = smem + a.t_off;
+    float* Rs = smem + a.r_off;
+    const int D = a.D, W = a.r_pad, off = a.itself ? 1 : 0;
+    for (int o = tid; o < 16 * W; o += kThreads) {
+      const int row = o / W, c = o - row * W;
+      const float* t = Ts + row * a.t_ld;
+      float v = 0.f;
+      if (c < D) {
+        v = t[swz(c, row)];
+      } else if (c < D + a.P) {
+        // BatchGather order: row i of the (strictly) lower triangle starts at i(i-1)/2 (+ i with itself)
+        const int p = c - D;
+        int i = off ? 0 : 1;
+        while ((i + 1) * (i + off * 2) / 2 <= p) ++i;   // start of row i+1: (i+1)(i+2*off)/2
+        const int j = p - i * (i - 1 + 2 * off) / 2;
+        const int bi = i * D, bj = j * D;
+        for (int k = 0; k < D; ++k) v = fmaf(t[swz(bi + k, row)], t[swz(bj + k, row)], v);
+      }
+      Rs[row * a.r_ld + swz(c, row)] = v;
+      if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
+    }
+    __syncthreads();
+  };
+
   // ---- consume iterator ------------------------------------------------------------------
+  int c_tile = 0;
   int c_l = 0, c_n0 = 0, c_c = 0;
   SLayer cl = a.L[0];
   int c_nch = (cl.K + 63) >> 6;
@@ -587,6 +622,8 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
 #define DRS_ROUND(BUF, RB_FETCH, RB_STASH)                                                        \
   {                                                                                               \
     TL(10);                                                                                       \
+    if (a.inter_on && c_tile == a.inter_tile) interact();                                         \
+    ++c_tile;                                                                                     \
     fetch(RB_FETCH);                                                                              \
     TL(11);                                                                                       \
     const int col = c_n0 + wave * 16 + r;                                                         \
@@ -882,14 +919,23 @@ static inline int pad64(int n) { return (n + 63) & ~63; }
 
 // Lay the chain(s) out for stream_kernel.  false = not applicable (caller uses chain_kernel).
 static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, bool publish,
-                        SArgs* out, size_t* lds_bytes) {
+                        SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr) {
   SArgs& p = *out;
   memset(&p, 0, sizeof p);
   const int na = a.n_layers, nb = b ? b->n_layers : 0;
   if (na + nb > DRS_MAX_STREAM_LAYERS) return false;
   // second chain must read the buffer the first one writes (dense_out slot in front)
   const int d_out = a.width[na];
-  if (b && (b->x != a.y || b->ldx != a.ldy || d_out > b->width[0] || (d_out & 3))) return false;
+  int dotP = 0;
+  if (dot) {
+    // bottom -> T (dense_out slot) -> interaction -> R -> top
+    dotP = dot->F * (dot->F - 1) / 2 + (dot->itself ? dot->F : 0);
+    if (!b || dot->T != a.y || dot->ldt != a.ldy || dot->R != b->x || dot->ldr != b->ldx ||
+        dot->D != d_out || (d_out & 3) || b->width[0] != d_out + dotP || dot->F < 2)
+      return false;
+  } else if (b && (b->x != a.y || b->ldx != a.ldy || d_out > b->width[0] || (d_out & 3))) {
+    return false;
+  }
   auto ok_ptr = [](const void* q) { return aligned16(q); };
   if (!ok_ptr(a.x) || (a.ldx & 3)) return false;
   for (int i = 0; i < xs.q.n_q; ++i) if (!ok_ptr(xs.x[i])) return false;
@@ -910,8 +956,14 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
   p.sB_off = off; off += 2 * 128 * 68;
   const int x0_ld = pad64(a.width[0]) + 4;
   const int x0_off = off; off += 16 * x0_ld;
-  int rs_off = -1, rs_ld = 0;
-  if (b) { rs_ld = pad64(b->width[0]) + 4; rs_off = off; off += 16 * rs_ld; }
+  // RS: what the first chain's last layer writes its dense_out slot into and the pooled rows
+  // are pulled beside: the second chain's input (cat) or the interaction's T slab (dot)
+  int rs_off = -1, rs_ld = 0, rs_cols = 0, ri_off = -1, ri_ld = 0;
+  if (b) {
+    rs_cols = dot ? dot->F * dot->D : b->width[0];
+    rs_ld = pad64(rs_cols) + 4; rs_off = off; off += 16 * rs_ld;
+    if (dot) { ri_ld = pad64(b->width[0]) + 4; ri_off = off; off += 16 * ri_ld; }
+  }
   // ping-pong widths
   int wP = 0, wQ = 0;
   {
@@ -943,7 +995,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
       L.g_sc1 = last_of_all && publish;
       if (!last_of_all) {           // dense_out slot of the second chain's input slab
         L.out_off = rs_off; L.out_ld = rs_ld; L.out_pad = L.N;
-        cur_off = rs_off; cur_ld = rs_ld;
+        cur_off = dot ? ri_off : rs_off; cur_ld = dot ? ri_ld : rs_ld;
       }
     } else {
       L.out_off = which ? q_off : p_off; L.out_ld = which ? q_ld : p_ld; L.out_pad = pad64(L.N);
@@ -968,16 +1020,33 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
   p.n_inputs = 1;
   if (b) {
     SInput& i1 = p.in[1];
-    i1.src = b->x; i1.ld = b->ldx; i1.col0 = d_out; i1.cols = b->width[0] - d_out;
-    i1.cols_pad = pad64(b->width[0]) - d_out;
+    i1.src = dot ? dot->T : b->x; i1.ld = dot ? dot->ldt : b->ldx; i1.col0 = d_out; i1.cols = rs_cols - d_out;
+    i1.cols_pad = pad64(rs_cols) - d_out;
     i1.lds_off = rs_off; i1.lds_ld = rs_ld; i1.lds_col0 = d_out; i1.use_xs = 0;
     p.n_inputs = 2;
+  }
+  if (dot) {
+    p.inter_on = 1; p.F = dot->F; p.D = dot->D; p.itself = dot->itself ? 1 : 0; p.P = dotP;
+    p.t_off = rs_off; p.t_ld = rs_ld; p.r_off = ri_off; p.r_ld = ri_ld; p.r_pad = pad64(b->width[0]);
+    p.g_R = dot->R; p.g_ldr = dot->ldr;
+    p.inter_tile = 0;
+    for (int l = 0; l < na; ++l) p.inter_tile += ((a.width[l + 1] + 127) / 128) * ((a.width[l] + 63) / 64);
   }
   return true;
 }
 
+bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xsrc, const DotArgs* dot) {
+  if (!g_mlp_stream || init_mlp_kernels() != hipSuccess) return false;
+  XSrc xs;
+  memset(&xs, 0, sizeof xs);
+  if (xsrc) xs = *xsrc;
+  SArgs sp;
+  size_t lds = 0;
+  return stream_plan(a, &b, xs, true, &sp, &lds, dot);
+}
+
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, const Done* done,
-                         const XSrc* xsrc) {
+                         const XSrc* xsrc, const DotArgs* dot) {
   if (a.M <= 0) return hipSuccess;
   Done d;
   memset(&d, 0, sizeof d);
@@ -992,7 +1061,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
   if (g_mlp_stream) {
     SArgs sp;
     size_t slds = 0;
-    if (stream_plan(a, b, xs, d.counter != nullptr, &sp, &slds)) {
+    if (stream_plan(a, b, xs, d.counter != nullptr, &sp, &slds, dot)) {
 #ifdef DRS_TIMELINE
       slds += 8192;
 #endif
@@ -1000,6 +1069,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
       return hipGetLastError();
     }
   }
+  if (dot) return hipErrorInvalidValue;   // only the stream kernel has the interaction (callers check stream_applicable)
   int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
   if (!chain_plan(a, b, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;
@@ -1031,7 +1101,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
-  return launch_chain2(a, nullptr, s, done, xsrc);
+  return launch_chain2(a, nullptr, s, done, xsrc, nullptr);
 }
 
 #ifdef DRS_TIMELINE

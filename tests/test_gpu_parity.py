@@ -191,10 +191,10 @@ def test_interact_dot_is_bitwise(op_engine, F, D, itself):
 
 # ------------------------------------------------------------------------------------
 # BASELINE.json sizes: device-filled tables, oracle on the same counter-based fill
-def _big_case(rows, D, T, L, bot, top, B, nb=2, seed=99):
+def _big_case(rows, D, T, L, bot, top, B, nb=2, seed=99, op="cat"):
     from deeprecsys_amd.data_generator.dlrm_data import generate_fast_input_data
     args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join([str(rows)] * T),
-                       arch_mlp_bot=bot, arch_mlp_top=top, arch_interaction_op="cat",
+                       arch_mlp_bot=bot, arch_mlp_top=top, arch_interaction_op=op,
                        num_indices_per_lookup=L, num_batches=nb, max_mini_batch_size=B,
                        mini_batch_size=B, numpy_rand_seed=seed, accel_table_init="device",
                        model_type="dlrm", accel_slots=3)
@@ -341,6 +341,7 @@ def test_coalesced_queries_equal_individual_queries(kind):
 # MLP launch structures: weight-tile stream kernel vs per-layer chain kernel vs one launch
 # per MLP, single stream vs pipelined gather/MLP streams -- every one the same k-ordered
 # fma chains, so the same bits
+@pytest.mark.parametrize("op", ["cat", "dot"])
 @pytest.mark.parametrize("D,T,bot,top", [
     (8, 3, "20-36-8", "100-200-1"),        # K tails (20, 36, 100), N not a multiple of 16, 2 passes (200)
     (64, 8, "128-64-64", "256-64-1"),      # BASELINE RMC1 widths
@@ -348,9 +349,9 @@ def test_coalesced_queries_equal_individual_queries(kind):
     (16, 2, "64-16", "300-4-1"),           # 3 passes, a 4-wide layer, fewer tiles than the prefetch ring
     (4, 1, "4-4", "4-1"),                  # smallest legal widths: 3 tiles in total
 ])
-def test_mlp_launch_structures_are_bit_identical(D, T, bot, top):
+def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
     rows, L, B = 5000, 3, 100
-    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, bot, top, B, nb=2, seed=7)
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, bot, top, B, nb=2, seed=7, op=op)
     net.create(lX[0], lS_l[0], lS_i[0], None)
     try:
         net.stage_batches(lX, lS_l, lS_i)
@@ -383,6 +384,12 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top):
         for name, got in results.items():
             assert np.array_equal(got, results["stream"]), name
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
+        # the interaction tensor the top MLP saw (cat layout / dot triangle), default structure
+        for k, v in dict(mlp_stream=1, mlp_fuse=1, shared_stream=2).items():
+            eng.set_option(k, v)
+        eng.forward(1, 37)
+        _, R_exp = om.forward(lX[1], lS_i[1], lS_l[1], bs=37, want_R=True, nthreads=0)
+        assert np.array_equal(eng.fetch_interaction(37), R_exp)
     finally:
         net.engine.close()
 
