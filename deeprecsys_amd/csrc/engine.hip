@@ -41,6 +41,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// pinned host block of a slot: [flag | err | pad | pad | outputs...]: outputs 16-B aligned
+constexpr int kOutOffset = 4;
+
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 struct Layer {
@@ -436,7 +439,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   if (prof && e->zero_copy) { done.ts = s.d_ts; done.ts_blocks = (uint32_t)s.ts_blocks; done.span_acc = s.d_span_acc; done.host_span = s.dm_span; }
   const Done* dp = e->zero_copy ? &done : nullptr;
   float* out = s.d_out;          // kernels store to the device buffer; see Done::host_out
-  done.dev_out = s.d_out; done.host_out = reinterpret_cast<float*>(s.dm_out + 2);
+  done.dev_out = s.d_out; done.host_out = reinterpret_cast<float*>(s.dm_out + kOutOffset);
   done.out_words = (uint32_t)(Mv * e->n_out);
   XSrc xs;
   memset(&xs, 0, sizeof xs);
@@ -482,7 +485,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     s.ev_pending = true;
   }
   if (!e->zero_copy) {
-    HIP_TRY(e, hipMemcpyAsync(s.h_out + 2, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
+    HIP_TRY(e, hipMemcpyAsync(s.h_out + kOutOffset, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
                               hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(e, hipMemcpyAsync(s.h_out + 1, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   }
@@ -546,7 +549,7 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
   }
   if (h_out && s.last_bs > 0) {
     // queries sit at 16-row aligned virtual offsets: pack them back to back
-    const float* src = reinterpret_cast<const float*>(s.h_out + 2);
+    const float* src = reinterpret_cast<const float*>(s.h_out + kOutOffset);
     size_t o = 0;
     for (int i = 0; i < s.last_n; ++i) {
       memcpy(h_out + o, src + (size_t)s.q_vstart[i] * e->n_out, sizeof(float) * (size_t)s.q_bs[i] * e->n_out);
@@ -706,7 +709,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipMalloc(&s.H, sizeof(float) * (size_t)e->max_rows * e->ldH));
     CREATE_TRY(hipMalloc(&s.Hb, sizeof(float) * (size_t)e->max_rows * e->ldH));
     CREATE_TRY(hipMalloc(&s.H2, sizeof(float) * (size_t)e->max_rows * (e->num_int + 4)));
-    const size_t out_words = 2 + (size_t)e->max_rows * n_out_cap;
+    const size_t out_words = kOutOffset + (size_t)e->max_rows * n_out_cap;
     CREATE_TRY(hipMalloc(&s.d_out, sizeof(float) * out_words));
     CREATE_TRY(hipMalloc(&s.d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&s.d_counter, sizeof(uint32_t)));
