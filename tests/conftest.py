@@ -31,3 +31,24 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def cpu_abi(monkeypatch):
+    """The C ABI of include/drs.h restated on the CPU oracle (oracle/drs_cpu_abi.cpp), bound in
+    place of libdrs_hip.so FOR THIS TEST ONLY: the host code above the ABI (ctypes binding,
+    model wrappers, engine request loop) runs unchanged, without a GPU.  Test infrastructure:
+    nothing in deeprecsys_amd/ can reach this library on its own."""
+    import ctypes
+    import subprocess
+    from deeprecsys_amd import _native
+    path = os.path.join(ROOT, "oracle", "_build", "libdrs_cpu.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(path)
+    for name, res, args in _native.SYMBOLS:
+        fn = getattr(L, name)          # AttributeError = the restatement misses an entry point
+        fn.restype = res
+        fn.argtypes = args
+    monkeypatch.setattr(_native, "_lib", L)
+    return L

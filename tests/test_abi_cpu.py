@@ -1,0 +1,163 @@
+"""CPU suite for everything ABOVE the C ABI: the ctypes binding, the model wrappers that
+mirror the reference's classes, and the accelerator engine's request loop -- driven through
+oracle/libdrs_cpu.so, the CPU restatement of include/drs.h (`cpu_abi` fixture, tests only).
+The HIP library itself is covered by tests/test_gpu_parity.py on the GPU box."""
+import queue
+import re
+
+import numpy as np
+import pytest
+
+from deeprecsys_amd import _native as N
+from tests import helpers as H
+
+
+def test_cpu_abi_restates_every_entry_point_of_the_header(cpu_abi):
+    import os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "drs.h")).read()
+    declared = set(re.findall(r"\b(drs_[a-z0-9_]+)\s*\(", hdr))
+    bound = {name for name, _, _ in N.SYMBOLS}
+    assert declared == bound, declared ^ bound          # the binding covers the whole header ...
+    for name in declared:
+        assert hasattr(cpu_abi, name), name              # ... and so does the CPU restatement
+    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 1
+
+
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_wrappers_through_the_abi_match_oracle_and_golden(cpu_abi, case):
+    """materialize -> create -> stage_batches -> run_staged / run / run_queues: every wrapper
+    call lands on the ABI with the right arrays in the right order (tables, bottom, top,
+    final; int64 ids; prefix slicing), so the outputs equal the oracle called directly."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    om = H.oracle_model(net)
+    ncf = args.model_type == "ncf"
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    try:
+        net.stage_batches(None if ncf else lX, lS_l, lS_i)
+        n = len(lS_l[0][0])
+        for bid in range(len(lS_l)):
+            for bs in sorted({n, 1, max(1, n // 2)}):
+                got = net.run_staged(bid, bs)
+                exp, R_exp = om.forward(None if ncf else lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True)
+                assert np.array_equal(got, exp), (case, bid, bs)
+                assert np.array_equal(net.engine.fetch_interaction(bs), R_exp)
+        assert H.close(net.run_staged(0, n), z["expected/prob_click"], rtol=H.RTOL_OUT)
+        # several queries in one call, results back to back
+        outs = net.run_staged_multi([0, len(lS_l) - 1, 0], [n, 1, max(1, n // 2)])
+        assert [o.shape[0] for o in outs] == [n, 1, max(1, n // 2)]
+        assert np.array_equal(outs[1], net.run_staged(len(lS_l) - 1, 1))
+        # the reference's stand-alone run(X, S_lengths, S_indices) signature: per-call host inputs
+        net.run(None if ncf else lX[0], lS_l[0], lS_i[0])
+        assert np.array_equal(net.fetch_output(), net.run_staged(0, n))
+    finally:
+        net.engine.close()
+
+
+def test_abi_status_codes_surface_as_DrsError(cpu_abi):
+    e = N.Engine(N.MODEL_DLRM, [50, 60], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
+                 max_batch=4, max_lookups=3, num_staged_batches=2, num_slots=2)
+    try:
+        rng = np.random.RandomState(0)
+        idx = [rng.randint(0, 50, 8).astype(np.int64), rng.randint(0, 60, 8).astype(np.int64)]
+        lens = [np.full(4, 2, np.int32), np.full(4, 2, np.int32)]
+        dense = rng.rand(4, 4).astype(np.float32)
+        with pytest.raises(N.DrsError) as ei:           # nothing staged yet
+            e.forward(0, 1)
+        assert ei.value.code == N.ERR_STATE
+        e.stage_batch(0, dense, idx, lens)
+        with pytest.raises(N.DrsError) as ei:           # tables / weights missing
+            e.forward(0, 1)
+        assert ei.value.code == N.ERR_STATE
+        bad = [idx[0].copy(), idx[1].copy()]
+        bad[1][3] = 60                                  # Caffe2 ENFORCE: index < rows
+        with pytest.raises(N.DrsError) as ei:
+            e.stage_batch(1, dense, bad, lens)
+        assert ei.value.code == N.ERR_INDEX_RANGE
+        with pytest.raises(N.DrsError) as ei:           # Caffe2 ENFORCE: sum(lengths) == len(indices)
+            e.stage_batch(1, dense, idx, [np.full(4, 2, np.int32), np.array([2, 2, 2, 1], np.int32)])
+        assert ei.value.code == N.ERR_LENGTHS_SUM
+        for t, r in enumerate((50, 60)):
+            e.set_table(t, rng.rand(r, 8).astype(np.float32))
+        e.set_fc(N.MLP_BOT, 0, rng.rand(8, 4).astype(np.float32), rng.rand(8).astype(np.float32))
+        e.set_fc(N.MLP_TOP, 0, rng.rand(4, 24).astype(np.float32), rng.rand(4).astype(np.float32))
+        e.set_fc(N.MLP_TOP, 1, rng.rand(1, 4).astype(np.float32), rng.rand(1).astype(np.float32))
+        with pytest.raises(N.DrsError) as ei:           # a layer of the wrong shape
+            e.set_fc(N.MLP_TOP, 1, rng.rand(2, 4).astype(np.float32), rng.rand(2).astype(np.float32))
+        assert ei.value.code == N.ERR_BAD_ARG
+        assert e.forward(0, 4).shape == (4, 1) and e.forward(0, 0).shape == (0, 1)
+        with pytest.raises(N.DrsError) as ei:           # more samples than the staged batch holds
+            e.forward(0, 5)
+        assert ei.value.code == N.ERR_BAD_ARG
+        with pytest.raises(N.DrsError):
+            e.forward_multi_async(0, [0] * 9, [1] * 9)  # DRS_MAX_COALESCE
+        assert e.gather_bytes(0, 4) == 4 * 2 * (2 * 8 * 4 + 2 * 4 + 4 + 8 * 4)
+    finally:
+        e.close()
+    with pytest.raises(N.DrsError) as ei:               # the reference's sys.exit shape checks
+        N.Engine(N.MODEL_DLRM, [50], 8, [4, 6], [16, 1], N.INTERACT_CAT, sigmoid_top=1, max_batch=4,
+                 max_lookups=3, num_staged_batches=1, num_slots=1)
+    assert ei.value.code == N.ERR_BAD_ARG
+
+
+def _engine_args(tmp_path, **kw):
+    from deeprecsys_amd.utils.utils import cli
+    a = cli(["--queue", "--model_accel", "--inference_engines", "0", "--num_batches", "4", "--nepochs", "1",
+             "--max_mini_batch_size", "16", "--arch_sparse_feature_size", "8", "--arch_embedding_size", "40-50-60",
+             "--arch_mlp_bot", "5-16-8", "--arch_mlp_top", "12-1", "--arch_interaction_op", "dot",
+             "--num_indices_per_lookup", "4", "--model_type", "dlrm", "--log_file", str(tmp_path / "o.log")])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_accel_engine_request_loop_in_process(cpu_abi, tmp_path):
+    """The accelerator engine's loop (ready token, coalescing of queued requests, several launch
+    sets in flight, responses in request order per set, None sentinel) against in-process queues,
+    with the real model wrappers on the CPU ABI; outputs sizes and response fields as the
+    reference's engine stamps them (accelInferenceEngine.py:46-83)."""
+    from deeprecsys_amd.accelInferenceEngine import accelInferenceEngine
+    from deeprecsys_amd.utils.packets import ServiceRequest
+    a = _engine_args(tmp_path, accel_slots=2, accel_coalesce=3)
+    req, resp, ready = queue.Queue(), queue.Queue(), queue.Queue()
+    sizes = [16, 1, 7, 3, 16, 2, 9, 5, 11, 4]
+    for i, bs in enumerate(sizes):
+        req.put(ServiceRequest(batch_id=i % a.num_batches, epoch=0, arrival_time=float(i), batch_size=bs,
+                               sub_id=0, total_sub_batches=1, exp_packet=False))
+    req.put(None)
+    accelInferenceEngine(a, req, 0, resp, ready)
+    assert ready.get_nowait() is True
+    got = []
+    while True:
+        r = resp.get_nowait()
+        if r is None:
+            break
+        got.append(r)
+    assert resp.empty()
+    assert sorted((r.batch_id, r.batch_size, r.arrival_time) for r in got) == \
+        sorted((i % a.num_batches, bs, float(i)) for i, bs in enumerate(sizes))
+    assert all(r.out_batch_size == r.batch_size and r.consumer_id == 0 and r.model_id == 0 for r in got)
+    assert all(r.queue_start_time <= r.inference_end_time for r in got)
+
+
+def test_accel_engine_serves_a_mixed_model_stream_in_process(cpu_abi, tmp_path):
+    from deeprecsys_amd.accelInferenceEngine import accelInferenceEngine
+    from deeprecsys_amd.utils.packets import ServiceRequest
+    from tests.test_harness import _write_mix_configs
+    a = _engine_args(tmp_path, accel_slots=2, accel_coalesce=4, mix_config_files=_write_mix_configs(tmp_path))
+    req, resp, ready = queue.Queue(), queue.Queue(), queue.Queue()
+    plan = [(0, 5), (1, 3), (1, 16), (0, 1), (0, 8), (1, 2), (0, 16), (1, 7)]
+    for i, (mid, bs) in enumerate(plan):
+        req.put(ServiceRequest(batch_id=i % a.num_batches, epoch=0, arrival_time=float(i), batch_size=bs,
+                               sub_id=0, total_sub_batches=1, exp_packet=False, model_id=mid))
+    req.put(None)
+    accelInferenceEngine(a, req, 0, resp, ready)
+    got = []
+    while True:
+        r = resp.get_nowait()
+        if r is None:
+            break
+        got.append(r)
+    assert sorted((r.model_id, r.batch_size) for r in got) == sorted(plan)
+    assert all(r.out_batch_size == r.batch_size for r in got)
