@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--timed_only", action="store_true",
+                    help="warm-up + timed region only: skip the cross-check / single-query / host-input "
+                         "legs and the CPU baseline (profiling runs: every gather launch rocprofv3 sees "
+                         "is then an 8-query launch of the benchmark itself)")
     ap.add_argument("--sweep", action="store_true", help="also A/B the gather variants (stderr)")
     ap.add_argument("--set", action="append", default=[], help="engine option key=value")
     return ap.parse_args()
@@ -219,20 +223,23 @@ def main():
     sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
     gbytes = eng.gather_bytes(0, bs) * co          # algorithmic bytes of one gather launch
 
-    # cross-check leg (not part of `value`): HIP events recorded around the gather launch on the
-    # stream it is launched on; they bracket several us of packet processing as well
-    eng.reset_kernel_time()
-    eng.set_profiling(2)
-    run_queries(eng, min(opt.steps, 1000), bs, nb, slots, coalesce=co)
-    eng.set_profiling(0)
-    ev_ms, ev_n = eng.kernel_time(N.KERNEL_SLS)
-    mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
-    # reference point: the same gather serving ONE query per launch, nothing else in flight
-    eng.reset_kernel_time()
-    eng.set_profiling(1)
-    run_queries(eng, 300, bs, nb, 1, coalesce=1)
-    eng.set_profiling(0)
-    one_ms, one_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
+    extra = not opt.timed_only
+    ev_ms = ev_n = mlp_ms = mlp_n = one_ms = one_n = 0
+    if extra:
+        # cross-check leg (not part of `value`): HIP events recorded around the gather launch on the
+        # stream it is launched on; they bracket several us of packet processing as well
+        eng.reset_kernel_time()
+        eng.set_profiling(2)
+        run_queries(eng, min(opt.steps, 1000), bs, nb, slots, coalesce=co)
+        eng.set_profiling(0)
+        ev_ms, ev_n = eng.kernel_time(N.KERNEL_SLS)
+        mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
+        # reference point: the same gather serving ONE query per launch, nothing else in flight
+        eng.reset_kernel_time()
+        eng.set_profiling(1)
+        run_queries(eng, 300, bs, nb, 1, coalesce=1)
+        eng.set_profiling(0)
+        one_ms, one_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
     # PCIe-inclusive leg (never `value`): the same queries handed over as HOST arrays per call --
     # int64 ids / int32 lengths / fp32 dense, the reference's run_queues signature -- through
     # drs_forward_inputs_async with `slots` calls in flight
@@ -255,9 +262,11 @@ def main():
             if busy[s_]:
                 eng.wait(s_, bs)
         return time.perf_counter() - t0
-    host_leg(100)
-    host_n = 1000
-    host_el = host_leg(host_n)
+    host_n, host_el = 0, 1.0
+    if extra:
+        host_leg(100)
+        host_n = 1000
+        host_el = host_leg(host_n)
 
     from deeprecsys_amd import stats
     hist = stats.latency_histogram(lat)
@@ -322,12 +331,13 @@ def main():
                              "bytes": gbytes // co, "avg_launch_us": round(one_ms / one_n * 1e3, 3),
                              "frac": round(gbytes / co / (one_ms / one_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
         }
-        out["host_inputs_leg"] = {
-            "value": round(host_n / host_el, 1), "unit": "queries/s", "queries": host_n,
-            "what": "PCIe-inclusive: per-call host arrays (%d KB/query) converted into pinned memory and "
-                    "read in place by the kernels, one query per launch set, %d calls in flight"
-                    % ((bs * (len(lS_i[0]) * L * 8 + len(lS_i[0]) * 4 + lX[0].shape[1] * 4)) // 1024, slots)}
-        if not opt.no_cpu_baseline and world == 1:
+        if extra:
+          out["host_inputs_leg"] = {
+              "value": round(host_n / host_el, 1), "unit": "queries/s", "queries": host_n,
+              "what": "PCIe-inclusive: per-call host arrays (%d KB/query) converted into pinned memory and "
+                      "read in place by the kernels, one query per launch set, %d calls in flight"
+                      % ((bs * (len(lS_i[0]) * L * 8 + len(lS_i[0]) * 4 + lX[0].shape[1] * 4)) // 1024, slots)}
+        if not opt.no_cpu_baseline and not opt.timed_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt, net, data, opt.cpu_seconds)
         print(json.dumps(out), flush=True)
 
