@@ -32,7 +32,7 @@ def main():
         eng.set_option(k, int(v))
     nb, B, slots = opt.num_batches, opt.batch, opt.slots
     rng = np.random.RandomState(1)
-    sizes = sorted({B, 1, 2, 17, 64, 65, 165 if B >= 165 else B // 2, B - 1})
+    sizes = sorted(s for s in {B, 1, 2, 17, 64, 65, 165, B // 2, B - 1} if 1 <= s <= B)
     # ground truth: each (batch, size) alone, single stream, nothing else in flight
     eng.set_option("shared_stream", 1)
     truth = {(b, s): eng.forward(b, s).copy() for b in range(nb) for s in sizes}
