@@ -440,3 +440,18 @@ def test_rmc3_baseline_size_counting_property():
         assert ei.value.code == N.ERR_INDEX_RANGE
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------------------------
+# race hunt: random launch sets on random slots, pipelined streams, every result bit-identical
+# to the same query served alone on an idle engine (tools/stress.py)
+@pytest.mark.parametrize("extra", [[], ["--workload", "rmc1_dot"], ["--workload", "ncf", "--batch", "64"],
+                                   ["--set", "shared_stream=0"]])
+def test_pipelined_engine_race_hunt(extra):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "--seconds", "3"] + extra,
+                       capture_output=True, text=True, timeout=200, cwd=root)
+    assert r.returncode == 0 and "stress OK" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
