@@ -134,7 +134,7 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
-  int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (2+: no gain measured)
+  int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used
   int zero_copy_inputs = 1;         // drs_forward_inputs: kernels read the inputs in place from pinned host memory
   int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
@@ -750,6 +750,19 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     }
   }
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream_g, hipStreamNonBlocking));
+  {
+    // Which side bounds a launch set?  FLOP of the MLPs per byte the gather moves, per sample.
+    // Gather-bound models (RM1: 2 FLOP/B, RM2: 0.6) keep ONE MLP stream: more only takes CUs
+    // from the gather that sets the pace.  MLP-bound models (RM3: 230, W&D: 440, NCF: 145) let
+    // the MLP launches of consecutive sets overlap on one stream per slot: their kernels are
+    // latency-bound and half of them cover only 128 CUs (measured: W&D 57 k -> 68 k q/s, RM3
+    // 39 k -> 50 k, NCF 128 k -> 200 k; RM1 122 k -> 100 k, hence the rule).
+    double flop = 0;
+    for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
+      for (size_t i = 0; i + 1 < mm->ln.size(); ++i) flop += 2.0 * mm->ln[i] * (mm->ln[i + 1] > 0 ? mm->ln[i + 1] : 64);
+    const double bytes = (double)T * e->max_lookups * D * 4.0;
+    e->mlp_streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
+  }
   apply_stream_mode(e);
 #undef CREATE_TRY
   *out = e;

@@ -231,8 +231,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                  each set (MLPs, interaction, completion) behind an event on a second
  *                  stream, so the HBM-bound gather of set i+1 runs beside the latency-bound
  *                  MLP of set i and gathers never overlap each other
- *                  ("mlp_streams" n: alternate the MLP side over n streams; default 1, more
- *                  measured no gain)
+ *                  ("mlp_streams" n: alternate the MLP side over n streams; default 1 for
+ *                  gather-bound models, one per slot (up to 4) for MLP-bound ones, decided in
+ *                  drs_create from MLP FLOP per gathered byte)
  *                1 one stream: sets strictly back to back, each kernel has the chip to itself
  *                0 one stream per slot: whole sets overlap freely
  *   "zero_copy_inputs" 1 (default) drs_forward_inputs converts the caller's arrays into the
