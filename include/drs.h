@@ -200,7 +200,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_exact"  0 (default) wave-split gather: a wave per bag, rows spread over its lane
  *                groups, wave-wide butterfly at the end (fp32 sum order differs from the
  *                reference: compare with a tolerance) | 1 sequential-order gather,
- *                bit-identical to the Caffe2 CPU SparseLengthsSum (about 15% slower)
+ *                bit-identical to the Caffe2 CPU SparseLengthsSum (same speed alone, 4-8% slower
+ *                beside an MLP launch)
  *   "sls_short_bag" fixed-length batches with at most this many lookups per bag (default 8;
  *                W&D and NCF have 1) always take the sequential-order variant: a lane group
  *                per bag instead of a mostly idle wave per bag | -1 never
