@@ -50,7 +50,11 @@ def _build_hip_model(args, engine_id):
     from . import dlrm_s_hip as M
     from .data_generator.dlrm_data import DLRMDataGenerator
     first = getattr(args, "accel_first_engine_id", engine_id if engine_id is not None else 0)
-    args._drs_device = int(getattr(args, "accel_device_offset", 0)) + int((engine_id or 0) - first)
+    # engine k of this run -> GPU offset + k, wrapping when there are more engines than GPUs
+    # (several engine processes then share a device, e.g. two engines on a one-GPU box)
+    from . import _native
+    ndev = max(_native.device_count(), 1)
+    args._drs_device = (int(getattr(args, "accel_device_offset", 0)) + int((engine_id or 0) - first)) % ndev
     if args.model_type not in M.WRAPPERS:
         raise SystemExit("Model type %r has no accelerator path (dlrm | wnd | ncf)" % args.model_type)
     datagen = DLRMDataGenerator(args)

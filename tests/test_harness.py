@@ -187,3 +187,20 @@ def test_scheduler_in_the_loop_with_measured_latencies(tmp_path, capfd):
     assert "Optimal batch_size configuration" in out and "Optimal accel configuration" in out
     assert s["responses"] > 0 and s["qps"] > 0
     assert s["accel_requests"] > 0 and s["cpu_requests"] > 0      # both kinds of engine served queries
+
+
+@pytest.mark.gpu
+def test_two_real_accel_engines_share_the_queue(tmp_path):
+    """k accelerator engine processes pull from the single accelRequestQueue
+    (work stealing); on a one-GPU box both engines land on GPU 0.  Every query is answered
+    exactly once and both engines serve some."""
+    a = _args(tmp_path, accel_backend="hip", num_accels=2, arch_sparse_feature_size=16,
+              arch_embedding_size="2000-3000-1000", arch_mlp_bot="13-32-16", arch_mlp_top="32-1",
+              arch_interaction_op="dot", num_indices_per_lookup=10, model_type="dlrm", nepochs=16,
+              avg_arrival_rate=0.2)
+    s = DeepRecSys(a, quiet=True)
+    n = a.nepochs * a.num_batches
+    assert s["accel_requests"] == n and s["responses"] == n
+    lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
+    assert sorted((l["epoch"], l["batch_id"]) for l in lines) == sorted((e, b) for e in range(a.nepochs) for b in range(a.num_batches))
+    assert {l["consumer_id"] for l in lines} <= {0, 1}
