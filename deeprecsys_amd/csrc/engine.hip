@@ -13,6 +13,7 @@
 //            memory, and a host-mapped pinned input block for per-call inputs
 // Streams: every gather on stream_g, the rest of each launch set on a second stream behind
 // an event; completion is a flag in pinned memory, not a stream sync.
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -502,7 +503,9 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
     uint64_t spins = 0;
     while (*flag != s.seq) {
       __builtin_ia32_pause();
-      if ((++spins & 0xfffff) == 0 &&
+      // 8 ranks on a node share its cores with each other's runtime threads: do not starve them
+      if ((++spins & 0xfff) == 0) sched_yield();
+      if ((spins & 0xfffff) == 0 &&
           std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
         HIP_TRY(e, hipStreamSynchronize(s.stream));
         if (*flag != s.seq) {
