@@ -161,3 +161,26 @@ def test_accel_engine_serves_a_mixed_model_stream_in_process(cpu_abi, tmp_path):
         got.append(r)
     assert sorted((r.model_id, r.batch_size) for r in got) == sorted(plan)
     assert all(r.out_batch_size == r.batch_size for r in got)
+
+
+def test_hip_library_loads_and_exports_every_symbol_of_the_header():
+    """libdrs_hip.so itself (the product): loads without a GPU, exports exactly what
+    include/drs.h declares, and -- with no device visible -- refuses to create an engine
+    instead of falling back to anything."""
+    import ctypes
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(N.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(root, "deeprecsys_amd", "csrc")], stdout=subprocess.DEVNULL)
+    L = ctypes.CDLL(N.LIB_PATH)
+    declared = set(re.findall(r"\b(drs_[a-z0-9_]+)\s*\(", open(os.path.join(root, "include", "drs.h")).read()))
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(L, name), "libdrs_hip.so does not export %s" % name
+    assert N.lib().drs_abi_version() == 1
+    if N.device_count() == 0:
+        with pytest.raises(N.DrsError) as ei:
+            N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
+                     max_batch=4, max_lookups=2, num_staged_batches=1, num_slots=1)
+        assert ei.value.code == N.ERR_HIP and "no CPU fallback" in str(ei.value)
