@@ -45,7 +45,8 @@ struct SlsArgs {
 };
 
 // launch on `stream`; exact != 0 selects the sequential-order variant.
-hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t stream);
+// stop_event (optional): recorded by the gather dispatch itself when it completes
+hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t stream, hipEvent_t stop_event = nullptr);
 int64_t sls_grid_blocks(int D, int64_t n_bags, int exact);
 
 // Completion hand-off to the host without a copy or a stream sync: the LAST kernel of a

@@ -419,9 +419,11 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   for (int i = 0; i < q.n_q; ++i) short_bags = short_bags && qb[i]->uniform_len >= 0 && qb[i]->uniform_len <= e->sls_short_bag;
   const int exact_now = e->sls_exact || short_bags;
   s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, exact_now) : 0;
-  HIP_TRY(e, launch_sls(a, exact_now, s.gather_stream));
+  // pipelined mode: the event the MLP stream waits for is recorded by the gather dispatch itself
+  // (hipExtLaunchKernel's stop event = the packet's completion signal): no marker packet sits
+  // between consecutive gathers (a hipEventRecord there costs ~2 us per set)
+  HIP_TRY(e, launch_sls(a, exact_now, s.gather_stream, piped ? s.ev_sls : nullptr));
   if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.gather_stream));
-  if (piped) HIP_TRY(e, hipEventRecord(s.ev_sls, s.gather_stream));
   bool joined = !piped;   // has s.stream been made to wait for the gather yet?
   auto join = [&]() -> hipError_t {
     if (joined) return hipSuccess;

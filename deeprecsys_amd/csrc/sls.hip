@@ -27,6 +27,8 @@
 //     all 256 CUs; workgroups never cooperate.
 //   - index range is checked per row (Caffe2 ENFORCEs it): an out-of-range index
 //     raises bit 0 of *err and contributes zero instead of faulting.
+#include <hip/hip_ext.h>
+
 #include "drs_internal.h"
 
 namespace drs {
@@ -237,27 +239,35 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   }
 }
 
+// stop: optional event recorded BY the kernel dispatch itself (its completion signal) -- no
+// separate marker packet between this launch and the next one on the stream
+template <typename K>
+void launch_k(K kernel, unsigned grid, hipStream_t s, hipEvent_t stop, const SlsArgs& a) {
+  if (stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, nullptr, stop, 0, a);
+  else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, a);
+}
+
 template <int G, int V, int U>
-hipError_t launch_variant(const SlsArgs& a, int exact, hipStream_t s) {
+hipError_t launch_variant(const SlsArgs& a, int exact, hipStream_t s, hipEvent_t stop) {
   const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
   if (n_bags == 0) return hipSuccess;
   if (exact) {
     constexpr int BAGS = 64 / G;
     const unsigned grid = (unsigned)((n_bags + BAGS - 1) / BAGS);
-    hipLaunchKernelGGL((sls_kernel<G, V, U, true>), dim3(grid), dim3(64), 0, s, a);
+    launch_k(sls_kernel<G, V, U, true>, grid, s, stop, a);
   } else {
-    hipLaunchKernelGGL((sls_kernel<G, V, U, false>), dim3((unsigned)n_bags), dim3(64), 0, s, a);
+    launch_k(sls_kernel<G, V, U, false>, (unsigned)n_bags, s, stop, a);
   }
   return hipGetLastError();
 }
 
 template <int G, int V>
-hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s) {
+hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s, hipEvent_t stop) {
   switch (u) {
-    case 4: return launch_variant<G, V, 4>(a, exact, s);
-    case 8: return launch_variant<G, V, 8>(a, exact, s);
-    case 20: return launch_variant<G, V, 20>(a, exact, s);
-    default: return launch_variant<G, V, 16>(a, exact, s);
+    case 4: return launch_variant<G, V, 4>(a, exact, s, stop);
+    case 8: return launch_variant<G, V, 8>(a, exact, s, stop);
+    case 20: return launch_variant<G, V, 20>(a, exact, s, stop);
+    default: return launch_variant<G, V, 16>(a, exact, s, stop);
   }
 }
 
@@ -278,17 +288,17 @@ int64_t sls_grid_blocks(int D, int64_t n_bags, int exact) {
   return (n_bags + bags - 1) / bags;
 }
 
-hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s) {
+hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s, hipEvent_t stop) {
   const int D = a.D;
   if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
   const int u = g_sls_u ? g_sls_u : (exact ? 16 : 4);
-  if (D == 32 && g_sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s);
-  if (D <= 8) return launch_u<2, 4>(a, exact, u, s);
-  if (D <= 16) return launch_u<4, 4>(a, exact, u, s);
-  if (D <= 32) return launch_u<8, 4>(a, exact, u, s);
-  if (D <= 64) return launch_u<16, 4>(a, exact, u, s);
-  if (D <= 128) return launch_u<32, 4>(a, exact, u, s);
-  return launch_u<64, 4>(a, exact, u, s);
+  if (D == 32 && g_sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s, stop);
+  if (D <= 8) return launch_u<2, 4>(a, exact, u, s, stop);
+  if (D <= 16) return launch_u<4, 4>(a, exact, u, s, stop);
+  if (D <= 32) return launch_u<8, 4>(a, exact, u, s, stop);
+  if (D <= 64) return launch_u<16, 4>(a, exact, u, s, stop);
+  if (D <= 128) return launch_u<32, 4>(a, exact, u, s, stop);
+  return launch_u<64, 4>(a, exact, u, s, stop);
 }
 
 // ---------------------------------------------------------------------------
