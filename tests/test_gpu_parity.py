@@ -175,6 +175,36 @@ def test_fc_matches_oracle_chain(op_engine, M, K, N_, act):
         assert np.array_equal(got, exp)   # MFMA == k-ordered fmaf chain, bit for bit
 
 
+@pytest.mark.parametrize("tile", [22, 12, 21, 11, 0])
+@pytest.mark.parametrize("M,K,N_", [(300, 896, 1024), (65, 68, 130), (2048, 1024, 512), (31, 132, 64), (129, 64, 200)])
+def test_gemm_kernel_every_tile_shape_is_bitwise(op_engine, tile, M, K, N_):
+    """gemm.hip: each per-wave tile shape (2x2, 1x2, 2x1, 1x1 MFMA tiles; 0 = chosen by block
+    count) on shapes with row, column and K tails -- one k-ordered chain per output, bit for bit
+    the oracle's."""
+    torch = torch_cuda()
+    rng = np.random.RandomState(M * 7 + K + N_)
+    x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = rng.normal(0, 0.1, (N_, K)).astype(np.float32)
+    b = rng.normal(0, 0.1, N_).astype(np.float32)
+    exp = orc.fc(x, W, b, N.ACT_RELU)
+    dx, dW, db = (torch.from_numpy(a).cuda() for a in (x, W, b))
+    y = torch.full((M, N_), float("nan"), device="cuda")
+    op_engine.set_option("mlp_gemm_tile", tile)
+    try:
+        op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, N.ACT_RELU, y.data_ptr())
+    finally:
+        op_engine.set_option("mlp_gemm_tile", 0)
+    assert np.array_equal(y.cpu().numpy(), exp)
+    # and the kernel it replaces agrees
+    op_engine.set_option("mlp_gemm", 0)
+    try:
+        y2 = torch.full((M, N_), float("nan"), device="cuda")
+        op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, N.ACT_RELU, y2.data_ptr())
+    finally:
+        op_engine.set_option("mlp_gemm", 1)
+    assert np.array_equal(y2.cpu().numpy(), exp)
+
+
 @pytest.mark.parametrize("F,D,itself", [(4, 8, False), (4, 8, True), (9, 32, False), (9, 64, True),
                                         (33, 64, False), (11, 32, False), (17, 16, False)])
 def test_interact_dot_is_bitwise(op_engine, F, D, itself):
