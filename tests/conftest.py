@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:
+    # torch bundles its own HIP runtime: it has to be loaded BEFORE libdrs_hip.so brings in the
+    # system one, or torch.cuda sees no device in the operator-level GPU tests
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
