@@ -44,6 +44,8 @@ WORKLOADS = {
     "rmc1_ref": dict(rows=4_000_000, T=8, D=32, L=80, bot="128-64-32", top="256-64-1", op="cat"),
     "rmc2_ref": dict(rows=500_000, T=32, D=64, L=120, bot="256-128-64", top="128-64-1", op="cat"),
     "rmc3_ref": dict(rows=2_000_000, T=10, D=32, L=20, bot="2560-1024-256-32", top="512-256-1", op="cat"),
+    # BASELINE.json config 3 as written: 12 tables x 10M rows x 32 (15.4 GB), run with --batch 512
+    "rmc3": dict(rows=10_000_000, T=12, D=32, L=20, bot="2560-1024-256-32", top="512-256-1", op="cat"),
     "rmc1_dot": dict(rows=1_000_000, T=8, D=64, L=80, bot="128-64-64", top="256-64-1", op="dot"),
     # BASELINE config 4's models, the reference's models/configs/{wide_and_deep,ncf}.json
     "wnd": dict(kind="wnd", rows=1_000_000, T=27, D=32, L=1, bot="512", top="1024-512-256-1", op="cat"),

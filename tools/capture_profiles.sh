@@ -41,6 +41,7 @@ run 300 python bench.py --no_cpu_baseline --steps 4000 --warmup 400 --coalesce 1
 for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf; do
   run 300 python bench.py --workload $w --no_cpu_baseline --steps 4000 --warmup 400 > "$OUT/bench_$w.json" 2>/dev/null
 done
+run 400 python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --steps 2000 --warmup 200 > "$OUT/bench_rmc3.json" 2>/dev/null
 # 4b. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
 for m in rm1 rm2 rm3; do
   run 300 python tools/characterize.py --model $m --out "$OUT/accelerator_mi355x/" > "$OUT/characterize_$m.txt" 2>&1

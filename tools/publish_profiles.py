@@ -22,7 +22,7 @@ def main(tag, prefix):
              "kernel_trace_by_grid.txt": "kernel_trace_by_grid.txt", "pmc_summary.txt": "pmc_summary.txt",
              "bench_single_stream.json": "bench_single_stream.json", "bench_coalesce1.json": "bench_coalesce1.json",
              "bench_torchrun_n1.json": "bench_torchrun_n1.json"}
-    for w in ("rmc1_ref", "rmc2_ref", "rmc3_ref", "rmc1_dot", "wnd", "ncf"):
+    for w in ("rmc1_ref", "rmc2_ref", "rmc3_ref", "rmc3", "rmc1_dot", "wnd", "ncf"):
         names["bench_%s.json" % w] = "bench_%s.json" % w
     for f in ("serve_rmc1.json", "serve_mix_wnd_ncf.json"):
         names[f] = f
