@@ -273,10 +273,10 @@ hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s, hipEvent_
 
 }  // namespace
 
-// Tunables (set through drs_set_option): rows in flight per lane (0 = measured best:
-// 16 for the sequential variant, 4 for the wave-split one, whose 8 waves per CU already
-// provide the memory-level parallelism) and the lane width used for D == 32
-// (8 lanes x 16 B or 16 lanes x 8 B).
+// Tunables (set through drs_set_option): row loads per register ring and lane (0 = measured
+// best for 8-query launches: 4 for both variants -- two rings, so 4..8 in flight per lane; the
+// waves per CU provide the rest of the memory-level parallelism) and the lane width used for
+// D == 32 (8 lanes x 16 B or 16 lanes x 8 B).
 int g_sls_u = 0;
 int g_sls_v_d32 = 4;
 
@@ -291,7 +291,7 @@ int64_t sls_grid_blocks(int D, int64_t n_bags, int exact) {
 hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s, hipEvent_t stop) {
   const int D = a.D;
   if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
-  const int u = g_sls_u ? g_sls_u : (exact ? 16 : 4);
+  const int u = g_sls_u ? g_sls_u : 4;
   if (D == 32 && g_sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s, stop);
   if (D <= 8) return launch_u<2, 4>(a, exact, u, s, stop);
   if (D <= 16) return launch_u<4, 4>(a, exact, u, s, stop);

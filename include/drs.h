@@ -205,8 +205,7 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_short_bag" fixed-length batches with at most this many lookups per bag (default 8;
  *                W&D and NCF have 1) always take the sequential-order variant: a lane group
  *                per bag instead of a mostly idle wave per bag | -1 never
- *   "sls_u"      row loads kept in flight per lane: 0 (default: 16 sequential / 4 split)
- *                | 4 | 8 | 16 | 20
+ *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums
