@@ -202,9 +202,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                reference: compare with a tolerance) | 1 sequential-order gather,
  *                bit-identical to the Caffe2 CPU SparseLengthsSum (same speed alone, 4-8% slower
  *                beside an MLP launch)
- *   "sls_short_bag" fixed-length batches with at most this many lookups per bag (default 8;
- *                W&D and NCF have 1) always take the sequential-order variant: a lane group
- *                per bag instead of a mostly idle wave per bag | -1 never
+ *   "sls_short_bag" fixed-length batches with at most this many lookups per bag (default
+ *                2048 / D: RM3's 20 and W&D's / NCF's 1 qualify, RM1's 80 does not) always take
+ *                the sequential-order variant: a lane group per bag instead of a mostly idle
+ *                wave per bag | -1 never
  *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
