@@ -19,7 +19,7 @@
 //   6 float4 per thread each, inline asm + explicit vmcnt so the ring is never drained);
 //   64 MFMAs on chunk c from LDS buffer c&1, operands read one 4-step group ahead;
 //   the 12 ds_write_b64 that stash chunk c+1 into buffer (c+1)&1 ride in the MFMA shadow;
-//   one barrier.
+//   one barrier, placed three quarters into the chunk (see DRS_GROUND).
 #include <string.h>
 
 #include "drs_internal.h"
@@ -145,27 +145,35 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
   const float* const pa0 = sA + (16 * TM * wm + r) * GLD + gs;
   const float* const pb0 = sB + (16 * TN * wn + r) * GLD + gs;
 
+  // operand registers: [ping/pong][tile][k-step of a 4-step group]; set 0 always enters a round
+  // holding group 0 of the round's chunk (loaded right after the previous round's barrier)
+  float av[2][TM][4], bv[2][TN][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i][s] = pa0[16 * i * GLD + 4 * s];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j][s] = pb0[16 * j * GLD + 4 * s];
+  }
+
   // One K chunk: MFMAs on buffer BUF, stash of the NEXT chunk (sets RAS/RBS) into BUF^1,
-  // request of chunk +4 into the sets this chunk came from (RAF/RBF).
+  // request of chunk +4 into the sets this chunk came from (RAF/RBF).  The barrier sits after
+  // the THIRD of the four operand groups: by then every stash write of the next chunk has been
+  // issued and every operand of this chunk has been read, so the last 16 (TM x TN x 4) MFMAs
+  // run behind the barrier together with the first operand reads of the next chunk -- the MFMA
+  // pipe does not drain while the workgroup synchronises and LDS answers.
 #define DRS_GROUND(BUF, RAF, RBF, RAS, RBS)                                                       \
   {                                                                                               \
     fetch(RAF, RBF);                                                                              \
     const float* pa = pa0 + (BUF) * GBM * GLD;                                                    \
     const float* pb = pb0 + (BUF) * GBN * GLD;                                                    \
-    float av[2][TM][4], bv[2][TN][4];   /* [ping/pong][tile][step of the group] */                \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i][s] = pa[16 * i * GLD + 4 * s];      \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j][s] = pb[16 * j * GLD + 4 * s];      \
-    }                                                                                             \
     DRS_GWAIT(RAS, RBS, 18);                                                                      \
     int wq = 0;   /* stash writes issued so far (compile-time after unrolling) */                  \
-    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                            \
+    _Pragma("unroll") for (int gq = 0; gq < 3; ++gq) {                                            \
       const int cur = gq & 1, nxt = cur ^ 1;                                                      \
-      if (gq < 3) {                                                                               \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                           \
-          _Pragma("unroll") for (int i = 0; i < TM; ++i) av[nxt][i][s] = pa[16 * i * GLD + 16 * (gq + 1) + 4 * s]; \
-          _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[nxt][j][s] = pb[16 * j * GLD + 16 * (gq + 1) + 4 * s]; \
-        }                                                                                         \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[nxt][i][s] = pa[16 * i * GLD + 16 * (gq + 1) + 4 * s]; \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[nxt][j][s] = pb[16 * j * GLD + 16 * (gq + 1) + 4 * s]; \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
@@ -176,7 +184,22 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
         __builtin_amdgcn_sched_barrier(0);                                                        \
       }                                                                                           \
     }                                                                                             \
+    static_assert(NQ <= 12, "all stash writes must precede the barrier");                         \
     __syncthreads();                                                                              \
+    {                                                                                             \
+      const float* pan = pa0 + ((BUF) ^ 1) * GBM * GLD;                                           \
+      const float* pbn = pb0 + ((BUF) ^ 1) * GBN * GLD;                                           \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i][s] = pan[16 * i * GLD + 4 * s];   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j][s] = pbn[16 * j * GLD + 4 * s];   \
+      }                                                                                           \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i][s], bv[1][j][s], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
   }
 
   for (int c = 0; c < nch; c += 4) {
