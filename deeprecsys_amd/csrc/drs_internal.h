@@ -123,12 +123,24 @@ struct DotArgs {
   float* R;         // == b->x: interaction output, ld = ldr (also kept for drs_fetch_interaction)
   int64_t ldr;
 };
+// Optional NCF-style join (models/ncf.py:301-305,317-346): the second chain's input buffer is
+// [ src[:, col_a:col_a+cols] + src[:, col_b:col_b+cols] | output of the first chain ], i.e.
+// Sum of two pooled embeddings in front of the MLP branch.  dst (== b->x) receives the summed
+// block as well (the first chain stores its output right behind it, a.y == dst + cols).
+struct SumArgs {
+  const float* src;
+  int64_t ld;
+  int32_t col_a, col_b, cols;
+  float* dst;
+  int64_t ldd;
+};
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t stream,
                          const Done* done = nullptr, const XSrc* xs = nullptr,
-                         const DotArgs* dot = nullptr);
+                         const DotArgs* dot = nullptr, const SumArgs* sum = nullptr);
 // would launch_chain2(a, &b, ..., dot) run as the stream kernel?  (With a dot interaction in
 // between it is the only kernel that can.)
-bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xs, const DotArgs* dot);
+bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xs, const DotArgs* dot,
+                       const SumArgs* sum = nullptr);
 size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot

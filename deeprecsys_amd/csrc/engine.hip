@@ -454,9 +454,26 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     const int wl = e->top.ln.back();
     const int64_t ldc = D + wl;
     HIP_TRY(e, join());
-    HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, Mv, D, s.stream));
-    if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
-    if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
+    // one launch when it fits: Sum, MLP branch and predictor of a 16-row slab in the stream kernel
+    bool fused = false;
+    const int nt = (int)e->top.layers.size();
+    if (e->mlp_fuse && nt >= 1 && nt <= DRS_MAX_CHAIN && e->fin.layers.size() == 1) {
+      ChainArgs ca, cb;
+      fill_chain(ca, e->top, 0, nt, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc);
+      fill_chain(cb, e->fin, 0, 1, s.H2, ldc, Mv, out, e->n_out);
+      SumArgs sum = {s.T, e->ldT, 0, D, D, s.H2, ldc};
+      bool wide = false;
+      for (int l = 0; l < nt; ++l) wide = wide || is_wide(e, e->top, l);
+      if (!wide && !is_wide(e, e->fin, 0) && stream_applicable(ca, cb, nullptr, nullptr, &sum)) {
+        HIP_TRY(e, launch_chain2(ca, &cb, s.stream, dp, nullptr, nullptr, &sum));
+        fused = true;
+      }
+    }
+    if (!fused) {
+      HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, Mv, D, s.stream));
+      if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
+      if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
+    }
   } else {
     bool fused = false;
     if (!e->bot.layers.empty()) {

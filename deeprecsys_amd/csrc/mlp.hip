@@ -418,6 +418,7 @@ struct SLayer {
   int32_t in_off, in_ld;   // input slab: float offset in LDS, leading dimension
   int32_t out_off, out_ld; // output slab (out_off < 0: none)
   int32_t out_pad;         // columns [N, out_pad) of the output slab are zero filled
+  int32_t out_col0;        // first column of this layer's outputs inside the output slab
   int32_t b_off;           // LDS copy of the bias (zeros when b == nullptr), N floats
   float* g_out;            // global output or nullptr
   int64_t g_ld;
@@ -428,7 +429,10 @@ struct SInput {            // 16 x cols block of a global matrix -> LDS slab, ze
   int64_t ld;
   int32_t col0, cols, cols_pad;
   int32_t lds_off, lds_ld, lds_col0;
-  int32_t use_xs, pad_;
+  int32_t use_xs;
+  int32_t col2;            // >= 0: the block is src[:, col0..] + src[:, col2..] (NCF's Sum)
+  float* g_dst;            // also store the block to global (row-major, ld g_ldd) or nullptr
+  int64_t g_ldd;
 };
 #define DRS_MAX_STREAM_LAYERS (2 * DRS_MAX_CHAIN)
 struct SArgs {
@@ -553,12 +557,21 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         off = k < in.cols ? off : (int64_t)(zero - base);
         asm("" : "+v"(off));
         v[j] = *reinterpret_cast<const float4*>(base + off);
+        if (in.col2 >= 0) {      // uniform
+          int64_t off2 = grow * in.ld + in.col2 + k;
+          off2 = k < in.cols ? off2 : (int64_t)(zero - base);
+          asm("" : "+v"(off2));
+          const float4 w = *reinterpret_cast<const float4*>(base + off2);
+          v[j] = make_float4(v[j].x + w.x, v[j].y + w.y, v[j].z + w.z, v[j].w + w.w);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = i0 + tid + j * kThreads;
         const int row = idx / qpr, k = (idx - row * qpr) * 4;
         if (idx < total) *reinterpret_cast<float4*>(dst + row * in.lds_ld + k) = swz4(v[j], row);
+        if (in.g_dst && idx < total && k < in.cols && m0 + row < a.M)
+          *reinterpret_cast<float4*>(in.g_dst + (m0 + row) * in.g_ldd + k) = v[j];
       }
     }
   }
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
           const int row = g * 4 + i;                                                              \
           const float v = col < cl.N ? act_apply(acc[i] + bias_v, cl.act) : 0.f;                  \
-          if (cl.out_off >= 0) smem[cl.out_off + row * cl.out_ld + swz(col, row)] = v;            \
+          if (cl.out_off >= 0) smem[cl.out_off + row * cl.out_ld + swz(col + cl.out_col0, row)] = v; \
           if (cl.g_out && col < cl.N && m0 + row < a.M) {                                         \
             float* dstg = cl.g_out + (m0 + row) * cl.g_ld + col;                                  \
             if (cl.g_sc1) __hip_atomic_store(dstg, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\
@@ -919,7 +932,8 @@ static inline int pad64(int n) { return (n + 63) & ~63; }
 
 // Lay the chain(s) out for stream_kernel.  false = not applicable (caller uses chain_kernel).
 static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, bool publish,
-                        SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr) {
+                        SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr,
+                        const SumArgs* sum = nullptr) {
   SArgs& p = *out;
   memset(&p, 0, sizeof p);
   const int na = a.n_layers, nb = b ? b->n_layers : 0;
@@ -933,6 +947,14 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
     if (!b || dot->T != a.y || dot->ldt != a.ldy || dot->R != b->x || dot->ldr != b->ldx ||
         dot->D != d_out || (d_out & 3) || b->width[0] != d_out + dotP || dot->F < 2)
       return false;
+  } else if (sum) {
+    // [ sum of two column blocks | first chain's output ] -> second chain
+    if (!b || dot || sum->cols <= 0 || (sum->cols & 3) || (sum->col_a & 3) || (sum->col_b & 3) || (sum->ld & 3) ||
+        (sum->ldd & 3) || !aligned16(sum->src) || !aligned16(sum->dst) || b->x != sum->dst ||
+        b->ldx != sum->ldd || a.y != sum->dst + sum->cols || a.ldy != sum->ldd ||
+        b->width[0] != sum->cols + d_out || (d_out & 3))
+      return false;
+    if (pad64(b->width[0]) - sum->cols > ((d_out + 127) / 128) * 128) return false;   // zero pad must fall in an existing pass
   } else if (b && (b->x != a.y || b->ldx != a.ldy || d_out > b->width[0] || (d_out & 3))) {
     return false;
   }
@@ -987,7 +1009,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
     SLayer& L = p.L[n++];
     L.W = c.W[l]; L.b = c.b[l]; L.K = c.width[l]; L.N = c.width[l + 1]; L.act = c.act[l];
     L.in_off = cur_off; L.in_ld = cur_ld;
-    L.out_off = -1; L.out_ld = 0; L.out_pad = L.N;
+    L.out_off = -1; L.out_ld = 0; L.out_pad = L.N; L.out_col0 = 0;
     L.g_out = nullptr; L.g_ld = 0; L.g_sc1 = 0;
     L.b_off = boff; boff += (L.N + 3) & ~3;
     if (last_of_chain) {
@@ -995,6 +1017,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
       L.g_sc1 = last_of_all && publish;
       if (!last_of_all) {           // dense_out slot of the second chain's input slab
         L.out_off = rs_off; L.out_ld = rs_ld; L.out_pad = L.N;
+        if (sum) { L.out_col0 = sum->cols; L.out_pad = pad64(b->width[0]) - sum->cols; }   // behind the summed block, zero tail
         cur_off = dot ? ri_off : rs_off; cur_ld = dot ? ri_ld : rs_ld;
       }
     } else {
@@ -1017,12 +1040,18 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
   SInput& i0 = p.in[0];
   i0.src = a.x; i0.ld = a.ldx; i0.col0 = 0; i0.cols = a.width[0]; i0.cols_pad = pad64(a.width[0]);
   i0.lds_off = x0_off; i0.lds_ld = x0_ld; i0.lds_col0 = 0; i0.use_xs = xs.q.n_q > 0;
+  p.in[0].col2 = p.in[1].col2 = -1;
   p.n_inputs = 1;
   if (b) {
     SInput& i1 = p.in[1];
     i1.src = dot ? dot->T : b->x; i1.ld = dot ? dot->ldt : b->ldx; i1.col0 = d_out; i1.cols = rs_cols - d_out;
     i1.cols_pad = pad64(rs_cols) - d_out;
     i1.lds_off = rs_off; i1.lds_ld = rs_ld; i1.lds_col0 = d_out; i1.use_xs = 0;
+    if (sum) {
+      i1.src = sum->src; i1.ld = sum->ld; i1.col0 = sum->col_a; i1.col2 = sum->col_b;
+      i1.cols = i1.cols_pad = sum->cols; i1.lds_col0 = 0;
+      i1.g_dst = sum->dst; i1.g_ldd = sum->ldd;
+    }
     p.n_inputs = 2;
   }
   if (dot) {
@@ -1035,18 +1064,19 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
   return true;
 }
 
-bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xsrc, const DotArgs* dot) {
+bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xsrc, const DotArgs* dot,
+                       const SumArgs* sum) {
   if (!g_mlp_stream || init_mlp_kernels() != hipSuccess) return false;
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   if (xsrc) xs = *xsrc;
   SArgs sp;
   size_t lds = 0;
-  return stream_plan(a, &b, xs, true, &sp, &lds, dot);
+  return stream_plan(a, &b, xs, true, &sp, &lds, dot, sum);
 }
 
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, const Done* done,
-                         const XSrc* xsrc, const DotArgs* dot) {
+                         const XSrc* xsrc, const DotArgs* dot, const SumArgs* sum) {
   if (a.M <= 0) return hipSuccess;
   Done d;
   memset(&d, 0, sizeof d);
@@ -1061,7 +1091,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
   if (g_mlp_stream) {
     SArgs sp;
     size_t slds = 0;
-    if (stream_plan(a, b, xs, d.counter != nullptr, &sp, &slds, dot)) {
+    if (stream_plan(a, b, xs, d.counter != nullptr, &sp, &slds, dot, sum)) {
 #ifdef DRS_TIMELINE
       slds += 8192;
 #endif
@@ -1069,7 +1099,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
       return hipGetLastError();
     }
   }
-  if (dot) return hipErrorInvalidValue;   // only the stream kernel has the interaction (callers check stream_applicable)
+  if (dot || sum) return hipErrorInvalidValue;   // only the stream kernel has these joins (callers check stream_applicable)
   int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
   if (!chain_plan(a, b, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;
@@ -1101,7 +1131,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
-  return launch_chain2(a, nullptr, s, done, xsrc, nullptr);
+  return launch_chain2(a, nullptr, s, done, xsrc, nullptr, nullptr);
 }
 
 #ifdef DRS_TIMELINE

@@ -176,7 +176,9 @@ int32_t drs_interaction_width(drs_handle h, int32_t* num_int);
 
 /* ---- operator-level entry points (same semantics as the Caffe2 ops) ----------
  * All pointers are DEVICE pointers on the engine's GPU; launches go to slot 0's
- * stream and the call returns after the stream is idle.
+ * stream and the call returns after the stream is idle.  The operands must be complete
+ * when the call is made: a caller that produced them on another stream (e.g. torch's)
+ * synchronises that stream first -- the engine cannot order itself behind foreign work.
  *
  * drs_sls  == SparseLengthsSum([tbl, idx, len]) (models/dlrm_s_caffe2.py:317-325)
  *   out[b,:] = sum over the bag's indices of W[idx,:], fp32, sequential in

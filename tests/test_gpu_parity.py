@@ -114,10 +114,12 @@ def test_sls_exact_is_bitwise_and_split_is_close(op_engine, D, L):
     for u in (0, 4, 8, 16, 20):
         op_engine.set_option("sls_u", u)
         out.fill_(float("nan"))
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
                       out.data_ptr(), exact_order=True)
         assert np.array_equal(out.cpu().numpy(), exp), (D, L, u)
         out.fill_(float("nan"))
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
                       out.data_ptr(), exact_order=False)
         assert H.close(out.cpu().numpy(), exp, rtol=1e-5, atol_scale=1e-6), (D, L, u)
@@ -125,6 +127,7 @@ def test_sls_exact_is_bitwise_and_split_is_close(op_engine, D, L):
     if D == 32:
         op_engine.set_option("sls_v_d32", 2)
         out.fill_(float("nan"))
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
                       out.data_ptr(), exact_order=True)
         op_engine.set_option("sls_v_d32", 4)
@@ -138,19 +141,23 @@ def test_sls_enforces_like_caffe2(op_engine):
     idx = torch.tensor([1, 10, 2], dtype=torch.int32, device="cuda")
     ln = torch.tensor([2, 1], dtype=torch.int32, device="cuda")
     with pytest.raises(N.DrsError) as e:
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 3, out.data_ptr())
     assert e.value.code == N.ERR_INDEX_RANGE
     idx = torch.tensor([1, -1, 2], dtype=torch.int32, device="cuda")
     with pytest.raises(N.DrsError) as e:
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 3, out.data_ptr())
     assert e.value.code == N.ERR_INDEX_RANGE
     ln = torch.tensor([2, 2], dtype=torch.int32, device="cuda")
     with pytest.raises(N.DrsError) as e:
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 3, out.data_ptr())
     assert e.value.code == N.ERR_LENGTHS_SUM
     # all-empty bags -> zeros
     ln = torch.zeros(2, dtype=torch.int32, device="cuda")
     out.fill_(7.0)
+    torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
     op_engine.sls(W.data_ptr(), 10, 8, idx.data_ptr(), ln.data_ptr(), 2, 0, out.data_ptr())
     assert float(out.abs().sum()) == 0.0
 
@@ -167,6 +174,7 @@ def test_fc_matches_oracle_chain(op_engine, M, K, N_, act):
     exp = orc.fc(x, W, b, act)
     dx, dW, db = (torch.from_numpy(a).cuda() for a in (x, W, b))
     y = torch.full((M, N_), float("nan"), device="cuda")
+    torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
     op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, act, y.data_ptr())
     got = y.cpu().numpy()
     if act == N.ACT_SIGMOID:
@@ -191,6 +199,7 @@ def test_gemm_kernel_every_tile_shape_is_bitwise(op_engine, tile, M, K, N_):
     y = torch.full((M, N_), float("nan"), device="cuda")
     op_engine.set_option("mlp_gemm_tile", tile)
     try:
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, N.ACT_RELU, y.data_ptr())
     finally:
         op_engine.set_option("mlp_gemm_tile", 0)
@@ -199,6 +208,7 @@ def test_gemm_kernel_every_tile_shape_is_bitwise(op_engine, tile, M, K, N_):
     op_engine.set_option("mlp_gemm", 0)
     try:
         y2 = torch.full((M, N_), float("nan"), device="cuda")
+        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
         op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, N.ACT_RELU, y2.data_ptr())
     finally:
         op_engine.set_option("mlp_gemm", 1)
@@ -215,6 +225,7 @@ def test_interact_dot_is_bitwise(op_engine, F, D, itself):
     exp = orc.interact_dot(T, itself)
     dT = torch.from_numpy(T).cuda()
     R = torch.full(exp.shape, float("nan"), device="cuda")
+    torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
     op_engine.interact_dot(dT.data_ptr(), B, F, D, itself, R.data_ptr())
     assert np.array_equal(R.cpu().numpy(), exp)
 
