@@ -150,6 +150,8 @@ hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F
 // out[i] = a[i] + b[i] rows of width D (NCF Sum, models/ncf.py:301-305) and strided copies
 hipError_t launch_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
                            int64_t ldo, int64_t M, int32_t D, hipStream_t stream);
+// dense rows of all coalesced queries (xs.x[q], m_den wide) -> their virtual rows of `out`
+hipError_t launch_copy_rows_multi(const XSrc& xs, int32_t m_den, float* out, int64_t ldo, hipStream_t stream);
 hipError_t launch_copy_rows(const float* a, int64_t lda, float* out, int64_t ldo, int64_t M,
                             int32_t D, hipStream_t stream);
 

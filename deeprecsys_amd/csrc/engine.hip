@@ -484,9 +484,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     if (fused) {
       // nothing else to launch
     } else if (e->bot.layers.empty()) {
-      for (int i = 0; i < q.n_q; ++i)
-        HIP_TRY(e, launch_copy_rows(qb[i]->dense, e->m_den, s.T + (int64_t)q.vstart[i] * e->ldT, e->ldT,
-                                    q.bs[i], e->w0, s.stream));
+      HIP_TRY(e, launch_copy_rows_multi(xs, e->m_den, s.T, e->ldT, s.stream));
     } else {
       if ((rc = run_mlp(e, s, e->bot, nullptr, e->m_den, Mv, s.T, e->ldT, nullptr, &xs))) return rc;
     }

@@ -780,6 +780,29 @@ __global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const 
   }
 }
 
+// Dense rows of up to 8 coalesced queries (one staged array per query) -> their virtual rows
+// of the concat buffer, in ONE launch (W&D has no bottom MLP: models/wide_and_deep.py:271-281).
+__global__ void copy_rows_multi_kernel(XSrc xs, int m_den, float* __restrict__ o, int64_t ldo) {
+  const int64_t Mv = xs.q.vstart[xs.q.n_q];
+  const int64_t n = Mv * m_den;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / m_den;
+    const int d = (int)(i - v * m_den);
+    const float* p = xs.x[0];
+    int lo = xs.q.vstart[0], nb = xs.q.bs[0];
+#pragma unroll
+    for (int k = 1; k < DRS_MAX_COALESCE; ++k) {
+      const bool in = k < xs.q.n_q && v >= xs.q.vstart[k];
+      p = in ? xs.x[k] : p;
+      lo = in ? xs.q.vstart[k] : lo;
+      nb = in ? xs.q.bs[k] : nb;
+    }
+    const int64_t r = v - lo;
+    if (r < nb) o[v * ldo + d] = p[r * m_den + d];
+  }
+}
+
 }  // namespace
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1180,6 +1203,13 @@ hipError_t launch_add_rows(const float* a, int64_t lda, const float* b, int64_t 
 hipError_t launch_copy_rows(const float* a, int64_t lda, float* out, int64_t ldo, int64_t M,
                             int32_t D, hipStream_t s) {
   return launch_add_rows(a, lda, nullptr, 0, out, ldo, M, D, s);
+}
+
+hipError_t launch_copy_rows_multi(const XSrc& xs, int32_t m_den, float* out, int64_t ldo, hipStream_t s) {
+  const int64_t Mv = xs.q.n_q > 0 ? xs.q.vstart[xs.q.n_q] : 0;
+  if (Mv <= 0 || m_den <= 0) return hipSuccess;
+  hipLaunchKernelGGL(copy_rows_multi_kernel, dim3(ew_grid(Mv * m_den)), dim3(256), 0, s, xs, m_den, out, ldo);
+  return hipGetLastError();
 }
 
 }  // namespace drs
