@@ -1,30 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec under a p99 latency SLA, DLRM-RMC1 synthetic, on N MI355X.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus N --steps K --warmup W        (N > 1: spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one query: one pass of the hot path (multi-table SparseLengthsSum gather,
-bottom MLP, feature interaction, top MLP, sigmoid) over one batch of `--batch`
-samples whose inputs are already resident in HBM (the reference engine keeps its
-pre-generated input sets in process memory and a request only names
-(batch_id, batch_size): inferenceEngine.py:83,200-215).  Queries are submitted
-through the C ABI (include/drs.h) with `--slots` in flight; each query's latency is
-taken from its submit to the moment its result is observed on the host, and the p99
-over the timed steps is checked against the SLA.
+A "step" is one BLOCK of `--queries_per_step` queries (default 8192; named in `config`):
+each query is one pass of the hot path (multi-table SparseLengthsSum gather, bottom MLP,
+feature interaction, top MLP, sigmoid) over one batch of `--batch` samples whose inputs are
+already resident in HBM (the reference engine keeps its pre-generated input sets in process
+memory and a request only names (batch_id, batch_size): inferenceEngine.py:83,200-215).
+`--steps 20 --warmup 5` therefore times 163 840 queries (~1.3 s on one MI355X) after 40 960
+untimed ones: the launch pipeline and the chip's power state are in steady state, and p99 is
+taken over every query of the region.  Queries are submitted through the C ABI
+(include/drs.h), `--coalesce` per launch set and `--slots` sets in flight; a query's latency
+runs from the submit of its launch set to the moment its result is observed on the host.
 
 Workload at N=1: BASELINE.json configs[1] -- DLRM-RMC1, 8 tables x 1M rows x 64-dim,
 80 lookups per bag, bottom MLP 128-64-64, top MLP 576-256-64-1 (cat), batch 256.
-Multi-GPU: queries are independent, the model is replicated per GPU, every rank
-serves its own K steps (weak scaling); RCCL (torch.distributed "nccl") only
-all-reduces the elapsed time and the latency histogram at the end.
+Multi-GPU: queries are independent, the model is replicated per GPU, every rank serves its
+own K steps (weak scaling); the ONE collective of the run -- MAX(elapsed), SUM(count, latency
+histogram) -- is drs_stats_allreduce: RCCL over xGMI behind the C ABI (torch.distributed/gloo
+only carries the 128-byte communicator id between the ranks; `--collective gloo` keeps the
+whole exchange on gloo for the CPU tests).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,14 +57,18 @@ WORKLOADS = {
     "wnd": dict(kind="wnd", rows=1_000_000, T=27, D=32, L=1, bot="512", top="1024-512-256-1", op="cat"),
     "ncf": dict(kind="ncf", rows=[140_000, 140_000, 28_000, 28_000], T=4, D=64, L=1, bot="512",
                 top="256-256-128-64-64", op="cat"),
+    # CPU-test size (tests/test_harness.py drives the rank entry through the CPU restatement of the ABI)
+    "tiny": dict(rows=1000, T=4, D=16, L=4, bot="16-16", top="32-1", op="cat"),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16000)
-    ap.add_argument("--warmup", type=int, default=1600)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--queries_per_step", type=int, default=8192,
+                    help="queries in one step (block); steps*queries_per_step queries are timed")
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
@@ -66,15 +76,21 @@ def parse():
     ap.add_argument("--coalesce", type=int, default=8,
                     help="queries per launch set (the engine coalesces requests that are already queued)")
     ap.add_argument("--seed", type=int, default=123)
-    ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of each cpu_baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--timed_only", action="store_true",
                     help="warm-up + timed region only: skip the cross-check / single-query / host-input "
                          "legs and the CPU baseline (profiling runs: every gather launch rocprofv3 sees "
-                         "is then an 8-query launch of the benchmark itself)")
+                         "is then a launch of the benchmark itself)")
+    ap.add_argument("--collective", default="rccl", choices=("rccl", "gloo"),
+                    help="N > 1: how the run statistics are combined (rccl = drs_stats_allreduce)")
     ap.add_argument("--sweep", action="store_true", help="also A/B the gather variants (stderr)")
     ap.add_argument("--set", action="append", default=[], help="engine option key=value")
-    return ap.parse_args()
+    ap.add_argument("--torch_cpu_leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--allow_device_sharing", action="store_true",
+                    help="ranks beyond the visible device count wrap around instead of failing "
+                         "(CPU tests of the rank entry; never a valid N-GPU measurement)")
+    return ap.parse_args(argv)
 
 
 def make_model(opt, device):
@@ -152,132 +168,298 @@ def host_cores():
     return n
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(opt, net, data, budget_s):
-    """The CPU oracle (a port of the reference's CPU path, oracle/drs_oracle.c) timed on
-    this host's cores on a bounded sample of the same workload."""
+    """Two CPU legs on this host's cores, each on a bounded sample of the same workload:
+    (a) the CPU oracle, a port of the reference's CPU path (oracle/drs_oracle.c, OpenMP, FC
+        weights transposed once at model build);
+    (b) torch-CPU `embedding_bag(sum)` + `addmm` (the Caffe2-lineage perfkernel and MKL/oneDNN
+        sgemm), torch.set_num_threads(cores), in a subprocess of its own.
+    `value` is the faster of the two."""
     from oracle import oracle as orc
     from tests import helpers as H
     w = WORKLOADS[opt.workload]
     lX, lS_l, lS_i = data
     cores = host_cores()
-    lo, hi = -float(np.sqrt(1 / w["rows"])), float(np.sqrt(1 / w["rows"]))
+    rows = w["rows"] if isinstance(w["rows"], list) else [w["rows"]] * w["T"]
     t0 = time.perf_counter()
-    net.emb_w = [orc.fill_table_uniform(w["rows"], w["D"], t, lo, hi, opt.seed, nthreads=cores)
-                 for t in range(w["T"])]
+    net.emb_w = [orc.fill_table_uniform(rows[t], w["D"], t, -float(np.sqrt(1 / rows[t])), float(np.sqrt(1 / rows[t])),
+                                        opt.seed, nthreads=cores) for t in range(w["T"])]
     om = H.oracle_model(net)
     fill_s = time.perf_counter() - t0
-    om.forward(lX[0], lS_i[0], lS_l[0], bs=opt.batch, nthreads=cores)   # warm
+    dense = (lambda b: None) if w.get("kind") == "ncf" else (lambda b: lX[b])
+    om.forward(dense(0), lS_i[0], lS_l[0], bs=opt.batch, nthreads=cores)   # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        om.forward(lX[n % len(lX)], lS_i[n % len(lX)], lS_l[n % len(lX)], bs=opt.batch, nthreads=cores)
+        b = n % len(lS_l)
+        om.forward(dense(b), lS_i[b], lS_l[b], bs=opt.batch, nthreads=cores)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 20000:
             break
-    return {"value": round(n / el, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+    port = {"value": round(n / el, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "impl": "oracle/drs_oracle.c (OpenMP; sequential-order SparseLengthsSum, k-ordered fmaf FC chains)",
             "sample": "%d queries of batch %d (%s) in %.1f s, OpenMP over %d threads; "
                       "tables filled in %.1f s" % (n, opt.batch, opt.workload, el, cores, fill_s)}
+    del om
+    net.emb_w = None
+    torch_leg = None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch_cpu_leg", "--workload", opt.workload,
+                            "--batch", str(opt.batch), "--num_batches", str(min(opt.num_batches, 8)),
+                            "--seed", str(opt.seed), "--cpu_seconds", str(budget_s)],
+                           capture_output=True, text=True, timeout=budget_s * 4 + 240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        torch_leg = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+    except Exception as e:    # the sanity leg must never take the benchmark line down
+        torch_leg = {"error": repr(e)[:300]}
+    out = dict(port)
+    if torch_leg and torch_leg.get("value", 0) > port["value"]:
+        out.update({k: torch_leg[k] for k in ("value", "impl", "sample")})
+    out["host"] = host_cpu_model()
+    out["legs"] = {"oracle_port": {k: port[k] for k in ("value", "impl", "sample")}, "torch_cpu": torch_leg}
+    return out
+
+
+def torch_cpu_leg(opt):
+    """Subprocess entry: the same forward on torch-CPU operators (embedding_bag(sum) descends
+    from the Caffe2 perfkernel and is bit-identical to sequential fp32 pooling; addmm is the
+    library sgemm), all host cores, timed for ~cpu_seconds.  Prints one JSON line."""
+    import torch
+    import torch.nn.functional as F
+    from deeprecsys_amd.data_generator.dlrm_data import generate_fast_input_data
+    w = WORKLOADS[opt.workload]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    kind = w.get("kind", "dlrm")
+    T, D, L, bs = w["T"], w["D"], w["L"], opt.batch
+    rows = w["rows"] if isinstance(w["rows"], list) else [w["rows"]] * T
+    g = torch.Generator().manual_seed(opt.seed)
+    tables = [(torch.rand(r, D, generator=g) * 2 - 1) * float(np.sqrt(1 / r)) for r in rows]
+    ln_bot = [int(x) for x in w["bot"].split("-")]
+    top = [int(x) for x in w["top"].split("-")]
+    F_ = T + 1
+    if kind == "dlrm":
+        num_int = F_ * D if w["op"] == "cat" else D + F_ * (F_ - 1) // 2
+        ln_top = [num_int] + top
+    elif kind == "wnd":
+        ln_top = [T * D + ln_bot[0]] + top
+    else:
+        ln_top = top[:-1]            # NCF: MLP branch widths, predictor = last entry
+
+    def mk(ln):
+        return [(torch.randn(ln[i + 1], ln[i], generator=g) * float(np.sqrt(2 / (ln[i] + ln[i + 1]))),
+                 torch.randn(ln[i + 1], generator=g) * float(np.sqrt(1 / ln[i + 1]))) for i in range(len(ln) - 1)]
+    bot_w = mk(ln_bot) if kind == "dlrm" else []
+    top_w = mk(ln_top)
+    fin_w = mk([D + ln_top[-1], top[-1]]) if kind == "ncf" else []
+    nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, bs, ln_bot[0], rows, L, opt.seed)
+    sets = []
+    for b in range(nb):
+        idx = [torch.from_numpy(np.ascontiguousarray(t[:bs * L]).astype(np.int64)) for t in lS_i[b]]
+        offs = torch.arange(0, bs * L, L, dtype=torch.int64)
+        x = None if kind == "ncf" else torch.from_numpy(np.ascontiguousarray(lX[b][:bs], dtype=np.float32))
+        sets.append((x, idx, offs))
+    li, lj = torch.tril_indices(F_, F_, -1)
+
+    def mlp(x, layers, sigmoid_last=False):
+        for i, (W, b_) in enumerate(layers):
+            x = torch.addmm(b_, x, W.t())
+            x = torch.sigmoid(x) if (sigmoid_last and i == len(layers) - 1) else torch.relu(x)
+        return x
+
+    def forward(x, idx, offs):
+        emb = [F.embedding_bag(idx[t], tables[t], offs, mode="sum") for t in range(T)]
+        if kind == "ncf":
+            mf = emb[0] + emb[1]
+            z = mlp(torch.cat([emb[2], emb[3]], 1), top_w)
+            return mlp(torch.cat([mf, z], 1), fin_w)
+        if kind == "wnd":
+            return mlp(torch.cat([x] + emb, 1), top_w, True)
+        d = mlp(x, bot_w)
+        if w["op"] == "cat":
+            R = torch.cat([d] + emb, 1)
+        else:
+            Tt = torch.stack([d] + emb, 1)
+            Z = torch.bmm(Tt, Tt.transpose(1, 2))
+            R = torch.cat([d, Z[:, li, lj]], 1)
+        return mlp(R, top_w, True)
+
+    with torch.no_grad():
+        forward(*sets[0])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            forward(*sets[n % nb])
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= opt.cpu_seconds or n >= 20000:
+                break
+    print(json.dumps({"value": round(n / el, 2), "unit": "queries/s", "cores": cores,
+                      "impl": "torch %s CPU: embedding_bag(sum) + addmm, set_num_threads(%d)" % (torch.__version__, cores),
+                      "sample": "%d queries of batch %d (%s) in %.1f s" % (n, bs, opt.workload, el)}), flush=True)
+
+
+def spawn_ranks(opt, argv):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (what
+    torch.distributed.run would do), relay rank 0's JSON line, fail if any rank fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(opt.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(opt.gpus),
+                    "LOCAL_WORLD_SIZE": str(opt.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=r == 0 or None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in (out0 or "").splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    if any(rcs):
+        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        sys.exit(1)
 
 
 def main():
-    opt = parse()
+    argv = sys.argv[1:]
+    opt = parse(argv)
+    if opt.torch_cpu_leg:
+        return torch_cpu_leg(opt)
+    if "WORLD_SIZE" not in os.environ and opt.gpus > 1:
+        return spawn_ranks(opt, argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    dist = comm = None
+    json_out = sys.stdout
     if world > 1:
-        import torch
+        # native libraries (gloo, RCCL) log to fd 1: keep stdout for rank 0's ONE JSON line
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        # torch first: it bundles its own HIP runtime, which must be the one in the process
+        import torch  # noqa: F401
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")          # plumbing: carries the communicator id (and the
+                                                 # statistics themselves under --collective gloo)
     from deeprecsys_amd import _native as N
+    from deeprecsys_amd import stats
 
-    args, net, data = make_model(opt, local)
+    device = local
+    if opt.allow_device_sharing:
+        device = local % max(N.device_count(), 1)
+    args, net, data = make_model(opt, device)
     eng = net.engine
     for kv in opt.set:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    if world > 1 and opt.collective == "rccl":
+        box = [N.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = N.Comm(box[0], rank, world, device)
     bs, nb, slots, co = opt.batch, opt.num_batches, opt.slots, opt.coalesce
-    stream_mode = {"2": "pipelined (gathers back to back on one stream, MLP launches on a second)",
-                   "1": "single stream", "0": "one stream per launch set"}[
-        dict(kv.split("=") for kv in opt.set).get("shared_stream", "2")]
+    qps_ = max(1, opt.queries_per_step)
+    n_timed, n_warm = opt.steps * qps_, opt.warmup * qps_
+    stream_mode = {2: "pipelined (gathers back to back on one stream, MLP launches on a second)",
+                   1: "single stream", 0: "one stream per launch set"}[eng.get_option("shared_stream")]
 
     def barrier():
         eng.sync()
-        if dist is not None:
-            import torch
+        if comm is not None:
+            comm.barrier()                       # RCCL all-reduce of one word + hipDeviceSynchronize
+        elif dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            eng.sync()
 
     # warmup
-    run_queries(eng, opt.warmup, bs, nb, slots, coalesce=co)
-    # timed region: exactly K steps per rank, barrier + sync on both sides.  Profiling level 1
-    # (device clock stamps of the gather launch, handed over with the results: no copy, no
-    # sync, no extra launch) stays on inside it, so the roofline figure is taken over the
-    # timed region itself.
+    run_queries(eng, n_warm, bs, nb, slots, coalesce=co)
+    # timed region: exactly K steps (K * queries_per_step queries) per rank, barrier + device sync
+    # on both sides.  Profiling level 1 (device clock stamps of the gather launch, handed over with
+    # the results: no copy, no sync, no extra launch) stays on inside it, so the roofline figure is
+    # taken over the timed region itself; the engine adds up the algorithmic bytes of exactly the
+    # launches it timed (a trailing partial launch set counts with its own bytes).
     lat = []
     eng.reset_kernel_time()
     eng.set_profiling(1)
     barrier()
-    elapsed = run_queries(eng, opt.steps, bs, nb, slots, lat, coalesce=co)
+    elapsed = run_queries(eng, n_timed, bs, nb, slots, lat, coalesce=co)
     barrier()
     eng.set_profiling(0)
     sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
-    gbytes = eng.gather_bytes(0, bs) * co          # algorithmic bytes of one gather launch
+    sls_bytes = eng.kernel_bytes(N.KERNEL_SLS_CLOCK)
 
     extra = not opt.timed_only
-    ev_ms = ev_n = mlp_ms = mlp_n = one_ms = one_n = 0
+    ev_ms = ev_n = ev_bytes = mlp_ms = mlp_n = one_ms = one_n = one_bytes = 0
     if extra:
         # cross-check leg (not part of `value`): HIP events recorded around the gather launch on the
         # stream it is launched on; they bracket several us of packet processing as well
         eng.reset_kernel_time()
         eng.set_profiling(2)
-        run_queries(eng, min(opt.steps, 1000), bs, nb, slots, coalesce=co)
+        run_queries(eng, min(n_timed, 4096), bs, nb, slots, coalesce=co)
         eng.set_profiling(0)
         ev_ms, ev_n = eng.kernel_time(N.KERNEL_SLS)
+        ev_bytes = eng.kernel_bytes(N.KERNEL_SLS)
         mlp_ms, mlp_n = eng.kernel_time(N.KERNEL_MLP)
         # reference point: the same gather serving ONE query per launch, nothing else in flight
         eng.reset_kernel_time()
         eng.set_profiling(1)
-        run_queries(eng, 300, bs, nb, 1, coalesce=1)
+        run_queries(eng, 500, bs, nb, 1, coalesce=1)
         eng.set_profiling(0)
         one_ms, one_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
+        one_bytes = eng.kernel_bytes(N.KERNEL_SLS_CLOCK)
     # PCIe-inclusive leg (never `value`): the same queries handed over as HOST arrays per call --
     # int64 ids / int32 lengths / fp32 dense, the reference's run_queues signature -- through
     # drs_forward_inputs_async with `slots` calls in flight
     lX, lS_l, lS_i = data
     L = WORKLOADS[opt.workload]["L"]
-    host_sets = [([np.ascontiguousarray(t[:bs * L]) for t in lS_i[b]], [np.ascontiguousarray(t[:bs]) for t in lS_l[b]],
-                  None if WORKLOADS[opt.workload].get("kind") == "ncf" else np.ascontiguousarray(lX[b][:bs]))
-                 for b in range(min(nb, 4))]
-    def host_leg(n):
-        busy = [False] * slots
-        t0 = time.perf_counter()
-        for i in range(n):
-            s_ = i % slots
-            if busy[s_]:
-                eng.wait(s_, bs)
-            ids, lens, x = host_sets[i % len(host_sets)]
-            eng.forward_inputs_async(x, ids, lens, bs, slot=s_)
-            busy[s_] = True
-        for s_ in range(slots):
-            if busy[s_]:
-                eng.wait(s_, bs)
-        return time.perf_counter() - t0
-    host_n, host_el = 0, 1.0
+    host_n, host_el, host_bytes = 0, 1.0, 0
     if extra:
-        host_leg(100)
-        host_n = 1000
+        host_sets = [([np.ascontiguousarray(t[:bs * L]) for t in lS_i[b]], [np.ascontiguousarray(t[:bs]) for t in lS_l[b]],
+                      None if WORKLOADS[opt.workload].get("kind") == "ncf" else np.ascontiguousarray(lX[b][:bs]))
+                     for b in range(min(nb, 4))]
+        host_bytes = sum(a.nbytes for a in host_sets[0][0]) + sum(a.nbytes for a in host_sets[0][1]) + \
+            (0 if host_sets[0][2] is None else host_sets[0][2].nbytes)
+
+        def host_leg(n):
+            busy = [False] * slots
+            t0 = time.perf_counter()
+            for i in range(n):
+                s_ = i % slots
+                if busy[s_]:
+                    eng.wait(s_, bs)
+                ids, lens, x = host_sets[i % len(host_sets)]
+                eng.forward_inputs_async(x, ids, lens, bs, slot=s_)
+                busy[s_] = True
+            for s_ in range(slots):
+                if busy[s_]:
+                    eng.wait(s_, bs)
+            return time.perf_counter() - t0
+        host_leg(200)
+        host_n = 2000
         host_el = host_leg(host_n)
 
-    from deeprecsys_amd import stats
     hist = stats.latency_histogram(lat)
-    tot_elapsed, tot_queries = elapsed, opt.steps
-    if dist is not None:
-        import torch
-        # the single collective of the run: MAX(elapsed), SUM(count, latency histogram) -- 32 KB
-        tot_elapsed, tot_queries, hist = stats.allreduce_run_stats(dist, elapsed, opt.steps, hist,
-                                                                   device=torch.device("cuda", local))
+    tot_elapsed, tot_queries = elapsed, n_timed
+    if comm is not None:
+        # the single collective of the run, RCCL over xGMI behind the C ABI: SUM(latency
+        # histogram), SUM(count), MAX(elapsed) -- 32 KB
+        hist, s4 = comm.stats_allreduce(hist, [float(n_timed), float(np.sum(lat)), elapsed, elapsed])
+        tot_queries, tot_elapsed = int(round(s4[0])), float(s4[3])
+    elif dist is not None:
+        tot_elapsed, tot_queries, hist = stats.allreduce_run_stats(dist, elapsed, n_timed, hist)
     p50, p95, p99 = (stats.percentile_from_histogram(hist, q) for q in (50, 95, 99))
 
     if rank == 0:
@@ -293,75 +475,92 @@ def main():
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         except (OSError, ValueError, KeyError):
             pass
-        ach = gbytes / (sls_ms / max(sls_n, 1) * 1e-3) / 1e9 if sls_n else None
+        gbps = lambda by, ms: None if not ms else by / (ms * 1e-3) / 1e9   # noqa: E731
+        ach = gbps(sls_bytes, sls_ms)
+        one = gbps(one_bytes, one_ms)
+        ev = gbps(ev_bytes, ev_ms)
         out = {
             "metric": "queries/sec under p99 latency SLA, %s synthetic"
                       % ("DLRM-RMC1" if opt.workload == "rmc1" else opt.workload),
             "value": round(tot_queries / tot_elapsed, 1),
             "unit": "queries/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
-            "ms_per_step": round(tot_elapsed / opt.steps * 1e3, 5),
+            "ms_per_step": round(tot_elapsed / opt.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s-%s: %d tables x %s rows x %d-dim, %d lookups/bag, "
                                    "bot %s, top %s (%s), batch %d, %d resident input sets"
                                    % (w.get("kind", "dlrm").upper(), opt.workload.upper(), w["T"], w["rows"], w["D"], w["L"], w["bot"],
                                       w["top"], w["op"], bs, nb),
+                       "queries_per_step": qps_,
+                       "timed_queries_per_gpu": n_timed, "timed_seconds": round(tot_elapsed, 4),
                        "parallelism": "dp%d (model replicated, independent queries)" % world,
                        "queries_per_launch": co, "launch_sets_in_flight": slots,
                        "streams": stream_mode,
+                       "collective": None if world == 1 else
+                       ("drs_stats_allreduce (RCCL, one grouped all-reduce of 32 KB)" if comm is not None else "gloo"),
                        "inputs": "device-resident (pre-staged)"},
             "latency_ms": {"p50": round(p50, 4), "p95": round(p95, 4), "p99": round(p99, 4),
-                           "sla": SLA_MS, "sla_met": bool(p99 <= SLA_MS)},
-            "roofline": {"bound": "hbm", "kernel": "sls_kernel (multi-table SparseLengthsSum)",
+                           "queries": int(np.sum(hist)), "sla": SLA_MS, "sla_met": bool(p99 <= SLA_MS)},
+            "roofline": {"bound": "hbm", "kernel": "sls gather (multi-table SparseLengthsSum)",
                          "achieved": None if ach is None else round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": gbytes,
+                         "bytes_timed": sls_bytes,
+                         "bytes_per_launch": None if not sls_n else int(sls_bytes / sls_n),
                          "avg_launch_us": None if not sls_n else round(sls_ms / sls_n * 1e3, 3),
                          "launches_timed": sls_n,
                          "timer": "device wall clock stamps of the launch's own workgroups "
-                                  "(max end - min start); hip-event bracket for comparison",
+                                  "(max end - min start), summed over every gather launch of the timed "
+                                  "region next to that launch's own algorithmic bytes; hip-event bracket "
+                                  "for comparison",
                          "hip_event_avg_us": None if not ev_n else round(ev_ms / ev_n * 1e3, 3),
+                         "hip_event_frac": None if ev is None else round(ev / HBM_PEAK_GBS, 4),
                          "gather_end_to_set_end_event_us": None if not mlp_n else round(mlp_ms / mlp_n * 1e3, 3),
                          # all gather launches of the timed region over its wall time: how busy
                          # the launch structure keeps HBM, gaps and MLP phases included
                          "sustained_over_timed_region": {
-                             "GBps": round(gbytes * (opt.steps / co) / elapsed / 1e9, 1),
-                             "frac": round(gbytes * (opt.steps / co) / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+                             "GBps": round(sls_bytes / elapsed / 1e9, 1),
+                             "frac": round(sls_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
                          "single_query_launch": None if not one_n else {
-                             "bytes": gbytes // co, "avg_launch_us": round(one_ms / one_n * 1e3, 3),
-                             "frac": round(gbytes / co / (one_ms / one_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                             "bytes": int(one_bytes / one_n), "avg_launch_us": round(one_ms / one_n * 1e3, 3),
+                             "frac": round(one / HBM_PEAK_GBS, 4)}},
         }
         if extra:
-          out["host_inputs_leg"] = {
-              "value": round(host_n / host_el, 1), "unit": "queries/s", "queries": host_n,
-              "what": "PCIe-inclusive: per-call host arrays (%d KB/query) converted into pinned memory and "
-                      "read in place by the kernels, one query per launch set, %d calls in flight"
-                      % ((bs * (len(lS_i[0]) * L * 8 + len(lS_i[0]) * 4 + lX[0].shape[1] * 4)) // 1024, slots)}
+            out["host_inputs_leg"] = {
+                "value": round(host_n / host_el, 1), "unit": "queries/s", "queries": host_n,
+                "h2d_GBps": round(host_bytes * host_n / host_el / 1e9, 2),
+                "what": "PCIe-inclusive: per-call host arrays (%d KB/query) converted into pinned memory and "
+                        "read in place by the kernels, one query per launch set, %d calls in flight"
+                        % (host_bytes // 1024, slots)}
         if not opt.no_cpu_baseline and not opt.timed_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt, net, data, opt.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     if opt.sweep and rank == 0:
         results = []
-        for exact in (1, 0):
-            for u in (4, 8, 16, 20):
+        for exact, flat in ((1, 0), (0, 0), (0, 1)):
+            for u in ((4,) if flat else (4, 8, 16)):
                 eng.set_option("sls_exact", exact)
+                eng.set_option("sls_flat", flat)
                 eng.set_option("sls_u", u)
-                run_queries(eng, 200, bs, nb, slots, coalesce=co)
+                run_queries(eng, 400, bs, nb, slots, coalesce=co)
+                el = run_queries(eng, 4000, bs, nb, slots, coalesce=co)
                 eng.reset_kernel_time()
-                el = run_queries(eng, 2000, bs, nb, slots, coalesce=co)
                 eng.set_profiling(1)
-                run_queries(eng, 1000, bs, nb, slots, coalesce=co)
+                run_queries(eng, 2000, bs, nb, slots, coalesce=co)
                 eng.set_profiling(0)
                 ms, n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
-                results.append({"exact": exact, "u": u, "qps": round(2000 / el, 1),
+                by = eng.kernel_bytes(N.KERNEL_SLS_CLOCK)
+                results.append({"exact": exact, "flat": flat, "u": u, "qps": round(4000 / el, 1),
                                 "sls_us": round(ms / n * 1e3, 3),
-                                "GBps": round(gbytes / (ms / n * 1e-3) / 1e9, 1)})
+                                "GBps": round(by / (ms * 1e-3) / 1e9, 1)})
                 print("sweep", json.dumps(results[-1]), file=sys.stderr, flush=True)
     eng.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

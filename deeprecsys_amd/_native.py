@@ -40,7 +40,7 @@ SYMBOLS = [
     ("drs_forward", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
     ("drs_forward_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     ("drs_forward_multi_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p]),
-    ("drs_wait", C.c_int32, [C.c_void_p, C.c_int32, _f32p]),
+    ("drs_wait", C.c_int32, [C.c_void_p, C.c_int32, _f32p, C.c_int64]),
     ("drs_sync", C.c_int32, [C.c_void_p]),
     ("drs_forward_inputs_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
                                              C.POINTER(_i32p)]),
@@ -56,12 +56,21 @@ SYMBOLS = [
     ("drs_interact_dot", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p]),
     ("drs_set_option", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("drs_get_option", C.c_int32, [C.c_void_p, C.c_char_p, _i64p]),
     ("drs_set_profiling", C.c_int32, [C.c_void_p, C.c_int32]),
     ("drs_kernel_time", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), _i64p]),
     ("drs_reset_kernel_time", C.c_int32, [C.c_void_p]),
+    ("drs_kernel_bytes", C.c_int32, [C.c_void_p, C.c_int32, _i64p]),
     ("drs_debug_gather_stamps", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _i64p]),
     ("drs_gather_bytes", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i64p]),
+    ("drs_comm_unique_id", C.c_int32, [C.POINTER(C.c_uint8)]),
+    ("drs_comm_create", C.c_int32, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("drs_comm_destroy", C.c_int32, [C.c_void_p]),
+    ("drs_comm_barrier", C.c_int32, [C.c_void_p]),
+    ("drs_stats_allreduce", C.c_int32, [C.c_void_p, _i64p, C.c_int32, C.POINTER(C.c_double)]),
+    ("drs_comm_last_error", C.c_char_p, []),
 ]
+COMM_ID_BYTES = 128
 
 
 class ModelCfg(C.Structure):
@@ -219,11 +228,13 @@ class Engine(object):
                                                   bs.ctypes.data_as(_i32p)), "drs_forward_multi_async")
 
     def wait(self, slot, bs=None):
+        """bs = total samples submitted on the slot (sum over coalesced queries); the library
+        checks the buffer against what is really in flight there."""
         if bs is None:
-            self._check(lib().drs_wait(self._h, slot, None), "drs_wait")
+            self._check(lib().drs_wait(self._h, slot, None, 0), "drs_wait")
             return None
         out = np.empty((bs, self.n_out), dtype=np.float32)
-        self._check(lib().drs_wait(self._h, slot, out.ctypes.data_as(_f32p)), "drs_wait")
+        self._check(lib().drs_wait(self._h, slot, out.ctypes.data_as(_f32p), out.size), "drs_wait")
         return out
 
     def sync(self):
@@ -273,6 +284,17 @@ class Engine(object):
     def set_option(self, key, value):
         self._check(lib().drs_set_option(self._h, key.encode(), int(value)), "drs_set_option")
 
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._check(lib().drs_get_option(self._h, key.encode(), C.byref(v)), "drs_get_option")
+        return int(v.value)
+
+    def kernel_bytes(self, kernel):
+        """Algorithmic gather bytes of exactly the launches kernel_time(kernel) has timed."""
+        b = C.c_int64(0)
+        self._check(lib().drs_kernel_bytes(self._h, kernel, C.byref(b)), "drs_kernel_bytes")
+        return int(b.value)
+
     def set_profiling(self, level):
         """0 off | 1 device clock stamps of the gather launch (free) | 2 also HIP events."""
         self._check(lib().drs_set_profiling(self._h, int(level)), "drs_set_profiling")
@@ -296,3 +318,46 @@ class Engine(object):
         b = C.c_int64(0)
         self._check(lib().drs_gather_bytes(self._h, batch_id, bs, C.byref(b)), "drs_gather_bytes")
         return int(b.value)
+
+
+class Comm(object):
+    """RCCL communicator behind the C ABI: the run's single collective (drs_stats_allreduce).
+    rank 0 creates the id (Comm.unique_id()), the caller ships the 128 bytes to the other
+    ranks, every rank then constructs Comm(id, rank, world, device)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = lib().drs_comm_unique_id(buf)
+        if rc != OK:
+            raise DrsError(rc, "drs_comm_unique_id", (lib().drs_comm_last_error() or b"").decode())
+        return bytes(buf)
+
+    def __init__(self, uid, rank, world, device):
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        rc = lib().drs_comm_create(buf, int(rank), int(world), int(device), C.byref(h))
+        if rc != OK:
+            raise DrsError(rc, "drs_comm_create", (lib().drs_comm_last_error() or b"").decode())
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise DrsError(rc, what, (lib().drs_comm_last_error() or b"").decode())
+
+    def barrier(self):
+        self._check(lib().drs_comm_barrier(self._h), "drs_comm_barrier")
+
+    def stats_allreduce(self, hist, sum_min_max):
+        """hist int64[n] SUM; sum_min_max float64[4]: [0],[1] SUM, [2] MIN, [3] MAX.  Returns copies."""
+        h = np.ascontiguousarray(hist, dtype=np.int64).copy()
+        s = np.ascontiguousarray(sum_min_max, dtype=np.float64).copy()
+        assert s.size == 4
+        self._check(lib().drs_stats_allreduce(self._h, h.ctypes.data_as(_i64p), h.size,
+                                              s.ctypes.data_as(C.POINTER(C.c_double))), "drs_stats_allreduce")
+        return h, s
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().drs_comm_destroy(self._h)
+            self._h = None

@@ -44,10 +44,30 @@ struct SlsArgs {
   uint64_t* ts;               // optional [2 * gridDim.x] start/end wall_clock64() per workgroup
 };
 
+// Per-engine tunables (drs_set_option) and the per-device resources every launch needs.
+// Nothing here is process-global: two engines in one process (the mixed-model accelerator
+// engine; engines on different GPUs) keep their own copy.
+struct Tune {
+  int device = 0;
+  const float* zero = nullptr;   // 256 B of zeros on `device`: source of out-of-range float4 loads
+  int sls_u = 0;                 // row loads per register ring and lane (0 = default 4)
+  int sls_v_d32 = 4;             // lane width for D == 32 (4 | 2)
+  int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once
+  int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
+  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 1, mlp_gemm = 1, gemm_tile = 0, mlp_debug = 0;
+};
+// Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs
+// it (HIP function attributes are per device) and the device's zero page.
+hipError_t device_init(int device, const float** zero_page);
+hipError_t mlp_set_attrs();    // mlp.hip's kernels, on the current device
+hipError_t gemm_set_attrs();   // gemm.hip's kernels, on the current device
+
 // launch on `stream`; exact != 0 selects the sequential-order variant.
 // stop_event (optional): recorded by the gather dispatch itself when it completes
-hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t stream, hipEvent_t stop_event = nullptr);
-int64_t sls_grid_blocks(int D, int64_t n_bags, int exact);
+hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t stream,
+                      hipEvent_t stop_event = nullptr);
+int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune);
+bool sls_flat_applicable(const SlsArgs& a, const Tune& tune);   // would a non-exact launch run the flat variant?
 
 // Completion hand-off to the host without a copy or a stream sync: the LAST kernel of a
 // query stores its outputs straight into host-mapped pinned memory and, once every one
@@ -85,12 +105,13 @@ struct XSrc {
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                     hipStream_t stream, const Done* done = nullptr, const XSrc* xs = nullptr);
+                     const Tune& tune, hipStream_t stream, const Done* done = nullptr,
+                     const XSrc* xs = nullptr);
 
 // Register-blocked GEMM for wide layers (gemm.hip); false = not applicable, use launch_fc's
 // own kernel.  zero_page: 16 B of zeros in device memory.
 bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
-                 int32_t N, int32_t act, float* y, int64_t ldy, const float* zero_page,
+                 int32_t N, int32_t act, float* y, int64_t ldy, const Tune& tune,
                  hipStream_t stream, const Done& done, const XSrc& xs, hipError_t* err);
 
 // Fused chain of up to DRS_MAX_CHAIN FC layers on 16-row slabs; intermediate
@@ -108,9 +129,9 @@ struct ChainArgs {
   float* y;
   int64_t ldy;
 };
-hipError_t launch_chain(const ChainArgs& a, hipStream_t stream, const Done* done = nullptr,
-                        const XSrc* xs = nullptr);
-size_t chain_lds_bytes(const ChainArgs& a);
+hipError_t launch_chain(const ChainArgs& a, const Tune& tune, hipStream_t stream,
+                        const Done* done = nullptr, const XSrc* xs = nullptr);
+size_t chain_lds_bytes(const ChainArgs& a, const Tune& tune);
 // two chains on the same rows in one launch (bottom MLP, then the top MLP that reads the
 // buffer the first one wrote its last layer into)
 // Optional dot interaction BETWEEN the two chains of launch_chain2 (DLRM "dot",
@@ -134,14 +155,14 @@ struct SumArgs {
   float* dst;
   int64_t ldd;
 };
-hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t stream,
+hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tune, hipStream_t stream,
                          const Done* done = nullptr, const XSrc* xs = nullptr,
                          const DotArgs* dot = nullptr, const SumArgs* sum = nullptr);
 // would launch_chain2(a, &b, ..., dot) run as the stream kernel?  (With a dot interaction in
 // between it is the only kernel that can.)
-bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xs, const DotArgs* dot,
-                       const SumArgs* sum = nullptr);
-size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b);
+bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const Tune& tune, const XSrc* xs,
+                       const DotArgs* dot, const SumArgs* sum = nullptr);
+size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b, const Tune& tune);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot
 hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F, int32_t D,

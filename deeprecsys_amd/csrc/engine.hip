@@ -25,18 +25,36 @@
 
 #include "drs_internal.h"
 
-namespace drs {
-extern int g_sls_u;
-extern int g_sls_v_d32;
-extern int g_mlp_preload;
-extern int g_mlp_kc;
-extern int g_mlp_stream;
-extern int g_mlp_gemm;
-extern int g_gemm_tile;
-extern int g_mlp_debug;
-}  // namespace drs
+#include <mutex>
 
 using namespace drs;
+
+// Per-device one-time setup: HIP function attributes and allocations belong to a
+// device, not to the process -- an engine on GPU 1 created after one on GPU 0 needs its own
+// > 64 KB LDS opt-in and its own zero page.  Thread-safe; the table is indexed by device id.
+namespace drs {
+hipError_t device_init(int device, const float** zero_page) {
+  constexpr int kMaxDevices = 64;
+  static std::mutex mu;
+  static bool done[kMaxDevices];
+  static float* zero[kMaxDevices];
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!done[device]) {
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = mlp_set_attrs();
+    if (e == hipSuccess) e = gemm_set_attrs();
+    if (e == hipSuccess && !zero[device]) {
+      e = hipMalloc(reinterpret_cast<void**>(&zero[device]), 256);
+      if (e == hipSuccess) e = hipMemset(zero[device], 0, 256);
+    }
+    if (e != hipSuccess) return e;
+    done[device] = true;
+  }
+  *zero_page = zero[device];
+  return hipSuccess;
+}
+}  // namespace drs
 
 namespace {
 
@@ -99,6 +117,7 @@ struct Slot {
   size_t h_stage_bytes = 0;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool ev_pending = false;
+  int64_t ts_bytes = 0;      // algorithmic bytes of the gather launch being timed
   int32_t last_bs = 0;       // total valid samples of the job in flight
   int32_t last_n = 0;        // queries coalesced into it
   int32_t q_bs[DRS_MAX_COALESCE] = {0};
@@ -144,7 +163,9 @@ struct drs_engine {
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
   int64_t k_n[DRS_KERNEL_COUNT] = {0, 0, 0};
+  int64_t k_bytes[DRS_KERNEL_COUNT] = {0, 0, 0};   // algorithmic bytes of exactly the launches in k_ms / k_n
   double wall_clock_khz = 100000.0;
+  Tune tune;                     // per-engine tunables + this device's zero page
   std::string err;
 };
 
@@ -273,7 +294,7 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
       while (l0 + cnt < n_layers && cnt < DRS_MAX_CHAIN && !is_wide(e, m, l0 + cnt)) ++cnt;
       for (;;) {
         fill_chain(c, m, l0, cnt, in, ldin, M, nullptr, 0);
-        if (chain_lds_bytes(c) <= kChainLds) break;
+        if (chain_lds_bytes(c, e->tune) <= kChainLds) break;
         if (cnt == 1) { standalone = true; break; }
         --cnt;
       }
@@ -283,11 +304,11 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
     const int64_t ldo = last ? ldy : e->ldH;
     if (standalone) {
       HIP_TRY(e, launch_fc(in, ldin, M, m.ln[l0], m.layers[l0].W, m.layers[l0].b, m.ln[l0 + 1],
-                           act_of(m, l0), out, ldo, s.stream, last ? done : nullptr,
+                           act_of(m, l0), out, ldo, e->tune, s.stream, last ? done : nullptr,
                            l0 == 0 ? xs : nullptr));
     } else {
       c.y = out; c.ldy = ldo;
-      HIP_TRY(e, launch_chain(c, s.stream, last ? done : nullptr, l0 == 0 ? xs : nullptr));
+      HIP_TRY(e, launch_chain(c, e->tune, s.stream, last ? done : nullptr, l0 == 0 ? xs : nullptr));
     }
     in = out; ldin = ldo; l0 += cnt;
   }
@@ -314,13 +335,13 @@ FusedPlan fused_plan(const drs_engine* e, const Slot& s, int64_t Mv, float* out,
   fill_chain(p.a, e->bot, 0, nb, nullptr, e->m_den, Mv, s.T, e->ldT);
   if (e->interaction_op == DRS_INTERACT_CAT) {
     fill_chain(p.b, e->top, 0, nt, s.T, e->ldT, Mv, out, e->n_out);
-    p.ok = chain2_lds_bytes(p.a, p.b) <= kChainLds || stream_applicable(p.a, p.b, xs, nullptr);
+    p.ok = chain2_lds_bytes(p.a, p.b, e->tune) <= kChainLds || stream_applicable(p.a, p.b, e->tune, xs, nullptr);
   } else {
     fill_chain(p.b, e->top, 0, nt, s.R, e->ldR, Mv, out, e->n_out);
     p.dot.T = s.T; p.dot.ldt = e->ldT; p.dot.F = e->T + 1; p.dot.D = e->D; p.dot.itself = e->itself;
     p.dot.R = s.R; p.dot.ldr = e->ldR;
     p.has_dot = true;
-    p.ok = stream_applicable(p.a, p.b, xs, &p.dot);   // only the stream kernel has the interaction
+    p.ok = stream_applicable(p.a, p.b, e->tune, xs, &p.dot);   // only the stream kernel has the interaction
   }
   return p;
 }
@@ -334,7 +355,7 @@ bool try_fused_bottom_top(drs_engine* e, Slot& s, int64_t Mv, float* out, const 
   *rc = DRS_OK;
   FusedPlan p = fused_plan(e, s, Mv, out, xs);
   if (!p.ok) return false;
-  hipError_t r = launch_chain2(p.a, &p.b, s.stream, dp, xs, p.has_dot ? &p.dot : nullptr);
+  hipError_t r = launch_chain2(p.a, &p.b, e->tune, s.stream, dp, xs, p.has_dot ? &p.dot : nullptr);
   if (r != hipSuccess) *rc = fail(e, DRS_ERR_HIP, "launch_chain2: %s", hipGetErrorString(r));
   return true;
 }
@@ -417,12 +438,24 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   // wave-per-bag variant: a lane group per bag is both faster there and bit-exact.
   bool short_bags = true;
   for (int i = 0; i < q.n_q; ++i) short_bags = short_bags && qb[i]->uniform_len >= 0 && qb[i]->uniform_len <= e->sls_short_bag;
-  const int exact_now = e->sls_exact || short_bags;
-  s.ts_blocks = prof ? sls_grid_blocks(e->D, (int64_t)c * e->T, exact_now) : 0;
+  // ... unless the flat variant takes the launch (fixed-length bags of >= 2 rows: several short
+  // bags share a wave and all of its row loads are in flight at once)
+  const int exact_now = e->sls_exact || (short_bags && !sls_flat_applicable(a, e->tune));
+  s.ts_blocks = prof ? sls_grid_blocks(a, exact_now, e->tune) : 0;
+  if (prof) {
+    // algorithmic bytes of THIS launch (rows + int32 indices + length + pooled output
+    // per bag), so that achieved GB/s = sum(bytes) / sum(duration) over exactly the timed launches
+    int64_t bytes = 0;
+    for (int i = 0; i < q.n_q; ++i)
+      for (int t = 0; t < e->T; ++t)
+        bytes += (int64_t)qb[i]->h_off[(size_t)t * (e->max_batch + 1) + q.bs[i]] * ((int64_t)e->D * 4 + 4) +
+                 (int64_t)q.bs[i] * (4 + (int64_t)e->D * 4);
+    s.ts_bytes = bytes;
+  }
   // pipelined mode: the event the MLP stream waits for is recorded by the gather dispatch itself
   // (hipExtLaunchKernel's stop event = the packet's completion signal): no marker packet sits
   // between consecutive gathers (a hipEventRecord there costs ~2 us per set)
-  HIP_TRY(e, launch_sls(a, exact_now, s.gather_stream, piped ? s.ev_sls : nullptr));
+  HIP_TRY(e, launch_sls(a, exact_now, e->tune, s.gather_stream, piped ? s.ev_sls : nullptr));
   if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.gather_stream));
   bool joined = !piped;   // has s.stream been made to wait for the gather yet?
   auto join = [&]() -> hipError_t {
@@ -464,8 +497,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       SumArgs sum = {s.T, e->ldT, 0, D, D, s.H2, ldc};
       bool wide = false;
       for (int l = 0; l < nt; ++l) wide = wide || is_wide(e, e->top, l);
-      if (!wide && !is_wide(e, e->fin, 0) && stream_applicable(ca, cb, nullptr, nullptr, &sum)) {
-        HIP_TRY(e, launch_chain2(ca, &cb, s.stream, dp, nullptr, nullptr, &sum));
+      if (!wide && !is_wide(e, e->fin, 0) && stream_applicable(ca, cb, e->tune, nullptr, nullptr, &sum)) {
+        HIP_TRY(e, launch_chain2(ca, &cb, e->tune, s.stream, dp, nullptr, nullptr, &sum));
         fused = true;
       }
     }
@@ -511,8 +544,13 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   return DRS_OK;
 }
 
-int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
+int32_t wait_slot(drs_engine* e, Slot& s, float* h_out, int64_t h_cap = -1) {
   if (!s.busy) return DRS_OK;
+  // the caller's buffer must hold what was SUBMITTED on this slot (a mismatched bs
+  // after a multi-query submit used to overflow the heap silently); the job stays in flight
+  if (h_out && h_cap >= 0 && h_cap < (int64_t)s.last_bs * e->n_out)
+    return fail(e, DRS_ERR_BAD_ARG, "output buffer holds %lld floats, the %d queries on this slot produce %lld",
+                (long long)h_cap, s.last_n, (long long)s.last_bs * e->n_out);
   if (s.polled && s.last_bs > 0) {
     // spin on the flag the last kernel publishes (bounded: fall back to a stream sync)
     volatile uint32_t* flag = s.h_out;
@@ -539,7 +577,7 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
   if (s.ev_pending) {
     HIP_TRY(e, hipEventSynchronize(s.ev[2]));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) { e->k_ms[DRS_KERNEL_SLS] += ms; e->k_n[DRS_KERNEL_SLS]++; }
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) { e->k_ms[DRS_KERNEL_SLS] += ms; e->k_n[DRS_KERNEL_SLS]++; e->k_bytes[DRS_KERNEL_SLS] += s.ts_bytes; }
     if (hipEventElapsedTime(&ms, s.ev[1], s.ev[2]) == hipSuccess) { e->k_ms[DRS_KERNEL_MLP] += ms; e->k_n[DRS_KERNEL_MLP]++; }
     s.ev_pending = false;
   }
@@ -557,6 +595,7 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out) {
     if (hi > lo) {
       e->k_ms[DRS_KERNEL_SLS_CLOCK] += (double)(hi - lo) / e->wall_clock_khz;
       e->k_n[DRS_KERNEL_SLS_CLOCK]++;
+      e->k_bytes[DRS_KERNEL_SLS_CLOCK] += s.ts_bytes;
     }
     s.ts_blocks_done = s.ts_blocks;
     s.ts_blocks = 0;
@@ -684,6 +723,9 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     if (e->rows[t] * (int64_t)D >= (1ll << 32)) return bail(DRS_ERR_UNSUPPORTED, "rows*D must be < 2^32 per table");
   }
 
+  // prefix sums and bag * length products are int32 on the device
+  if ((int64_t)cfg->max_batch * cfg->max_lookups >= (1ll << 31) / DRS_MAX_COALESCE)
+    return bail(DRS_ERR_UNSUPPORTED, "max_batch * max_lookups must stay below 2^31 / 8");
   if (set_device(e)) return bail(DRS_ERR_HIP, e->err.c_str());
   {
     int khz = 0;
@@ -698,8 +740,12 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     off += round_up(e->rows[t] * D, 64);  // 256-B aligned
   }
   e->table_set.assign(T, false);
-  auto hip_ok = [&](hipError_t rr) { if (rr != hipSuccess) { e->err = hipGetErrorString(rr); return false; } return true; };
-#define CREATE_TRY(call) if (!hip_ok(call)) return bail(DRS_ERR_OOM, (std::string(#call ": ") + e->err).c_str())
+  hipError_t last_rr = hipSuccess;
+  auto hip_ok = [&](hipError_t rr) { last_rr = rr; if (rr != hipSuccess) { e->err = hipGetErrorString(rr); return false; } return true; };
+  // only an allocation failure is DRS_ERR_OOM; stream/event creation, bad device ... are DRS_ERR_HIP
+#define CREATE_TRY(call) if (!hip_ok(call)) return bail(last_rr == hipErrorOutOfMemory ? DRS_ERR_OOM : DRS_ERR_HIP, (std::string(#call ": ") + e->err).c_str())
+  e->tune.device = device_id;
+  CREATE_TRY(device_init(device_id, &e->tune.zero));
   CREATE_TRY(hipMalloc(&e->tables, sizeof(float) * (size_t)off));
   CREATE_TRY(hipMalloc(&e->d_tab_off, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_tab_rows, sizeof(int64_t) * T));
@@ -910,7 +956,7 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
   const size_t dense_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1);
   const size_t idx_bytes = sizeof(int32_t) * (size_t)e->T * e->cap;
   const size_t off_bytes = sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1);
-  std::vector<int32_t> tmp_idx;
+  std::vector<int32_t> tmp_idx, tmp_off;
   int32_t* idx32;
   int32_t* off32;
   float* dense_stage = nullptr;
@@ -919,13 +965,19 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
     idx32 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(pinned) + dense_bytes);
     off32 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(pinned) + dense_bytes + idx_bytes);
   } else {
+    // validate into temporaries: a failure part-way (index range on table 3) must leave a
+    // previously staged batch exactly as it was
     tmp_idx.resize((size_t)e->T * e->cap);
+    tmp_off.resize((size_t)e->T * (e->max_batch + 1));
     idx32 = tmp_idx.data();
-    off32 = b.h_off.data();
+    off32 = tmp_off.data();
   }
   int32_t rc = convert_inputs(e, n, h_idx, n_idx, h_len, idx32, off32);
-  if (rc) return rc;
-  if (pinned) memcpy(b.h_off.data(), off32, off_bytes);
+  if (rc) {
+    if (pinned) { b.staged = false; b.n_samples = 0; }   // the slot's pinned block was overwritten: nothing valid in it
+    return rc;
+  }
+  memcpy(b.h_off.data(), off32, off_bytes);
   if (in_place) {
     // `b` aliases the pinned block: the converted indices/offsets are already where the
     // kernels will read them (over PCIe, once); only the dense rows need a host copy
@@ -1001,17 +1053,18 @@ int32_t drs_forward_multi_async(drs_handle e, int32_t slot, int32_t n, const int
   return enqueue_forward(e, s, n, bts, bs);
 }
 
-int32_t drs_wait(drs_handle e, int32_t slot, float* h_out) {
+int32_t drs_wait(drs_handle e, int32_t slot, float* h_out, int64_t h_out_floats) {
   int32_t rc = check_handle(e);
   if (rc) return rc;
   if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
-  return wait_slot(e, e->slots[slot], h_out);
+  if (h_out && h_out_floats < 0) return fail(e, DRS_ERR_BAD_ARG, "negative output capacity");
+  return wait_slot(e, e->slots[slot], h_out, h_out_floats);
 }
 
 int32_t drs_forward(drs_handle e, int32_t batch_id, int32_t bs, float* h_out) {
   int32_t rc = drs_forward_async(e, 0, batch_id, bs);
   if (rc) return rc;
-  return drs_wait(e, 0, h_out);
+  return wait_slot(e, e->slots[0], h_out);
 }
 
 int32_t drs_sync(drs_handle e) {
@@ -1061,7 +1114,9 @@ int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* 
 int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R) {
   int32_t rc = check_handle(e);
   if (rc) return rc;
-  if (slot < 0 || slot >= e->n_slots || !h_R || bs < 0 || bs > e->max_batch) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
+  // rows are VIRTUAL rows of the slot: coalesced query i sits at the 64-row aligned offset
+  // sum of round_up(bs_j, 64) over j < i; a single query starts at row 0
+  if (slot < 0 || slot >= e->n_slots || !h_R || bs < 0 || bs > e->max_rows) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
   Slot& s = e->slots[slot];
   HIP_TRY(e, hipStreamSynchronize(s.stream));
   const float* src;
@@ -1127,7 +1182,7 @@ int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const i
     a.q.n_q = 1; a.q.vstart[1] = (int32_t)n_bags; a.q.cum[1] = (int32_t)n_bags; a.q.bs[0] = (int32_t)n_bags;
     a.idx[0] = d_idx; a.off[0] = d_off; a.uniform_len[0] = -1;
     a.out = d_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.err = d_err; a.ts = nullptr;
-    r = launch_sls(a, exact_order, s.stream);
+    r = launch_sls(a, exact_order, e->tune, s.stream);
   }
   if (r == hipSuccess) r = hipStreamSynchronize(s.stream);
   if (r == hipSuccess) r = hipMemcpy(&h_err, d_err, sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -1145,7 +1200,7 @@ int32_t drs_fc(drs_handle e, const float* d_x, int64_t M, int32_t K, const float
   if (!d_x || !d_W || !d_y || M < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
   Slot& s = e->slots[0];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
-  HIP_TRY(e, launch_fc(d_x, K, M, K, d_W, d_b, N, act, d_y, N, s.stream));
+  HIP_TRY(e, launch_fc(d_x, K, M, K, d_W, d_b, N, act, d_y, N, e->tune, s.stream));
   HIP_TRY(e, hipStreamSynchronize(s.stream));
   return DRS_OK;
 }
@@ -1168,8 +1223,10 @@ int32_t drs_interact_dot(drs_handle e, const float* d_T, int64_t B, int32_t F, i
 int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   if (!e || !key) return DRS_ERR_BAD_ARG;
   if (!strcmp(key, "sls_exact")) e->sls_exact = value ? 1 : 0;
-  else if (!strcmp(key, "sls_u") && (value == 0 || value == 4 || value == 8 || value == 16 || value == 20)) g_sls_u = (int)value;
-  else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) g_sls_v_d32 = (int)value;
+  else if (!strcmp(key, "sls_u") && (value == 0 || value == 4 || value == 8 || value == 16 || value == 20)) e->tune.sls_u = (int)value;
+  else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) e->tune.sls_v_d32 = (int)value;
+  else if (!strcmp(key, "sls_flat")) e->tune.sls_flat = value ? 1 : 0;
+  else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
   else if (!strcmp(key, "shared_stream")) {
@@ -1190,12 +1247,12 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
-  else if (!strcmp(key, "mlp_preload")) g_mlp_preload = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_stream")) g_mlp_stream = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_gemm")) g_mlp_gemm = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11)) g_gemm_tile = (int)value;
-  else if (!strcmp(key, "mlp_debug")) g_mlp_debug = (int)value;
-  else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) g_mlp_kc = (int)value;
+  else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_stream")) e->tune.mlp_stream = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11)) e->tune.gemm_tile = (int)value;
+  else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
+  else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;
@@ -1229,8 +1286,30 @@ int32_t drs_debug_gather_stamps(drs_handle e, int32_t slot, uint64_t* out, int64
 
 int32_t drs_reset_kernel_time(drs_handle e) {
   if (!e) return DRS_ERR_BAD_ARG;
-  for (int i = 0; i < DRS_KERNEL_COUNT; ++i) { e->k_ms[i] = 0; e->k_n[i] = 0; }
+  for (int i = 0; i < DRS_KERNEL_COUNT; ++i) { e->k_ms[i] = 0; e->k_n[i] = 0; e->k_bytes[i] = 0; }
   return DRS_OK;
+}
+
+int32_t drs_kernel_bytes(drs_handle e, int32_t kernel, int64_t* bytes) {
+  if (!e || kernel < 0 || kernel >= DRS_KERNEL_COUNT || !bytes) return DRS_ERR_BAD_ARG;
+  *bytes = e->k_bytes[kernel];
+  return DRS_OK;
+}
+
+int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
+  if (!e || !key || !value) return DRS_ERR_BAD_ARG;
+  const Tune& t = e->tune;
+  struct { const char* k; int64_t v; } tab[] = {
+      {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
+      {"sls_bpw", t.sls_bpw}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
+      {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
+      {"mlp_debug", t.mlp_debug}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
+      {"zero_copy_inputs", e->zero_copy_inputs}, {"zero_copy", e->zero_copy}, {"device", e->device}};
+  for (auto& kv : tab)
+    if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
+  return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);
 }
 
 int32_t drs_gather_bytes(drs_handle e, int32_t batch_id, int32_t bs, int64_t* bytes) {

@@ -240,26 +240,27 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
 
 }  // namespace
 
-int g_mlp_gemm = 1;   // drs_set_option "mlp_gemm": wide layers through gemm_kernel
-int g_gemm_tile = 0;  // "mlp_gemm_tile": force TM*10+TN (22 | 12 | 21 | 11), 0 = by block count
+// per device (device_init, engine.hip)
+hipError_t gemm_set_attrs() {
+  for (const void* k : {reinterpret_cast<const void*>(gemm_kernel<2, 2>), reinterpret_cast<const void*>(gemm_kernel<1, 2>),
+                        reinterpret_cast<const void*>(gemm_kernel<2, 1>), reinterpret_cast<const void*>(gemm_kernel<1, 1>)}) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
+// tune.mlp_gemm ("mlp_gemm"): wide layers through gemm_kernel; tune.gemm_tile ("mlp_gemm_tile"):
+// force TM*10+TN (22 | 12 | 21 | 11), 0 = by block count
 // false = not applicable (caller falls back to fc_kernel)
 bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
-                 int32_t N, int32_t act, float* y, int64_t ldy, const float* zero_page,
+                 int32_t N, int32_t act, float* y, int64_t ldy, const Tune& tune,
                  hipStream_t s, const Done& d, const XSrc& xs, hipError_t* err) {
   *err = hipSuccess;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  if (!g_mlp_gemm || !zero_page || (K & 3) || (ldx & 3) || !al(x) || !al(W)) return false;
+  const float* zero_page = tune.zero;
+  if (!tune.mlp_gemm || !zero_page || (K & 3) || (ldx & 3) || !al(x) || !al(W)) return false;
   for (int i = 0; i < xs.q.n_q; ++i) if (!al(xs.x[i])) return false;
-  static bool attr = false;
-  if (!attr) {
-    for (const void* k : {reinterpret_cast<const void*>(gemm_kernel<2, 2>), reinterpret_cast<const void*>(gemm_kernel<1, 2>),
-                          reinterpret_cast<const void*>(gemm_kernel<2, 1>), reinterpret_cast<const void*>(gemm_kernel<1, 1>)}) {
-      *err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (*err != hipSuccess) return true;
-    }
-    attr = true;
-  }
   GArgs a;
   memset(&a, 0, sizeof a);
   a.x = x; a.ldx = ldx; a.M = M; a.W = W; a.b = b; a.y = y; a.ldy = ldy; a.zero = zero_page;
@@ -268,7 +269,7 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   // weight panel is the shared operand, re-read once per row block)
   auto blocks = [&](int tm, int tn) { return ((M + 32 * tm - 1) / (32 * tm)) * (int64_t)((N + 64 * tn - 1) / (64 * tn)); };
   int tm = 2, tn = 2;
-  if (g_gemm_tile) { tm = g_gemm_tile / 10; tn = g_gemm_tile % 10; }
+  if (tune.gemm_tile) { tm = tune.gemm_tile / 10; tn = tune.gemm_tile % 10; }
   else if (blocks(2, 2) >= 256) { tm = 2; tn = 2; }
   else if (blocks(1, 2) >= 256) { tm = 1; tn = 2; }
   else if (blocks(2, 1) >= 256) { tm = 2; tn = 1; }

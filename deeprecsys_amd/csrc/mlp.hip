@@ -814,13 +814,12 @@ static size_t stage_bytes(int kc, int nbuf, int) {
 }
 
 // Fewest K rounds that fit the LDS budget next to `extra` bytes of slabs.
-int g_mlp_kc = 0;   // drs_set_option "mlp_kc": force the K chunk (0 = fewest rounds that fit)
-
-static bool pick_kc(int maxK, size_t extra, int nt, int* kc_out, int* nbuf_out) {
+// force_kc: drs_set_option "mlp_kc" (0 = fewest rounds that fit)
+static bool pick_kc(int maxK, size_t extra, int nt, int force_kc, int* kc_out, int* nbuf_out) {
   const int cands[4] = {256, 192, 128, 64};
   int best_kc = 0, best_nbuf = 0, best_rounds = 1 << 30;
   for (int kc : cands) {
-    if (g_mlp_kc && kc != g_mlp_kc) continue;
+    if (force_kc && kc != force_kc) continue;
     const int rounds = (maxK + kc - 1) / kc;
     const int nbuf = rounds > 1 ? 2 : 1;
     if (stage_bytes(kc, nbuf, nt) + extra > kLdsBudget) continue;
@@ -841,17 +840,10 @@ static hipError_t set_max_lds(F kernel) {
 
 #define DRS_FOR_EACH_KC(X) X(64) X(128) X(192) X(256)
 
-static float* g_zero_dev = nullptr;
-
-static hipError_t init_mlp_kernels() {
-  static bool done = false;
-  if (done) return hipSuccess;
+// HIP function attributes are per device: device_init() (engine.hip) calls this once for
+// every device an engine is created on.
+hipError_t mlp_set_attrs() {
   hipError_t e = hipSuccess;
-  if (!g_zero_dev) {
-    e = hipMalloc(reinterpret_cast<void**>(&g_zero_dev), 256);
-    if (e == hipSuccess) e = hipMemset(g_zero_dev, 0, 256);
-    if (e != hipSuccess) return e;
-  }
 #define SET_ATTR(KC_)                                                               \
   if (e == hipSuccess) e = set_max_lds(fc_kernel<true, KC_>);                       \
   if (e == hipSuccess) e = set_max_lds(fc_kernel<false, KC_>);                      \
@@ -860,13 +852,13 @@ static hipError_t init_mlp_kernels() {
   DRS_FOR_EACH_KC(SET_ATTR)
 #undef SET_ATTR
   if (e == hipSuccess) e = set_max_lds(stream_kernel);
-  if (e == hipSuccess) done = true;
+  if (e == hipSuccess) e = set_max_lds(interact_dot_kernel);
   return e;
 }
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
                      const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                     hipStream_t s, const Done* done, const XSrc* xsrc) {
+                     const Tune& tune, hipStream_t s, const Done* done, const XSrc* xsrc) {
   if (M <= 0) return hipSuccess;
   Done d;
   memset(&d, 0, sizeof d);
@@ -874,14 +866,12 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   if (xsrc) xs = *xsrc;
-  hipError_t e = init_mlp_kernels();
-  if (e != hipSuccess) return e;
   if (N >= 64 && K >= 64) {
     hipError_t ge = hipSuccess;
-    if (launch_gemm(x, ldx, M, K, W, b, N, act, y, ldy, g_zero_dev, s, d, xs, &ge)) return ge;
+    if (launch_gemm(x, ldx, M, K, W, b, N, act, y, ldy, tune, s, d, xs, &ge)) return ge;
   }
   int kc = 64, nbuf = 2;
-  if (!pick_kc(K, 0, 2, &kc, &nbuf)) return hipErrorInvalidValue;
+  if (!pick_kc(K, 0, 2, tune.mlp_kc, &kc, &nbuf)) return hipErrorInvalidValue;
 #ifdef DRS_TIMELINE
   const size_t lds = stage_bytes(kc, nbuf, 2) + 8192;
 #else
@@ -911,11 +901,9 @@ static int chain_slab_ld2(const ChainArgs& a, const ChainArgs* b) {
   return (w + 3) / 4 * 4 + 4;
 }
 
-int g_mlp_preload = 0;   // drs_set_option "mlp_preload"
-
 // ldA > 0: the chains' input slab (16 x K0) is preloaded into LDS (see run_chain)
-static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbuf, size_t* lds,
-                       int* ldA) {
+static bool chain_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune, int* kc, int* nbuf,
+                       size_t* lds, int* ldA) {
   int maxK = 1, k0 = a.width[0];
   for (int l = 0; l < a.n_layers; ++l) maxK = a.width[l] > maxK ? a.width[l] : maxK;
   if (b) {
@@ -924,38 +912,35 @@ static bool chain_plan(const ChainArgs& a, const ChainArgs* b, int* kc, int* nbu
   }
   const size_t slabs = sizeof(float) * (size_t)2 * 16 * chain_slab_ld2(a, b);
   const int lda = (k0 + 3) / 4 * 4 + 4;
-  const size_t pre = (g_mlp_preload && k0 <= 640) ? sizeof(float) * (size_t)16 * lda : 0;
-  if (pre && pick_kc(maxK, slabs + pre, 2, kc, nbuf)) {
+  const size_t pre = (tune.mlp_preload && k0 <= 640) ? sizeof(float) * (size_t)16 * lda : 0;
+  if (pre && pick_kc(maxK, slabs + pre, 2, tune.mlp_kc, kc, nbuf)) {
     *lds = stage_bytes(*kc, *nbuf, 2) + slabs + pre;
     *ldA = lda;
     return true;
   }
-  if (!pick_kc(maxK, slabs, 2, kc, nbuf)) return false;
+  if (!pick_kc(maxK, slabs, 2, tune.mlp_kc, kc, nbuf)) return false;
   *lds = stage_bytes(*kc, *nbuf, 2) + slabs;
   *ldA = 0;
   return true;
 }
 
-size_t chain_lds_bytes(const ChainArgs& a) {
+size_t chain_lds_bytes(const ChainArgs& a, const Tune& tune) {
   int kc, nbuf, lda;
   size_t lds;
-  return chain_plan(a, nullptr, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
+  return chain_plan(a, nullptr, tune, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
 }
 
-size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b) {
+size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b, const Tune& tune) {
   int kc, nbuf, lda;
   size_t lds;
-  return chain_plan(a, &b, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
+  return chain_plan(a, &b, tune, &kc, &nbuf, &lds, &lda) ? lds : (size_t)1 << 30;
 }
-
-int g_mlp_debug = 0;
-int g_mlp_stream = 1;   // drs_set_option "mlp_stream": use stream_kernel where it applies
 
 static inline int pad64(int n) { return (n + 63) & ~63; }
 
 // Lay the chain(s) out for stream_kernel.  false = not applicable (caller uses chain_kernel).
-static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, bool publish,
-                        SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr,
+static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune, const XSrc& xs,
+                        bool publish, SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr,
                         const SumArgs* sum = nullptr) {
   SArgs& p = *out;
   memset(&p, 0, sizeof p);
@@ -1058,8 +1043,8 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
   p.bias_off = bias_off;
   p.bias = a.b[0];
   p.M = a.M;
-  p.zero = g_zero_dev;
-  p.dbg = g_mlp_debug;
+  p.zero = tune.zero;
+  p.dbg = tune.mlp_debug;
   SInput& i0 = p.in[0];
   i0.src = a.x; i0.ld = a.ldx; i0.col0 = 0; i0.cols = a.width[0]; i0.cols_pad = pad64(a.width[0]);
   i0.lds_off = x0_off; i0.lds_ld = x0_ld; i0.lds_col0 = 0; i0.use_xs = xs.q.n_q > 0;
@@ -1087,19 +1072,19 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const XSrc& xs, 
   return true;
 }
 
-bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const XSrc* xsrc, const DotArgs* dot,
-                       const SumArgs* sum) {
-  if (!g_mlp_stream || init_mlp_kernels() != hipSuccess) return false;
+bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const Tune& tune, const XSrc* xsrc,
+                       const DotArgs* dot, const SumArgs* sum) {
+  if (!tune.mlp_stream || !tune.zero) return false;
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   if (xsrc) xs = *xsrc;
   SArgs sp;
   size_t lds = 0;
-  return stream_plan(a, &b, xs, true, &sp, &lds, dot, sum);
+  return stream_plan(a, &b, tune, xs, true, &sp, &lds, dot, sum);
 }
 
-hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, const Done* done,
-                         const XSrc* xsrc, const DotArgs* dot, const SumArgs* sum) {
+hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tune, hipStream_t s,
+                         const Done* done, const XSrc* xsrc, const DotArgs* dot, const SumArgs* sum) {
   if (a.M <= 0) return hipSuccess;
   Done d;
   memset(&d, 0, sizeof d);
@@ -1109,12 +1094,10 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
   if (xsrc) xs = *xsrc;
   if (a.n_layers < 1 || a.n_layers > DRS_MAX_CHAIN || (b && (b->n_layers < 1 || b->n_layers > DRS_MAX_CHAIN)))
     return hipErrorInvalidValue;
-  hipError_t e = init_mlp_kernels();
-  if (e != hipSuccess) return e;
-  if (g_mlp_stream) {
+  if (tune.mlp_stream && tune.zero) {
     SArgs sp;
     size_t slds = 0;
-    if (stream_plan(a, b, xs, d.counter != nullptr, &sp, &slds, dot, sum)) {
+    if (stream_plan(a, b, tune, xs, d.counter != nullptr, &sp, &slds, dot, sum)) {
 #ifdef DRS_TIMELINE
       slds += 8192;
 #endif
@@ -1125,7 +1108,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
   if (dot || sum) return hipErrorInvalidValue;   // only the stream kernel has these joins (callers check stream_applicable)
   int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
-  if (!chain_plan(a, b, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;
+  if (!chain_plan(a, b, tune, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;
 #ifdef DRS_TIMELINE
   lds += 8192;
 #endif
@@ -1153,8 +1136,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, hipStream_t s, 
   return hipGetLastError();
 }
 
-hipError_t launch_chain(const ChainArgs& a, hipStream_t s, const Done* done, const XSrc* xsrc) {
-  return launch_chain2(a, nullptr, s, done, xsrc, nullptr, nullptr);
+hipError_t launch_chain(const ChainArgs& a, const Tune& tune, hipStream_t s, const Done* done,
+                        const XSrc* xsrc) {
+  return launch_chain2(a, nullptr, tune, s, done, xsrc, nullptr, nullptr);
 }
 
 #ifdef DRS_TIMELINE
@@ -1174,14 +1158,7 @@ hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F
   if (B <= 0) return hipSuccess;
   const int Fp = (F + 15) & ~15;
   const size_t lds = sizeof(float) * 4 * (size_t)Fp * (D + 1);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(interact_dot_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (lds > 160 * 1024) return hipErrorInvalidValue;   // (attribute: mlp_set_attrs, per device)
   hipLaunchKernelGGL(interact_dot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, s, T, ldt,
                      B, F, D, itself, R, ldr);
   return hipGetLastError();

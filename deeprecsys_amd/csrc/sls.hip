@@ -18,6 +18,14 @@
 //   - SPLIT variant: the wave owns one bag, lane group g takes rows g, g+64/G, ...
 //     and the partial sums are combined with a wave-wide xor butterfly
 //     (different fp32 summation order -> tolerance compare, not bitwise).
+//   - FLAT variant (fixed-length bags -- every shipped reference config generates
+//     num_indices_per_lookup_fixed inputs): a wave owns BPW consecutive bags of one sample
+//     (R = BPW*L flattened rows), lane group g takes rows g, g+64/G, ... and ALL of a
+//     lane's NL = ceil(R / (64/G)) row loads are issued before the first one is consumed;
+//     the indices come from ONE coalesced read (lane i owns row i) and reach the loading
+//     lanes through the cross-lane network (ds_bpermute), not LDS.  Two dependent HBM round
+//     trips per wave (indices, rows) instead of the five or more of a ring walk: short bags
+//     (RM3: 20 x 128 B) and single-query launches spend their time streaming, not waiting.
 //   - the bag's offsets come from the staged prefix-sum vector; its indices are
 //     staged in LDS by one coalesced read per wave (CH at a time) and then
 //     broadcast-read by the lanes of the group; no __syncthreads: a wave only
@@ -239,12 +247,127 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// FLAT variant: fixed-length bags, G lanes per row (16 B per lane), NL loads per lane, BPW
+// bags (same sample, consecutive tables) per wave.  Requires L * BPW <= NL * (64 / G) and
+// T % BPW == 0 (checked by launch_sls).
+template <int G, int NL, int BPW>
+__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
+  constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
+  constexpr int NI = (NL * NG + 63) / 64;          // index registers per lane
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int col = min(gl * 4, a.D - 4);            // clamp idle lanes onto valid columns
+  const bool col_ok = gl * 4 < a.D;
+
+  // the wave's bags: all of one sample (T % BPW == 0), tables t0 .. t0+BPW-1 -- uniform
+  const int64_t bag0 = (int64_t)blockIdx.x * BPW;
+  const int smp = (int)(bag0 / a.T);
+  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
+  int b = smp, vrow = a.q.vstart[0] + smp;
+  const int32_t* qidx = a.idx[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    qidx = in ? a.idx[i] : qidx;
+  }
+  const int R = BPW * L;
+  const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
+  const float* Wk[BPW];
+  uint32_t rows_k[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) {
+    Wk[k] = a.tables + a.tab_off[t0 + k] + col;
+    rows_k[k] = (uint32_t)a.tab_rows[t0 + k];
+  }
+  // which of the wave's bags does flattened row j belong to (j < R)
+  auto bag_of = [&](int j) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < BPW; ++q) k += j >= q * L ? 1 : 0;
+    return k;
+  };
+
+  // ONE coalesced index read: lane i owns flattened rows i, i+64, ...; range check (Caffe2
+  // ENFORCE) and the row's element offset inside its table are computed by the owner
+  uint32_t roff[NI];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int i = lane + 64 * q;
+    const int ii = min(i, R - 1);
+    const int k = bag_of(ii);
+    const int32_t* ip = qidx + (int64_t)(t0 + k) * a.idx_stride + (int64_t)b * L + (ii - k * L);
+    uint32_t r = (uint32_t)*ip;
+    uint32_t rk = rows_k[0];
+#pragma unroll
+    for (int z = 1; z < BPW; ++z) rk = k == z ? rows_k[z] : rk;
+    bad |= i < R && r >= rk;
+    r = r < rk ? r : 0u;
+    roff[q] = r * Du;
+  }
+
+  // every row load of the wave, back to back
+  float4 v[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;                      // (j >> 6) == (NG * u) >> 6: compile time
+    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], j & 63);
+    const float* W = Wk[0];
+    if (BPW > 1) {
+      const int k = bag_of(min(j, R - 1));
+#pragma unroll
+      for (int z = 1; z < BPW; ++z) W = k == z ? Wk[z] : W;
+    }
+    v[u] = *reinterpret_cast<const float4*>(W + (uint64_t)ro);
+  }
+
+  float4 acc[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) acc[k] = vzero4();
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;
+    if (BPW == 1) {
+      vadd(acc[0], vsel<4>(j < R, v[u]));
+    } else {
+      const int kj = bag_of(min(j, R - 1));
+#pragma unroll
+      for (int k = 0; k < BPW; ++k) vadd(acc[k], vsel<4>(j < R && kj == k, v[u]));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < BPW; ++k)
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) vadd(acc[k], vshfl_xor(acc[k], m));
+
+  if (bad) atomicOr(a.err, 1);
+  // lane group k stores bag k (every group holds every sum after the butterfly)
+  if (col_ok && g < BPW) {
+    float4 o4 = acc[0];
+#pragma unroll
+    for (int k = 1; k < BPW; ++k) o4 = g == k ? acc[k] : o4;
+    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)(t0 + g) * a.D + col;
+    *reinterpret_cast<float4*>(o) = o4;
+  }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);   // include the output store in the span
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
 // stop: optional event recorded BY the kernel dispatch itself (its completion signal) -- no
 // separate marker packet between this launch and the next one on the stream
-template <typename K>
-void launch_k(K kernel, unsigned grid, hipStream_t s, hipEvent_t stop, const SlsArgs& a) {
-  if (stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, nullptr, stop, 0, a);
-  else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, a);
+template <typename K, typename... X>
+void launch_k(K kernel, unsigned grid, hipStream_t s, hipEvent_t stop, const X&... x) {
+  if (stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, nullptr, stop, 0, x...);
+  else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, x...);
 }
 
 template <int G, int V, int U>
@@ -271,28 +394,98 @@ hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s, hipEvent_
   }
 }
 
+int lanes_per_row(int D) { return D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64; }
+
+// Shape of the flat variant for this launch, or ok == false: every coalesced query must have
+// the same fixed bag length L >= 1, G must be one of the instantiated widths, BPW must divide T
+// (a wave's bags belong to one sample) and BPW * L rows must fit NL loads per lane.
+struct FlatPlan {
+  bool ok = false;
+  int G = 0, NL = 0, BPW = 1, L = 0;
+};
+FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
+  FlatPlan p;
+  if (!tune.sls_flat || a.q.n_q < 1) return p;
+  const int L = a.uniform_len[0];
+  for (int i = 1; i < a.q.n_q; ++i) if (a.uniform_len[i] != L) return p;
+  if (L < 2) return p;                      // L == 1 is a copy: the lane-group-per-bag kernel
+  const int G = lanes_per_row(a.D);
+  if (G != 8 && G != 16 && G != 32) return p;
+  const int NG = 64 / G;
+  int bpw = 1;
+  if (tune.sls_bpw > 0) {
+    bpw = tune.sls_bpw;
+    if ((bpw != 1 && bpw != 2 && bpw != 4) || a.T % bpw) return p;
+  } else {
+    // short bags share a wave until it has about ten loads per lane to issue
+    for (int c : {4, 2})
+      if (a.T % c == 0 && c * L <= 10 * NG) { bpw = c; break; }
+  }
+  const int need = (bpw * L + NG - 1) / NG;
+  const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : 0;
+  if (!nl || (bpw > 1 && nl > 10)) return p;
+  p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L;
+  return p;
+}
+
+template <int G, int NL>
+hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, unsigned grid, hipStream_t s, hipEvent_t stop) {
+  if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L);
+  else if constexpr (NL <= 10) {
+    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L);
+    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L);
+  }
+  return hipGetLastError();
+}
+template <int G>
+hipError_t launch_flat_g(const SlsArgs& a, const FlatPlan& p, unsigned grid, hipStream_t s, hipEvent_t stop) {
+  switch (p.NL) {
+    case 5: return launch_flat_b<G, 5>(a, p, grid, s, stop);
+    case 10: return launch_flat_b<G, 10>(a, p, grid, s, stop);
+    default: return launch_flat_b<G, 20>(a, p, grid, s, stop);
+  }
+}
+hipError_t launch_flat(const SlsArgs& a, const FlatPlan& p, hipStream_t s, hipEvent_t stop) {
+  const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
+  if (n_bags == 0) return hipSuccess;
+  const unsigned grid = (unsigned)(n_bags / p.BPW);
+  switch (p.G) {
+    case 8: return launch_flat_g<8>(a, p, grid, s, stop);
+    case 16: return launch_flat_g<16>(a, p, grid, s, stop);
+    default: return launch_flat_g<32>(a, p, grid, s, stop);
+  }
+}
+
 }  // namespace
 
-// Tunables (set through drs_set_option): row loads per register ring and lane (0 = measured
-// best for 8-query launches: 4 for both variants -- two rings, so 4..8 in flight per lane; the
-// waves per CU provide the rest of the memory-level parallelism) and the lane width used for
-// D == 32 (8 lanes x 16 B or 16 lanes x 8 B).
-int g_sls_u = 0;
-int g_sls_v_d32 = 4;
+// Tunables (drs_set_option, kept per engine in Tune): "sls_u" row loads per register ring and
+// lane of the ring-walk kernel (0 = measured best for 8-query launches: 4 for both variants --
+// two rings, so 4..8 in flight per lane; the waves per CU provide the rest of the memory-level
+// parallelism), "sls_v_d32" the lane width used for D == 32 (8 lanes x 16 B or 16 lanes x 8 B),
+// "sls_flat" / "sls_bpw" the flat variant and its bags per wave (0 = auto).
+bool sls_flat_applicable(const SlsArgs& a, const Tune& tune) { return flat_plan(a, tune).ok; }
 
-int64_t sls_grid_blocks(int D, int64_t n_bags, int exact) {
-  if (!exact) return n_bags;
-  int G = D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
-  if (D == 32 && g_sls_v_d32 == 2) G = 16;
+int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
+  const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
+  if (!exact) {
+    const FlatPlan p = flat_plan(a, tune);
+    return p.ok ? n_bags / p.BPW : n_bags;
+  }
+  int G = lanes_per_row(a.D);
+  if (a.D == 32 && tune.sls_v_d32 == 2) G = 16;
   const int bags = 64 / G;
   return (n_bags + bags - 1) / bags;
 }
 
-hipError_t launch_sls(const SlsArgs& a, int exact, hipStream_t s, hipEvent_t stop) {
+hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t s, hipEvent_t stop) {
   const int D = a.D;
   if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
-  const int u = g_sls_u ? g_sls_u : 4;
-  if (D == 32 && g_sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s, stop);
+  if (!exact) {
+    const FlatPlan p = flat_plan(a, tune);
+    if (p.ok) return launch_flat(a, p, s, stop);
+  }
+  const int u = tune.sls_u ? tune.sls_u : 4;
+  if (D == 32 && tune.sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s, stop);
   if (D <= 8) return launch_u<2, 4>(a, exact, u, s, stop);
   if (D <= 16) return launch_u<4, 4>(a, exact, u, s, stop);
   if (D <= 32) return launch_u<8, 4>(a, exact, u, s, stop);

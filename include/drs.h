@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRS_ABI_VERSION 1
+#define DRS_ABI_VERSION 2
 
 typedef struct drs_engine* drs_handle;
 
@@ -153,7 +153,9 @@ int32_t drs_forward_async(drs_handle h, int32_t slot, int32_t batch_id, int32_t 
 #define DRS_MAX_COALESCE 8
 int32_t drs_forward_multi_async(drs_handle h, int32_t slot, int32_t n, const int32_t* batch_ids,
                                 const int32_t* bs);
-int32_t drs_wait(drs_handle h, int32_t slot, float* h_out);
+/* h_out_floats: capacity of h_out in floats; must hold sum(bs) * n_out of what was submitted
+ * on the slot (DRS_ERR_BAD_ARG otherwise, the job stays in flight); ignored when h_out is NULL */
+int32_t drs_wait(drs_handle h, int32_t slot, float* h_out, int64_t h_out_floats);
 int32_t drs_sync(drs_handle h);
 /* non-staged inputs (the run_queues(ids, lengths, fc, bs) signature,
  * models/dlrm_s_caffe2.py:162-174): int64 -> int32 narrowing (the Cast op, :308-309) and the
@@ -168,8 +170,9 @@ int32_t drs_forward_inputs_async(drs_handle h, int32_t slot, int32_t bs,
                                  const float* h_dense,
                                  const int64_t* const* h_idx, const int64_t* n_idx,
                                  const int32_t* const* h_len);
-/* read back an intermediate activation of the last forward on `slot`
- * (parity tests): which = 0 interaction input R [bs, num_int] ... */
+/* read back the interaction tensor R [bs, num_int] (the top MLP's input) of the last forward
+ * on `slot` (parity tests).  Rows are the slot's virtual rows: a single query starts at row 0,
+ * coalesced query i at the sum of round_up(bs_j, 64) over j < i; bs may span several queries. */
 int32_t drs_fetch_interaction(drs_handle h, int32_t slot, int32_t bs, float* h_R);
 int32_t drs_out_width(drs_handle h, int32_t* n_out);
 int32_t drs_interaction_width(drs_handle h, int32_t* num_int);
@@ -190,7 +193,8 @@ int32_t drs_sls(drs_handle h, const float* d_W, int64_t rows, int32_t D,
 /* drs_fc == FC([x,W,b]) + Relu|Sigmoid (models/dlrm_s_caffe2.py:258-272)
  *   y = act(x . W^T + b); accumulation is a k-ordered fp32 fma chain (MFMA).   */
 int32_t drs_fc(drs_handle h, const float* d_x, int64_t M, int32_t K, const float* d_W /*[N,K]*/,
-               const float* d_b /*[N]*/, int32_t N, int32_t act, float* d_y /*[M,N]*/);
+               const float* d_b /*[N], or NULL = no bias (zeros)*/, int32_t N, int32_t act,
+               float* d_y /*[M,N]*/);
 /* drs_interact_dot == Concat(add_axis) + BatchMatMul(trans_b) + Flatten +
  * BatchGather(tril) + Concat  (models/dlrm_s_caffe2.py:334-354, :529-535)
  *   d_T [B,F,D] -> d_R [B, D + F(F-1)/2 (+F if itself)]                        */
@@ -208,6 +212,13 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                2048 / D: RM3's 20 and W&D's / NCF's 1 qualify, RM1's 80 does not) always take
  *                the sequential-order variant: a lane group per bag instead of a mostly idle
  *                wave per bag | -1 never
+ *   "sls_flat"   1 (default) batches whose bags all have one length L >= 2 (every shipped
+ *                reference config) run the flat variant when sls_exact is 0: a wave owns 1, 2 or 4
+ *                consecutive bags of a sample, reads their indices with one coalesced load and has
+ *                ALL of its row loads (up to 20 x 16 B per lane) in flight at once; same tolerance
+ *                as the wave-split variant | 0 ring-walk kernels only
+ *   "sls_bpw"    bags per wave of the flat variant: 0 (default: as many of 4 | 2 | 1 as divide the
+ *                table count and keep a lane at <= 10 loads) | 1 | 2 | 4
  *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
@@ -244,8 +255,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                PCIe (no H2D copies) | 0 copy them to HBM first
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
- * unknown key -> DRS_ERR_BAD_ARG                                               */
+ * unknown key -> DRS_ERR_BAD_ARG.  Options belong to the handle: two engines in one process
+ * (the mixed-model accelerator engine) keep their own values.                    */
 int32_t drs_set_option(drs_handle h, const char* key, int64_t value);
+int32_t drs_get_option(drs_handle h, const char* key, int64_t* value);
 
 /* ---- measurement ------------------------------------------------------------
  * Live timing of the engine's own launches (bench.py roofline leg).
@@ -262,6 +275,10 @@ int32_t drs_set_profiling(drs_handle h, int32_t level);
 int32_t drs_kernel_time(drs_handle h, int32_t kernel /*DRS_KERNEL_*/,
                         double* sum_ms, int64_t* launches);
 int32_t drs_reset_kernel_time(drs_handle h);
+/* algorithmic bytes (drs_gather_bytes' formula) of exactly the gather launches whose durations
+ * drs_kernel_time(kernel) has accumulated since the last reset: achieved GB/s =
+ * bytes / sum_ms whatever mix of full and partial launch sets was timed            */
+int32_t drs_kernel_bytes(drs_handle h, int32_t kernel /*DRS_KERNEL_SLS | _SLS_CLOCK*/, int64_t* bytes);
 /* per-workgroup [start, end] device clock ticks (100 MHz) of the last profiled gather
  * launch on `slot`; out holds 2*n_blocks words.  Tuning aid (tools/gather_timeline.py) */
 int32_t drs_debug_gather_stamps(drs_handle h, int32_t slot, uint64_t* out, int64_t cap,
@@ -269,6 +286,28 @@ int32_t drs_debug_gather_stamps(drs_handle h, int32_t slot, uint64_t* out, int64
 /* algorithmic bytes of the gather for a query of `bs` samples of `batch_id`:
  * sum over bags of len*D*4 + len*4 + 4 + D*4  (SURVEY.md 8d / BASELINE.md 2)   */
 int32_t drs_gather_bytes(drs_handle h, int32_t batch_id, int32_t bs, int64_t* bytes);
+
+/* ---- multi-GPU: the single collective ---------------------
+ * replaces: the parent process merging every engine's responseQueue and computing QPS /
+ * tail latency over all of them (DeepRecSys.py:89-135, :168-175).  With one engine process
+ * per GPU the per-rank latency histogram and run scalars are combined by ONE grouped RCCL
+ * all-reduce over xGMI (~32 KB; nothing on the data path crosses GPUs).
+ *   rank 0 calls drs_comm_unique_id and hands the 128 bytes to the other ranks by any
+ *   out-of-band means (bench.py: torch.distributed gloo broadcast); every rank then calls
+ *   drs_comm_create(id, rank, world, its GPU).
+ * RCCL is bound at run time; without it these return DRS_ERR_UNSUPPORTED.          */
+#define DRS_COMM_ID_BYTES 128
+typedef struct drs_comm_s* drs_comm;
+int32_t drs_comm_unique_id(uint8_t* id /*[DRS_COMM_ID_BYTES]*/);
+int32_t drs_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device_id,
+                        drs_comm* out);
+int32_t drs_comm_destroy(drs_comm c);
+/* every rank has arrived and its GPU is idle */
+int32_t drs_comm_barrier(drs_comm c);
+/* in place, result on every rank: hist[nbins] SUM; sum_min_max[0], [1] SUM (query count, sum
+ * of latencies), [2] MIN (first completion time), [3] MAX (last completion time / elapsed) */
+int32_t drs_stats_allreduce(drs_comm c, int64_t* hist, int32_t nbins, double* sum_min_max /*[4]*/);
+const char* drs_comm_last_error(void);
 
 #ifdef __cplusplus
 }

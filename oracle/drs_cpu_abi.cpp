@@ -40,6 +40,9 @@ typedef struct orc_model {
   const float* final_b;
   int32_t final_m;
   int32_t interaction_op, itself, sigmoid_top;
+  const float* const* bot_Wt;
+  const float* const* top_Wt;
+  const float* final_Wt;
 } orc_model;
 int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense, const int64_t* const* idx,
                     const int64_t* n_idx, const int32_t* const* len, float* out, float* R_out,
@@ -219,8 +222,11 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
   return DRS_OK;
 }
 
-int32_t finish(drs_engine* e, Slot& s, float* h_out) {
+int32_t finish(drs_engine* e, Slot& s, float* h_out, int64_t h_cap = -1) {
   if (!s.busy) return DRS_OK;
+  if (h_out && h_cap >= 0 && h_cap < s.rows * e->n_out)
+    return fail(e, DRS_ERR_BAD_ARG, "output buffer holds %lld floats, the slot produces %lld",
+                (long long)h_cap, (long long)(s.rows * e->n_out));
   s.busy = false;
   if (h_out && s.rows > 0) memcpy(h_out, s.out.data(), sizeof(float) * (size_t)s.rows * e->n_out);
   return DRS_OK;
@@ -382,11 +388,12 @@ int32_t drs_forward_async(drs_handle e, int32_t slot, int32_t batch_id, int32_t 
   return drs_forward_multi_async(e, slot, 1, &batch_id, &bs);
 }
 
-int32_t drs_wait(drs_handle e, int32_t slot, float* h_out) {
+int32_t drs_wait(drs_handle e, int32_t slot, float* h_out, int64_t h_out_floats) {
   int32_t rc = check_handle(e);
   if (rc) return rc;
   if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
-  return finish(e, e->slots[slot], h_out);
+  if (h_out && h_out_floats < 0) return fail(e, DRS_ERR_BAD_ARG, "negative output capacity");
+  return finish(e, e->slots[slot], h_out, h_out_floats);
 }
 
 int32_t drs_sync(drs_handle e) {
@@ -399,7 +406,7 @@ int32_t drs_sync(drs_handle e) {
 int32_t drs_forward(drs_handle e, int32_t batch_id, int32_t bs, float* h_out) {
   int32_t rc = drs_forward_async(e, 0, batch_id, bs);
   if (rc) return rc;
-  return drs_wait(e, 0, h_out);
+  return finish(e, e->slots[0], h_out);
 }
 
 int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
@@ -419,7 +426,7 @@ int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* 
                            const int32_t* const* h_len, float* h_out) {
   int32_t rc = drs_forward_inputs_async(e, slot, bs, h_dense, h_idx, n_idx, h_len);
   if (rc) return rc;
-  return drs_wait(e, slot, h_out);
+  return finish(e, e->slots[slot], h_out);
 }
 
 int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R) {
@@ -481,6 +488,26 @@ int32_t drs_kernel_time(drs_handle e, int32_t, double* sum_ms, int64_t* launches
   return DRS_OK;
 }
 int32_t drs_reset_kernel_time(drs_handle e) { return e ? DRS_OK : DRS_ERR_BAD_ARG; }
+int32_t drs_kernel_bytes(drs_handle e, int32_t, int64_t* bytes) {
+  if (!e || !bytes) return DRS_ERR_BAD_ARG;
+  *bytes = 0;
+  return DRS_OK;
+}
+int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
+  if (!e || !key || !value) return DRS_ERR_BAD_ARG;
+  *value = 0;
+  return DRS_OK;
+}
+// the collective is RCCL over xGMI: no CPU restatement (the CPU suite combines ranks over gloo)
+int32_t drs_comm_unique_id(uint8_t*) { return DRS_ERR_UNSUPPORTED; }
+int32_t drs_comm_create(const uint8_t*, int32_t, int32_t, int32_t, drs_comm* out) {
+  if (out) *out = nullptr;
+  return DRS_ERR_UNSUPPORTED;
+}
+int32_t drs_comm_destroy(drs_comm) { return DRS_OK; }
+int32_t drs_comm_barrier(drs_comm) { return DRS_ERR_UNSUPPORTED; }
+int32_t drs_stats_allreduce(drs_comm, int64_t*, int32_t, double*) { return DRS_ERR_UNSUPPORTED; }
+const char* drs_comm_last_error(void) { return "no RCCL behind the CPU restatement of the ABI"; }
 int32_t drs_debug_gather_stamps(drs_handle e, int32_t, uint64_t*, int64_t, int64_t* n_blocks) {
   if (!e || !n_blocks) return DRS_ERR_BAD_ARG;
   *n_blocks = 0;

@@ -169,16 +169,23 @@ static inline float act_apply(float v, int32_t act) {
 }
 
 /* y[m, n] = act( (k-ordered fma chain from 0 of x[m,k]*W[n,k]) + b[n] )        */
+/* Wt_pre (optional): W already transposed to [K][N] by the caller (the model object does it
+ * once at build time -- a CPU engine would not re-transpose its weights per query); NULL =
+ * transpose here, per call (operator-level entry point).                               */
 static int32_t fc_impl(const float* x, int64_t M, int32_t K, int64_t ldx, const float* W,
-                       const float* b, int32_t N, int32_t act, float* y, int64_t ldy,
-                       int32_t nthreads) {
+                       const float* Wt_pre, const float* b, int32_t N, int32_t act, float* y,
+                       int64_t ldy, int32_t nthreads) {
   if (!x || !W || !y || M < 0 || K <= 0 || N <= 0) return ORC_ERR_BAD_ARG;
-  /* transpose W to [K][N] so the n-loop vectorises while every output keeps
-   * its own k-ordered chain */
-  float* Wt = (float*)malloc(sizeof(float) * (size_t)K * (size_t)N);
-  if (!Wt) return ORC_ERR_OOM;
-  for (int32_t n = 0; n < N; ++n)
-    for (int32_t k = 0; k < K; ++k) Wt[(size_t)k * N + n] = W[(size_t)n * K + k];
+  /* W as [K][N] so the n-loop vectorises while every output keeps its own k-ordered chain */
+  float* Wt_own = NULL;
+  const float* Wt = Wt_pre;
+  if (!Wt) {
+    Wt_own = (float*)malloc(sizeof(float) * (size_t)K * (size_t)N);
+    if (!Wt_own) return ORC_ERR_OOM;
+    for (int32_t n = 0; n < N; ++n)
+      for (int32_t k = 0; k < K; ++k) Wt_own[(size_t)k * N + n] = W[(size_t)n * K + k];
+    Wt = Wt_own;
+  }
   set_threads(nthreads);
 #pragma omp parallel
   {
@@ -197,13 +204,13 @@ static int32_t fc_impl(const float* x, int64_t M, int32_t K, int64_t ldx, const 
     }
     free(acc);
   }
-  free(Wt);
+  free(Wt_own);
   return ORC_OK;
 }
 
 int32_t orc_fc(const float* x, int64_t M, int32_t K, const float* W, const float* b, int32_t N,
                int32_t act, float* y, int32_t nthreads) {
-  return fc_impl(x, M, K, K, W, b, N, act, y, N, nthreads);
+  return fc_impl(x, M, K, K, W, NULL, b, N, act, y, N, nthreads);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -261,10 +268,15 @@ typedef struct orc_model {
   const float* final_b;
   int32_t final_m;
   int32_t interaction_op, itself, sigmoid_top;
+  /* optional: the FC weights once more, transposed to [K][N] at model build (NULL = per call) */
+  const float* const* bot_Wt;
+  const float* const* top_Wt;
+  const float* final_Wt;
 } orc_model;
 
 static int32_t mlp_chain(const float* in, int64_t B, int64_t ld_in, int32_t n_l,
-                         const int32_t* ln, const float* const* Ws, const float* const* bs,
+                         const int32_t* ln, const float* const* Ws, const float* const* Wts,
+                         const float* const* bs,
                          int32_t sigmoid_layer, float* out_last, int64_t ld_out,
                          int32_t nthreads) {
   /* layers 1..n_l-1; activation Relu except Sigmoid at sigmoid_layer
@@ -287,7 +299,7 @@ static int32_t mlp_chain(const float* in, int64_t B, int64_t ld_in, int32_t n_l,
     const int last = (i == n_l - 1);
     float* dst = last ? out_last : tmp[i & 1];
     int64_t ldd = last ? ld_out : ln[i];
-    rc = fc_impl(cur, B, ln[i - 1], ld, Ws[i - 1], bs[i - 1], ln[i],
+    rc = fc_impl(cur, B, ln[i - 1], ld, Ws[i - 1], Wts ? Wts[i - 1] : NULL, bs[i - 1], ln[i],
                  i == sigmoid_layer ? ORC_ACT_SIGMOID : ORC_ACT_RELU, dst, ldd, nthreads);
     cur = dst;
     ld = ldd;
@@ -327,12 +339,12 @@ int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense,
           mlp_in[b * 2 * D + d] = emb[(2 * B + b) * D + d];
           mlp_in[b * 2 * D + D + d] = emb[(3 * B + b) * D + d];
         }
-      rc = mlp_chain(mlp_in, B, 2 * D, m->n_top, m->ln_top, m->top_W, m->top_b, -1,
+      rc = mlp_chain(mlp_in, B, 2 * D, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, -1,
                      cat + D, D + wl, nthreads);
     }
     if (rc == ORC_OK && R_out) memcpy(R_out, cat, sizeof(float) * (size_t)B * (size_t)(D + wl));
     if (rc == ORC_OK)
-      rc = fc_impl(cat, B, D + wl, D + wl, m->final_W, m->final_b, m->final_m, ORC_ACT_RELU, out,
+      rc = fc_impl(cat, B, D + wl, D + wl, m->final_W, m->final_Wt, m->final_b, m->final_m, ORC_ACT_RELU, out,
                    m->final_m, nthreads);
     free(emb); free(cat); free(mlp_in);
     return rc;
@@ -348,7 +360,7 @@ int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense,
                   cat + w0 + (int64_t)t * D, ldc, nthreads);
   if (rc == ORC_OK) {
     if (m->n_bot > 1) {
-      rc = mlp_chain(dense, B, m->ln_bot[0], m->n_bot, m->ln_bot, m->bot_W, m->bot_b, -1, cat, ldc,
+      rc = mlp_chain(dense, B, m->ln_bot[0], m->n_bot, m->ln_bot, m->bot_W, m->bot_Wt, m->bot_b, -1, cat, ldc,
                      nthreads);
     } else {
       for (int64_t b = 0; b < B; ++b) memcpy(cat + b * ldc, dense + b * w0, sizeof(float) * w0);
@@ -376,7 +388,7 @@ int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense,
   if (rc == ORC_OK && ld_top != m->ln_top[0]) rc = ORC_ERR_BAD_ARG;
   if (rc == ORC_OK && R_out) memcpy(R_out, top_in, sizeof(float) * (size_t)B * (size_t)ld_top);
   if (rc == ORC_OK)
-    rc = mlp_chain(top_in, B, ld_top, m->n_top, m->ln_top, m->top_W, m->top_b, m->sigmoid_top, out,
+    rc = mlp_chain(top_in, B, ld_top, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, m->sigmoid_top, out,
                    m->ln_top[m->n_top - 1], nthreads);
   free(R);
   free(cat);

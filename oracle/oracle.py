@@ -48,6 +48,7 @@ class _Model(C.Structure):
         ("top_W", C.POINTER(_f32p)), ("top_b", C.POINTER(_f32p)),
         ("final_W", _f32p), ("final_b", _f32p), ("final_m", C.c_int32),
         ("interaction_op", C.c_int32), ("itself", C.c_int32), ("sigmoid_top", C.c_int32),
+        ("bot_Wt", C.POINTER(_f32p)), ("top_Wt", C.POINTER(_f32p)), ("final_Wt", _f32p),
     ]
 
 
@@ -190,6 +191,16 @@ class Model(object):
             m.final_b = self.final[1].ctypes.data_as(_f32p)
             m.final_m = self.final[0].shape[0]
         m.interaction_op, m.itself, m.sigmoid_top = interaction_op, int(self.itself), self.sigmoid_top
+        # weights transposed ONCE at model build ([K][N], what fc_impl's inner loop walks): a CPU
+        # engine does not re-lay-out its weights per query
+        self._botT = [np.ascontiguousarray(W.T) for W, _ in self.bot]
+        self._topT = [np.ascontiguousarray(W.T) for W, _ in self.top]
+        self._bWt = (_f32p * nb)(*[W.ctypes.data_as(_f32p) for W in self._botT])
+        self._tWt = (_f32p * nt)(*[W.ctypes.data_as(_f32p) for W in self._topT])
+        m.bot_Wt, m.top_Wt = self._bWt, self._tWt
+        if self.final is not None:
+            self._finT = np.ascontiguousarray(self.final[0].T)
+            m.final_Wt = self._finT.ctypes.data_as(_f32p)
         self._c = m
 
     @property

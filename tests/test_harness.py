@@ -140,7 +140,95 @@ def test_multi_rank_stats_allreduce_gloo():
     assert p99 == pytest.approx(np.percentile(lat, 99, method="higher") * 1e3, rel=0.01)
 
 
+def _bench(extra, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+_TINY = ["--workload", "tiny", "--steps", "3", "--warmup", "1", "--queries_per_step", "20", "--batch", "4",
+         "--num_batches", "2", "--no_cpu_baseline", "--timed_only"]
+
+
+def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
+    """`python bench.py --gpus 2` with no launcher spawns its own two ranks; each
+    runs the rank entry end to end -- model build, warm-up, K timed steps, barrier on both sides,
+    the statistics collective -- above the CPU restatement of the C ABI (tests only; the
+    collective on gloo), and rank 0 prints one line for the whole job."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # one OpenMP thread per rank: two oracle-backed ranks spinning on all cores starve each other
+    cpu = {"DRS_HIP_LIB": os.path.join(root, "oracle", "_build", "libdrs_cpu.so"), "OMP_NUM_THREADS": "1"}
+    two = _bench(["--gpus", "2", "--collective", "gloo", "--allow_device_sharing"] + _TINY, cpu)
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["warmup"] == 1 and two["scaling"] == "weak"
+    assert two["config"]["queries_per_step"] == 20 and two["config"]["timed_queries_per_gpu"] == 60
+    assert two["latency_ms"]["queries"] == 120                      # both ranks' histograms, summed
+    # whole-job throughput: all ranks' queries over the slowest rank's time
+    assert two["value"] == pytest.approx(120 / two["config"]["timed_seconds"], rel=0.02)   # (both rounded)
+    assert two["ms_per_step"] == pytest.approx(two["config"]["timed_seconds"] / 3 * 1e3, rel=0.02)
+    one = _bench(["--gpus", "1"] + _TINY, cpu)
+    assert one["n_gpus"] == 1 and one["latency_ms"]["queries"] == 60 and one["config"]["collective"] is None
+    # identical line structure at N = 1 and N = 2
+    assert set(one) == set(two) and set(one["roofline"]) == set(two["roofline"])
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import subprocess
+    import sys
+    env = dict(os.environ, DRS_HIP_LIB=os.path.join(root, "oracle", "_build", "libdrs_cpu.so"), OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective", "gloo"] + _TINY,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "device 1 of 1" in r.stderr and not r.stdout.strip()
+
+
 # ---- the real thing ------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_stats_allreduce_over_rccl_through_the_c_abi():
+    """drs_stats_allreduce on real RCCL: world size 1 in-process (identity), and two ranks that
+    share GPU 0 when the box has a single device (RCCL refuses duplicate devices on some
+    versions: that refusal must surface as a DrsError, not a hang)."""
+    from deeprecsys_amd import _native as N
+    uid = N.Comm.unique_id()
+    assert len(uid) == N.COMM_ID_BYTES
+    c = N.Comm(uid, 0, 1, 0)
+    try:
+        h = np.arange(4095, dtype=np.int64)
+        h2, s4 = c.stats_allreduce(h, [5.0, 0.25, 1.5, 2.5])
+        assert np.array_equal(h2, h) and list(s4) == [5.0, 0.25, 1.5, 2.5]
+        c.barrier()
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_bench_self_spawn_n1_equals_plain_n1_line_shape():
+    """On the GPU: `--gpus 1` (in-process) prints the same line structure the driver reads, with
+    per-launch byte accounting (frac follows from bytes_timed / launches, whatever the mix of
+    full and partial launch sets)."""
+    out = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--queries_per_step", "1001",
+                  "--no_cpu_baseline", "--timed_only"])
+    r = out["roofline"]
+    assert out["n_gpus"] == 1 and out["config"]["timed_queries_per_gpu"] == 2002
+    assert r["launches_timed"] == (2002 + 7) // 8                    # 250 full sets + one of 2 queries
+    assert r["bytes_timed"] == 2002 * 43130880                       # RMC1: 43.13 MB per query, exactly
+    assert r["frac"] == pytest.approx(r["bytes_timed"] / (r["avg_launch_us"] * 1e-6 * r["launches_timed"]) / 8e12, rel=2e-3)
+    assert 0.3 < r["frac"] < 0.8                                       # above the copy ceiling = accounting bug
+
+
+
 @pytest.mark.gpu
 def test_harness_with_a_real_accelerator_engine(tmp_path):
     a = _args(tmp_path, accel_backend="hip", num_accels=1, arch_sparse_feature_size=16,
