@@ -86,6 +86,9 @@ def parse(argv=None):
                     help="N > 1: how the run statistics are combined (rccl = drs_stats_allreduce)")
     ap.add_argument("--sweep", action="store_true", help="also A/B the gather variants (stderr)")
     ap.add_argument("--set", action="append", default=[], help="engine option key=value")
+    ap.add_argument("--rows", type=int, default=0, help="override the rows per table (footprint experiments)")
+    ap.add_argument("--lookups", type=int, default=0, help="override the lookups per bag")
+    ap.add_argument("--tables", type=int, default=0, help="override the number of tables")
     ap.add_argument("--torch_cpu_leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--allow_device_sharing", action="store_true",
                     help="ranks beyond the visible device count wrap around instead of failing "
@@ -336,6 +339,15 @@ def spawn_ranks(opt, argv):
 def main():
     argv = sys.argv[1:]
     opt = parse(argv)
+    if opt.rows or opt.lookups or opt.tables:
+        w = dict(WORKLOADS[opt.workload])
+        if opt.rows:
+            w["rows"] = opt.rows
+        if opt.lookups:
+            w["L"] = opt.lookups
+        if opt.tables:
+            w["T"] = opt.tables
+        WORKLOADS[opt.workload] = w
     if opt.torch_cpu_leg:
         return torch_cpu_leg(opt)
     if "WORLD_SIZE" not in os.environ and opt.gpus > 1:

@@ -785,12 +785,12 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipHostMalloc(&s.h_out, sizeof(uint32_t) * out_words, hipHostMallocMapped | hipHostMallocCoherent));
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_out), s.h_out, 0));
-    CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * (size_t)e->max_rows * T));
+    CREATE_TRY(hipMalloc(&s.d_ts, sizeof(uint64_t) * 2 * ((size_t)e->max_rows * T + 8)));   // + 8: the XCD-ordered grid is rounded up to 8
     CREATE_TRY(hipMalloc(&s.d_span_acc, sizeof(uint64_t) * 2 * 65536));
     CREATE_TRY(hipHostMalloc(&s.h_span, sizeof(uint64_t) * 2, hipHostMallocMapped | hipHostMallocCoherent));
     s.h_span[0] = s.h_span[1] = 0;
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dm_span), s.h_span, 0));
-    s.h_ts.resize(2 * (size_t)e->max_rows * T);
+    s.h_ts.resize(2 * ((size_t)e->max_rows * T + 8));
     for (auto& ev : s.ev) CREATE_TRY(hipEventCreate(&ev));
     // Cross-stream ordering on ONE device only (no host reader): the kernels' own agent-scope
     // release/acquire at their boundaries carries the data; the system-scope fence an event
@@ -1226,6 +1226,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_u") && (value == 0 || value == 4 || value == 8 || value == 16 || value == 20)) e->tune.sls_u = (int)value;
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) e->tune.sls_v_d32 = (int)value;
   else if (!strcmp(key, "sls_flat")) e->tune.sls_flat = value ? 1 : 0;
+  else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
@@ -1301,7 +1302,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
       {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},

@@ -253,10 +253,27 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
 // bags (same sample, consecutive tables) per wave.  Requires L * BPW <= NL * (64 / G) and
 // T % BPW == 0 (checked by launch_sls).
 template <int G, int NL, int BPW>
-__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
+__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_order) {
   constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
-  constexpr int NI = (NL * NG + 63) / 64;          // index registers per lane
-  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+  // Work item w = (table group, sample), numbered TABLE-MAJOR; everything that depends only on
+  // the wave (sample, query, tables) is scalar.  XCD-aware order (xcd_order != 0): workgroup id
+  // lands on XCD id % 8 (observed dispatch order; speed only, never correctness), and XCD x walks
+  // the contiguous slice [x*per, (x+1)*per) of the work list -- so one XCD's L2 and TLBs see one or
+  // two tables (and contiguous pieces of their index arrays) instead of all T of them.
+  const unsigned wg = blockIdx.x;
+  if (a.ts && threadIdx.x == 0) a.ts[2 * wg] = wall_clock64();
+  const unsigned n_smp = (unsigned)a.q.cum[a.q.n_q];
+  const unsigned n_work = n_smp * (unsigned)(a.T / BPW);
+  unsigned w = wg;
+  if (xcd_order) {
+    const unsigned per = (n_work + 7u) >> 3;
+    w = (wg & 7u) * per + (wg >> 3);
+    if ((wg >> 3) >= per || w >= n_work) {
+      if (a.ts && threadIdx.x == 0) a.ts[2 * wg + 1] = a.ts[2 * wg];   // keep (min, max) well defined
+      return;
+    }
+  }
+  const unsigned tg = (unsigned)__builtin_amdgcn_readfirstlane((int)(w / n_smp));
 
   const int lane = threadIdx.x;
   const int g = lane / G;
@@ -264,10 +281,8 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
   const int col = min(gl * 4, a.D - 4);            // clamp idle lanes onto valid columns
   const bool col_ok = gl * 4 < a.D;
 
-  // the wave's bags: all of one sample (T % BPW == 0), tables t0 .. t0+BPW-1 -- uniform
-  const int64_t bag0 = (int64_t)blockIdx.x * BPW;
-  const int smp = (int)(bag0 / a.T);
-  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
+  const int smp = (int)(w - tg * n_smp);
+  const int t0 = (int)tg * BPW;
   int b = smp, vrow = a.q.vstart[0] + smp;
   const int32_t* qidx = a.idx[0];
 #pragma unroll
@@ -279,12 +294,18 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
   }
   const int R = BPW * L;
   const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
-  const float* Wk[BPW];
-  uint32_t rows_k[BPW];
+  // table bases and row counts of the wave's BPW tables: scalar loads, issued now and waited
+  // for only when the row addresses are formed, i.e. in the shadow of the index loads.  (Left
+  // to the compiler they become vector loads -- it cannot prove the arrays are not written by
+  // this kernel -- and cost a dependent round trip BEFORE the index loads.)
+  uint64_t tab_off_k[BPW], tab_rows_k[BPW];
+  {
+    const uint32_t boff = (uint32_t)__builtin_amdgcn_readfirstlane(t0) * 8u;
 #pragma unroll
-  for (int k = 0; k < BPW; ++k) {
-    Wk[k] = a.tables + a.tab_off[t0 + k] + col;
-    rows_k[k] = (uint32_t)a.tab_rows[t0 + k];
+    for (int k = 0; k < BPW; ++k) {
+      asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(tab_off_k[k]) : "s"(a.tab_off), "s"(boff + 8u * k));
+      asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(tab_rows_k[k]) : "s"(a.tab_rows), "s"(boff + 8u * k));
+    }
   }
   // which of the wave's bags does flattened row j belong to (j < R)
   auto bag_of = [&](int j) {
@@ -294,40 +315,52 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
     return k;
   };
 
-  // ONE coalesced index read: lane i owns flattened rows i, i+64, ...; range check (Caffe2
-  // ENFORCE) and the row's element offset inside its table are computed by the owner
-  uint32_t roff[NI];
-  bool bad = false;
-#pragma unroll
-  for (int q = 0; q < NI; ++q) {
-    const int i = lane + 64 * q;
-    const int ii = min(i, R - 1);
-    const int k = bag_of(ii);
-    const int32_t* ip = qidx + (int64_t)(t0 + k) * a.idx_stride + (int64_t)b * L + (ii - k * L);
-    uint32_t r = (uint32_t)*ip;
-    uint32_t rk = rows_k[0];
-#pragma unroll
-    for (int z = 1; z < BPW; ++z) rk = k == z ? rows_k[z] : rk;
-    bad |= i < R && r >= rk;
-    r = r < rk ? r : 0u;
-    roff[q] = r * Du;
-  }
-
-  // every row load of the wave, back to back
-  float4 v[NL];
+  // ---- phase 1: the index of every row this lane will load.  The G lanes of a group read the
+  // same word and the 64/G groups adjacent words: one 32..128-B segment per instruction, all NL
+  // of them in flight together -------------------------------------------------------------
+  const int32_t* ip[NL];
+  int kj[NL];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
-    const int j = g + NG * u;                      // (j >> 6) == (NG * u) >> 6: compile time
-    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], j & 63);
-    const float* W = Wk[0];
-    if (BPW > 1) {
-      const int k = bag_of(min(j, R - 1));
-#pragma unroll
-      for (int z = 1; z < BPW; ++z) W = k == z ? Wk[z] : W;
-    }
-    v[u] = *reinterpret_cast<const float4*>(W + (uint64_t)ro);
+    const int jj = min(g + NG * u, R - 1);
+    kj[u] = bag_of(jj);
+    ip[u] = qidx + (int64_t)(t0 + kj[u]) * a.idx_stride + (int64_t)b * L + (jj - kj[u] * L);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t ridx[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) ridx[u] = (uint32_t)*ip[u];
+  __builtin_amdgcn_sched_barrier(0);
+  // (the s_loads above: not tracked by the compiler's counters)
+  if (BPW == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tab_off_k[0]), "+s"(tab_rows_k[0]));
+  else if (BPW == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tab_off_k[0]), "+s"(tab_rows_k[0]), "+s"(tab_off_k[BPW > 1 ? 1 : 0]), "+s"(tab_rows_k[BPW > 1 ? 1 : 0]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tab_off_k[0]), "+s"(tab_rows_k[0]), "+s"(tab_off_k[BPW > 1 ? 1 : 0]), "+s"(tab_rows_k[BPW > 1 ? 1 : 0]),
+                    "+s"(tab_off_k[BPW > 2 ? 2 : 0]), "+s"(tab_rows_k[BPW > 2 ? 2 : 0]), "+s"(tab_off_k[BPW > 3 ? 3 : 0]), "+s"(tab_rows_k[BPW > 3 ? 3 : 0]));
 
+  // ---- phase 2: range check (Caffe2 ENFORCE) and every row address of the wave ----------------
+  const float* rp[NL];
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const float* W = a.tables + tab_off_k[0];
+    uint32_t rk = (uint32_t)tab_rows_k[0];
+#pragma unroll
+    for (int z = 1; z < BPW; ++z) {
+      W = kj[u] == z ? a.tables + tab_off_k[z] : W;
+      rk = kj[u] == z ? (uint32_t)tab_rows_k[z] : rk;
+    }
+    bad |= g + NG * u < R && ridx[u] >= rk;
+    const uint32_t ro = (ridx[u] < rk ? ridx[u] : 0u) * Du + (uint32_t)col;
+    rp[u] = W + (uint64_t)ro;
+  }
+  // ---- phase 3: all row loads, back to back, nothing else in between --------------------------
+  __builtin_amdgcn_sched_barrier(0);
+  float4 v[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) v[u] = *reinterpret_cast<const float4*>(rp[u]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- phase 4: per-bag sums in arrival order, then the butterfly over the lane groups --------
   float4 acc[BPW];
 #pragma unroll
   for (int k = 0; k < BPW; ++k) acc[k] = vzero4();
@@ -337,9 +370,8 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
     if (BPW == 1) {
       vadd(acc[0], vsel<4>(j < R, v[u]));
     } else {
-      const int kj = bag_of(min(j, R - 1));
 #pragma unroll
-      for (int k = 0; k < BPW; ++k) vadd(acc[k], vsel<4>(j < R && kj == k, v[u]));
+      for (int k = 0; k < BPW; ++k) vadd(acc[k], vsel<4>(j < R && kj[u] == k, v[u]));
     }
   }
 #pragma unroll
@@ -348,26 +380,27 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L) {
     for (int m = G; m < 64; m <<= 1) vadd(acc[k], vshfl_xor(acc[k], m));
 
   if (bad) atomicOr(a.err, 1);
-  // lane group k stores bag k (every group holds every sum after the butterfly)
-  if (col_ok && g < BPW) {
-    float4 o4 = acc[0];
+  // every group holds every sum after the butterfly; group 0 stores them, one 128..512-B row per
+  // bag.  (Letting group k store bag k needs acc[g]: the optimiser turns that select chain into a
+  // dynamically indexed array, i.e. SCRATCH memory -- which capped the BPW > 1 variants at half
+  // the speed of BPW == 1 until it was spotted in the ISA.)
+  if (col_ok && g == 0) {
+    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)t0 * a.D + col;
 #pragma unroll
-    for (int k = 1; k < BPW; ++k) o4 = g == k ? acc[k] : o4;
-    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)(t0 + g) * a.D + col;
-    *reinterpret_cast<float4*>(o) = o4;
+    for (int k = 0; k < BPW; ++k) *reinterpret_cast<float4*>(o + (int64_t)k * a.D) = acc[k];
   }
   if (a.ts) {
     __builtin_amdgcn_s_waitcnt(0);   // include the output store in the span
-    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+    if (threadIdx.x == 0) a.ts[2 * wg + 1] = wall_clock64();
   }
 }
 
 // stop: optional event recorded BY the kernel dispatch itself (its completion signal) -- no
 // separate marker packet between this launch and the next one on the stream
 template <typename K, typename... X>
-void launch_k(K kernel, unsigned grid, hipStream_t s, hipEvent_t stop, const X&... x) {
-  if (stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, nullptr, stop, 0, x...);
-  else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, x...);
+void launch_k(K kernel, dim3 grid, hipStream_t s, hipEvent_t stop, const X&... x) {
+  if (stop) hipExtLaunchKernelGGL(kernel, grid, dim3(64), 0, s, nullptr, stop, 0, x...);
+  else hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, x...);
 }
 
 template <int G, int V, int U>
@@ -401,7 +434,8 @@ int lanes_per_row(int D) { return D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 
 // (a wave's bags belong to one sample) and BPW * L rows must fit NL loads per lane.
 struct FlatPlan {
   bool ok = false;
-  int G = 0, NL = 0, BPW = 1, L = 0;
+  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1;
+  unsigned grid = 0;
 };
 FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
   FlatPlan p;
@@ -417,28 +451,32 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
     bpw = tune.sls_bpw;
     if ((bpw != 1 && bpw != 2 && bpw != 4) || a.T % bpw) return p;
   } else {
-    // short bags share a wave until it has about ten loads per lane to issue
+    // short bags share a wave until it has five loads per lane to issue (measured on RM3,
+    // 12 x 10M x 32, L = 20, beside its GEMM launches: 2 bags per wave 0.48 of peak, 1 or 4 bags
+    // 0.44; the chip to itself: 0.60 / 0.55 / 0.59)
     for (int c : {4, 2})
-      if (a.T % c == 0 && c * L <= 10 * NG) { bpw = c; break; }
+      if (a.T % c == 0 && c * L <= 5 * NG) { bpw = c; break; }
   }
   const int need = (bpw * L + NG - 1) / NG;
   const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : 0;
   if (!nl || (bpw > 1 && nl > 10)) return p;
-  p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L;
+  p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = tune.sls_xcd ? 1 : 0;
+  const unsigned n_work = (unsigned)a.q.cum[a.q.n_q] * (unsigned)(a.T / bpw);
+  p.grid = p.xcd ? 8u * ((n_work + 7u) / 8u) : n_work;
   return p;
 }
 
 template <int G, int NL>
-hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, unsigned grid, hipStream_t s, hipEvent_t stop) {
-  if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L);
+hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
+  if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd);
   else if constexpr (NL <= 10) {
-    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L);
-    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L);
+    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd);
+    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L, p.xcd);
   }
   return hipGetLastError();
 }
 template <int G>
-hipError_t launch_flat_g(const SlsArgs& a, const FlatPlan& p, unsigned grid, hipStream_t s, hipEvent_t stop) {
+hipError_t launch_flat_g(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
   switch (p.NL) {
     case 5: return launch_flat_b<G, 5>(a, p, grid, s, stop);
     case 10: return launch_flat_b<G, 10>(a, p, grid, s, stop);
@@ -448,7 +486,7 @@ hipError_t launch_flat_g(const SlsArgs& a, const FlatPlan& p, unsigned grid, hip
 hipError_t launch_flat(const SlsArgs& a, const FlatPlan& p, hipStream_t s, hipEvent_t stop) {
   const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
   if (n_bags == 0) return hipSuccess;
-  const unsigned grid = (unsigned)(n_bags / p.BPW);
+  const dim3 grid(p.grid);
   switch (p.G) {
     case 8: return launch_flat_g<8>(a, p, grid, s, stop);
     case 16: return launch_flat_g<16>(a, p, grid, s, stop);
@@ -469,7 +507,7 @@ int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
   const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
   if (!exact) {
     const FlatPlan p = flat_plan(a, tune);
-    return p.ok ? n_bags / p.BPW : n_bags;
+    return p.ok ? (int64_t)p.grid : n_bags;
   }
   int G = lanes_per_row(a.D);
   if (a.D == 32 && tune.sls_v_d32 == 2) G = 16;
