@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HOST_LEG_CALLS = 6         # per-call host-input leg: calls in flight (one per slot)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SLA_MS = 25.0              # run_DeepRecSys.sh:42 target_latency
 
@@ -112,7 +113,7 @@ def make_model(opt, device):
     args.max_mini_batch_size = args.mini_batch_size = opt.batch
     args.numpy_rand_seed = opt.seed
     args.accel_table_init = "device"          # counter-based fill, bit-identical in oracle/
-    args.accel_slots = opt.slots
+    args.accel_slots = max(opt.slots, HOST_LEG_CALLS)   # the timed region uses opt.slots of them
     kind = w.get("kind", "dlrm")
     args.model_type = args.model_name = kind
     args.num_indices_per_lookup_fixed = True
@@ -439,23 +440,27 @@ def main():
     L = WORKLOADS[opt.workload]["L"]
     host_n, host_el, host_bytes = 0, 1.0, 0
     if extra:
-        host_sets = [([np.ascontiguousarray(t[:bs * L]) for t in lS_i[b]], [np.ascontiguousarray(t[:bs]) for t in lS_l[b]],
+        # what the reference's feeder passes: ids [T, bs*L] int64, lengths [T, bs] int32, fc [bs, m_den]
+        host_sets = [(np.stack([np.asarray(t[:bs * L], dtype=np.int64) for t in lS_i[b]]),
+                      np.stack([np.asarray(t[:bs], dtype=np.int32) for t in lS_l[b]]),
                       None if WORKLOADS[opt.workload].get("kind") == "ncf" else np.ascontiguousarray(lX[b][:bs]))
                      for b in range(min(nb, 4))]
-        host_bytes = sum(a.nbytes for a in host_sets[0][0]) + sum(a.nbytes for a in host_sets[0][1]) + \
+        host_bytes = host_sets[0][0].nbytes + host_sets[0][1].nbytes + \
             (0 if host_sets[0][2] is None else host_sets[0][2].nbytes)
 
+        hslots = max(slots, HOST_LEG_CALLS)
+
         def host_leg(n):
-            busy = [False] * slots
+            busy = [False] * hslots
             t0 = time.perf_counter()
             for i in range(n):
-                s_ = i % slots
+                s_ = i % hslots
                 if busy[s_]:
                     eng.wait(s_, bs)
                 ids, lens, x = host_sets[i % len(host_sets)]
                 eng.forward_inputs_async(x, ids, lens, bs, slot=s_)
                 busy[s_] = True
-            for s_ in range(slots):
+            for s_ in range(hslots):
                 if busy[s_]:
                     eng.wait(s_, bs)
             return time.perf_counter() - t0
@@ -542,9 +547,11 @@ def main():
             out["host_inputs_leg"] = {
                 "value": round(host_n / host_el, 1), "unit": "queries/s", "queries": host_n,
                 "h2d_GBps": round(host_bytes * host_n / host_el / 1e9, 2),
-                "what": "PCIe-inclusive: per-call host arrays (%d KB/query) converted into pinned memory and "
-                        "read in place by the kernels, one query per launch set, %d calls in flight"
-                        % (host_bytes // 1024, slots)}
+                "what": "PCIe-inclusive: per-call host arrays in the reference's run_queues layout (%d KB/query: "
+                        "int64 ids, int32 lengths, fp32 dense) narrowed + ENFORCE-checked into a pinned block by "
+                        "%s host threads, one DMA copy per query, one query per launch set, %d calls in flight; "
+                        "h2d_GBps counts the caller's bytes"
+                        % (host_bytes // 1024, "min(T,7)+1", hslots)}
         if not opt.no_cpu_baseline and not opt.timed_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt, net, data, opt.cpu_seconds)
         print(json.dumps(out), file=json_out, flush=True)

@@ -46,6 +46,8 @@ SYMBOLS = [
                                              C.POINTER(_i32p)]),
     ("drs_forward_inputs", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
                                        C.POINTER(_i32p), _f32p]),
+    ("drs_run_queues_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_int64, C.c_void_p, C.c_int64]),
     ("drs_fetch_interaction", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
     ("drs_out_width", C.c_int32, [C.c_void_p, _i32p]),
     ("drs_interaction_width", C.c_int32, [C.c_void_p, _i32p]),
@@ -192,6 +194,20 @@ class Engine(object):
     # -- inputs -------------------------------------------------------------------
     @staticmethod
     def _pack_sparse(idx, lengths):
+        """-> (idx, lengths, n_idx, T pointers, T pointers).  Fast path: the reference's feeder
+        hands run_queues 2-D arrays (ids [T, bs*L] int64, lengths [T, bs] int32, rows possibly
+        strided slices of the pre-generated sets, inferenceEngine.py:200-206); their row pointers
+        are base + t * stride -- no per-table Python objects on the per-query path."""
+        if (isinstance(idx, np.ndarray) and idx.ndim == 2 and idx.dtype == np.int64 and idx.strides[1] == 8 and
+                isinstance(lengths, np.ndarray) and lengths.ndim == 2 and lengths.dtype == np.int32 and
+                lengths.strides[1] == 4 and lengths.shape[0] == idx.shape[0]):
+            T = idx.shape[0]
+            steps = np.arange(T, dtype=np.int64)
+            ia = (steps * idx.strides[0] + idx.ctypes.data).astype(np.uint64)
+            la = (steps * lengths.strides[0] + lengths.ctypes.data).astype(np.uint64)
+            n_idx = np.full(T, idx.shape[1], dtype=np.int64)
+            # (idx, ia) / (lengths, la): the caller keeps these alive across the C call
+            return (idx, ia), (lengths, la), n_idx, ia.ctypes.data_as(C.POINTER(_i64p)), la.ctypes.data_as(C.POINTER(_i32p))
         idx = [np.ascontiguousarray(i, dtype=np.int64) for i in idx]
         lengths = [np.ascontiguousarray(l, dtype=np.int32) for l in lengths]
         T = len(idx)
@@ -201,8 +217,8 @@ class Engine(object):
         return idx, lengths, n_idx, ip, lp
 
     def stage_batch(self, batch_id, dense, idx, lengths):
+        n = int(np.asarray(lengths[0]).size)
         idx, lengths, n_idx, ip, lp = self._pack_sparse(idx, lengths)
-        n = int(lengths[0].size)
         dp = None
         if dense is not None:
             dense = _f32(dense)
@@ -241,6 +257,9 @@ class Engine(object):
         self._check(lib().drs_sync(self._h), "drs_sync")
 
     def forward_inputs(self, dense, idx, lengths, bs, slot=0):
+        if type(idx) is np.ndarray and idx.ndim == 2:
+            self.forward_inputs_async(dense, idx, lengths, bs, slot=slot)
+            return self.wait(slot, bs)
         idx, lengths, n_idx, ip, lp = self._pack_sparse(idx, lengths)
         dp = None
         if dense is not None:
@@ -254,6 +273,16 @@ class Engine(object):
     def forward_inputs_async(self, dense, idx, lengths, bs, slot=0):
         """Enqueue only; wait(slot, bs) returns the result.  The arrays are consumed (converted
         into the slot's pinned block) before this returns."""
+        if (type(idx) is np.ndarray and idx.ndim == 2 and idx.dtype == np.int64 and idx.strides[1] == 8 and
+                type(lengths) is np.ndarray and lengths.ndim == 2 and lengths.dtype == np.int32 and
+                lengths.strides[1] == 4 and lengths.shape[0] == idx.shape[0] == self.T and
+                (dense is None or (type(dense) is np.ndarray and dense.dtype == np.float32 and dense.flags.c_contiguous))):
+            # the reference feeder's arrays as they are: two base pointers and two row strides
+            self._check(lib().drs_run_queues_async(self._h, slot, bs, None if dense is None else dense.ctypes.data,
+                                                   idx.ctypes.data, idx.strides[0] // 8, idx.shape[1],
+                                                   lengths.ctypes.data, lengths.strides[0] // 4),
+                        "drs_run_queues_async")
+            return
         idx, lengths, n_idx, ip, lp = self._pack_sparse(idx, lengths)
         dp = None
         if dense is not None:

@@ -20,12 +20,16 @@
 
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "drs_internal.h"
 
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 using namespace drs;
 
@@ -89,7 +93,8 @@ struct Batch {
 };
 
 struct Slot {
-  hipStream_t stream = nullptr;   // the stream this slot launches on (shared or own)
+  hipStream_t stream = nullptr;   // the stream the job in flight launches its MLP side on
+  hipStream_t base_stream = nullptr;   // ... as assigned by apply_stream_mode (shared or own)
   hipStream_t own_stream = nullptr;
   hipStream_t gather_stream = nullptr;   // where the gather is launched (== stream unless pipelined)
   hipEvent_t ev_sls = nullptr;           // pipelined mode: gather done -> the MLP stream may go on
@@ -113,6 +118,8 @@ struct Slot {
   uint64_t* h_span = nullptr;  // pinned [2]: (min start, max end) of the gather launch
   uint64_t* dm_span = nullptr;
   Batch scratch;             // drs_forward_inputs staging
+  char* d_stage = nullptr;   // device copy of the staging block (one-DMA-copy input path)
+  Batch dc;                  // ... viewed as a batch: [dense | idx | off]
   void* h_stage = nullptr;   // pinned host staging for forward_inputs
   size_t h_stage_bytes = 0;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -127,6 +134,8 @@ struct Slot {
 };
 
 }  // namespace
+
+namespace { class HostPool; }
 
 struct drs_engine {
   int device = 0;
@@ -156,9 +165,10 @@ struct drs_engine {
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
   int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
-  int zero_copy_inputs = 1;         // drs_forward_inputs: kernels read the inputs in place from pinned host memory
+  int zero_copy_inputs = 3;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 auto
   int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
+  int64_t mlp_small_rows = 1024;      // launch sets up to this many rows: MLP side on the slot's own stream
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -166,6 +176,8 @@ struct drs_engine {
   int64_t k_bytes[DRS_KERNEL_COUNT] = {0, 0, 0};   // algorithmic bytes of exactly the launches in k_ms / k_n
   double wall_clock_khz = 100000.0;
   Tune tune;                     // per-engine tunables + this device's zero page
+  std::unique_ptr<HostPool> pool;   // workers of the per-call input pass (created on first use)
+  int host_threads = -1;         // "host_threads": workers beside the caller (-1 = auto: min(T, 7))
   std::string err;
 };
 
@@ -210,39 +222,163 @@ void free_batch(Batch& b) {
   b = Batch();
 }
 
+// ---- host-side worker pool for the per-call input pass ----------------------------------------
+// drs_forward_inputs converts 160 k indices per RMC1 query on the host; one thread doing that
+// (plus the Python call) capped the PCIe-inclusive path at 12 k queries/s.  The
+// tables of a query are independent, so they are spread over a few workers.  Workers spin for a
+// short while after a job (the next query usually follows within microseconds) and then sleep on
+// a condition variable; the calling thread always takes part, so a pool of zero workers is just
+// the plain loop.
+class HostPool {
+ public:
+  explicit HostPool(int workers) {
+    for (int i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int workers() const { return (int)th_.size(); }
+  // fn(i) for i in [0, n), on the caller and the workers; returns when all are done
+  void run(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    fn_ = &fn; n_ = n;
+    next_.store(0, std::memory_order_relaxed);
+    pending_.store(n, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> l(mu_);     // pairs with the sleepers' predicate check
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+    work();
+    while (pending_.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1, std::memory_order_acq_rel);
+      if (i >= n_) return;
+      (*fn_)(i);
+      pending_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void loop() {
+    uint64_t seen = gen_.load(std::memory_order_acquire);
+    for (;;) {
+      // spin ~50 us for the next job, then sleep
+      bool got = false;
+      for (int spin = 0; spin < 20000; ++spin) {
+        if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
+        __builtin_ia32_pause();
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> l(mu_);
+        sleepers_.fetch_add(1, std::memory_order_acq_rel);
+        cv_.wait(l, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      if (stop_) return;
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int> next_{0}, pending_{0}, sleepers_{0};
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0;
+  bool stop_ = false;
+};
+
+// int64 -> int32 with the range ENFORCE, branch-free so it vectorises (AVX2 where the host has
+// it); returns the position of the first offending index or -1
+template <int>
+static inline int64_t narrow_checked_impl(const int64_t* __restrict__ src, int64_t n, int64_t rows,
+                                          int32_t* __restrict__ dst) {
+  uint64_t bad = 0;
+  const uint64_t R = (uint64_t)rows;
+  for (int64_t j = 0; j < n; ++j) {
+    const uint64_t v = (uint64_t)src[j];       // negative -> huge: one unsigned compare
+    bad |= (uint64_t)(v >= R);
+    dst[j] = (int32_t)v;
+  }
+  if (!bad) return -1;
+  for (int64_t j = 0; j < n; ++j)
+    if ((uint64_t)src[j] >= R) return j;
+  return -1;
+}
+__attribute__((target("avx2"))) static int64_t narrow_checked_avx2(const int64_t* s, int64_t n, int64_t r, int32_t* d) {
+  return narrow_checked_impl<1>(s, n, r, d);
+}
+static int64_t narrow_checked_base(const int64_t* s, int64_t n, int64_t r, int32_t* d) {
+  return narrow_checked_impl<0>(s, n, r, d);
+}
+static int64_t narrow_checked(const int64_t* s, int64_t n, int64_t r, int32_t* d) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  return avx2 ? narrow_checked_avx2(s, n, r, d) : narrow_checked_base(s, n, r, d);
+}
+
 // Validate (the Caffe2 ENFORCEs) and narrow int64 -> int32 (the Cast op,
 // models/dlrm_s_caffe2.py:308-309) into caller-provided host buffers.
 int32_t convert_inputs(drs_engine* e, int32_t n, const int64_t* const* h_idx, const int64_t* n_idx,
                        const int32_t* const* h_len, int32_t* idx32 /*[T][cap]*/,
-                       int32_t* off /*[T][max_batch+1]*/) {
-  for (int t = 0; t < e->T; ++t) {
-    if (!h_idx[t] && n_idx[t] > 0) return fail(e, DRS_ERR_BAD_ARG, "h_idx[%d] is NULL", t);
-    if (!h_len[t]) return fail(e, DRS_ERR_BAD_ARG, "h_len[%d] is NULL", t);
-    if (n_idx[t] < 0 || n_idx[t] > e->cap)
-      return fail(e, DRS_ERR_BAD_ARG, "table %d: %lld indices exceed staging capacity %lld", t,
-                  (long long)n_idx[t], (long long)e->cap);
+                       int32_t* off /*[T][max_batch+1]*/, HostPool* pool = nullptr,
+                       const std::function<void()>* also = nullptr /*one more independent work item*/) {
+  // per table: status + where it went wrong; the lowest failing table reports (what a
+  // sequential pass would have hit first)
+  struct Res { int32_t code = DRS_OK; int32_t bag = 0; int64_t pos = 0, val = 0, total = 0; };
+  std::vector<Res> res((size_t)e->T);
+  auto one = [&](int t) {
+    Res& r = res[t];
+    if (!h_idx[t] && n_idx[t] > 0) { r.code = DRS_ERR_BAD_ARG; r.pos = -1; return; }
+    if (!h_len[t]) { r.code = DRS_ERR_BAD_ARG; r.pos = -2; return; }
+    if (n_idx[t] < 0 || n_idx[t] > e->cap) { r.code = DRS_ERR_BAD_ARG; r.pos = -3; return; }
     int32_t* o = off + (size_t)t * (e->max_batch + 1);
     int64_t total = 0;
     o[0] = 0;
     for (int b = 0; b < n; ++b) {
-      if (h_len[t][b] < 0) return fail(e, DRS_ERR_LENGTHS_SUM, "table %d bag %d: negative length", t, b);
+      if (h_len[t][b] < 0) { r.code = DRS_ERR_LENGTHS_SUM; r.bag = b; r.pos = -1; return; }
       total += h_len[t][b];
       if (total > n_idx[t]) break;
       o[b + 1] = (int32_t)total;
     }
-    if (total != n_idx[t])
-      return fail(e, DRS_ERR_LENGTHS_SUM, "table %d: sum(lengths)=%lld != len(indices)=%lld", t,
-                  (long long)total, (long long)n_idx[t]);
+    r.total = total;
+    if (total != n_idx[t]) { r.code = DRS_ERR_LENGTHS_SUM; r.pos = 0; return; }
     for (int b = n; b < e->max_batch; ++b) o[b + 1] = (int32_t)total;
-    int32_t* dst = idx32 + (size_t)t * e->cap;
-    const int64_t R = e->rows[t];
-    for (int64_t j = 0; j < n_idx[t]; ++j) {
-      const int64_t v = h_idx[t][j];
-      if (v < 0 || v >= R)
-        return fail(e, DRS_ERR_INDEX_RANGE, "table %d: index %lld at position %lld outside [0, %lld)",
-                    t, (long long)v, (long long)j, (long long)R);
-      dst[j] = (int32_t)v;
+    const int64_t j = narrow_checked(h_idx[t], n_idx[t], e->rows[t], idx32 + (size_t)t * e->cap);
+    if (j >= 0) { r.code = DRS_ERR_INDEX_RANGE; r.pos = j; r.val = h_idx[t][j]; }
+  };
+  int64_t work = 0;
+  for (int t = 0; t < e->T; ++t) work += n_idx[t] > 0 ? n_idx[t] : 0;
+  auto item = [&](int i) { if (i < e->T) one(i); else (*also)(); };
+  const int n_items = e->T + (also ? 1 : 0);
+  if (pool && work >= 32768) pool->run(n_items, item);
+  else for (int i = 0; i < n_items; ++i) item(i);
+  for (int t = 0; t < e->T; ++t) {
+    const Res& r = res[t];
+    if (r.code == DRS_OK) continue;
+    if (r.code == DRS_ERR_BAD_ARG) {
+      if (r.pos == -1) return fail(e, DRS_ERR_BAD_ARG, "h_idx[%d] is NULL", t);
+      if (r.pos == -2) return fail(e, DRS_ERR_BAD_ARG, "h_len[%d] is NULL", t);
+      return fail(e, DRS_ERR_BAD_ARG, "table %d: %lld indices exceed staging capacity %lld", t,
+                  (long long)n_idx[t], (long long)e->cap);
     }
+    if (r.code == DRS_ERR_LENGTHS_SUM) {
+      if (r.pos == -1) return fail(e, DRS_ERR_LENGTHS_SUM, "table %d bag %d: negative length", t, r.bag);
+      return fail(e, DRS_ERR_LENGTHS_SUM, "table %d: sum(lengths)=%lld != len(indices)=%lld", t,
+                  (long long)r.total, (long long)n_idx[t]);
+    }
+    return fail(e, DRS_ERR_INDEX_RANGE, "table %d: index %lld at position %lld outside [0, %lld)", t,
+                (long long)r.val, (long long)r.pos, (long long)e->rows[t]);
   }
   return DRS_OK;
 }
@@ -373,9 +509,21 @@ void apply_stream_mode(drs_engine* e) {
   for (auto& s : e->slots) {
     if (e->shared_stream == 2) s.stream = e->slots[k % nm].own_stream;
     else s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
+    s.base_stream = s.stream;
     s.gather_stream = e->shared_stream == 2 ? e->stream_g : s.stream;
     ++k;
   }
+}
+
+// the stream the MLP side of a job of Mv virtual rows goes on (see enqueue_forward)
+hipStream_t job_stream(const drs_engine* e, const Slot& s, int64_t Mv) {
+  return (e->shared_stream == 2 && Mv <= e->mlp_small_rows) ? s.own_stream : s.base_stream;
+}
+// ... and the stream its gather goes on: a small set runs entirely on the slot's own stream (no
+// cross-stream event; short gathers of different slots may overlap -- they are latency-bound,
+// by PCIe when the inputs are read in place from host memory)
+hipStream_t job_gather_stream(const drs_engine* e, const Slot& s, int64_t Mv) {
+  return (e->shared_stream == 2 && Mv <= e->mlp_small_rows) ? s.own_stream : s.gather_stream;
 }
 
 // Enqueue n >= 1 coalesced queries (query i = first bs[i] samples of *bts[i]) as ONE set of
@@ -416,10 +564,18 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   s.polled = false;
   if (c == 0) return DRS_OK;
   const int64_t Mv = v;
+  // Pipelined mode, small launch set (a single query: 256 rows = 16 MLP workgroups on a 256-CU
+  // chip): its latency-bound MLP launch goes on the SLOT's own stream, so the MLP launches of
+  // consecutive sets overlap each other instead of queueing on the one shared MLP stream
+  // (one query per launch set: 23 k -> see DESIGN 3.5).  Full sets (8 queries, 128 workgroups)
+  // keep the shared stream: there the extra concurrency only takes CUs from the gather.
+  // Safe: a slot is reused only after its previous job was observed complete on the host.
+  s.stream = job_stream(e, s, Mv);
+  const hipStream_t gstream = job_gather_stream(e, s, Mv);
   const bool prof = e->profiling >= 1;
   const bool evts = e->profiling >= 2;
-  const bool piped = s.gather_stream != s.stream;
-  if (evts) HIP_TRY(e, hipEventRecord(s.ev[0], s.gather_stream));
+  const bool piped = gstream != s.stream;
+  if (evts) HIP_TRY(e, hipEventRecord(s.ev[0], gstream));
 
   SlsArgs a;
   memset(&a, 0, sizeof a);
@@ -455,8 +611,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   // pipelined mode: the event the MLP stream waits for is recorded by the gather dispatch itself
   // (hipExtLaunchKernel's stop event = the packet's completion signal): no marker packet sits
   // between consecutive gathers (a hipEventRecord there costs ~2 us per set)
-  HIP_TRY(e, launch_sls(a, exact_now, e->tune, s.gather_stream, piped ? s.ev_sls : nullptr));
-  if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], s.gather_stream));
+  HIP_TRY(e, launch_sls(a, exact_now, e->tune, gstream, piped ? s.ev_sls : nullptr));
+  if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], gstream));
   bool joined = !piped;   // has s.stream been made to wait for the gather yet?
   auto join = [&]() -> hipError_t {
     if (joined) return hipSuccess;
@@ -813,6 +969,12 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       s.zc.idx = reinterpret_cast<int32_t*>(dm + dense_bytes);
       s.zc.off = reinterpret_cast<int32_t*>(dm + dense_bytes + idx_bytes);
       s.zc.h_off.assign((size_t)T * (e->max_batch + 1), 0);
+      // the same layout once more in HBM: target of the one-copy input path
+      CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&s.d_stage), s.h_stage_bytes));
+      s.dc.dense = reinterpret_cast<float*>(s.d_stage);
+      s.dc.idx = reinterpret_cast<int32_t*>(s.d_stage + dense_bytes);
+      s.dc.off = reinterpret_cast<int32_t*>(s.d_stage + dense_bytes + idx_bytes);
+      s.dc.h_off.assign((size_t)T * (e->max_batch + 1), 0);
     }
   }
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream_g, hipStreamNonBlocking));
@@ -861,6 +1023,8 @@ int32_t drs_destroy(drs_handle e) {
     if (s.d_counter) (void)hipFree(s.d_counter);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_stage) (void)hipHostFree(s.h_stage);
+    if (s.d_stage) (void)hipFree(s.d_stage);
+    s.dc = Batch();
     for (auto& ev : s.ev) if (ev) (void)hipEventDestroy(ev);
     free_batch(s.scratch);
   }
@@ -972,7 +1136,17 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
     idx32 = tmp_idx.data();
     off32 = tmp_off.data();
   }
-  int32_t rc = convert_inputs(e, n, h_idx, n_idx, h_len, idx32, off32);
+  if (pinned && !e->pool) {
+    int w = e->host_threads >= 0 ? e->host_threads : (e->T < 7 ? e->T : 7);   // T tables + the dense rows
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && w > hw - 1) w = hw - 1;
+    e->pool.reset(new HostPool(w < 0 ? 0 : w));
+  }
+  // zero-copy path: the dense rows' copy into the pinned block rides along as one more work item
+  std::function<void()> copy_dense = [&] { memcpy(dense_stage, h_dense, sizeof(float) * (size_t)n * e->m_den); };
+  const bool dense_in_pool = in_place && e->m_den > 0 && n > 0;
+  int32_t rc = convert_inputs(e, n, h_idx, n_idx, h_len, idx32, off32, pinned ? e->pool.get() : nullptr,
+                              dense_in_pool ? &copy_dense : nullptr);
   if (rc) {
     if (pinned) { b.staged = false; b.n_samples = 0; }   // the slot's pinned block was overwritten: nothing valid in it
     return rc;
@@ -981,7 +1155,7 @@ static int32_t stage_into(drs_engine* e, Batch& b, int32_t n, const float* h_den
   if (in_place) {
     // `b` aliases the pinned block: the converted indices/offsets are already where the
     // kernels will read them (over PCIe, once); only the dense rows need a host copy
-    if (e->m_den > 0 && n > 0) memcpy(dense_stage, h_dense, sizeof(float) * (size_t)n * e->m_den);
+    // (dense rows: copied beside the index conversion above)
   } else {
   // copy only what is used of each table's index row
   for (int t = 0; t < e->T; ++t)
@@ -1087,20 +1261,65 @@ int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const f
   Slot& s = e->slots[slot];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
   const Batch* bt;
-  if (e->zero_copy_inputs) {
+  // the copies below must go on the stream the job's MLP side will use
+  if (bs >= 0) s.stream = job_stream(e, s, ((int64_t)bs + 63) / 64 * 64);
+  // how the converted inputs reach the kernels: 1 = read in place from the pinned block over PCIe
+  // (no copy: best for small queries, kernel-issued PCIe reads top out near 20 GB/s), 2 = ONE
+  // DMA copy of the packed block into its HBM twin (the copy engine moves it at PCIe rate beside
+  // the kernels of the other slots), 3 (default) = 2 when the query carries >= 128 KB, else 1
+  int mode = e->zero_copy_inputs;
+  if (mode == 3) {
+    int64_t bytes = (int64_t)bs * e->m_den * 4;
+    for (int t = 0; t < e->T && n_idx; ++t) bytes += n_idx[t] * 4;
+    mode = bytes >= 128 * 1024 ? 2 : 1;
+  }
+  if (mode == 2) {
+    if ((rc = stage_into(e, s.dc, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage, true))) return rc;
+    const hipStream_t gstream = job_gather_stream(e, s, ((int64_t)bs + 63) / 64 * 64);
+    // the used prefix of the block: dense rows, then index rows up to the last table's last index
+    const size_t dense_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1);
+    const size_t used = dense_bytes + sizeof(int32_t) * ((size_t)(e->T - 1) * e->cap + (size_t)n_idx[e->T - 1]);
+    const size_t idx_bytes = sizeof(int32_t) * (size_t)e->T * e->cap;
+    HIP_TRY(e, hipMemcpyAsync(s.d_stage, s.h_stage, used, hipMemcpyHostToDevice, gstream));
+    if (s.dc.uniform_len < 0)   // ragged bags: the kernels read the prefix sums as well
+      HIP_TRY(e, hipMemcpyAsync(s.d_stage + dense_bytes + idx_bytes, static_cast<char*>(s.h_stage) + dense_bytes + idx_bytes,
+                                sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1), hipMemcpyHostToDevice, gstream));
+    if (gstream != s.stream) {   // the MLP side reads the dense rows: order it behind the copy
+      HIP_TRY(e, hipEventRecord(s.ev_in, gstream));
+      HIP_TRY(e, hipStreamWaitEvent(s.stream, s.ev_in, 0));
+    }
+    bt = &s.dc;
+  } else if (mode == 1) {
     // no H2D copies at all: convert straight into the slot's host-mapped pinned block and let
     // the gather / first MLP layer read it in place (795 KB per RMC1 query, read once)
     if ((rc = stage_into(e, s.zc, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage, true))) return rc;
     bt = &s.zc;
   } else {
     if ((rc = stage_into(e, s.scratch, bs, h_dense, h_idx, n_idx, h_len, s.stream, s.h_stage))) return rc;
-    if (s.gather_stream != s.stream) {   // the gather runs on another stream: order it behind the copies
+    const hipStream_t gstream = job_gather_stream(e, s, ((int64_t)bs + 63) / 64 * 64);
+    if (gstream != s.stream) {   // the gather runs on another stream: order it behind the copies
       HIP_TRY(e, hipEventRecord(s.ev_in, s.stream));
-      HIP_TRY(e, hipStreamWaitEvent(s.gather_stream, s.ev_in, 0));
+      HIP_TRY(e, hipStreamWaitEvent(gstream, s.ev_in, 0));
     }
     bt = &s.scratch;
   }
   return enqueue_forward(e, s, 1, &bt, &bs);
+}
+
+int32_t drs_run_queues_async(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
+                             const int64_t* h_ids, int64_t ids_row_stride, int64_t n_idx_per_table,
+                             const int32_t* h_lengths, int64_t len_row_stride) {
+  if (!e) return fail(nullptr, DRS_ERR_BAD_ARG, "null handle");
+  if (!h_ids || !h_lengths || n_idx_per_table < 0 || e->T > 256) return fail(e, DRS_ERR_BAD_ARG, "bad 2-D input arrays");
+  const int64_t* ip[256];
+  const int32_t* lp[256];
+  int64_t ni[256];
+  for (int t = 0; t < e->T; ++t) {
+    ip[t] = h_ids + (int64_t)t * ids_row_stride;
+    lp[t] = h_lengths + (int64_t)t * len_row_stride;
+    ni[t] = n_idx_per_table;
+  }
+  return drs_forward_inputs_async(e, slot, bs, h_dense, ip, ni, lp);
 }
 
 int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
@@ -1238,7 +1457,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     apply_stream_mode(e);
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
-  else if (!strcmp(key, "zero_copy_inputs")) e->zero_copy_inputs = value ? 1 : 0;
+  else if (!strcmp(key, "zero_copy_inputs") && value >= 0 && value <= 3) e->zero_copy_inputs = (int)value;
+  else if (!strcmp(key, "host_threads") && value >= -1 && value <= 64) { e->host_threads = (int)value; e->pool.reset(); }
   else if (!strcmp(key, "mlp_streams") && value >= 1 && value <= 8) {
     int32_t rc = drs_sync(e);
     if (rc) return rc;
@@ -1248,6 +1468,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
+  else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "mlp_stream")) e->tune.mlp_stream = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
@@ -1304,10 +1525,10 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
       {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
-      {"zero_copy_inputs", e->zero_copy_inputs}, {"zero_copy", e->zero_copy}, {"device", e->device}};
+      {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);

@@ -113,7 +113,10 @@ class _HipNet(object):
         return load_time
 
     def run_queued(self, ids, lengths, fc, batch_size):
-        self._out = self.engine.forward_inputs(fc, list(ids), list(lengths), int(batch_size))
+        # 2-D arrays (what the reference's feeder passes) go down as they are: row pointers only
+        if not (isinstance(ids, np.ndarray) and isinstance(lengths, np.ndarray)):
+            ids, lengths = list(ids), list(lengths)
+        self._out = self.engine.forward_inputs(fc, ids, lengths, int(batch_size))
         return self._out
 
     def stage_batches(self, lX, lS_l, lS_i):

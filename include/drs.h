@@ -170,6 +170,14 @@ int32_t drs_forward_inputs_async(drs_handle h, int32_t slot, int32_t bs,
                                  const float* h_dense,
                                  const int64_t* const* h_idx, const int64_t* n_idx,
                                  const int32_t* const* h_len);
+/* The same call for the arrays exactly as the reference's feeder holds them
+ * (DLRM_Wrapper.run_queues(ids, lengths, fc, batch_size), models/dlrm_s_caffe2.py:162-174;
+ * sliced from the pre-generated sets at inferenceEngine.py:200-206): ids is a [T, n_idx_per_table]
+ * int64 array and lengths a [T, bs] int32 array, rows `*_row_stride` ELEMENTS apart (a column
+ * slice of a bigger array is fine).  Saves the binding a pointer table per query. */
+int32_t drs_run_queues_async(drs_handle h, int32_t slot, int32_t bs, const float* h_dense,
+                             const int64_t* h_ids, int64_t ids_row_stride, int64_t n_idx_per_table,
+                             const int32_t* h_lengths, int64_t len_row_stride);
 /* read back the interaction tensor R [bs, num_int] (the top MLP's input) of the last forward
  * on `slot` (parity tests).  Rows are the slot's virtual rows: a single query starts at row 0,
  * coalesced query i at the sum of round_up(bs_j, 64) over j < i; bs may span several queries. */
@@ -250,9 +258,18 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                  drs_create from MLP FLOP per gathered byte)
  *                1 one stream: sets strictly back to back, each kernel has the chip to itself
  *                0 one stream per slot: whole sets overlap freely
- *   "zero_copy_inputs" 1 (default) drs_forward_inputs converts the caller's arrays into the
- *                slot's host-mapped pinned block and the kernels read them in place over
- *                PCIe (no H2D copies) | 0 copy them to HBM first
+ *   "zero_copy_inputs" how drs_forward_inputs' converted inputs (one packed, pinned block per slot:
+ *                dense | int32 indices | prefix sums) reach the kernels: 1 read in place over PCIe
+ *                (no copy; kernel-issued PCIe reads top out near 20 GB/s) | 2 ONE DMA copy of the
+ *                block's used prefix into its HBM twin, on the job's gather stream | 3 (default)
+ *                2 for queries of >= 128 KB, else 1 | 0 one copy per array (first version)
+ *   "host_threads" workers of the per-call input pass (int64 -> int32 + ENFORCEs, one table per
+ *                work item, the dense rows' copy one more) beside the calling thread:
+ *                -1 (default) min(T, 7) | 0 the caller alone | n.  They spin ~50 us after a call and
+ *                then sleep; they do not exist until the first per-call-input query.
+ *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
+ *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
+ *                MLP launches of consecutive small sets overlap each other
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG.  Options belong to the handle: two engines in one process

@@ -421,6 +421,19 @@ int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const f
   return run(e, e->slots[slot], 1, &bt, &bs);
 }
 
+int32_t drs_run_queues_async(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
+                             const int64_t* h_ids, int64_t ids_row_stride, int64_t n_idx_per_table,
+                             const int32_t* h_lengths, int64_t len_row_stride) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (!h_ids || !h_lengths || n_idx_per_table < 0) return fail(e, DRS_ERR_BAD_ARG, "bad 2-D input arrays");
+  std::vector<const int64_t*> ip(e->T);
+  std::vector<const int32_t*> lp(e->T);
+  std::vector<int64_t> ni(e->T, n_idx_per_table);
+  for (int t = 0; t < e->T; ++t) { ip[t] = h_ids + (int64_t)t * ids_row_stride; lp[t] = h_lengths + (int64_t)t * len_row_stride; }
+  return drs_forward_inputs_async(e, slot, bs, h_dense, ip.data(), ni.data(), lp.data());
+}
+
 int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
                            const int64_t* const* h_idx, const int64_t* n_idx,
                            const int32_t* const* h_len, float* h_out) {

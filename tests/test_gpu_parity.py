@@ -87,10 +87,12 @@ def test_queue_requests_from_reference_engine(case):
             assert out.shape == (bs, 1)
             assert H.close(out, z["req/%d/expected/prob_click" % r], rtol=H.RTOL_OUT)
             # per-call inputs read in place from pinned host memory (default) == copied to HBM
-            net.engine.set_option("zero_copy_inputs", 0)
-            copied = w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)
-            net.engine.set_option("zero_copy_inputs", 1)
-            assert np.array_equal(out, copied)
+            # however the converted inputs reach the kernels (per-array copies, read in place over
+            # PCIe, one DMA copy of the packed block; default: by size): the same bits
+            for mode in (0, 1, 2):
+                net.engine.set_option("zero_copy_inputs", mode)
+                assert np.array_equal(out, w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)), mode
+            net.engine.set_option("zero_copy_inputs", 3)
     finally:
         net.engine.close()
 
@@ -277,6 +279,77 @@ def test_full_size_rmc1_baseline_shape_matches_oracle():
         assert eng.gather_bytes(0, 256) == 256 * T * (L * D * 4 + L * 4 + 4 + D * 4)
     finally:
         net.engine.close()
+
+
+FULL_SIZE = {
+    # reference models/configs/wide_and_deep.json (BASELINE config 4): 27 x 1M x 32, one lookup per
+    # table, 512 dense features, top MLP 896-1024-512-256-1 (two GEMM launches + a chain)
+    "wnd": dict(kind="wnd", rows=[1_000_000] * 27, D=32, L=1, bot="512", top="1024-512-256-1"),
+    # reference models/configs/ncf.json (BASELINE config 4)
+    "ncf": dict(kind="ncf", rows=[140_000, 140_000, 28_000, 28_000], D=64, L=1, bot="512", top="256-256-128-64-64"),
+    # reference models/configs/dlrm_rm2.json (BASELINE config 5): 32 x 500k x 64, 120 lookups per
+    # bag, top input 2112 wide (too wide for an LDS slab: the per-layer chain kernel)
+    "rm2": dict(kind="dlrm", rows=[500_000] * 32, D=64, L=120, bot="256-128-64", top="128-64-1"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE))
+def test_full_size_reference_shapes_match_oracle(name):
+    """The shapes BASELINE configs 4 and 5 serve, at FULL size and batch 256, against the oracle
+    on the same counter-based table fill: interaction tensor bitwise and outputs to 1e-6 with the
+    sequential-order gather, the default gather within its tolerance, 8 coalesced queries equal
+    to the same queries served alone, and the launch-structure options bit-identical."""
+    from deeprecsys_amd.data_generator.dlrm_data import generate_fast_input_data
+    w = FULL_SIZE[name]
+    B, seed, nb = 256, 77, 2
+    rows, D, L, T = w["rows"], w["D"], w["L"], len(w["rows"])
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_bot=w["bot"], arch_mlp_top=w["top"], arch_interaction_op="cat",
+                       num_indices_per_lookup=L, num_batches=nb, max_mini_batch_size=B, mini_batch_size=B,
+                       numpy_rand_seed=seed, accel_table_init="device", model_type=w["kind"], accel_slots=2)
+    np.random.seed(seed)
+    net = H.NET_CLS[w["kind"]](args)
+    ncf = w["kind"] == "ncf"
+    m_den = int(w["bot"].split("-")[0])
+    _, lX, lS_l, lS_i = generate_fast_input_data(nb, B, m_den, rows, L, seed)
+    dense = (lambda b: None) if ncf else (lambda b: lX[b])
+    net.create(None if ncf else lX[0], lS_l[0], lS_i[0], None)
+    eng = net.engine
+    try:
+        net.stage_batches(None if ncf else lX, lS_l, lS_i)
+        net.emb_w = [orc.fill_table_uniform(rows[t], D, t, -float(np.sqrt(1 / rows[t])), float(np.sqrt(1 / rows[t])),
+                                            seed, nthreads=0) for t in range(T)]
+        om = H.oracle_model(net)
+        ref = {}
+        eng.set_option("sls_exact", 1)
+        for bid in (0, 1):
+            for bs in (B, 165, 1):
+                got = net.run_staged(bid, bs)
+                R = eng.fetch_interaction(bs)
+                exp, R_exp = om.forward(dense(bid), lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+                assert np.array_equal(R, R_exp), (name, bid, bs)
+                assert H.close(got, exp, rtol=1e-6, atol=1e-7), (name, bid, bs, np.abs(got - exp).max())
+                ref[(bid, bs)] = got
+        # 8 coalesced queries (one gather launch, one MLP pass) == the same queries served alone
+        jobs = [(0, B), (1, 165), (0, 1), (1, B), (0, 165), (1, 1), (0, B), (1, B)]
+        outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+        for (bid, bs), o in zip(jobs, outs):
+            assert np.array_equal(o, ref[(bid, bs)]), (name, bid, bs)
+        # other launch structures of the same arithmetic: bit-identical
+        for key, val in (("mlp_stream", 0), ("mlp_gemm", 0), ("mlp_fuse", 0), ("shared_stream", 1)):
+            eng.set_option(key, val)
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, key)
+            eng.set_option(key, {"shared_stream": 2}.get(key, 1))
+        # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
+        eng.set_option("sls_exact", 0)
+        got = net.run_staged(0, B)
+        R = eng.fetch_interaction(B)
+        _, R_exp = om.forward(dense(0), lS_i[0], lS_l[0], bs=B, want_R=True, nthreads=0)
+        assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6)
+        assert H.close(got, ref[(0, B)], rtol=H.RTOL_OUT)
+        assert eng.gather_bytes(0, B) == B * T * (L * D * 4 + L * 4 + 4 + D * 4)
+    finally:
+        eng.close()
 
 
 def test_split_variant_within_tolerance_full_size():
@@ -532,6 +605,54 @@ def test_flat_gather_variants_match_oracle(D, T, L):
         eng.set_option("sls_exact", 1)
         eng.forward(0, B)
         assert np.array_equal(eng.fetch_interaction(B)[:, D:], pooled(0, B))
+    finally:
+        eng.close()
+
+
+def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
+    """The run_queues signature (models/dlrm_s_caffe2.py:162-174) at RMC1 size: 2-D id / length
+    arrays (row pointers only, strided slices of a bigger set like inferenceEngine.py:200-206)
+    give the bits of per-table lists and of the staged path, with 0, 1 or 3 conversion workers;
+    the Caffe2 ENFORCEs fire from the worker pool and name the first failing table."""
+    T, rows, D, L, B = 8, 100_000, 64, 80, 256
+    rng = np.random.RandomState(21)
+    eng = N.Engine(N.MODEL_DLRM, [rows] * T, D, [16, D], [D * (T + 1), 8, 1], N.INTERACT_CAT, sigmoid_top=2,
+                   max_batch=B, max_lookups=L, num_staged_batches=1, num_slots=3)
+    try:
+        for t in range(T):
+            eng.fill_table_uniform(t, -0.1, 0.1, 3)
+        eng.set_fc(N.MLP_BOT, 0, rng.randn(D, 16).astype(np.float32), rng.randn(D).astype(np.float32))
+        eng.set_fc(N.MLP_TOP, 0, rng.randn(8, D * (T + 1)).astype(np.float32) * 0.05, np.zeros(8, np.float32))
+        eng.set_fc(N.MLP_TOP, 1, rng.randn(1, 8).astype(np.float32), np.zeros(1, np.float32))
+        big_ids = rng.randint(0, rows, size=(T, 2 * B * L)).astype(np.int64)      # a bigger pre-generated set
+        big_len = np.full((T, 2 * B), L, dtype=np.int32)
+        dense = rng.rand(B, 16).astype(np.float32)
+        for bs in (B, 165, 1):
+            ids, lens = big_ids[:, :bs * L], big_len[:, :bs]                      # strided 2-D slices
+            assert not ids.flags["C_CONTIGUOUS"] or bs == 2 * B
+            eng.stage_batch(0, dense[:bs], [r.copy() for r in ids], [r.copy() for r in lens])
+            ref = eng.forward(0, bs)
+            for workers, mode in ((0, 3), (1, 1), (3, 2), (-1, 0), (-1, 3)):
+                eng.set_option("host_threads", workers)
+                eng.set_option("zero_copy_inputs", mode)
+                assert np.array_equal(eng.forward_inputs(dense[:bs], ids, lens, bs), ref), (bs, workers, mode)
+                assert np.array_equal(eng.forward_inputs(dense[:bs], list(ids), list(lens), bs), ref)
+            # three calls in flight on three slots
+            for s_ in range(3):
+                eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=s_)
+            for s_ in range(3):
+                assert np.array_equal(eng.wait(s_, bs), ref)
+        bad = big_ids[:, :B * L].copy()
+        bad[5, 17] = rows            # table 5 ...
+        bad[2, 9000] = -1            # ... and table 2: the lower table reports, like a sequential pass
+        with pytest.raises(N.DrsError) as ei:
+            eng.forward_inputs(dense, bad, big_len[:, :B], B)
+        assert ei.value.code == N.ERR_INDEX_RANGE and "table 2" in ei.value.detail and "position 9000" in ei.value.detail
+        short = big_len[:, :B].copy()
+        short[6, 3] = L - 1
+        with pytest.raises(N.DrsError) as ei:
+            eng.forward_inputs(dense, big_ids[:, :B * L], short, B)
+        assert ei.value.code == N.ERR_LENGTHS_SUM and "table 6" in ei.value.detail
     finally:
         eng.close()
 

@@ -174,8 +174,8 @@ def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
     assert two["config"]["queries_per_step"] == 20 and two["config"]["timed_queries_per_gpu"] == 60
     assert two["latency_ms"]["queries"] == 120                      # both ranks' histograms, summed
     # whole-job throughput: all ranks' queries over the slowest rank's time
-    assert two["value"] == pytest.approx(120 / two["config"]["timed_seconds"], rel=0.02)   # (both rounded)
-    assert two["ms_per_step"] == pytest.approx(two["config"]["timed_seconds"] / 3 * 1e3, rel=0.02)
+    assert two["value"] == pytest.approx(120 / two["config"]["timed_seconds"], rel=0.15)   # (timed_seconds is rounded to 0.1 ms)
+    assert two["ms_per_step"] == pytest.approx(two["config"]["timed_seconds"] / 3 * 1e3, rel=0.15)
     one = _bench(["--gpus", "1"] + _TINY, cpu)
     assert one["n_gpus"] == 1 and one["latency_ms"]["queries"] == 60 and one["config"]["collective"] is None
     # identical line structure at N = 1 and N = 2
