@@ -50,6 +50,9 @@ struct SlsArgs {
 struct Tune {
   int device = 0;
   const float* zero = nullptr;   // 256 B of zeros on `device`: source of out-of-range float4 loads
+  const float* w_arena = nullptr;   // the engine's FC weight arena (biases + weights, one allocation) ...
+  uint64_t w_arena_floats = 0;
+  uint32_t w_zero_off = 0;          // ... whose first 64 floats are zeros (float offset of them)
   int sls_u = 0;                 // row loads per register ring and lane (0 = default 4)
   int sls_v_d32 = 4;             // lane width for D == 32 (4 | 2)
   int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once

@@ -166,7 +166,7 @@ struct drs_engine {
   int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
   int zero_copy_inputs = 3;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 auto
-  int64_t mlp_wide_kn = 512 * 1024;   // K*N from which a layer gets its own 2-D launch
+  int64_t mlp_wide_kn = 256 * 1024;   // K*N from which a layer gets its own 2-D launch (RM3's 1024x256 included)
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   int64_t mlp_small_rows = 1024;      // launch sets up to this many rows: MLP side on the slot's own stream
   // profiling
@@ -1088,16 +1088,19 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
           nbias += (out + 3) / 4 * 4;
         }
       nbias = (nbias + 63) / 64 * 64;
-      need += nbias;
+      const size_t zeros = 64;       // a zero page inside the arena (stream kernel: k beyond a layer's K)
+      need += nbias + zeros;
       e->w_arena_floats = need < (1u << 20) ? (1u << 20) : need;   // >= 4 MiB
       HIP_TRY(e, hipMalloc(&e->w_arena, sizeof(float) * e->w_arena_floats));
-      size_t boff = 0;
+      HIP_TRY(e, hipMemset(e->w_arena, 0, sizeof(float) * zeros));
+      e->tune.w_arena = e->w_arena; e->tune.w_arena_floats = e->w_arena_floats; e->tune.w_zero_off = 0;
+      size_t boff = zeros;
       for (Mlp* mm : {&e->bot, &e->top, &e->fin})
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
           mm->layers[i].b = e->w_arena + boff;
           boff += ((mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024) + 3) / 4 * 4;
         }
-      e->w_arena_used = nbias;
+      e->w_arena_used = zeros + nbias;
     }
     const size_t wsz = ((size_t)m * n + 63) / 64 * 64;
     if (e->w_arena_used + wsz > e->w_arena_floats) return fail(e, DRS_ERR_OOM, "weight arena exhausted");

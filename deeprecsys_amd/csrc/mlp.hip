@@ -413,6 +413,7 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
 // LDS; launch_chain2 falls back to chain_kernel otherwise.
 struct SLayer {
   const float* W;          // [N, K] row-major
+  uint32_t w_off, pad0_;   // ... as a float offset from SArgs::wbase (the engine's weight arena)
   const float* b;          // [N] or nullptr
   int32_t K, N, act;
   int32_t in_off, in_ld;   // input slab: float offset in LDS, leading dimension
@@ -450,6 +451,9 @@ struct SArgs {
   const float* zero;       // 16 B of zeros in device memory: source of every out-of-range float4 load
                            // (an address select keeps the load unconditional; a value select would
                            // put it under divergent control flow and serialise the tile's loads)
+  const float* wbase;      // the weight arena: every tile address is wbase + a 32-bit float offset, so
+  uint32_t zero_off, pad3_;// a tile load is `global_load_dwordx4 v, v_off, s[wbase]` (four VALU per
+                           // address); zero_off: zeros INSIDE the arena for k beyond a layer's K
   SLayer L[DRS_MAX_STREAM_LAYERS];
   SInput in[2];
 };
@@ -475,30 +479,24 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   const int st_lo = (frow & 8) ? 2 : 0, st_hi = 2 - st_lo;   // swz4 of my rows (same for all j)
   float* const st_base = sB + frow * LD + fk;
 
-  // ---- fetch iterator: two tiles ahead --------------------------------------------------
+  // ---- fetch iterator: six tiles ahead ----------------------------------------------------
   int f_l = 0, f_n0 = 0, f_c = 0, f_K = a.L[0].K, f_N = a.L[0].N;
-  const float* f_W = a.L[0].W;
-  int64_t f_zoff = zero - f_W;                 // the zero page, as an element offset from f_W
+  uint32_t f_woff = a.L[0].w_off;
   // The tile loads are issued through inline asm and waited for with an explicit
   // s_waitcnt (DRS_WAIT_TILE): the compiler's own counter model drains the whole ring at
   // the loop header (vmcnt(0) once per trip), which costs a full miss latency every six
   // rounds.  vmcnt retires in order, so waiting for "at most 20 newer" is exact for the
-  // set requested five rounds (5 x 4 loads) ago no matter how many stores came in between.
-  auto fetch = [&](f32x4 (&rb)[4]) {
+  // set requested five rounds ago no matter how many stores came in between.
+  // One of the four loads of a tile (rows frow + 32 j): scalar base + 32-bit offset.
+  auto fetch_part = [&](f32x4 (&rb)[4], int j) {
     const int k = f_c * 64 + fk;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = min(f_n0 + frow + 32 * j, f_N - 1);
-      // out-of-range k reads the zero page
-      int64_t off = (int64_t)row * f_K + k;
-#ifdef DRS_TIMELINE
-      if (a.dbg & 1) off = (int64_t)min(frow + 32 * j, f_N - 1) * f_K + fk;   // timing experiment: hot tile
-#endif
-      off = k < f_K ? off : f_zoff;
-      const float* p = f_W + off;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[j]) : "v"(p));
-    }
-    // advance (uniform)
+    const int row = min(f_n0 + frow + 32 * j, f_N - 1);
+    uint32_t off = f_woff + (uint32_t)row * (uint32_t)f_K + (uint32_t)k;
+    off = k < f_K ? off : a.zero_off;            // out-of-range k reads zeros
+    const uint32_t boff = off << 2;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[j]) : "v"(boff), "s"(a.wbase));
+  };
+  auto fetch_advance = [&]() {                   // (uniform)
     ++f_c;
     if (f_c * 64 >= f_K) {
       f_c = 0;
@@ -507,11 +505,15 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         f_n0 = 0;
         if (f_l + 1 < a.n_layers) {
           ++f_l;
-          f_K = a.L[f_l].K; f_N = a.L[f_l].N; f_W = a.L[f_l].W;
-          f_zoff = zero - f_W;
+          f_K = a.L[f_l].K; f_N = a.L[f_l].N; f_woff = a.L[f_l].w_off;
         }
       }
     }
+  };
+  auto fetch = [&](f32x4 (&rb)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fetch_part(rb, j);
+    fetch_advance();
   };
   // swz4 by address instead of by value: the halves of a float4 go to swapped 8-B slots
   // on rows 8..15 (two ds_write_b64, no selects)
@@ -538,53 +540,77 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   f32x4 rb0[4], rb1[4], rb2[4], rb3[4], rb4[4], rb5[4];
   fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3); fetch(rb4); fetch(rb5);   // tiles 0..5 (repeats past the end)
   TL(2);
-  // ---- chain inputs -> LDS slabs ---------------------------------------------------------
-  for (int q = 0; q < a.n_inputs; ++q) {
-    const SInput& in = a.in[q];
-    const float* base = in.src;
-    int64_t row0 = m0, rows = a.M;
-    if (in.use_xs) resolve_src(xs, in.src, a.M, m0, &base, &row0, &rows);
-    const int qpr = in.cols_pad >> 2, total = 16 * qpr;
-    float* dst = smem + in.lds_off + in.lds_col0;
-    for (int i0 = 0; i0 < total; i0 += 4 * kThreads) {
-      float4 v[4];
+  // ---- chain inputs and biases -> LDS ------------------------------------------------------
+  // Every load of the prologue -- the six weight tiles above, the 16-row blocks of both chain
+  // inputs, the biases -- is REQUESTED before the first one is waited for: one memory round
+  // trip instead of four (dense block, pooled block in two batches, biases: the in-kernel
+  // timeline showed 3.9 us here, cold HBM / Infinity-Cache misses each).  A slot is 512 float4
+  // (one per thread); slots [0, n0s) belong to input 0, the rest to input 1, so which input a
+  // slot reads is uniform.
+  {
+    constexpr int PRE = 8;                       // slots per batch (RMC1 needs 6, RM3's 1024-wide chain 8)
+    const SInput in0 = a.in[0];
+    const SInput in1 = a.in[a.n_inputs > 1 ? 1 : 0];
+    const int n0s = (16 * (in0.cols_pad >> 2) + kThreads - 1) / kThreads;
+    const int n1s = a.n_inputs > 1 ? (16 * (in1.cols_pad >> 2) + kThreads - 1) / kThreads : 0;
+    const float* base0 = in0.src;
+    int64_t row00 = m0, rows0 = a.M;
+    if (in0.use_xs) resolve_src(xs, in0.src, a.M, m0, &base0, &row00, &rows0);
+    // biases: requested first, stored last (the engine keeps the chains' biases back to back,
+    // padded to 4 floats: one flat copy; a global load in the epilogue would put a vmcnt(0)
+    // = the full latency of the weight tiles just requested at the end of every pass)
+    float bias_v[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = min(i0 + tid + j * kThreads, total - 1);
-        const int row = idx / qpr, k = (idx - row * qpr) * 4;
-        const int64_t grow = min(row0 + row, rows - 1);
-        int64_t off = grow * in.ld + in.col0 + k;
-        off = k < in.cols ? off : (int64_t)(zero - base);
-        asm("" : "+v"(off));
-        v[j] = *reinterpret_cast<const float4*>(base + off);
-        if (in.col2 >= 0) {      // uniform
-          int64_t off2 = grow * in.ld + in.col2 + k;
-          off2 = k < in.cols ? off2 : (int64_t)(zero - base);
-          asm("" : "+v"(off2));
-          const float4 w = *reinterpret_cast<const float4*>(base + off2);
-          v[j] = make_float4(v[j].x + w.x, v[j].y + w.y, v[j].z + w.z, v[j].w + w.w);
+    for (int j = 0; j < 2; ++j) bias_v[j] = a.bias[min(tid + j * kThreads, a.n_bias - 1)];
+    for (int s0 = 0; s0 < n0s + n1s; s0 += PRE) {
+      float4 v[PRE], w2[PRE];
+#pragma unroll
+      for (int j = 0; j < PRE; ++j) {
+        const int sl = s0 + j;
+        if (sl < n0s + n1s) {                    // uniform
+          const bool second = sl >= n0s;         // uniform
+          const SInput& in = second ? in1 : in0;
+          const float* base = second ? in1.src : base0;
+          const int64_t row0 = second ? m0 : row00, rows = second ? a.M : rows0;
+          const int qpr = in.cols_pad >> 2, total = 16 * qpr;
+          const int idx = min((sl - (second ? n0s : 0)) * kThreads + tid, total - 1);
+          const int row = idx / qpr, k = (idx - row * qpr) * 4;
+          const int64_t grow = min(row0 + row, rows - 1);
+          int64_t off = grow * in.ld + in.col0 + k;
+          off = k < in.cols ? off : (int64_t)(zero - base);      // out-of-range k reads the zero page
+          asm("" : "+v"(off));
+          v[j] = *reinterpret_cast<const float4*>(base + off);
+          if (in.col2 >= 0) {                    // uniform: the block is the SUM of two column blocks (NCF)
+            int64_t off2 = grow * in.ld + in.col2 + k;
+            off2 = k < in.cols ? off2 : (int64_t)(zero - base);
+            asm("" : "+v"(off2));
+            w2[j] = *reinterpret_cast<const float4*>(base + off2);
+          }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = i0 + tid + j * kThreads;
-        const int row = idx / qpr, k = (idx - row * qpr) * 4;
-        if (idx < total) *reinterpret_cast<float4*>(dst + row * in.lds_ld + k) = swz4(v[j], row);
-        if (in.g_dst && idx < total && k < in.cols && m0 + row < a.M)
-          *reinterpret_cast<float4*>(in.g_dst + (m0 + row) * in.g_ldd + k) = v[j];
+      for (int j = 0; j < PRE; ++j) {
+        const int sl = s0 + j;
+        if (sl < n0s + n1s) {
+          const bool second = sl >= n0s;
+          const SInput& in = second ? in1 : in0;
+          const int qpr = in.cols_pad >> 2, total = 16 * qpr;
+          const int idx = (sl - (second ? n0s : 0)) * kThreads + tid;
+          const int row = idx / qpr, k = (idx - row * qpr) * 4;
+          float4 x = v[j];
+          if (in.col2 >= 0) x = make_float4(x.x + w2[j].x, x.y + w2[j].y, x.z + w2[j].z, x.w + w2[j].w);
+          float* dst = smem + in.lds_off + in.lds_col0;
+          if (idx < total) *reinterpret_cast<float4*>(dst + row * in.lds_ld + k) = swz4(x, row);
+          if (in.g_dst && idx < total && k < in.cols && m0 + row < a.M)
+            *reinterpret_cast<float4*>(in.g_dst + (m0 + row) * in.g_ldd + k) = x;
+        }
       }
     }
-  }
-  // biases -> LDS: a global load in the epilogue would put a vmcnt(0) (= the full latency of
-  // the weight tiles just requested) at the end of every pass
-  // (the engine keeps the chains' biases back to back, padded to 4 floats: one flat copy)
-  for (int i0 = 0; i0 < a.n_bias; i0 += 4 * kThreads) {
-    float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = a.bias[min(i0 + tid + j * kThreads, a.n_bias - 1)];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i0 + tid + j * kThreads < a.n_bias) smem[a.bias_off + i0 + tid + j * kThreads] = v[j];
+    for (int j = 0; j < 2; ++j)
+      if (tid + j * kThreads < a.n_bias) smem[a.bias_off + tid + j * kThreads] = bias_v[j];
+    for (int i0 = 2 * kThreads; i0 < a.n_bias; i0 += kThreads)     // (more than 1024 bias words: not on any shipped config)
+      if (i0 + tid < a.n_bias) smem[a.bias_off + i0 + tid] = a.bias[i0 + tid];
   }
   TL(3);
   DRS_WAIT_TILE(rb0, 0);
@@ -637,7 +663,6 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     TL(10);                                                                                       \
     if (a.inter_on && c_tile == a.inter_tile) interact();                                         \
     ++c_tile;                                                                                     \
-    fetch(RB_FETCH);                                                                              \
     TL(11);                                                                                       \
     const int col = c_n0 + wave * 16 + r;                                                         \
     if (c_n0 + wave * 16 < cl.N) {                                                                \
@@ -645,8 +670,12 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       const float* pb = sB + ((BUF) * 128 + wave * 16 + r) * LD + gs;                             \
       float av[16], bv[16];                                                                       \
       _Pragma("unroll") for (int s = 0; s < 16; ++s) { av[s] = pa[4 * s]; bv[s] = pb[4 * s]; }    \
-      /* issue order, pinned: all operand reads; then the dependent MFMA chain with one LDS    */ \
-      /* write of the stash in the shadow of every second MFMA                                 */ \
+      /* issue order, pinned: the requests of the tile six ahead; all operand reads; then the    */ \
+      /* dependent MFMA chain with one LDS write of the stash in the shadow of every second MFMA.*/ \
+      /* Tried and dropped (r2, each 3-5 % slower on RMC1 / W&D / NCF): the requests spread INTO  */ \
+      /* the chain (anything between two MFMAs on one accumulator delays the dependent issue),   */ \
+      /* and the two waves of a SIMD running request / multiply halves in opposite order.        */ \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) fetch_part(RB_FETCH, q);                      \
       DRS_WAIT_TILE(RB_STASH, 20);                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                             \
@@ -658,9 +687,11 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         __builtin_amdgcn_sched_barrier(0);                                                        \
       }                                                                                           \
     } else {                                                                                      \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) fetch_part(RB_FETCH, q);                      \
       DRS_WAIT_TILE(RB_STASH, 20);                                                                \
       stash((BUF) ^ 1, RB_STASH);                                                                 \
     }                                                                                             \
+    fetch_advance();                                                                              \
     TL(12);                                                                                       \
     if (c_c == c_nch - 1) {                                                                       \
       if (col < (cl.out_off >= 0 ? cl.out_pad : cl.N)) {                                          \
@@ -967,6 +998,14 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     return false;
   }
   auto ok_ptr = [](const void* q) { return aligned16(q); };
+  // every weight matrix must live inside the engine's arena (tile addresses are 32-bit byte
+  // offsets from its base)
+  auto in_arena = [&](const float* w, int64_t n) {
+    return tune.w_arena && w >= tune.w_arena && w + n <= tune.w_arena + tune.w_arena_floats &&
+           tune.w_arena_floats < (1ull << 30);
+  };
+  for (int l = 0; l < na; ++l) if (!in_arena(a.W[l], (int64_t)a.width[l] * a.width[l + 1])) return false;
+  for (int l = 0; l < nb; ++l) if (!in_arena(b->W[l], (int64_t)b->width[l] * b->width[l + 1])) return false;
   if (!ok_ptr(a.x) || (a.ldx & 3)) return false;
   for (int i = 0; i < xs.q.n_q; ++i) if (!ok_ptr(xs.x[i])) return false;
   for (int l = 0; l < na; ++l) if (!ok_ptr(a.W[l]) || (a.width[l] & 3)) return false;
@@ -1015,7 +1054,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   int which = 0, cur_off = x0_off, cur_ld = x0_ld, n = 0, tiles = 0, boff = bias_off;
   auto add = [&](const ChainArgs& c, int l, bool last_of_chain, bool last_of_all) {
     SLayer& L = p.L[n++];
-    L.W = c.W[l]; L.b = c.b[l]; L.K = c.width[l]; L.N = c.width[l + 1]; L.act = c.act[l];
+    L.W = c.W[l]; L.w_off = (uint32_t)(c.W[l] - tune.w_arena); L.b = c.b[l]; L.K = c.width[l]; L.N = c.width[l + 1]; L.act = c.act[l];
     L.in_off = cur_off; L.in_ld = cur_ld;
     L.out_off = -1; L.out_ld = 0; L.out_pad = L.N; L.out_col0 = 0;
     L.g_out = nullptr; L.g_ld = 0; L.g_sc1 = 0;
@@ -1044,6 +1083,8 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   p.bias = a.b[0];
   p.M = a.M;
   p.zero = tune.zero;
+  p.wbase = tune.w_arena;
+  p.zero_off = tune.w_zero_off;
   p.dbg = tune.mlp_debug;
   SInput& i0 = p.in[0];
   i0.src = a.x; i0.ld = a.ldx; i0.col0 = 0; i0.cols = a.width[0]; i0.cols_pad = pad64(a.width[0]);

@@ -102,9 +102,27 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
   }
   __syncthreads();
   if (!s_u[0]) return;
-  // last workgroup of the launch: everything the query produced is visible to it.  Stream
-  // the outputs to host-mapped pinned memory, then ONE system-scope release and the flag.
-  // (16 bytes per lane and 4 loads in flight: NCF hands 512 KB per launch set over this way)
+  // last workgroup of the launch: everything the query produced is visible to it.  Stream the
+  // outputs, the device error word and the gather's clock span to host-mapped pinned memory in
+  // ONE batch of write-through system-scope stores, wait once for them, then publish the flag.
+  // (16 bytes per lane and 4 loads in flight: NCF hands 512 KB per launch set over this way.)
+  // Round trips on this path: [loads of outputs | error word | span partials, all in flight
+  // together] -> [host stores, one PCIe acknowledgement wait] -> flag.  The first version loaded
+  // the error word and stored it only after the outputs had been acknowledged: two more
+  // dependent round trips (~3 us) on every launch set.
+  unsigned err = 0;
+  if (threadIdx.x == 0) err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long lo = ~0ull, hi = 0ull;
+  if (d.ts) {
+    // fold the per-workgroup (min start, max end) pairs: all threads, then waves, then one lane
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
+    for (unsigned b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+      const unsigned long long a = __hip_atomic_load(acc + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long z = __hip_atomic_load(acc + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lo = a < lo ? a : lo;
+      hi = z > hi ? z : hi;
+    }
+  }
   {
     const unsigned n4 = d.out_words >> 2;
     const bool al = ((reinterpret_cast<uintptr_t>(d.dev_out) | reinterpret_cast<uintptr_t>(d.host_out)) & 15) == 0;
@@ -133,16 +151,7 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
                          __hip_atomic_load(d.dev_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sc1 load (bypasses my L1) -> write-through store
   }
-  unsigned long long lo = ~0ull, hi = 0ull;
   if (d.ts) {
-    // fold the per-workgroup (min start, max end) pairs: all threads, then waves, then one lane
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(d.span_acc);
-    for (unsigned b = threadIdx.x; b < n_blocks; b += blockDim.x) {
-      const unsigned long long a = __hip_atomic_load(acc + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long z = __hip_atomic_load(acc + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      lo = a < lo ? a : lo;
-      hi = z > hi ? z : hi;
-    }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
       const unsigned long long lo2 = __shfl_xor(lo, m), hi2 = __shfl_xor(hi, m);
@@ -151,14 +160,8 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
     }
     unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
     if ((threadIdx.x & 63) == 0) { s_q[2 * (threadIdx.x >> 6)] = lo; s_q[2 * (threadIdx.x >> 6) + 1] = hi; }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned err = __hip_atomic_load(d.dev_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d.ts) {
-      unsigned long long* s_q = reinterpret_cast<unsigned long long*>(s_u + 4);
+    __syncthreads();            // (uniform: d.ts is a kernel argument)
+    if (threadIdx.x == 0) {
       for (unsigned w = 1; w < blockDim.x / 64; ++w) {
         lo = s_q[2 * w] < lo ? s_q[2 * w] : lo;
         hi = s_q[2 * w + 1] > hi ? s_q[2 * w + 1] : hi;
@@ -166,12 +169,18 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_span) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // every payload store above is a write-through system-scope store that has been waited
-    // for (vmcnt(0) + barrier): the flag can follow without an L2 write-back fence (G16 R1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.host_err, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // every payload store above is a write-through system-scope store; once each wave has seen
+  // its own acknowledged (vmcnt(0)) and the workgroup has met, the flag can follow without an
+  // L2 write-back fence (G16 R1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Where do the 16 input rows of the slab starting at virtual row m0 come from?  With

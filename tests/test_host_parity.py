@@ -244,3 +244,56 @@ def test_response_aggregator_matches_reference_formulae():
     # (a histogram percentile is the upper edge of the bin holding the "higher" order statistic)
     assert stats.percentile_from_histogram(h, 99) == pytest.approx(
         np.percentile(finals, 99, method="higher") * 1e3, rel=0.01)
+
+
+# ---- locality-aware index traces: data_generator/trace_generator.py, trace_profile.py ----
+def _traces():
+    import json
+    with open(os.path.join(H.GOLDEN, "traces.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(H.GOLDEN, "traces.npz"))
+
+
+def test_trace_generate_lru_equals_reference_for_the_same_seeds():
+    """The LRU-stack walk (deque + cursor here, one big list there) gives the reference's trace
+    element for element: shipped profile (99.9 % new references) and a reuse-heavy one, table
+    exhaustion (64 lines, 400 references) and the padding mode."""
+    import random
+    from deeprecsys_amd.data_generator import trace_generator as TG
+    meta, z = _traces()
+    for c in meta["lru_cases"]:
+        lsd, csd = z[c["profile"] + "/list_sd"].tolist(), z[c["profile"] + "/cumm_sd"].tolist()
+        random.seed(c["seed"])
+        np.random.seed(c["seed"])
+        got = TG.trace_generate_lru(c["table_size"], lsd, csd, c["len"], c["padding"])
+        assert np.array_equal(np.array(got, dtype=np.uint64), z[c["key"]]), c
+        assert all(isinstance(v, np.uint64) for v in got[:3])
+    hot = z["lru/hot/500_1500_7_0"]
+    assert len(np.unique(hot)) < 0.7 * hot.size          # the reuse-heavy profile really reuses lines
+
+
+def test_trace_profile_and_distribution_equal_reference(tmp_path):
+    from deeprecsys_amd.data_generator import trace_generator as TG
+    meta, z = _traces()
+    tr = z["profile/trace"]
+    for max_sd in meta["profile_max_sd"]:
+        sds, lines = TG.trace_profile(tr, max_sd)
+        assert np.array_equal(sds, z["profile/%d/stack_distances" % max_sd])
+        assert np.array_equal(lines, z["profile/%d/line_accesses" % max_sd])
+    # distribution -> file -> back, in the reference's two-line format
+    list_sd, prob_sd, cumm_sd = TG.stack_distance_distribution(z["profile/1000/stack_distances"].tolist())
+    assert list_sd[0] == 0 and abs(cumm_sd[-1] - 1.0) < 1e-12 and abs(sum(prob_sd) - 1.0) < 1e-12
+    p = str(tmp_path / "sd_cumm")
+    TG.write_dist_to_file(p, list_sd, cumm_sd)
+    back = TG.read_dist_from_file(p)
+    assert back[0] == list_sd and np.allclose(back[1], cumm_sd, rtol=0, atol=0)
+    # a trace synthesised from a profile has (statistically) that profile's share of new lines
+    import random
+    random.seed(3)
+    np.random.seed(3)
+    syn = TG.trace_generate_lru(5000, z["hot/list_sd"].tolist(), z["hot/cumm_sd"].tolist(), 4000)
+    sds, _ = TG.trace_profile(np.array(syn, dtype=np.int64), 1000)
+    new_share = float(np.mean(np.array(sds) == 0))
+    assert abs(new_share - 0.45) < 0.05
+    bags = TG.bags_from_trace(syn, 50, 80)
+    assert bags.dtype == np.int64 and bags.size == 4000 and bags.max() < 5000
