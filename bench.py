@@ -379,10 +379,36 @@ def main():
     for kv in opt.set:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    comm_note = None
     if world > 1 and opt.collective == "rccl":
-        box = [N.Comm.unique_id() if rank == 0 else None]
+        # rank 0 creates the communicator id; gloo carries the 128 bytes.  Should RCCL refuse to
+        # come up on this node (every rank learns it: the outcome is all-reduced over gloo), the
+        # run still produces its line with the statistics combined over gloo -- and says so.
+        box = [None]
+        if rank == 0:
+            try:
+                box = [N.Comm.unique_id()]
+            except Exception as e:      # noqa: BLE001
+                box = ["ERR " + repr(e)[:200]]
         dist.broadcast_object_list(box, src=0)
-        comm = N.Comm(box[0], rank, world, device)
+        ok, err = 0, ""
+        if isinstance(box[0], bytes):
+            try:
+                comm = N.Comm(box[0], rank, world, device)
+                ok = 1
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)[:200]
+        else:
+            err = box[0]
+        import torch
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            comm_note = "gloo (RCCL communicator did not come up: %s)" % (err or "on another rank")
+            print("bench.py rank %d: %s" % (rank, comm_note), file=sys.stderr)
     bs, nb, slots, co = opt.batch, opt.num_batches, opt.slots, opt.coalesce
     qps_ = max(1, opt.queries_per_step)
     n_timed, n_warm = opt.steps * qps_, opt.warmup * qps_
@@ -515,7 +541,8 @@ def main():
                        "queries_per_launch": co, "launch_sets_in_flight": slots,
                        "streams": stream_mode,
                        "collective": None if world == 1 else
-                       ("drs_stats_allreduce (RCCL, one grouped all-reduce of 32 KB)" if comm is not None else "gloo"),
+                       ("drs_stats_allreduce (RCCL, one grouped all-reduce of 32 KB)" if comm is not None
+                        else (comm_note or "gloo")),
                        "inputs": "device-resident (pre-staged)"},
             "latency_ms": {"p50": round(p50, 4), "p95": round(p95, 4), "p99": round(p99, 4),
                            "queries": int(np.sum(hist)), "sla": SLA_MS, "sla_met": bool(p99 <= SLA_MS)},

@@ -1447,7 +1447,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   if (!strcmp(key, "sls_exact")) e->sls_exact = value ? 1 : 0;
   else if (!strcmp(key, "sls_u") && (value == 0 || value == 4 || value == 8 || value == 16 || value == 20)) e->tune.sls_u = (int)value;
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) e->tune.sls_v_d32 = (int)value;
-  else if (!strcmp(key, "sls_flat")) e->tune.sls_flat = value ? 1 : 0;
+  else if (!strcmp(key, "sls_flat") && value >= 0 && value <= 2) e->tune.sls_flat = (int)value;
   else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;

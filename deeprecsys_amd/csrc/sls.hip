@@ -395,6 +395,124 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
   }
 }
 
+// The first form of the flat variant, one bag per wave: ONE coalesced index read (lane i owns
+// row i), indices handed to the loading lanes over the cross-lane network, and the row loads /
+// sums left to the compiler's schedule -- which turns them into groups of four or five loads in
+// flight with the sums of one group under the next.  Measured against the phased form above
+// (everything in flight at once) on RMC1's 80 x 256-B bags beside the MLP launch: 0.74 vs 0.72 of
+// peak for 8-query launches, 0.57-0.59 vs 0.51 for a single query; so one-bag-per-wave launches
+// take this one ("sls_flat" 1) and the phased form serves the several-bags-per-wave shapes.
+template <int G, int NL>
+__global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
+  constexpr int BPW = 1;
+  constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
+  constexpr int NI = (NL * NG + 63) / 64;          // index registers per lane
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int col = min(gl * 4, a.D - 4);            // clamp idle lanes onto valid columns
+  const bool col_ok = gl * 4 < a.D;
+
+  // the wave's bags: all of one sample (T % BPW == 0), tables t0 .. t0+BPW-1 -- uniform
+  const int64_t bag0 = (int64_t)blockIdx.x * BPW;
+  const int smp = (int)(bag0 / a.T);
+  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
+  int b = smp, vrow = a.q.vstart[0] + smp;
+  const int32_t* qidx = a.idx[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    qidx = in ? a.idx[i] : qidx;
+  }
+  const int R = BPW * L;
+  const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
+  const float* Wk[BPW];
+  uint32_t rows_k[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) {
+    Wk[k] = a.tables + a.tab_off[t0 + k] + col;
+    rows_k[k] = (uint32_t)a.tab_rows[t0 + k];
+  }
+  // which of the wave's bags does flattened row j belong to (j < R)
+  auto bag_of = [&](int j) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < BPW; ++q) k += j >= q * L ? 1 : 0;
+    return k;
+  };
+
+  // ONE coalesced index read: lane i owns flattened rows i, i+64, ...; range check (Caffe2
+  // ENFORCE) and the row's element offset inside its table are computed by the owner
+  uint32_t roff[NI];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int i = lane + 64 * q;
+    const int ii = min(i, R - 1);
+    const int k = bag_of(ii);
+    const int32_t* ip = qidx + (int64_t)(t0 + k) * a.idx_stride + (int64_t)b * L + (ii - k * L);
+    uint32_t r = (uint32_t)*ip;
+    uint32_t rk = rows_k[0];
+#pragma unroll
+    for (int z = 1; z < BPW; ++z) rk = k == z ? rows_k[z] : rk;
+    bad |= i < R && r >= rk;
+    r = r < rk ? r : 0u;
+    roff[q] = r * Du;
+  }
+
+  // every row load of the wave, back to back
+  float4 v[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;                      // (j >> 6) == (NG * u) >> 6: compile time
+    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], j & 63);
+    const float* W = Wk[0];
+    if (BPW > 1) {
+      const int k = bag_of(min(j, R - 1));
+#pragma unroll
+      for (int z = 1; z < BPW; ++z) W = k == z ? Wk[z] : W;
+    }
+    v[u] = *reinterpret_cast<const float4*>(W + (uint64_t)ro);
+  }
+
+  float4 acc[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) acc[k] = vzero4();
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;
+    if (BPW == 1) {
+      vadd(acc[0], vsel<4>(j < R, v[u]));
+    } else {
+      const int kj = bag_of(min(j, R - 1));
+#pragma unroll
+      for (int k = 0; k < BPW; ++k) vadd(acc[k], vsel<4>(j < R && kj == k, v[u]));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < BPW; ++k)
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) vadd(acc[k], vshfl_xor(acc[k], m));
+
+  if (bad) atomicOr(a.err, 1);
+  // lane group k stores bag k (every group holds every sum after the butterfly)
+  if (col_ok && g < BPW) {
+    float4 o4 = acc[0];
+#pragma unroll
+    for (int k = 1; k < BPW; ++k) o4 = g == k ? acc[k] : o4;
+    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)(t0 + g) * a.D + col;
+    *reinterpret_cast<float4*>(o) = o4;
+  }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);   // include the output store in the span
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
 // stop: optional event recorded BY the kernel dispatch itself (its completion signal) -- no
 // separate marker packet between this launch and the next one on the stream
 template <typename K, typename... X>
@@ -434,7 +552,7 @@ int lanes_per_row(int D) { return D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 
 // (a wave's bags belong to one sample) and BPW * L rows must fit NL loads per lane.
 struct FlatPlan {
   bool ok = false;
-  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1;
+  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1, coal = 0;
   unsigned grid = 0;
 };
 FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
@@ -461,14 +579,16 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
   const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : 0;
   if (!nl || (bpw > 1 && nl > 10)) return p;
   p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = tune.sls_xcd ? 1 : 0;
+  p.coal = bpw == 1 && tune.sls_flat == 1;      // "sls_flat" 2 forces the phased form
   const unsigned n_work = (unsigned)a.q.cum[a.q.n_q] * (unsigned)(a.T / bpw);
-  p.grid = p.xcd ? 8u * ((n_work + 7u) / 8u) : n_work;
+  p.grid = p.coal ? n_work : (p.xcd ? 8u * ((n_work + 7u) / 8u) : n_work);
   return p;
 }
 
 template <int G, int NL>
 hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
-  if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd);
+  if (p.coal) launch_k(sls_flatc_kernel<G, NL>, grid, s, stop, a, p.L);
+  else if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd);
   else if constexpr (NL <= 10) {
     if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd);
     else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L, p.xcd);

@@ -176,6 +176,11 @@ def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
     # whole-job throughput: all ranks' queries over the slowest rank's time
     assert two["value"] == pytest.approx(120 / two["config"]["timed_seconds"], rel=0.15)   # (timed_seconds is rounded to 0.1 ms)
     assert two["ms_per_step"] == pytest.approx(two["config"]["timed_seconds"] / 3 * 1e3, rel=0.15)
+    # default --collective rccl above a library without RCCL: the run still produces its line, the
+    # statistics are combined over gloo and the line says why
+    fb = _bench(["--gpus", "2", "--allow_device_sharing"] + _TINY, cpu)
+    assert fb["n_gpus"] == 2 and fb["latency_ms"]["queries"] == 120
+    assert "RCCL communicator did not come up" in fb["config"]["collective"]
     one = _bench(["--gpus", "1"] + _TINY, cpu)
     assert one["n_gpus"] == 1 and one["latency_ms"]["queries"] == 60 and one["config"]["collective"] is None
     # identical line structure at N = 1 and N = 2

@@ -1,57 +1,98 @@
 #!/bin/bash
 # One gpurun session -> everything under profiles/ (run from the repo root ON THE GPU BOX):
-#   gpurun --timeout 1500 -- 'bash tools/capture_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'bash tools/capture_profiles.sh r02'
 # writes gpurun_out/<tag>/..., which tools/publish_profiles.py copies into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 run() { timeout "$@"; }
+# per-kernel counter averages of one `rocprofv3 --pmc` pass over a command, appended to a summary
+pmc() { # summary-file, counters, command...
+  local sum=$1 ctr=$2; shift 2
+  local d=$OUT/pmc_tmp; rm -rf "$d"
+  run 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$d" -- "$@" > /dev/null 2> "$OUT/pmc_last.err"
+  local C=$(find "$d" -name "*counter_collection.csv" | head -1)
+  echo "== rocprofv3 --kernel-trace --pmc $ctr -- $*" >> "$sum"
+  [ -n "$C" ] && run 120 python tools/pmc_stats.py "$C" | grep -v rocclr >> "$sum"
+  rm -rf "$d"
+}
+# rocprofv3's own per-kernel summary of a command: <name>_kernel_stats.csv + by-grid text
+trace() { # name, command...
+  local n=$1; shift
+  local d=$OUT/trace_tmp; rm -rf "$d"
+  run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- "$@" > "$OUT/${n}_traced.json" 2> "$OUT/${n}_trace.err"
+  local S=$(find "$d" -name "*kernel_stats.csv" | head -1); local T=$(find "$d" -name "*kernel_trace.csv" | head -1)
+  [ -n "$S" ] && cp "$S" "$OUT/${n}_rocprofv3_kernel_stats.csv"
+  [ -n "$T" ] && run 120 python tools/trace_stats.py "$T" > "$OUT/${n}_kernel_trace_by_grid.txt"
+  [ -n "$T" ] && run 120 python tools/trace_overlap.py "$T" > "$OUT/${n}_kernel_overlap.txt"
+  rm -rf "$d"
+}
 
-# 1. the bench line (N=1, defaults), with the CPU baseline leg
-run 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-# 2. rocprofv3's own per-kernel summary of the same command (+ the trace it is made from)
-#    (--timed_only: warm-up + timed region, no extra legs, so the summary's sls_kernel row is the
-#    benchmark's own 8-query gather launches and nothing else)
-run 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python bench.py --timed_only > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
-T=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
-S=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
-[ -n "$S" ] && cp "$S" "$OUT/rocprofv3_kernel_stats.csv"
-[ -n "$T" ] && run 120 python tools/trace_stats.py "$T" > "$OUT/kernel_trace_by_grid.txt"
-# 3. PMC passes, each in its own run (never combined with a trace domain other than kernel-trace)
-for pass in "FETCH_SIZE" "WRITE_SIZE" \
+# 1. the bench line exactly as the driver runs it (N=1), with the CPU baseline legs
+run 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+# 2. rocprofv3's per-kernel summary of the same warm-up + timed region (--timed_only: none of the
+#    extra legs, so every gather launch in the trace is a launch of the benchmark itself)
+trace bench python bench.py --gpus 1 --steps 20 --warmup 5 --timed_only
+mv "$OUT/bench_rocprofv3_kernel_stats.csv" "$OUT/rocprofv3_kernel_stats.csv" 2>/dev/null
+mv "$OUT/bench_kernel_trace_by_grid.txt" "$OUT/kernel_trace_by_grid.txt" 2>/dev/null
+mv "$OUT/bench_kernel_overlap.txt" "$OUT/kernel_overlap.txt" 2>/dev/null
+mv "$OUT/bench_traced.json" "$OUT/bench_traced.json" 2>/dev/null
+# 3. PMC passes on RMC1 (the headline workload), each in its own run
+B1="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
             "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  name=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
-  run 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- \
-      python bench.py --no_cpu_baseline --steps 1600 --warmup 160 > /dev/null 2> "$OUT/pmc_$name.err"
-  C=$(find "$OUT/pmc_$name" -name "*counter_collection.csv" | head -1)
-  if [ -n "$C" ]; then
-    echo "== rocprofv3 --kernel-trace --pmc $pass -- python bench.py --no_cpu_baseline --steps 1600 --warmup 160" >> "$OUT/pmc_summary.txt"
-    run 120 python tools/pmc_stats.py "$C" | grep -v rocclr >> "$OUT/pmc_summary.txt"
-  fi
+  pmc "$OUT/pmc_summary.txt" "$pass" $B1
 done
-# 4. other operating points (one line each)
-run 300 python bench.py --no_cpu_baseline --steps 8000 --warmup 800 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
-run 300 python bench.py --no_cpu_baseline --steps 4000 --warmup 400 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
+# 4. BASELINE config 3 (RMC3, 12 x 10M x 32, batch 512): the gather beside its GEMM launches
+#    (pipelined, default) and with the chip to itself (shared_stream=1); traffic counters; and the
+#    MFMA-busy counters of gemm_kernel / stream_kernel on the MLP-bound model
+R3="python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048"
+run 600 $R3 > "$OUT/rmc3_bench.json" 2>/dev/null
+run 600 $R3 --set shared_stream=1 > "$OUT/rmc3_bench_single_stream.json" 2>/dev/null
+trace rmc3 $R3
+trace rmc3_single_stream $R3 --set shared_stream=1
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
+  pmc "$OUT/rmc3_pmc_summary.txt" "$pass" $R3 --set shared_stream=1
+done
+pmc "$OUT/wnd_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+    python bench.py --workload wnd --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --set shared_stream=1
+# the wide-layer GEMM alone (tools/gemm_bench.py): durations + MFMA-busy
+trace gemm python tools/gemm_bench.py --iters 50
+pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --iters 20
+# 5. other operating points and shapes (one line each)
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
 for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf; do
-  run 300 python bench.py --workload $w --no_cpu_baseline --steps 4000 --warmup 400 > "$OUT/bench_$w.json" 2>/dev/null
+  run 400 python bench.py --workload $w --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 4096 > "$OUT/bench_$w.json" 2>/dev/null
+  run 400 python bench.py --workload $w --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 --set shared_stream=1 > "$OUT/bench_${w}_single_stream.json" 2>/dev/null
 done
-run 400 python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --steps 2000 --warmup 200 > "$OUT/bench_rmc3.json" 2>/dev/null
-# 4b. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
-for m in rm1 rm2 rm3; do
+run 400 python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 2048 > "$OUT/bench_rmc3.json" 2>/dev/null
+run 600 python bench.py --workload rmc3 --batch 512 --steps 3 --warmup 1 --queries_per_step 2048 --timed_only > /dev/null 2>&1
+# CPU baseline legs on the MLP-bound shapes as well (port + torch)
+run 600 python bench.py --workload wnd --steps 3 --warmup 1 --queries_per_step 4096 > "$OUT/bench_wnd_cpu.json" 2>/dev/null
+# 6. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
+for m in rm1 rm2 rm3 wnd ncf; do
   run 300 python tools/characterize.py --model $m --out "$OUT/accelerator_mi355x/" > "$OUT/characterize_$m.txt" 2>&1
 done
-# 4c. the queue harness end to end: one accel engine, RMC1 and the W&D + NCF mixed stream
+# 7. the queue harness end to end: one accel engine, RMC1 and the W&D + NCF mixed stream
 run 300 python tools/serve.py --avg_arrival_rate 0.01 2>/dev/null | tail -1 > "$OUT/serve_rmc1.json"
 run 300 python tools/serve.py --mix --avg_arrival_rate 0.01 2>/dev/null | tail -1 > "$OUT/serve_mix_wnd_ncf.json"
-# 5. the driver's multi-GPU launch line, on the one GPU of this box
+# 8. the driver's multi-GPU launch line, on the one GPU of this box (RCCL communicator of size 1 is
+#    not created: world == 1), and the self-spawn path
 run 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus 1 --steps 8000 --warmup 800 --no_cpu_baseline > "$OUT/bench_torchrun_n1.json" 2> "$OUT/bench_torchrun_n1.err"
-# keep the merge small: the raw traces stay on the box except the one kernel trace
+    bench.py --gpus 1 --steps 5 --warmup 2 --no_cpu_baseline > "$OUT/bench_torchrun_n1.json" 2> "$OUT/bench_torchrun_n1.err"
+# 9. locality-aware traces: the gather on uniform / shipped-profile / reuse-heavy indices
+for p in uniform shipped hot; do
+  run 300 python tools/trace_gather.py --profile $p 2>/dev/null | tail -1 >> "$OUT/traces_gather.jsonl"
+  pmc "$OUT/traces_tcc_summary.txt" "TCC_HIT_sum TCC_MISS_sum" python tools/trace_gather.py --profile $p --steps 1
+done
+# 10. where the host time of a query goes; raw PCIe rate of the box
+run 300 python tools/host_probe.py > "$OUT/host_probe.txt" 2>&1
+run 120 python tools/pcie_probe.py > "$OUT/pcie_probe.txt" 2>&1
 find "$OUT" -name "*.csv" -size +20M -delete
 ls -la "$OUT"
