@@ -58,6 +58,10 @@ WORKLOADS = {
     "wnd": dict(kind="wnd", rows=1_000_000, T=27, D=32, L=1, bot="512", top="1024-512-256-1", op="cat"),
     "ncf": dict(kind="ncf", rows=[140_000, 140_000, 28_000, 28_000], T=4, D=64, L=1, bot="512",
                 top="256-256-128-64-64", op="cat"),
+    # the reference's models/configs/mtwnd.json: 43 tables (41 x 500k, 2 x 5M) x 32, shared top
+    # 1888-1024-512 (all ReLU), one task head 512-256-128 (num_multi_tasks default)
+    "mtwnd": dict(kind="mtwnd", rows=[500_000] * 41 + [5_000_000] * 2, T=43, D=32, L=1, bot="512", top="1024-512",
+                  tasks="512-256-128", num_tasks=1, op="cat"),
     # CPU-test size (tests/test_harness.py drives the rank entry through the CPU restatement of the ABI)
     "tiny": dict(rows=1000, T=4, D=16, L=4, bot="16-16", top="32-1", op="cat"),
 }
@@ -119,7 +123,8 @@ def make_model(opt, device):
     args.num_indices_per_lookup_fixed = True
     args._drs_device = device
     np.random.seed(opt.seed)
-    net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF}[kind](args)
+    args.arch_mlp_tasks, args.num_multi_tasks = w.get("tasks", "4-2-1"), w.get("num_tasks", 1)
+    net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep}[kind](args)
     m_den = int(w["bot"].split("-")[0])
     nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
     net.create(lX[0], lS_l[0], lS_i[0], None)
@@ -255,7 +260,7 @@ def torch_cpu_leg(opt):
     if kind == "dlrm":
         num_int = F_ * D if w["op"] == "cat" else D + F_ * (F_ - 1) // 2
         ln_top = [num_int] + top
-    elif kind == "wnd":
+    elif kind in ("wnd", "mtwnd"):
         ln_top = [T * D + ln_bot[0]] + top
     else:
         ln_top = top[:-1]            # NCF: MLP branch widths, predictor = last entry
@@ -266,6 +271,7 @@ def torch_cpu_leg(opt):
     bot_w = mk(ln_bot) if kind == "dlrm" else []
     top_w = mk(ln_top)
     fin_w = mk([D + ln_top[-1], top[-1]]) if kind == "ncf" else []
+    task_w = [mk([int(x) for x in w["tasks"].split("-")]) for _ in range(w.get("num_tasks", 1))] if kind == "mtwnd" else []
     nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, bs, ln_bot[0], rows, L, opt.seed)
     sets = []
     for b in range(nb):
@@ -289,6 +295,9 @@ def torch_cpu_leg(opt):
             return mlp(torch.cat([mf, z], 1), fin_w)
         if kind == "wnd":
             return mlp(torch.cat([x] + emb, 1), top_w, True)
+        if kind == "mtwnd":
+            shared = mlp(torch.cat([x] + emb, 1), top_w)
+            return torch.cat([mlp(shared, head, True) for head in task_w], 1)
         d = mlp(x, bot_w)
         if w["op"] == "cat":
             R = torch.cat([d] + emb, 1)

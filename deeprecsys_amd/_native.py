@@ -15,10 +15,11 @@ LIB_PATH = os.environ.get("DRS_HIP_LIB") or os.path.join(_HERE, "libdrs_hip.so")
 # status codes (include/drs.h)
 OK, ERR_BAD_ARG, ERR_OOM, ERR_HIP, ERR_INDEX_RANGE, ERR_LENGTHS_SUM, ERR_STATE, ERR_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7
-MODEL_DLRM, MODEL_WND, MODEL_NCF = 0, 1, 2
+MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND = 0, 1, 2, 3
 INTERACT_DOT, INTERACT_CAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MLP_BOT, MLP_TOP, MLP_FINAL = 0, 1, 2
+MLP_TASK0 = 16     # + k: task head k (MT-WnD)
 KERNEL_SLS, KERNEL_MLP, KERNEL_SLS_CLOCK = 0, 1, 2
 
 _f32p = C.POINTER(C.c_float)
@@ -83,6 +84,7 @@ class ModelCfg(C.Structure):
         ("interaction_op", C.c_int32), ("interaction_itself", C.c_int32),
         ("sigmoid_top", C.c_int32), ("max_batch", C.c_int32), ("max_lookups", C.c_int32),
         ("num_staged_batches", C.c_int32), ("num_slots", C.c_int32),
+        ("n_task", C.c_int32), ("ln_task", _i32p), ("num_tasks", C.c_int32),
     ]
 
 
@@ -128,7 +130,7 @@ class Engine(object):
 
     def __init__(self, kind, table_rows, sparse_dim, ln_bot, ln_top, interaction_op=INTERACT_CAT,
                  interaction_itself=False, sigmoid_top=-1, max_batch=1, max_lookups=1,
-                 num_staged_batches=1, num_slots=1, device=0):
+                 num_staged_batches=1, num_slots=1, device=0, ln_task=None, num_tasks=0):
         L = lib()
         self._rows = np.ascontiguousarray(table_rows, dtype=np.int64)
         self._ln_bot = np.ascontiguousarray(ln_bot, dtype=np.int32)
@@ -138,6 +140,9 @@ class Engine(object):
                        self._ln_top.size, self._ln_top.ctypes.data_as(_i32p),
                        int(interaction_op), int(bool(interaction_itself)), int(sigmoid_top),
                        int(max_batch), int(max_lookups), int(num_staged_batches), int(num_slots))
+        if ln_task is not None:
+            self._ln_task = np.ascontiguousarray(ln_task, dtype=np.int32)
+            cfg.n_task, cfg.ln_task, cfg.num_tasks = self._ln_task.size, self._ln_task.ctypes.data_as(_i32p), int(num_tasks)
         h = C.c_void_p()
         rc = L.drs_create(C.byref(cfg), int(device), C.byref(h))
         if rc != OK:

@@ -105,6 +105,7 @@ struct Slot {
   float* H = nullptr;        // [max_batch, ldH]  inter-segment MLP scratch (ping)
   float* Hb = nullptr;       // (pong)
   float* H2 = nullptr;       // NCF: concat(mf, mlp_out)
+  float* H3 = nullptr;       // MT-WnD: output of the shared top MLP (input of every task head)
   float* d_out = nullptr;    // [max_batch*n_out] device outputs (copy path only)
   uint32_t* d_err = nullptr; // device error word (bit0: index out of range)
   uint32_t* d_counter = nullptr;  // arrival counter of the completion hand-off
@@ -147,6 +148,7 @@ struct drs_engine {
   int64_t* d_tab_rows = nullptr;
   std::vector<bool> table_set;
   Mlp bot, top, fin;
+  std::vector<Mlp> tasks;        // MT-WnD task heads
   float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the
   size_t w_arena_floats = 0;     // MLP kernels' per-CU TLBs then hold every weight page)
   size_t w_arena_used = 0;
@@ -165,7 +167,7 @@ struct drs_engine {
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
   int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
-  int zero_copy_inputs = 3;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 auto
+  int zero_copy_inputs = 1;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 by size
   int64_t mlp_wide_kn = 256 * 1024;   // K*N from which a layer gets its own 2-D launch (RM3's 1024x256 included)
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   int64_t mlp_small_rows = 1024;      // launch sets up to this many rows: MLP side on the slot's own stream
@@ -536,6 +538,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   if ((rc = mlp_ready(e, e->bot, "bottom")) || (rc = mlp_ready(e, e->top, "top")) ||
       (rc = mlp_ready(e, e->fin, "final")))
     return rc;
+  for (auto& tk : e->tasks)
+    if ((rc = mlp_ready(e, tk, "task"))) return rc;
   // layout of the job: zero-sized queries take no rows
   QTable q;
   memset(&q, 0, sizeof q);
@@ -685,7 +689,16 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       top_in = s.R;
       ld_top = e->ldR;
     }
-    if (!fused && (rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
+    if (e->kind == DRS_MODEL_MTWND) {
+      // shared top MLP (all ReLU) -> H3, then every task head reads H3 and writes its block of
+      // the output row; the last head's last launch carries the completion hand-off
+      const int wt = e->top.ln.back(), wo = e->tasks[0].ln.back();
+      if ((rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, s.H3, wt))) return rc;
+      for (size_t k = 0; k < e->tasks.size(); ++k)
+        if ((rc = run_mlp(e, s, e->tasks[k], s.H3, wt, Mv, out + k * wo, e->n_out,
+                          k + 1 == e->tasks.size() ? dp : nullptr)))
+          return rc;
+    } else if (!fused && (rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
   }
   if (evts) {
     HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
@@ -860,6 +873,26 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       e->n_out = e->top.ln.back();
       break;
     }
+    case DRS_MODEL_MTWND: {
+      if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "MT-W&D has no bottom MLP layers");
+      e->m_den = e->w0 = e->bot.ln.front();
+      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
+      e->num_int = T * D + e->w0;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
+      if (cfg->n_task < 2 || !cfg->ln_task || cfg->num_tasks < 1 || cfg->num_tasks > 64)
+        return bail(DRS_ERR_BAD_ARG, "MT-W&D needs arch_mlp_tasks and 1..64 task heads");
+      if (cfg->ln_task[0] != e->top.ln.back())
+        return bail(DRS_ERR_BAD_ARG, "Shared top layer and task MLP layers must have same input/output dimension");
+      e->tasks.resize(cfg->num_tasks);
+      for (auto& tk : e->tasks) {
+        tk.ln.assign(cfg->ln_task, cfg->ln_task + cfg->n_task);
+        tk.layers.resize(cfg->n_task - 1);
+        tk.sigmoid_layer = cfg->sigmoid_top;     // multi_task_wnd.py:309 passes self.sigmoid_top to the heads
+      }
+      e->top.sigmoid_layer = -1;                 // :301 create_mlp(self.ln_top, -1, ...)
+      e->n_out = cfg->num_tasks * cfg->ln_task[cfg->n_task - 1];
+      break;
+    }
     case DRS_MODEL_NCF: {
       if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
       if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
@@ -916,6 +949,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   int maxw = 4;
   for (int w : e->bot.ln) maxw = w > maxw ? w : maxw;
   for (int w : e->top.ln) maxw = w > maxw ? w : maxw;
+  for (auto& tk : e->tasks) for (int w : tk.ln) maxw = w > maxw ? w : maxw;
   e->ldH = round_up(maxw, 4);
   e->batches.resize(e->n_batches);
   for (auto& b : e->batches)
@@ -931,6 +965,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipMalloc(&s.H, sizeof(float) * (size_t)e->max_rows * e->ldH));
     CREATE_TRY(hipMalloc(&s.Hb, sizeof(float) * (size_t)e->max_rows * e->ldH));
     CREATE_TRY(hipMalloc(&s.H2, sizeof(float) * (size_t)e->max_rows * (e->num_int + 4)));
+    if (e->kind == DRS_MODEL_MTWND) CREATE_TRY(hipMalloc(&s.H3, sizeof(float) * (size_t)e->max_rows * e->ldH));
     const size_t out_words = kOutOffset + (size_t)e->max_rows * n_out_cap;
     CREATE_TRY(hipMalloc(&s.d_out, sizeof(float) * out_words));
     CREATE_TRY(hipMalloc(&s.d_err, sizeof(uint32_t)));
@@ -1015,6 +1050,7 @@ int32_t drs_destroy(drs_handle e) {
     if (s.H) (void)hipFree(s.H);
     if (s.Hb) (void)hipFree(s.Hb);
     if (s.H2) (void)hipFree(s.H2);
+    if (s.H3) (void)hipFree(s.H3);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.d_err) (void)hipFree(s.d_err);
     if (s.d_ts) (void)hipFree(s.d_ts);
@@ -1031,6 +1067,7 @@ int32_t drs_destroy(drs_handle e) {
   for (auto& b : e->batches) free_batch(b);
   for (Mlp* m : {&e->bot, &e->top, &e->fin})
     for (auto& l : m->layers) { l.W = l.b = nullptr; }
+  e->tasks.clear();
   if (e->w_arena) (void)hipFree(e->w_arena);
   if (e->tables) (void)hipFree(e->tables);
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
@@ -1066,6 +1103,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (rc) return rc;
   if (!h_W || !h_b) return fail(e, DRS_ERR_BAD_ARG, "null weights");
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
+  if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
   if (!M || layer < 0 || layer >= (int)M->layers.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");
@@ -1081,7 +1119,9 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
       // All biases sit in front, back to back in layer order (each padded to 4 floats), so a
       // fused MLP launch can pull every bias it needs into LDS with one flat copy.
       size_t need = 0, nbias = 0;
-      for (Mlp* mm : {&e->bot, &e->top, &e->fin})
+      std::vector<Mlp*> all = {&e->bot, &e->top, &e->fin};
+      for (auto& tk : e->tasks) all.push_back(&tk);
+      for (Mlp* mm : all)
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
           const size_t out = mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024;
           need += ((size_t)mm->ln[i] * out + 63) / 64 * 64;
@@ -1095,7 +1135,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
       HIP_TRY(e, hipMemset(e->w_arena, 0, sizeof(float) * zeros));
       e->tune.w_arena = e->w_arena; e->tune.w_arena_floats = e->w_arena_floats; e->tune.w_zero_off = 0;
       size_t boff = zeros;
-      for (Mlp* mm : {&e->bot, &e->top, &e->fin})
+      for (Mlp* mm : all)
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
           mm->layers[i].b = e->w_arena + boff;
           boff += ((mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024) + 3) / 4 * 4;

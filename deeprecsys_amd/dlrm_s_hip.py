@@ -3,6 +3,7 @@
     DLRM_Net / DLRM_Wrapper               <- models/dlrm_s_caffe2.py:79-569
     Wide_and_Deep / Wide_and_Deep_Wrapper <- models/wide_and_deep.py:165-477
     NCF / NCF_Wrapper                     <- models/ncf.py:140-523
+    MT_Wide_and_Deep / ..._Wrapper        <- models/multi_task_wnd.py:160-420
 
 Same constructor arguments, the same shape algebra and sys.exit() checks, the same
 numpy RNG consumption order for the weights (embeddings, then bottom MLP, then top
@@ -70,7 +71,7 @@ class _HipNet(object):
         return [_init_table(int(n), m) for n in ln_emb]
 
     # -- device -------------------------------------------------------------------
-    def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top):
+    def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top, ln_task=None, num_tasks=0):
         a = self.args
         n_stage = max(int(getattr(a, "num_batches", 0)), 1)
         max_batch = max(int(getattr(a, "max_mini_batch_size", 1)), int(getattr(a, "mini_batch_size", 1)), 1)
@@ -79,7 +80,13 @@ class _HipNet(object):
                        sigmoid_top=sigmoid_top, max_batch=max_batch,
                        max_lookups=max(int(a.num_indices_per_lookup), 1),
                        num_staged_batches=n_stage,
-                       num_slots=max(int(getattr(a, "accel_slots", 3)), 1), device=self._device)
+                       num_slots=max(int(getattr(a, "accel_slots", 3)), 1), device=self._device,
+                       ln_task=ln_task, num_tasks=num_tasks)
+        # A/B aid for runs through the queue harness: DRS_ENGINE_OPTS="key=value,key=value"
+        import os
+        for kv in filter(None, os.environ.get("DRS_ENGINE_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            eng.set_option(k.strip(), int(v))
         seed = int(getattr(a, "numpy_rand_seed", 0))
         for t, W in enumerate(self.emb_w):
             if W is None:
@@ -245,6 +252,34 @@ class Wide_and_Deep(_HipNet):
             self.engine.set_fc(N.MLP_TOP, i, W, b)
 
 
+class MT_Wide_and_Deep(Wide_and_Deep):
+    """Multi-task W&D (models/multi_task_wnd.py): the W&D trunk with an all-ReLU shared top MLP
+    (:301 passes sigmoid_layer -1), then `num_multi_tasks` task heads of widths arch_mlp_tasks
+    over its output, each with Sigmoid on the layer index the reference calls sigmoid_top
+    (= ln_top.size - 1, :399,309).  The reference builds and runs every head but keeps only the
+    last as `last_output` (:316); here the heads' outputs come back side by side,
+    [bs, num_tasks * ln_task[-1]] (the reference's last_output is the last ln_task[-1] columns)."""
+    kind = N.MODEL_MTWND
+
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None,
+                 fc_q=None):
+        # weights in the reference's order: embeddings, shared top, then each head (:286-312)
+        Wide_and_Deep.__init__(self, cli_args, model, tag, enable_prof)
+        self.ln_task = _ints(cli_args.arch_mlp_tasks)
+        if self.ln_top[-1] != self.ln_task[0]:
+            sys.exit("ERROR: Shared top layer and task MLP layers must have same input/output dimension")
+        self.num_tasks = int(cli_args.num_multi_tasks)
+        self.task_w = [_init_mlp(self.ln_task) for _ in range(self.num_tasks)]
+
+    def _create_engine(self):
+        self.engine = self._build_engine(self.ln_bot, self.ln_top, N.INTERACT_CAT, False, self.sigmoid_top,
+                                         ln_task=self.ln_task, num_tasks=self.num_tasks)
+        for i, (W, b) in enumerate(self.top_w):
+            self.engine.set_fc(N.MLP_TOP, i, W, b)
+        for k, head in enumerate(self.task_w):
+            for i, (W, b) in enumerate(head):
+                self.engine.set_fc(N.MLP_TASK0 + k, i, W, b)
+
 class NCF(_HipNet):
     kind = N.MODEL_NCF
 
@@ -334,4 +369,9 @@ class NCF_Wrapper(_Wrapper):
     net_cls, attr = NCF, "ncf"
 
 
-WRAPPERS = {"dlrm": DLRM_Wrapper, "wnd": Wide_and_Deep_Wrapper, "ncf": NCF_Wrapper}
+class MT_Wide_and_Deep_Wrapper(_Wrapper):
+    net_cls, attr = MT_Wide_and_Deep, "mtwnd"
+
+
+WRAPPERS = {"dlrm": DLRM_Wrapper, "wnd": Wide_and_Deep_Wrapper, "ncf": NCF_Wrapper,
+            "mtwnd": MT_Wide_and_Deep_Wrapper}

@@ -49,7 +49,11 @@ enum {
 enum {
   DRS_MODEL_DLRM = 0, /* models/dlrm_s_caffe2.py:367-389  (RMC1/2/3)                   */
   DRS_MODEL_WND = 1,  /* models/wide_and_deep.py:282-305  (SLS ++ raw dense -> top MLP) */
-  DRS_MODEL_NCF = 2   /* models/ncf.py:317-346            (MF Sum ++ MLP branch)        */
+  DRS_MODEL_NCF = 2,  /* models/ncf.py:317-346            (MF Sum ++ MLP branch)        */
+  DRS_MODEL_MTWND = 3 /* models/multi_task_wnd.py:286-316 (W&D trunk, all-ReLU shared top MLP,
+                         then num_tasks task heads over its output; outputs = the heads' last
+                         layers side by side, [bs, num_tasks * ln_task[-1]] -- the reference
+                         keeps the last head as `last_output`, :316)                          */
 };
 
 /* feature interaction (models/dlrm_s_caffe2.py:331-365) */
@@ -59,7 +63,8 @@ enum { DRS_INTERACT_DOT = 0, DRS_INTERACT_CAT = 1 };
 enum { DRS_ACT_NONE = 0, DRS_ACT_RELU = 1, DRS_ACT_SIGMOID = 2 };
 
 /* which MLP a layer belongs to in drs_set_fc */
-enum { DRS_MLP_BOT = 0, DRS_MLP_TOP = 1, DRS_MLP_FINAL = 2 /* NCF predictor */ };
+enum { DRS_MLP_BOT = 0, DRS_MLP_TOP = 1, DRS_MLP_FINAL = 2 /* NCF predictor */,
+       DRS_MLP_TASK0 = 16 /* + k: task head k of DRS_MODEL_MTWND */ };
 
 /* kernels that keep live HIP-event timings (drs_kernel_time) */
 enum {
@@ -94,6 +99,13 @@ typedef struct drs_model_cfg {
   int32_t max_lookups;          /* upper bound on indices per bag (staging capacity)    */
   int32_t num_staged_batches;   /* num_batches: how many input sets stay device-resident*/
   int32_t num_slots;            /* in-flight queries (streams); >=1                     */
+  /* DRS_MODEL_MTWND only (zero / NULL otherwise): arch_mlp_tasks and num_multi_tasks
+   * (multi_task_wnd.py:360,304-312); ln_task[0] == ln_top[-1]; sigmoid_top is the 1-based
+   * layer index of a TASK head that gets Sigmoid (the reference passes the shared top's
+   * ln_top.size-1 there, :399,309), the shared top MLP is all ReLU (:301)                   */
+  int32_t n_task;               /* len(ln_task)                                         */
+  const int32_t* ln_task;       /* [n_task]                                             */
+  int32_t num_tasks;            /* task heads                                           */
 } drs_model_cfg;
 
 /* ---- library / device ------------------------------------------------------ */
@@ -261,9 +273,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                0 one stream per slot: whole sets overlap freely
  *   "zero_copy_inputs" how drs_forward_inputs' converted inputs (one packed, pinned block per slot:
  *                dense | int32 indices | prefix sums) reach the kernels: 1 read in place over PCIe
- *                (no copy; kernel-issued PCIe reads top out near 20 GB/s) | 2 ONE DMA copy of the
- *                block's used prefix into its HBM twin, on the job's gather stream | 3 (default)
- *                2 for queries of >= 128 KB, else 1 | 0 one copy per array (first version)
+ *                (default: no copy; kernel-issued PCIe reads top out near 20-25 GB/s) | 2 ONE DMA
+ *                copy of the block's used prefix into its HBM twin, on the job's gather stream
+ *                (same throughput at 3 calls in flight, 20 us more latency per query) | 3: 2 for
+ *                queries of >= 128 KB, else 1 | 0 one copy per array (first version)
  *   "host_threads" workers of the per-call input pass (int64 -> int32 + ENFORCEs, one table per
  *                work item, the dense rows' copy one more) beside the calling thread:
  *                -1 (default) min(T, 7) | 0 the caller alone | n.  They spin ~50 us after a call and

@@ -43,6 +43,12 @@ typedef struct orc_model {
   const float* const* bot_Wt;
   const float* const* top_Wt;
   const float* final_Wt;
+  int32_t n_task;
+  const int32_t* ln_task;
+  int32_t num_tasks, task_sigmoid;
+  const float* const* task_W;
+  const float* const* task_b;
+  const float* const* task_Wt;
 } orc_model;
 int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense, const int64_t* const* idx,
                     const int64_t* n_idx, const int32_t* const* len, float* out, float* R_out,
@@ -92,6 +98,7 @@ struct drs_engine {
   std::vector<std::vector<float>> tables;
   std::vector<bool> table_set;
   Mlp bot, top, fin;
+  std::vector<Mlp> tasks;        // MT-WnD heads
   int32_t interaction_op = 0, itself = 0, sigmoid_top = -1;
   int32_t max_batch = 0, max_lookups = 0, n_batches = 0, n_slots = 1;
   int32_t m_den = 0, w0 = 0, num_int = 0, n_out = 0;
@@ -175,7 +182,7 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
     if (!e->table_set[t]) return fail(e, DRS_ERR_STATE, "table %d has no data", t);
   int32_t rc;
   if ((rc = mlp_ready(e, e->bot, "bottom")) || (rc = mlp_ready(e, e->top, "top")) ||
-      (rc = mlp_ready(e, e->fin, "final")))
+      (rc = mlp_ready(e, e->fin, "final")) || [&] { for (auto& tk : e->tasks) if ((rc = mlp_ready(e, tk, "task"))) return true; return false; }())
     return rc;
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
@@ -199,6 +206,14 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
   m.n_bot = (int32_t)e->bot.ln.size(); m.ln_bot = e->bot.ln.data(); m.bot_W = bw.data(); m.bot_b = bb.data();
   m.n_top = (int32_t)e->top.ln.size(); m.ln_top = e->top.ln.data(); m.top_W = tw.data(); m.top_b = tb.data();
   if (e->kind == DRS_MODEL_NCF) { m.final_W = e->fin.W[0].data(); m.final_b = e->fin.b[0].data(); m.final_m = e->n_out; }
+  std::vector<const float*> kw, kb;
+  if (e->kind == DRS_MODEL_MTWND) {
+    for (auto& tk : e->tasks)
+      for (size_t l = 0; l < tk.W.size(); ++l) { kw.push_back(tk.W[l].data()); kb.push_back(tk.b[l].data()); }
+    m.n_task = (int32_t)e->tasks[0].ln.size(); m.ln_task = e->tasks[0].ln.data();
+    m.num_tasks = (int32_t)e->tasks.size(); m.task_sigmoid = e->sigmoid_top;
+    m.task_W = kw.data(); m.task_b = kb.data();
+  }
   m.interaction_op = e->interaction_op; m.itself = e->itself; m.sigmoid_top = e->sigmoid_top;
 
   int64_t o = 0;
@@ -285,6 +300,20 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
       e->n_out = e->top.ln.back();
       break;
+    case DRS_MODEL_MTWND:
+      if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "MT-W&D has no bottom MLP layers");
+      e->m_den = e->w0 = e->bot.ln.front();
+      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
+      e->num_int = T * D + e->w0;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
+      if (cfg->n_task < 2 || !cfg->ln_task || cfg->num_tasks < 1 || cfg->num_tasks > 64)
+        return bail(DRS_ERR_BAD_ARG, "MT-W&D needs arch_mlp_tasks and 1..64 task heads");
+      if (cfg->ln_task[0] != e->top.ln.back())
+        return bail(DRS_ERR_BAD_ARG, "Shared top layer and task MLP layers must have same input/output dimension");
+      e->tasks.resize(cfg->num_tasks);
+      for (auto& tk : e->tasks) tk.ln.assign(cfg->ln_task, cfg->ln_task + cfg->n_task);
+      e->n_out = cfg->num_tasks * cfg->ln_task[cfg->n_task - 1];
+      break;
     case DRS_MODEL_NCF:
       if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
       if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
@@ -306,6 +335,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     m.W.assign(n, {}); m.b.assign(n, {}); m.set.assign(n, false);
   };
   init_mlp(e->bot); init_mlp(e->top); init_mlp(e->fin);
+  for (auto& tk : e->tasks) init_mlp(tk);
   e->tables.assign(T, {});
   e->table_set.assign(T, false);
   e->cap = (int64_t)e->max_batch * e->max_lookups;
@@ -347,6 +377,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (rc) return rc;
   if (!h_W || !h_b) return fail(e, DRS_ERR_BAD_ARG, "null weights");
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
+  if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
   if (!M || layer < 0 || layer >= (int)M->set.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");

@@ -54,7 +54,7 @@
 #define ORC_ERR_LENGTHS_SUM (-5)
 #define ORC_ERR_UNSUPPORTED (-7)
 
-enum { ORC_MODEL_DLRM = 0, ORC_MODEL_WND = 1, ORC_MODEL_NCF = 2 };
+enum { ORC_MODEL_DLRM = 0, ORC_MODEL_WND = 1, ORC_MODEL_NCF = 2, ORC_MODEL_MTWND = 3 };
 enum { ORC_INTERACT_DOT = 0, ORC_INTERACT_CAT = 1 };
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_SIGMOID = 2 };
 
@@ -272,6 +272,15 @@ typedef struct orc_model {
   const float* const* bot_Wt;
   const float* const* top_Wt;
   const float* final_Wt;
+  /* MT-WnD (models/multi_task_wnd.py:286-316): num_tasks heads of widths ln_task over the
+   * shared top MLP's (all-ReLU) output; task_W / task_b / task_Wt hold the heads' layers back
+   * to back, [num_tasks * (n_task - 1)]; task_sigmoid = 1-based head layer that gets Sigmoid */
+  int32_t n_task;
+  const int32_t* ln_task;
+  int32_t num_tasks, task_sigmoid;
+  const float* const* task_W;
+  const float* const* task_b;
+  const float* const* task_Wt;
 } orc_model;
 
 static int32_t mlp_chain(const float* in, int64_t B, int64_t ld_in, int32_t n_l,
@@ -387,7 +396,21 @@ int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense,
   }
   if (rc == ORC_OK && ld_top != m->ln_top[0]) rc = ORC_ERR_BAD_ARG;
   if (rc == ORC_OK && R_out) memcpy(R_out, top_in, sizeof(float) * (size_t)B * (size_t)ld_top);
-  if (rc == ORC_OK)
+  if (rc == ORC_OK && m->model_kind == ORC_MODEL_MTWND) {
+    /* shared top (no sigmoid, :301) -> every head reads it; outputs side by side */
+    const int32_t wt = m->ln_top[m->n_top - 1], wo = m->ln_task[m->n_task - 1];
+    const int32_t per = m->n_task - 1;
+    if (m->n_task < 2 || m->num_tasks < 1 || m->ln_task[0] != wt) rc = ORC_ERR_BAD_ARG;
+    float* shared = rc == ORC_OK ? (float*)malloc(sizeof(float) * (size_t)B * (size_t)wt) : NULL;
+    if (rc == ORC_OK && !shared) rc = ORC_ERR_OOM;
+    if (rc == ORC_OK)
+      rc = mlp_chain(top_in, B, ld_top, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, -1, shared, wt, nthreads);
+    for (int32_t k = 0; k < m->num_tasks && rc == ORC_OK; ++k)
+      rc = mlp_chain(shared, B, wt, m->n_task, m->ln_task, m->task_W + (size_t)k * per,
+                     m->task_Wt ? m->task_Wt + (size_t)k * per : NULL, m->task_b + (size_t)k * per,
+                     m->task_sigmoid, out + (size_t)k * wo, (int64_t)m->num_tasks * wo, nthreads);
+    free(shared);
+  } else if (rc == ORC_OK)
     rc = mlp_chain(top_in, B, ld_top, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, m->sigmoid_top, out,
                    m->ln_top[m->n_top - 1], nthreads);
   free(R);

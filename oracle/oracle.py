@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libdrs_oracle.so")
 
-MODEL_DLRM, MODEL_WND, MODEL_NCF = 0, 1, 2
+MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND = 0, 1, 2, 3
 INTERACT_DOT, INTERACT_CAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -49,6 +49,8 @@ class _Model(C.Structure):
         ("final_W", _f32p), ("final_b", _f32p), ("final_m", C.c_int32),
         ("interaction_op", C.c_int32), ("itself", C.c_int32), ("sigmoid_top", C.c_int32),
         ("bot_Wt", C.POINTER(_f32p)), ("top_Wt", C.POINTER(_f32p)), ("final_Wt", _f32p),
+        ("n_task", C.c_int32), ("ln_task", _i32p), ("num_tasks", C.c_int32), ("task_sigmoid", C.c_int32),
+        ("task_W", C.POINTER(_f32p)), ("task_b", C.POINTER(_f32p)), ("task_Wt", C.POINTER(_f32p)),
     ]
 
 
@@ -154,7 +156,8 @@ class Model(object):
     """
 
     def __init__(self, kind, tables, ln_bot, bot, ln_top, top, interaction_op=INTERACT_CAT,
-                 itself=False, sigmoid_top=-1, final=None):
+                 itself=False, sigmoid_top=-1, final=None, ln_task=None, tasks=None):
+        """MT-WnD: ln_task = head widths, tasks = list (one per head) of lists of (W, b)."""
         self.kind = kind
         self.tables = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
         self.D = int(self.tables[0].shape[1])
@@ -201,10 +204,26 @@ class Model(object):
         if self.final is not None:
             self._finT = np.ascontiguousarray(self.final[0].T)
             m.final_Wt = self._finT.ctypes.data_as(_f32p)
+        self.tasks = None
+        if tasks is not None:
+            self.ln_task = np.ascontiguousarray(ln_task, dtype=np.int32)
+            self.tasks = [[(np.ascontiguousarray(W, np.float32), np.ascontiguousarray(b, np.float32)) for W, b in head]
+                          for head in tasks]
+            flat = [wb for head in self.tasks for wb in head]
+            self._kT = [np.ascontiguousarray(W.T) for W, _ in flat]
+            nk = len(flat)
+            self._kW = (_f32p * nk)(*[W.ctypes.data_as(_f32p) for W, _ in flat])
+            self._kb = (_f32p * nk)(*[b.ctypes.data_as(_f32p) for _, b in flat])
+            self._kWt = (_f32p * nk)(*[W.ctypes.data_as(_f32p) for W in self._kT])
+            m.n_task, m.ln_task = self.ln_task.size, self.ln_task.ctypes.data_as(_i32p)
+            m.num_tasks, m.task_sigmoid = len(self.tasks), self.sigmoid_top
+            m.task_W, m.task_b, m.task_Wt = self._kW, self._kb, self._kWt
         self._c = m
 
     @property
     def n_out(self):
+        if self.tasks is not None:
+            return len(self.tasks) * int(self.ln_task[-1])
         return int(self.final[0].shape[0]) if self.final is not None else int(self.ln_top[-1])
 
     @property

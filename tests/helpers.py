@@ -14,8 +14,8 @@ from oracle import oracle as orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["dlrm_dot_small", "dlrm_dot_itself_small", "dlrm_cat_small", "dlrm_cat_queue_small",
                "dlrm_dot_queue_small", "dlrm_rm1_mini", "dlrm_rm2_mini", "dlrm_rm3_mini", "wnd_mini",
-               "ncf_mini"]
-NET_CLS = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF}
+               "ncf_mini", "mtwnd_mini"]
+NET_CLS = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep}
 
 
 def sha(a):
@@ -27,6 +27,14 @@ def load_fixture(case):
         meta = json.load(f)
     arrays = np.load(os.path.join(GOLDEN, case + ".npz"))
     return meta, arrays
+
+
+def golden_output(meta, z):
+    """The model's output as the fixtures hold it: `prob_click`, or for MT-WnD the task heads'
+    last blobs side by side (the layout the engine returns)."""
+    if meta.get("output_blobs"):
+        return np.concatenate([z["expected/" + b] for b in meta["output_blobs"]], axis=1)
+    return z["expected/prob_click"]
 
 
 def args_from(meta_args, **override):
@@ -56,6 +64,9 @@ def oracle_model(net):
     if net.kind == M.N.MODEL_NCF:
         return orc.Model(orc.MODEL_NCF, net.emb_w, [0], [], net.ln_top[:-1], net.top_w,
                          final=net.final_w[0])
+    if net.kind == M.N.MODEL_MTWND:
+        return orc.Model(orc.MODEL_MTWND, net.emb_w, net.ln_bot, [], net.ln_top, net.top_w,
+                         sigmoid_top=net.sigmoid_top, ln_task=net.ln_task, tasks=net.task_w)
     if net.kind == M.N.MODEL_WND:
         return orc.Model(orc.MODEL_WND, net.emb_w, net.ln_bot, [], net.ln_top, net.top_w,
                          sigmoid_top=net.sigmoid_top)

@@ -43,7 +43,7 @@ def test_wrappers_through_the_abi_match_oracle_and_golden(cpu_abi, case):
                 exp, R_exp = om.forward(None if ncf else lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True)
                 assert np.array_equal(got, exp), (case, bid, bs)
                 assert np.array_equal(net.engine.fetch_interaction(bs), R_exp)
-        assert H.close(net.run_staged(0, n), z["expected/prob_click"], rtol=H.RTOL_OUT)
+        assert H.close(net.run_staged(0, n), H.golden_output(meta, z), rtol=H.RTOL_OUT)
         # several queries in one call, results back to back
         outs = net.run_staged_multi([0, len(lS_l) - 1, 0], [n, 1, max(1, n // 2)])
         assert [o.shape[0] for o in outs] == [n, 1, max(1, n // 2)]

@@ -61,7 +61,7 @@ def test_forward_matches_oracle_and_golden(case):
                         assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (case, bid, bs)
                         assert H.close(got, exp, rtol=H.RTOL_OUT)
         full = net.run_staged(0, n)
-        assert H.close(full, z["expected/prob_click"], rtol=H.RTOL_OUT)
+        assert H.close(full, H.golden_output(meta, z), rtol=H.RTOL_OUT)
         # non-staged inputs (run_queues signature) give the same bits as the staged path
         again = net.run_queued(lS_i[0], lS_l[0], None if args.model_type == "ncf" else lX[0], n)
         assert np.array_equal(full, again)
@@ -92,7 +92,7 @@ def test_queue_requests_from_reference_engine(case):
             for mode in (0, 1, 2):
                 net.engine.set_option("zero_copy_inputs", mode)
                 assert np.array_equal(out, w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)), mode
-            net.engine.set_option("zero_copy_inputs", 3)
+            net.engine.set_option("zero_copy_inputs", 1)
     finally:
         net.engine.close()
 

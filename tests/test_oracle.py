@@ -21,13 +21,13 @@ def test_oracle_forward_matches_golden(case):
     om = H.oracle_model(net)
     dense = None if args.model_type == "ncf" else lX[0]
     out, R = om.forward(dense, lS_i[0], lS_l[0], want_R=True)
-    exp = z["expected/prob_click"]
+    exp = H.golden_output(meta, z)
     assert out.shape == exp.shape
     # fp32 k-ordered chains vs fp64-accumulated truth: well inside the 1e-4 north-star bar
     assert H.close(out, exp, rtol=2e-5, atol=1e-6), np.abs(out - exp).max()
     # interaction tensor (input of the top MLP) where the fixture has it; RM3's bottom
     # MLP has K=2560 all-positive inputs, so allow cancellation noise relative to max|R|
-    key = {"dlrm": "expected/interaction", "wnd": "expected/interaction",
+    key = {"dlrm": "expected/interaction", "wnd": "expected/interaction", "mtwnd": "expected/interaction",
            "ncf": "expected/feat_int"}[args.model_type]
     if key in z.files:
         assert H.close(R, z[key], rtol=2e-5, atol_scale=2e-6)

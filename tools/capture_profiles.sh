@@ -67,7 +67,7 @@ pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
-for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf; do
+for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf mtwnd; do
   run 400 python bench.py --workload $w --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 4096 > "$OUT/bench_$w.json" 2>/dev/null
   run 400 python bench.py --workload $w --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 --set shared_stream=1 > "$OUT/bench_${w}_single_stream.json" 2>/dev/null
 done
@@ -76,12 +76,12 @@ run 600 python bench.py --workload rmc3 --batch 512 --steps 3 --warmup 1 --queri
 # CPU baseline legs on the MLP-bound shapes as well (port + torch)
 run 600 python bench.py --workload wnd --steps 3 --warmup 1 --queries_per_step 4096 > "$OUT/bench_wnd_cpu.json" 2>/dev/null
 # 6. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
-for m in rm1 rm2 rm3 wnd ncf; do
+for m in rm1 rm2 rm3 wnd ncf mtwnd; do
   run 300 python tools/characterize.py --model $m --out "$OUT/accelerator_mi355x/" > "$OUT/characterize_$m.txt" 2>&1
 done
 # 7. the queue harness end to end: one accel engine, RMC1 and the W&D + NCF mixed stream
-run 300 python tools/serve.py --avg_arrival_rate 0.01 2>/dev/null | tail -1 > "$OUT/serve_rmc1.json"
-run 300 python tools/serve.py --mix --avg_arrival_rate 0.01 2>/dev/null | tail -1 > "$OUT/serve_mix_wnd_ncf.json"
+run 300 python tools/serve.py --avg_arrival_rate 0.01 --nepochs 512 2>/dev/null | tail -1 > "$OUT/serve_rmc1.json"
+run 300 python tools/serve.py --mix --avg_arrival_rate 0.01 --nepochs 512 2>/dev/null | tail -1 > "$OUT/serve_mix_wnd_ncf.json"
 # 8. the driver's multi-GPU launch line, on the one GPU of this box (RCCL communicator of size 1 is
 #    not created: world == 1), and the self-spawn path
 run 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \

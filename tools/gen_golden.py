@@ -265,7 +265,7 @@ def capture_model(case, ref, argv, queue_requests=None):
     nb, lX, lS_l, lS_i = datagen.generate_input_data()
     nb, lT = datagen.generate_output_data()
     wrapper_cls = {"dlrm": ref["DLRM_Wrapper"], "wnd": ref["Wide_and_Deep_Wrapper"],
-                   "ncf": ref["NCF_Wrapper"]}[args.model_type]
+                   "ncf": ref["NCF_Wrapper"], "mtwnd": ref.get("MT_Wide_and_Deep_Wrapper")}[args.model_type]
     with mock.patch("builtins.print"):
         model = wrapper_cls(args)
         model.create(lX[0], lS_l[0], lS_i[0], lT[0])
@@ -274,7 +274,7 @@ def capture_model(case, ref, argv, queue_requests=None):
                        "(inputs, cli); expected_* are restated by oracle/c2ops.py")
     fx.meta["argv"] = list(argv)
     fx.meta["args"] = jsonable(vars(args))
-    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF"}[args.model_type]
+    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF", "mtwnd": "MT_Wide_and_Deep"}[args.model_type]
     ops = [op for op in REC.ops if op["net"] == net_name]
     fx.meta["ops"] = ops
     fx.meta["feed_order"] = [n for n, _ in REC.feeds]
@@ -310,6 +310,10 @@ def capture_model(case, ref, argv, queue_requests=None):
             if o in ws and not o.endswith("_info") and op["type"] not in ("DequeueBlobs",):
                 fx.put("expected/" + o, ws[o])
     fx.meta["output_blob"] = "prob_click"
+    if args.model_type == "mtwnd":
+        # every task head's last blob, in task order (the reference keeps only the last one as
+        # `last_output`, multi_task_wnd.py:316, but builds and runs them all)
+        fx.meta["output_blobs"] = [t[-1] if isinstance(t[-1], str) else str(t[-1]) for t in model.mtwnd.task_l]
 
     if queue_requests:
         # the reference engine's own request slicing (inferenceEngine.py:191-230), executed
@@ -492,6 +496,7 @@ def capture_harness(ref, ref_root):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--only", default="", help="regenerate only this fixture (e.g. mtwnd_mini)")
     opt = ap.parse_args()
     ref_root = os.path.abspath(opt.reference)
     if not os.path.isdir(ref_root):
@@ -507,12 +512,25 @@ def main():
         from models.dlrm_s_caffe2 import DLRM_Wrapper
         from models.wide_and_deep import Wide_and_Deep_Wrapper
         from models.ncf import NCF_Wrapper
+        from models.multi_task_wnd import MT_Wide_and_Deep_Wrapper
         from inferenceEngine import inferenceEngine
     finally:
         os.chdir(cwd)
     ref = dict(cli=cli, ServiceRequest=ServiceRequest, DLRMDataGenerator=DLRMDataGenerator,
                DLRM_Wrapper=DLRM_Wrapper, Wide_and_Deep_Wrapper=Wide_and_Deep_Wrapper,
-               NCF_Wrapper=NCF_Wrapper, inferenceEngine=inferenceEngine)
+               NCF_Wrapper=NCF_Wrapper, inferenceEngine=inferenceEngine,
+               MT_Wide_and_Deep_Wrapper=MT_Wide_and_Deep_Wrapper)
+
+    def mtwnd():
+        # multi-task W&D (models/multi_task_wnd.py), shrunk tables, TWO task heads
+        with open(os.path.join(ref_root, "models", "configs", "mtwnd.json")) as f:
+            cfg = json.load(f)
+        cfg["arch_embedding_size"] = "-".join(["300"] * 43)
+        p = write_tmp_config(cfg, "/tmp/_drs_mtwnd_mini.json")
+        capture_model("mtwnd_mini", ref, ["--config_file", p, "--num_batches", "1", "--num_multi_tasks", "2",
+                                          "--max_mini_batch_size", "8", "--mini_batch_size", "8"])
+    if opt.only == "mtwnd_mini":
+        return mtwnd()
 
     small = ["--arch_sparse_feature_size", "8", "--arch_embedding_size", "60-40-50",
              "--arch_mlp_bot", "6-12-8", "--num_indices_per_lookup", "4",
@@ -561,6 +579,7 @@ def main():
     capture_model("ncf_mini", ref, ["--config_file", p, "--num_batches", "1",
                                     "--max_mini_batch_size", "8", "--mini_batch_size", "8"])
 
+    mtwnd()
     capture_harness(ref, ref_root)
 
 

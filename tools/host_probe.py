@@ -72,7 +72,7 @@ def main():
                 el = time.perf_counter() - t0
                 print("host inputs, host_threads=%d zero_copy_inputs=%d slots=%d: %.1f us/query; submit %.1f us, wait %.1f us"
                       % (ht, zc, slots, el / n * 1e6, t_sub / n * 1e6, t_wait / n * 1e6))
-    eng.set_option("zero_copy_inputs", 3)
+    eng.set_option("zero_copy_inputs", 1)
     eng.set_option("host_threads", -1)
     # sync forward latency
     t0 = time.perf_counter()
