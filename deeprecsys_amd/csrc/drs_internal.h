@@ -59,6 +59,7 @@ struct Tune {
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
   int sls_xcd = 1;               // ... table-major work order, one contiguous slice per XCD
   int sls_split = 1;             // ... two waves per bag when a launch has few bags (single query)
+  int sls_depth = 0;             // ... explicit-schedule kernel with this many row loads in flight (0 = compiler's schedule)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 1, mlp_gemm = 1, gemm_tile = 0, mlp_debug = 0;
 };
 // Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs

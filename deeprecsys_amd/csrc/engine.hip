@@ -1490,6 +1490,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_flat") && value >= 0 && value <= 2) e->tune.sls_flat = (int)value;
   else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "sls_split")) e->tune.sls_split = value ? 1 : 0;
+  else if (!strcmp(key, "sls_depth") && (value == 0 || value == 6 || value == 8 || value == 10 || value == 12 || value == 14)) e->tune.sls_depth = (int)value;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
@@ -1567,7 +1568,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
       {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},

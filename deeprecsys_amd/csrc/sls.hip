@@ -402,11 +402,214 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
 // (everything in flight at once) on RMC1's 80 x 256-B bags beside the MLP launch: 0.74 vs 0.72 of
 // peak for 8-query launches, 0.57-0.59 vs 0.51 for a single query; so one-bag-per-wave launches
 // take this one ("sls_flat" 1) and the phased form serves the several-bags-per-wave shapes.
+template <int G, int NL>
+__global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
+  constexpr int BPW = 1;
+  constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
+  constexpr int NI = (NL * NG + 63) / 64;          // index registers per lane
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int col = min(gl * 4, a.D - 4);            // clamp idle lanes onto valid columns
+  const bool col_ok = gl * 4 < a.D;
+
+  // the wave's bags: all of one sample (T % BPW == 0), tables t0 .. t0+BPW-1 -- uniform
+  const int64_t bag0 = (int64_t)blockIdx.x * BPW;
+  const int smp = (int)(bag0 / a.T);
+  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
+  int b = smp, vrow = a.q.vstart[0] + smp;
+  const int32_t* qidx = a.idx[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    qidx = in ? a.idx[i] : qidx;
+  }
+  const int R = BPW * L;
+  const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
+  const float* Wk[BPW];
+  uint32_t rows_k[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) {
+    Wk[k] = a.tables + a.tab_off[t0 + k] + col;
+    rows_k[k] = (uint32_t)a.tab_rows[t0 + k];
+  }
+  // which of the wave's bags does flattened row j belong to (j < R)
+  auto bag_of = [&](int j) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < BPW; ++q) k += j >= q * L ? 1 : 0;
+    return k;
+  };
+
+  // ONE coalesced index read: lane i owns flattened rows i, i+64, ...; range check (Caffe2
+  // ENFORCE) and the row's element offset inside its table are computed by the owner
+  uint32_t roff[NI];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int i = lane + 64 * q;
+    const int ii = min(i, R - 1);
+    const int k = bag_of(ii);
+    const int32_t* ip = qidx + (int64_t)(t0 + k) * a.idx_stride + (int64_t)b * L + (ii - k * L);
+    uint32_t r = (uint32_t)*ip;
+    uint32_t rk = rows_k[0];
+#pragma unroll
+    for (int z = 1; z < BPW; ++z) rk = k == z ? rows_k[z] : rk;
+    bad |= i < R && r >= rk;
+    r = r < rk ? r : 0u;
+    roff[q] = r * Du;
+  }
+
+  // every row load of the wave, back to back
+  float4 v[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;                      // (j >> 6) == (NG * u) >> 6: compile time
+    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], j & 63);
+    const float* W = Wk[0];
+    if (BPW > 1) {
+      const int k = bag_of(min(j, R - 1));
+#pragma unroll
+      for (int z = 1; z < BPW; ++z) W = k == z ? Wk[z] : W;
+    }
+    v[u] = *reinterpret_cast<const float4*>(W + (uint64_t)ro);
+  }
+
+  float4 acc[BPW];
+#pragma unroll
+  for (int k = 0; k < BPW; ++k) acc[k] = vzero4();
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;
+    if (BPW == 1) {
+      vadd(acc[0], vsel<4>(j < R, v[u]));
+    } else {
+      const int kj = bag_of(min(j, R - 1));
+#pragma unroll
+      for (int k = 0; k < BPW; ++k) vadd(acc[k], vsel<4>(j < R && kj == k, v[u]));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < BPW; ++k)
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) vadd(acc[k], vshfl_xor(acc[k], m));
+
+  if (bad) atomicOr(a.err, 1);
+  // lane group k stores bag k (every group holds every sum after the butterfly)
+  if (col_ok && g < BPW) {
+    float4 o4 = acc[0];
+#pragma unroll
+    for (int k = 1; k < BPW; ++k) o4 = g == k ? acc[k] : o4;
+    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)(t0 + g) * a.D + col;
+    *reinterpret_cast<float4*>(o) = o4;
+  }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);   // include the output store in the span
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
+// The same kernel with the schedule written down instead of left to the compiler: the row
+// loads go through inline asm (the compiler neither reorders nor counts them), DEPTH of them
+// are requested up front, and from then on each sum of the oldest outstanding row is followed
+// by the request of the next one -- DEPTH loads in flight per lane throughout, whatever a
+// future compiler would make of the plain C++ form.
+template <int G, int NL, int DEPTH>
+__global__ __launch_bounds__(64) void sls_flatx_kernel(SlsArgs a, int L) {
+  constexpr int NG = 64 / G;
+  constexpr int NI = (NL * NG + 63) / 64;
+  constexpr int DP = DEPTH < NL ? DEPTH : NL;
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int col = min(gl * 4, a.D - 4);
+  const bool col_ok = gl * 4 < a.D;
+  const int64_t bag0 = (int64_t)blockIdx.x;
+  const int smp = (int)(bag0 / a.T);
+  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
+  int b = smp, vrow = a.q.vstart[0] + smp;
+  const int32_t* qidx = a.idx[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    qidx = in ? a.idx[i] : qidx;
+  }
+  const int R = L;
+  const uint32_t Du = (uint32_t)a.D;
+  const float* W0 = a.tables + a.tab_off[t0] + col;
+  const uint32_t rows0 = (uint32_t)a.tab_rows[t0];
+  uint32_t roff[NI];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int i = lane + 64 * q;
+    const int ii = min(i, R - 1);
+    const int32_t* ip = qidx + (int64_t)t0 * a.idx_stride + (int64_t)b * L + ii;
+    uint32_t r = (uint32_t)*ip;
+    bad |= i < R && r >= rows0;
+    r = r < rows0 ? r : 0u;
+    roff[q] = r * Du;
+  }
+  // every row address first (the index loads above are the compiler's: it waits for them here)
+  const float* rp[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int j = g + NG * u;
+    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], j & 63);
+    rp[u] = W0 + (uint64_t)ro;
+  }
+  __builtin_amdgcn_s_waitcnt(0);            // nothing of the compiler's own left in flight
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 v[NL];
+#pragma unroll
+  for (int u = 0; u < DP; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(rp[u]));
+  float4 acc = vzero4();
+  auto add = [&](int u) {
+    const bool keep = g + NG * u < R;
+    acc.x += keep ? v[u][0] : 0.f; acc.y += keep ? v[u][1] : 0.f;
+    acc.z += keep ? v[u][2] : 0.f; acc.w += keep ? v[u][3] : 0.f;
+  };
+#pragma unroll
+  for (int u = DP; u < NL; ++u) {
+    // oldest outstanding row is u - DP: at most DP - 1 newer ones may still be in flight
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[u - DP]) : "n"(DP - 1));
+    add(u - DP);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(rp[u]));
+  }
+#pragma unroll
+  for (int u = NL - DP; u < NL; ++u) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[u]) : "n"(NL - 1 - u));
+    add(u);
+  }
+#pragma unroll
+  for (int m = G; m < 64; m <<= 1) vadd(acc, vshfl_xor(acc, m));
+  if (bad) atomicOr(a.err, 1);
+  if (col_ok && g == 0) {
+    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)t0 * a.D + col;
+    *reinterpret_cast<float4*>(o) = acc;
+  }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
+// (The one-wave kernel above is kept byte for byte as first written: its speed comes from the
+// schedule the compiler happens to give it -- about ten row loads in flight per lane -- and a
+// source-level rewrite that only generalised it to WV waves came out 7 % slower (82 instead of
+// 106 VGPRs, seven loads in flight at the start).  The two-wave form is its own kernel.)
 // WV = 2: the bag is split over the two waves of a 128-thread workgroup (rows [0, NL*NG) and
 // [NL*NG, 2*NL*NG)), partial sums combined through LDS: launches of a single query (2 048 bags on
 // 256 CUs) get twice the waves, each with half the serial work.
 template <int G, int NL, int WV>
-__global__ __launch_bounds__(64 * WV) void sls_flatc_kernel(SlsArgs a, int L) {
+__global__ __launch_bounds__(64 * WV) void sls_flatc2_kernel(SlsArgs a, int L) {
   constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
   constexpr int NI = (NL * NG + 63) / 64;          // index registers per lane
   __shared__ float4 s_part[WV > 1 ? G : 1];
@@ -526,7 +729,7 @@ int lanes_per_row(int D) { return D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 
 // (a wave's bags belong to one sample) and BPW * L rows must fit NL loads per lane.
 struct FlatPlan {
   bool ok = false;
-  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1, coal = 0, split = 0;
+  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1, coal = 0, split = 0, depth = 0;
   unsigned grid = 0;
 };
 FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
@@ -554,6 +757,7 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
   if (!nl || (bpw > 1 && nl > 10)) return p;
   p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = tune.sls_xcd ? 1 : 0;
   p.coal = bpw == 1 && tune.sls_flat == 1;      // "sls_flat" 2 forces the phased form
+  p.depth = tune.sls_depth;
   const unsigned n_work = (unsigned)a.q.cum[a.q.n_q] * (unsigned)(a.T / bpw);
   // few bags (a single query: 2 048 on 256 CUs) and at least ten loads per lane: two waves per bag
   if (p.coal && tune.sls_split && n_work <= 4096 && (nl == 20 || nl == 10)) { p.split = 1; p.NL = nl / 2; }
@@ -563,8 +767,13 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
 
 template <int G, int NL>
 hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
-  if (p.coal && p.split) launch_kb(sls_flatc_kernel<G, NL, 2>, grid, dim3(128), s, stop, a, p.L);
-  else if (p.coal) launch_k(sls_flatc_kernel<G, NL, 1>, grid, s, stop, a, p.L);
+  if (p.coal && p.split) launch_kb(sls_flatc2_kernel<G, NL, 2>, grid, dim3(128), s, stop, a, p.L);
+  else if (p.coal && p.depth == 6) launch_k(sls_flatx_kernel<G, NL, 6>, grid, s, stop, a, p.L);
+  else if (p.coal && p.depth == 8) launch_k(sls_flatx_kernel<G, NL, 8>, grid, s, stop, a, p.L);
+  else if (p.coal && p.depth == 10) launch_k(sls_flatx_kernel<G, NL, 10>, grid, s, stop, a, p.L);
+  else if (p.coal && p.depth == 12) launch_k(sls_flatx_kernel<G, NL, 12>, grid, s, stop, a, p.L);
+  else if (p.coal && p.depth == 14) launch_k(sls_flatx_kernel<G, NL, 14>, grid, s, stop, a, p.L);
+  else if (p.coal) launch_k(sls_flatc_kernel<G, NL>, grid, s, stop, a, p.L);
   else if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd);
   else if constexpr (NL <= 10) {
     if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd);
