@@ -116,8 +116,35 @@ class _HipNet(object):
             self._cur_inputs = (X, S_lengths, S_indices)
         bs = len(S_lengths[0])
         load_time = time.time()
-        self._out = self.engine.forward_inputs(X, S_indices, S_lengths, bs)
+        if enable_prof:
+            self._run_profiled(X, S_lengths, S_indices, bs)
+        else:
+            self._out = self.engine.forward_inputs(X, S_indices, S_lengths, bs)
         return load_time
+
+    def _run_profiled(self, X, S_lengths, S_indices, bs):
+        """--enable_profiling: the reference runs `workspace.C.benchmark_net(net, 0, 1, True)`
+        (models/dlrm_s_caffe2.py:565-566), whose per-operator-type table
+        experiments/operator_breakdown/sweep_p.py:21-28 parses (`<ms> ms. <pct>%. <OpType>`,
+        value = field 0, type = field 3).  Here a query is two kinds of launches, timed with HIP
+        events on the streams they run on: the multi-table gather (= every SparseLengthsSum of the
+        graph) and the MLP launches (= every FC with its fused Relu / Sigmoid, the Concat /
+        BatchMatMul / BatchGather interaction and the Cast, which have no launch of their own)."""
+        eng = self.engine
+        eng.reset_kernel_time()
+        eng.set_profiling(2)
+        try:
+            self._out = eng.forward_inputs(X, S_indices, S_lengths, bs)
+        finally:
+            eng.set_profiling(0)
+        sls_ms, _ = eng.kernel_time(N.KERNEL_SLS)
+        mlp_ms, _ = eng.kernel_time(N.KERNEL_MLP)
+        tot = max(sls_ms + mlp_ms, 1e-12)
+        print("Time per operator type:")
+        for ms, name in sorted(((sls_ms, "SparseLengthsSum"), (mlp_ms, "FC")), reverse=True):
+            print("%16.6g ms. %10.5g%%. %s" % (ms, 100.0 * ms / tot, name))
+        print("%16.6g ms in Total" % tot)
+        sys.stdout.flush()
 
     def run_queued(self, ids, lengths, fc, batch_size):
         # 2-D arrays (what the reference's feeder passes) go down as they are: row pointers only

@@ -400,11 +400,16 @@ def test_engine_ragged_bags_and_device_error_path():
                 else:
                     assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6)
                 assert H.close(got, exp, rtol=H.RTOL_OUT)
+        before = net.run_staged(0, B).copy()
+        bytes_before = net.engine.gather_bytes(0, B)
         bad = [i.copy() for i in idx]
         bad[1][3] = rows[1]
         with pytest.raises(N.DrsError) as e:
             net.engine.stage_batch(0, X, bad, lens)
         assert e.value.code == N.ERR_INDEX_RANGE
+        # a staging call that fails validation part-way (table 1 of 3) leaves the batch that was
+        # staged before exactly as it was: device data AND the host-side offsets
+        assert np.array_equal(net.run_staged(0, B), before) and net.engine.gather_bytes(0, B) == bytes_before
         with pytest.raises(N.DrsError) as e:
             net.engine.stage_batch(0, X, [i[:-1] for i in idx], lens)
         assert e.value.code == N.ERR_LENGTHS_SUM
@@ -655,6 +660,34 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
         assert ei.value.code == N.ERR_LENGTHS_SUM and "table 6" in ei.value.detail
     finally:
         eng.close()
+
+
+def test_enable_profiling_prints_the_per_operator_type_table(capsys):
+    """run(..., enable_prof=True) prints what the reference's benchmark_net prints per operator
+    type, in the layout experiments/operator_breakdown/sweep_p.py:21-28 parses."""
+    meta, z = H.load_fixture("dlrm_rm1_mini")
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    try:
+        net.run(lX[0], lS_l[0], lS_i[0], enable_prof=True)
+        ops = {}
+        for line in capsys.readouterr().out.splitlines():
+            if "ms." in line:                                   # sweep_p.py's own rule
+                ops[line.rstrip().split()[3]] = float(line.rstrip().split()[0])
+        assert set(ops) == {"SparseLengthsSum", "FC"} and all(0 < v < 50 for v in ops.values()), ops
+        assert H.close(net.fetch_output(), z["expected/prob_click"], rtol=H.RTOL_OUT)
+    finally:
+        net.engine.close()
+
+
+def test_create_rejects_what_the_int32_offsets_cannot_hold():
+    """Prefix sums and bag * length products are int32 on the device: a staging capacity at
+    2^31 / 8 coalesced queries is refused at drs_create, not left to overflow."""
+    with pytest.raises(N.DrsError) as e:
+        N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
+                 max_batch=1 << 16, max_lookups=1 << 12, num_staged_batches=0, num_slots=1)
+    assert e.value.code == N.ERR_UNSUPPORTED
 
 
 def test_options_are_per_handle_and_engines_coexist():
