@@ -58,7 +58,9 @@ struct Tune {
   int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
   int sls_xcd = 1;               // ... table-major work order, one contiguous slice per XCD
-  int sls_split = 1;             // ... two waves per bag when a launch has few bags (single query)
+  int sls_split = 0;             // ... two waves per bag when a launch has few bags (single query): OFF by
+                                 // default -- it makes a query's fp32 summation order depend on how many
+                                 // queries were coalesced with it (caught by the race hunt), for 0.2 us
   int sls_depth = 0;             // ... explicit-schedule kernel with this many row loads in flight (0 = compiler's schedule)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 1, mlp_gemm = 1, gemm_tile = 0, mlp_debug = 0;
 };

@@ -239,6 +239,13 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                as the wave-split variant | 0 ring-walk kernels only
  *   "sls_bpw"    bags per wave of the flat variant: 0 (default: as many of 4 | 2 | 1 as divide the
  *                table count and keep a lane at <= 10 loads) | 1 | 2 | 4
+ *   "sls_split"  0 (default) | 1: launches of <= 4096 fixed-length bags (a single query) split each
+ *                bag over two waves (0.2 us faster; a query's fp32 summation order then depends on
+ *                the size of the launch it was coalesced into)
+ *   "sls_depth"  0 (default: the compiler's schedule of the one-bag-per-wave flat kernel) | 6 | 8 |
+ *                10 | 12 | 14: the same kernel with exactly that many row loads in flight per lane
+ *   "sls_xcd"    1 (default) | 0: several-bags-per-wave flat kernel walks its work list table-major,
+ *                one contiguous slice per XCD
  *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
  *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
