@@ -375,6 +375,9 @@ def main():
         # torch first: it bundles its own HIP runtime, which must be the one in the process
         import torch  # noqa: F401
         import torch.distributed as dist
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+            # single node: gloo must not try to resolve the container's hostname
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo")          # plumbing: carries the communicator id (and the
                                                  # statistics themselves under --collective gloo)
     from deeprecsys_amd import _native as N
