@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 HOST_LEG_CALLS = 6         # per-call host-input leg: calls in flight (one per slot)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SLA_MS = 25.0              # run_DeepRecSys.sh:42 target_latency
+NO_DENSE = ("ncf", "din")  # model kinds whose query has no dense input
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -62,6 +63,11 @@ WORKLOADS = {
     # 1888-1024-512 (all ReLU), one task head 512-256-128 (num_multi_tasks default)
     "mtwnd": dict(kind="mtwnd", rows=[500_000] * 41 + [5_000_000] * 2, T=43, D=32, L=1, bot="512", top="1024-512",
                   tasks="512-256-128", num_tasks=1, op="cat"),
+    # the reference's models/configs/din.json after utils/utils.py:132-149 expanded it: user profile 1M,
+    # 251 behaviour tables x 100k (user_behavior_tables 250 + the one in the string), ad 10M, context 10M;
+    # one attention unit 96-1-32 per behaviour table, top 128-200-80-2 (5.9 GB of tables)
+    "din": dict(kind="din", rows=[1_000_000] + [100_000] * 251 + [10_000_000] * 2, T=254, D=32, L=3, bot="1",
+                top="200-80-2", op="cat"),
     # CPU-test size (tests/test_harness.py drives the rank entry through the CPU restatement of the ABI)
     "tiny": dict(rows=1000, T=4, D=16, L=4, bot="16-16", top="32-1", op="cat"),
 }
@@ -124,11 +130,12 @@ def make_model(opt, device):
     args._drs_device = device
     np.random.seed(opt.seed)
     args.arch_mlp_tasks, args.num_multi_tasks = w.get("tasks", "4-2-1"), w.get("num_tasks", 1)
-    net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep}[kind](args)
+    net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep,
+           "din": M.DIN_Net}[kind](args)
     m_den = int(w["bot"].split("-")[0])
     nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
     net.create(lX[0], lS_l[0], lS_i[0], None)
-    net.stage_batches(None if kind == "ncf" else lX, lS_l, lS_i)
+    net.stage_batches(None if kind in NO_DENSE else lX, lS_l, lS_i)
     return args, net, (lX, lS_l, lS_i)
 
 
@@ -205,7 +212,7 @@ def cpu_baseline(opt, net, data, budget_s):
                                         opt.seed, nthreads=cores) for t in range(w["T"])]
     om = H.oracle_model(net)
     fill_s = time.perf_counter() - t0
-    dense = (lambda b: None) if w.get("kind") == "ncf" else (lambda b: lX[b])
+    dense = (lambda b: None) if w.get("kind") in NO_DENSE else (lambda b: lX[b])
     om.forward(dense(0), lS_i[0], lS_l[0], bs=opt.batch, nthreads=cores)   # warm
     n, t0 = 0, time.perf_counter()
     while True:
@@ -262,6 +269,8 @@ def torch_cpu_leg(opt):
         ln_top = [num_int] + top
     elif kind in ("wnd", "mtwnd"):
         ln_top = [T * D + ln_bot[0]] + top
+    elif kind == "din":
+        ln_top = [4 * D] + top
     else:
         ln_top = top[:-1]            # NCF: MLP branch widths, predictor = last entry
 
@@ -271,13 +280,14 @@ def torch_cpu_leg(opt):
     bot_w = mk(ln_bot) if kind == "dlrm" else []
     top_w = mk(ln_top)
     fin_w = mk([D + ln_top[-1], top[-1]]) if kind == "ncf" else []
+    att_w = [mk([3 * D] + ln_bot + [D]) for _ in range(T - 3)] if kind == "din" else []
     task_w = [mk([int(x) for x in w["tasks"].split("-")]) for _ in range(w.get("num_tasks", 1))] if kind == "mtwnd" else []
     nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, bs, ln_bot[0], rows, L, opt.seed)
     sets = []
     for b in range(nb):
         idx = [torch.from_numpy(np.ascontiguousarray(t[:bs * L]).astype(np.int64)) for t in lS_i[b]]
         offs = torch.arange(0, bs * L, L, dtype=torch.int64)
-        x = None if kind == "ncf" else torch.from_numpy(np.ascontiguousarray(lX[b][:bs], dtype=np.float32))
+        x = None if kind in NO_DENSE else torch.from_numpy(np.ascontiguousarray(lX[b][:bs], dtype=np.float32))
         sets.append((x, idx, offs))
     li, lj = torch.tril_indices(F_, F_, -1)
 
@@ -293,6 +303,13 @@ def torch_cpu_leg(opt):
             mf = emb[0] + emb[1]
             z = mlp(torch.cat([emb[2], emb[3]], 1), top_w)
             return mlp(torch.cat([mf, z], 1), fin_w)
+        if kind == "din":
+            ad = emb[T - 2]
+            z = None
+            for u, unit in enumerate(att_w):
+                y = mlp(torch.cat([emb[1 + u], ad, emb[1 + u] + ad], 1), unit)
+                z = y if z is None else z + y
+            return mlp(torch.cat([emb[0], z, ad, emb[T - 1]], 1), top_w)
         if kind == "wnd":
             return mlp(torch.cat([x] + emb, 1), top_w, True)
         if kind == "mtwnd":
@@ -481,7 +498,7 @@ def main():
         # what the reference's feeder passes: ids [T, bs*L] int64, lengths [T, bs] int32, fc [bs, m_den]
         host_sets = [(np.stack([np.asarray(t[:bs * L], dtype=np.int64) for t in lS_i[b]]),
                       np.stack([np.asarray(t[:bs], dtype=np.int32) for t in lS_l[b]]),
-                      None if WORKLOADS[opt.workload].get("kind") == "ncf" else np.ascontiguousarray(lX[b][:bs]))
+                      None if WORKLOADS[opt.workload].get("kind") in NO_DENSE else np.ascontiguousarray(lX[b][:bs]))
                      for b in range(min(nb, 4))]
         host_bytes = host_sets[0][0].nbytes + host_sets[0][1].nbytes + \
             (0 if host_sets[0][2] is None else host_sets[0][2].nbytes)

@@ -184,6 +184,12 @@ hipError_t launch_copy_rows_multi(const XSrc& xs, int32_t m_den, float* out, int
 hipError_t launch_copy_rows(const float* a, int64_t lda, float* out, int64_t ldo, int64_t M,
                             int32_t D, hipStream_t stream);
 
+// DIN attention (models/din.py:247-285): T [M, Tn*D] pooled rows -> R [M, 4*D] =
+// [ profile | Sum_i relu(W2_i relu(W1_i [u_i, ad, u_i+ad] + b1_i) + b2_i) | ad | context ];
+// att: device array of 4 pointers per unit (W1 [h, 3D], b1 [h], W2 [D, h], b2 [D])
+hipError_t launch_din_attention(const float* T, int64_t ldt, int64_t M, int32_t Tn, int32_t D, int32_t h,
+                                const float* const* att, float* R, int64_t ldr, hipStream_t stream);
+
 hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
                                hipStream_t stream);
 

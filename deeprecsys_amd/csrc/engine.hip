@@ -149,6 +149,8 @@ struct drs_engine {
   std::vector<bool> table_set;
   Mlp bot, top, fin;
   std::vector<Mlp> tasks;        // MT-WnD task heads
+  std::vector<Mlp> att;          // DIN attention units (one small MLP per behaviour table)
+  const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2), uploaded at first forward
   float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the
   size_t w_arena_floats = 0;     // MLP kernels' per-CU TLBs then hold every weight page)
   size_t w_arena_used = 0;
@@ -540,6 +542,14 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     return rc;
   for (auto& tk : e->tasks)
     if ((rc = mlp_ready(e, tk, "task"))) return rc;
+  for (auto& au : e->att)
+    if ((rc = mlp_ready(e, au, "attention"))) return rc;
+  if (!e->att.empty() && !e->d_att) {
+    std::vector<const float*> hp;
+    for (auto& au : e->att) { hp.push_back(au.layers[0].W); hp.push_back(au.layers[0].b); hp.push_back(au.layers[1].W); hp.push_back(au.layers[1].b); }
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att), sizeof(float*) * hp.size()));
+    HIP_TRY(e, hipMemcpy(e->d_att, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice));
+  }
   // layout of the job: zero-sized queries take no rows
   QTable q;
   memset(&q, 0, sizeof q);
@@ -641,7 +651,12 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   memset(&xs, 0, sizeof xs);
   xs.q = q;
   for (int i = 0; i < q.n_q; ++i) xs.x[i] = qb[i]->dense;
-  if (e->kind == DRS_MODEL_NCF) {
+  if (e->kind == DRS_MODEL_DIN) {
+    // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
+    HIP_TRY(e, join());
+    HIP_TRY(e, launch_din_attention(s.T, e->ldT, Mv, e->T, e->D, e->att[0].ln[1], e->d_att, s.R, e->ldR, s.stream));
+    if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
+  } else if (e->kind == DRS_MODEL_NCF) {
     // mf = Sum(sls0, sls1); mlp = Concat(sls2, sls3) -> MLP; Concat(mf, mlp_out) -> FC+Relu
     const int D = e->D;
     const int wl = e->top.ln.back();
@@ -893,6 +908,20 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       e->n_out = cfg->num_tasks * cfg->ln_task[cfg->n_task - 1];
       break;
     }
+    case DRS_MODEL_DIN: {
+      if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIN needs at least 4 embedding tables");
+      if (cfg->n_bot != 3 || e->bot.ln[0] != 3 * D || e->bot.ln[2] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
+        return bail(DRS_ERR_UNSUPPORTED, "DIN attention unit must be 3*D -> h -> D with 1 <= h <= 64");
+      e->m_den = 0; e->w0 = 0;
+      e->num_int = 4 * D;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
+      e->att.resize(T - 3);
+      for (auto& au : e->att) { au.ln = e->bot.ln; au.layers.resize(2); au.sigmoid_layer = -1; }
+      e->bot.ln = {0}; e->bot.layers.clear();      // no bottom MLP of its own
+      e->top.sigmoid_layer = -1;
+      e->n_out = e->top.ln.back();
+      break;
+    }
     case DRS_MODEL_NCF: {
       if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
       if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
@@ -944,7 +973,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
 
   e->cap = (int64_t)e->max_batch * e->max_lookups;
   e->max_rows = (int64_t)DRS_MAX_COALESCE * ((e->max_batch + 63) / 64 * 64);
-  e->ldT = e->kind == DRS_MODEL_NCF ? 4 * D : e->w0 + (int64_t)T * D;
+  e->ldT = e->kind == DRS_MODEL_NCF ? 4 * D : e->w0 + (int64_t)T * D;   // (DIN: w0 == 0)
   e->ldR = round_up(e->num_int, 4);
   int maxw = 4;
   for (int w : e->bot.ln) maxw = w > maxw ? w : maxw;
@@ -1068,6 +1097,8 @@ int32_t drs_destroy(drs_handle e) {
   for (Mlp* m : {&e->bot, &e->top, &e->fin})
     for (auto& l : m->layers) { l.W = l.b = nullptr; }
   e->tasks.clear();
+  e->att.clear();
+  if (e->d_att) (void)hipFree(e->d_att);
   if (e->w_arena) (void)hipFree(e->w_arena);
   if (e->tables) (void)hipFree(e->tables);
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
@@ -1104,6 +1135,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (!h_W || !h_b) return fail(e, DRS_ERR_BAD_ARG, "null weights");
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
   if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
+  if (mlp >= DRS_MLP_ATT0 && mlp - DRS_MLP_ATT0 < (int)e->att.size()) M = &e->att[mlp - DRS_MLP_ATT0];
   if (!M || layer < 0 || layer >= (int)M->layers.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");
@@ -1121,6 +1153,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
       size_t need = 0, nbias = 0;
       std::vector<Mlp*> all = {&e->bot, &e->top, &e->fin};
       for (auto& tk : e->tasks) all.push_back(&tk);
+      for (auto& au : e->att) all.push_back(&au);
       for (Mlp* mm : all)
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
           const size_t out = mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024;
@@ -1384,6 +1417,7 @@ int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R
   const float* src;
   int64_t ld;
   if (e->kind == DRS_MODEL_NCF) { src = s.H2; ld = e->num_int; }
+  else if (e->kind == DRS_MODEL_DIN) { src = s.R; ld = e->ldR; }
   else if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) { src = s.R; ld = e->ldR; }
   else { src = s.T; ld = e->ldT; }
   HIP_TRY(e, hipMemcpy2D(h_R, sizeof(float) * e->num_int, src, sizeof(float) * ld,

@@ -4,6 +4,7 @@
     Wide_and_Deep / Wide_and_Deep_Wrapper <- models/wide_and_deep.py:165-477
     NCF / NCF_Wrapper                     <- models/ncf.py:140-523
     MT_Wide_and_Deep / ..._Wrapper        <- models/multi_task_wnd.py:160-420
+    DIN_Net / DIN_Wrapper                 <- models/din.py:24-470
 
 Same constructor arguments, the same shape algebra and sys.exit() checks, the same
 numpy RNG consumption order for the weights (embeddings, then bottom MLP, then top
@@ -307,7 +308,30 @@ class MT_Wide_and_Deep(Wide_and_Deep):
             for i, (W, b) in enumerate(head):
                 self.engine.set_fc(N.MLP_TASK0 + k, i, W, b)
 
-class NCF(_HipNet):
+class _NoDenseNet(_HipNet):
+    """Models whose query is sparse features only (NCF, DIN): the dense argument of the
+    reference's signatures is accepted and ignored, as the reference ignores it."""
+
+    def run(self, X=None, S_lengths=None, S_indices=None, enable_prof=False):
+        if S_indices is None:
+            X, S_lengths, S_indices = self._cur_inputs
+        else:
+            self._cur_inputs = (X, S_lengths, S_indices)
+        bs = len(S_lengths[0])
+        load_time = time.time()
+        self._out = self.engine.forward_inputs(None, S_indices, S_lengths, bs)
+        return load_time
+
+    def run_queued(self, ids, lengths, fc, batch_size):
+        self._out = self.engine.forward_inputs(None, list(ids), list(lengths), int(batch_size))
+        return self._out
+
+    def stage_batches(self, lX, lS_l, lS_i):
+        for j in range(len(lS_l)):
+            self.engine.stage_batch(j, None, lS_i[j], lS_l[j])
+
+
+class NCF(_NoDenseNet):
     kind = N.MODEL_NCF
 
     def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None):
@@ -340,23 +364,41 @@ class NCF(_HipNet):
         W, b = self.final_w[0]
         self.engine.set_fc(N.MLP_FINAL, 0, W, b)
 
-    def run(self, X=None, S_lengths=None, S_indices=None, enable_prof=False):
-        if S_indices is None:
-            X, S_lengths, S_indices = self._cur_inputs
-        else:
-            self._cur_inputs = (X, S_lengths, S_indices)
-        bs = len(S_lengths[0])
-        load_time = time.time()
-        self._out = self.engine.forward_inputs(None, S_indices, S_lengths, bs)   # NCF has no dense input
-        return load_time
 
-    def run_queued(self, ids, lengths, fc, batch_size):
-        self._out = self.engine.forward_inputs(None, list(ids), list(lengths), int(batch_size))
-        return self._out
+class DIN_Net(_NoDenseNet):
+    """Deep Interest Network (models/din.py:247-390).  Tables = [user profile | the behaviour
+    tables | candidate ad | context] (utils.cli has already replicated the behaviour table
+    `user_behavior_tables` times, utils/utils.py:132-149).  Per behaviour table one attention unit
+    with its OWN MLP 3*D -> arch_mlp_bot -> D over Concat(u_i, ad, u_i + ad) (:247-285);
+    atten_out = Sum of the units; top MLP over Concat(profile, atten_out, ad, context)
+    (:311-323); every activation is ReLU (the reference passes no sigmoid layer, :274,323)."""
+    kind = N.MODEL_DIN
 
-    def stage_batches(self, lX, lS_l, lS_i):
-        for j in range(len(lS_l)):
-            self.engine.stage_batch(j, None, lS_i[j], lS_l[j])
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None):
+        self._common_init(cli_args)
+        m_spa = int(cli_args.arch_sparse_feature_size)
+        ln_emb = _ints(cli_args.arch_embedding_size)
+        if ln_emb.size < 4:                         # the reference asserts (:356)
+            sys.exit("ERROR: DIN needs user profile, user behavior, candidate ad and context tables")
+        num_int = 4 * m_spa
+        ln_top = _ints(str(num_int) + "-" + cli_args.arch_mlp_top)
+        self.ln_att = _ints(str(3 * m_spa) + "-" + cli_args.arch_mlp_bot + "-" + str(m_spa))   # :255-260
+        self.m_spa, self.ln_emb, self.ln_top = m_spa, ln_emb, ln_top
+        self.ln_bot = self.ln_att
+        self.arch_interaction_op = "cat"
+        self.arch_interaction_itself = cli_args.arch_interaction_itself
+        # create order (:288-323): embeddings, each unit's MLP in table order, top MLP
+        self.emb_w = self._make_tables(m_spa, ln_emb)
+        self.att_w = [_init_mlp(self.ln_att) for _ in range(ln_emb.size - 3)]
+        self.top_w = _init_mlp(ln_top)
+
+    def _create_engine(self):
+        self.engine = self._build_engine(self.ln_att, self.ln_top, N.INTERACT_CAT, False, -1)
+        for u, unit in enumerate(self.att_w):
+            for i, (W, b) in enumerate(unit):
+                self.engine.set_fc(N.MLP_ATT0 + u, i, W, b)
+        for i, (W, b) in enumerate(self.top_w):
+            self.engine.set_fc(N.MLP_TOP, i, W, b)
 
 
 # =====================================================================================
@@ -400,5 +442,9 @@ class MT_Wide_and_Deep_Wrapper(_Wrapper):
     net_cls, attr = MT_Wide_and_Deep, "mtwnd"
 
 
+class DIN_Wrapper(_Wrapper):
+    net_cls, attr = DIN_Net, "din"
+
+
 WRAPPERS = {"dlrm": DLRM_Wrapper, "wnd": Wide_and_Deep_Wrapper, "ncf": NCF_Wrapper,
-            "mtwnd": MT_Wide_and_Deep_Wrapper}
+            "mtwnd": MT_Wide_and_Deep_Wrapper, "din": DIN_Wrapper}

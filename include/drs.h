@@ -54,6 +54,13 @@ enum {
                          then num_tasks task heads over its output; outputs = the heads' last
                          layers side by side, [bs, num_tasks * ln_task[-1]] -- the reference
                          keeps the last head as `last_output`, :316)                          */
+  ,
+  DRS_MODEL_DIN = 4   /* models/din.py:247-330: tables = [user profile | U behaviour tables |
+                         candidate ad | context], U = num_tables - 3; per behaviour table an
+                         attention unit with its OWN two-layer MLP over Concat(u_i, ad, u_i + ad);
+                         atten_out = Sum over the units; top MLP over Concat(profile, atten_out,
+                         ad, context); every activation ReLU.  cfg: ln_bot = the unit's widths
+                         [3*D, h, D] (arch_mlp_bot "h"), ln_top = [4*D, ...], no dense input      */
 };
 
 /* feature interaction (models/dlrm_s_caffe2.py:331-365) */
@@ -64,7 +71,8 @@ enum { DRS_ACT_NONE = 0, DRS_ACT_RELU = 1, DRS_ACT_SIGMOID = 2 };
 
 /* which MLP a layer belongs to in drs_set_fc */
 enum { DRS_MLP_BOT = 0, DRS_MLP_TOP = 1, DRS_MLP_FINAL = 2 /* NCF predictor */,
-       DRS_MLP_TASK0 = 16 /* + k: task head k of DRS_MODEL_MTWND */ };
+       DRS_MLP_TASK0 = 16 /* + k: task head k of DRS_MODEL_MTWND */,
+       DRS_MLP_ATT0 = 1024 /* + i: attention unit i of DRS_MODEL_DIN */ };
 
 /* kernels that keep live HIP-event timings (drs_kernel_time) */
 enum {

@@ -49,6 +49,10 @@ typedef struct orc_model {
   const float* const* task_W;
   const float* const* task_b;
   const float* const* task_Wt;
+  int32_t n_att;
+  const int32_t* ln_att;
+  const float* const* att_W;
+  const float* const* att_b;
 } orc_model;
 int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense, const int64_t* const* idx,
                     const int64_t* n_idx, const int32_t* const* len, float* out, float* R_out,
@@ -99,6 +103,7 @@ struct drs_engine {
   std::vector<bool> table_set;
   Mlp bot, top, fin;
   std::vector<Mlp> tasks;        // MT-WnD heads
+  std::vector<Mlp> att;          // DIN attention units
   int32_t interaction_op = 0, itself = 0, sigmoid_top = -1;
   int32_t max_batch = 0, max_lookups = 0, n_batches = 0, n_slots = 1;
   int32_t m_den = 0, w0 = 0, num_int = 0, n_out = 0;
@@ -182,7 +187,8 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
     if (!e->table_set[t]) return fail(e, DRS_ERR_STATE, "table %d has no data", t);
   int32_t rc;
   if ((rc = mlp_ready(e, e->bot, "bottom")) || (rc = mlp_ready(e, e->top, "top")) ||
-      (rc = mlp_ready(e, e->fin, "final")) || [&] { for (auto& tk : e->tasks) if ((rc = mlp_ready(e, tk, "task"))) return true; return false; }())
+      (rc = mlp_ready(e, e->fin, "final")) || [&] { for (auto& tk : e->tasks) if ((rc = mlp_ready(e, tk, "task"))) return true; return false; }() ||
+      [&] { for (auto& au : e->att) if ((rc = mlp_ready(e, au, "attention"))) return true; return false; }())
     return rc;
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
@@ -213,6 +219,14 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
     m.n_task = (int32_t)e->tasks[0].ln.size(); m.ln_task = e->tasks[0].ln.data();
     m.num_tasks = (int32_t)e->tasks.size(); m.task_sigmoid = e->sigmoid_top;
     m.task_W = kw.data(); m.task_b = kb.data();
+  }
+  std::vector<const float*> aw, ab;
+  if (e->kind == DRS_MODEL_DIN) {
+    for (auto& au : e->att)
+      for (size_t l = 0; l < au.W.size(); ++l) { aw.push_back(au.W[l].data()); ab.push_back(au.b[l].data()); }
+    m.n_att = (int32_t)e->att[0].ln.size(); m.ln_att = e->att[0].ln.data();
+    m.att_W = aw.data(); m.att_b = ab.data();
+    m.n_bot = 0; m.ln_bot = nullptr; m.bot_W = nullptr; m.bot_b = nullptr;
   }
   m.interaction_op = e->interaction_op; m.itself = e->itself; m.sigmoid_top = e->sigmoid_top;
 
@@ -314,6 +328,19 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       for (auto& tk : e->tasks) tk.ln.assign(cfg->ln_task, cfg->ln_task + cfg->n_task);
       e->n_out = cfg->num_tasks * cfg->ln_task[cfg->n_task - 1];
       break;
+    case DRS_MODEL_DIN:
+      if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIN needs at least 4 embedding tables");
+      if (cfg->n_bot != 3 || e->bot.ln[0] != 3 * D || e->bot.ln[2] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
+        return bail(DRS_ERR_UNSUPPORTED, "DIN attention unit must be 3*D -> h -> D with 1 <= h <= 64");
+      e->m_den = 0; e->w0 = 0;
+      e->num_int = 4 * D;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
+      e->att.resize(T - 3);
+      for (auto& au : e->att) au.ln = e->bot.ln;
+      e->bot.ln = {0};
+      e->sigmoid_top = -1;
+      e->n_out = e->top.ln.back();
+      break;
     case DRS_MODEL_NCF:
       if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
       if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
@@ -336,6 +363,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   };
   init_mlp(e->bot); init_mlp(e->top); init_mlp(e->fin);
   for (auto& tk : e->tasks) init_mlp(tk);
+  for (auto& au : e->att) init_mlp(au);
   e->tables.assign(T, {});
   e->table_set.assign(T, false);
   e->cap = (int64_t)e->max_batch * e->max_lookups;
@@ -378,6 +406,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (!h_W || !h_b) return fail(e, DRS_ERR_BAD_ARG, "null weights");
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
   if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
+  if (mlp >= DRS_MLP_ATT0 && mlp - DRS_MLP_ATT0 < (int)e->att.size()) M = &e->att[mlp - DRS_MLP_ATT0];
   if (!M || layer < 0 || layer >= (int)M->set.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");

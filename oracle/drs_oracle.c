@@ -54,7 +54,7 @@
 #define ORC_ERR_LENGTHS_SUM (-5)
 #define ORC_ERR_UNSUPPORTED (-7)
 
-enum { ORC_MODEL_DLRM = 0, ORC_MODEL_WND = 1, ORC_MODEL_NCF = 2, ORC_MODEL_MTWND = 3 };
+enum { ORC_MODEL_DLRM = 0, ORC_MODEL_WND = 1, ORC_MODEL_NCF = 2, ORC_MODEL_MTWND = 3, ORC_MODEL_DIN = 4 };
 enum { ORC_INTERACT_DOT = 0, ORC_INTERACT_CAT = 1 };
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_SIGMOID = 2 };
 
@@ -281,6 +281,16 @@ typedef struct orc_model {
   const float* const* task_W;
   const float* const* task_b;
   const float* const* task_Wt;
+  /* DIN (models/din.py:247-330): tables = [user profile | U behaviour tables | candidate ad |
+   * context]; per behaviour table an attention unit with ITS OWN MLP of widths ln_att
+   * (ln_att[0] == 3*D: Concat(u_i, ad, Sum(u_i, ad)); ln_att[-1] == D; all ReLU); att_W / att_b
+   * hold the units' layers back to back, [U * (n_att - 1)]; atten_out = Sum of the units' outputs
+   * in unit order; top input = Concat(user profile, atten_out, ad, context) [B, 4*D]; top MLP all
+   * ReLU (din.py:186, no Sigmoid anywhere)                                                    */
+  int32_t n_att;
+  const int32_t* ln_att;
+  const float* const* att_W;
+  const float* const* att_b;
 } orc_model;
 
 static int32_t mlp_chain(const float* in, int64_t B, int64_t ld_in, int32_t n_l,
@@ -356,6 +366,45 @@ int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense,
       rc = fc_impl(cat, B, D + wl, D + wl, m->final_W, m->final_Wt, m->final_b, m->final_m, ORC_ACT_RELU, out,
                    m->final_m, nthreads);
     free(emb); free(cat); free(mlp_in);
+    return rc;
+  }
+
+  if (m->model_kind == ORC_MODEL_DIN) {
+    const int32_t U = T - 3, per = m->n_att - 1;
+    if (T < 4 || m->n_att < 2 || m->ln_att[0] != 3 * D || m->ln_att[m->n_att - 1] != D || m->ln_top[0] != 4 * D)
+      return ORC_ERR_BAD_ARG;
+    const int64_t ldE = (int64_t)T * D;
+    float* E = (float*)malloc(sizeof(float) * (size_t)B * (size_t)ldE);
+    float* X = (float*)malloc(sizeof(float) * (size_t)B * 3 * D);
+    float* Y = (float*)malloc(sizeof(float) * (size_t)B * D);
+    float* Rin = (float*)malloc(sizeof(float) * (size_t)B * 4 * D);
+    if (!E || !X || !Y || !Rin) { free(E); free(X); free(Y); free(Rin); return ORC_ERR_OOM; }
+    for (int32_t t = 0; t < T && rc == ORC_OK; ++t)
+      rc = sls_impl(m->tables[t], m->rows[t], D, idx[t], NULL, len[t], B, n_idx[t], E + (int64_t)t * D, ldE, nthreads);
+    for (int32_t i = 0; i < U && rc == ORC_OK; ++i) {
+      for (int64_t b = 0; b < B; ++b) {
+        const float* u = E + b * ldE + (int64_t)(1 + i) * D;
+        const float* ad = E + b * ldE + (int64_t)(T - 2) * D;
+        float* x = X + b * 3 * D;
+        for (int32_t d = 0; d < D; ++d) { x[d] = u[d]; x[D + d] = ad[d]; x[2 * D + d] = u[d] + ad[d]; }   /* Sum, Concat (:262-271) */
+      }
+      rc = mlp_chain(X, B, 3 * D, m->n_att, m->ln_att, m->att_W + (size_t)i * per, NULL, m->att_b + (size_t)i * per, -1, Y, D, nthreads);
+      if (rc == ORC_OK)
+        for (int64_t b = 0; b < B; ++b)
+          for (int32_t d = 0; d < D; ++d) {
+            float* z = Rin + b * 4 * D + D + d;          /* atten_out = Sum(fc_outs), in unit order (:283) */
+            *z = i == 0 ? Y[b * D + d] : *z + Y[b * D + d];
+          }
+    }
+    if (rc == ORC_OK)
+      for (int64_t b = 0; b < B; ++b) {
+        memcpy(Rin + b * 4 * D, E + b * ldE, sizeof(float) * D);                                  /* user profile */
+        memcpy(Rin + b * 4 * D + 2 * D, E + b * ldE + (int64_t)(T - 2) * D, sizeof(float) * 2 * D); /* candidate ad, context */
+      }
+    if (rc == ORC_OK && R_out) memcpy(R_out, Rin, sizeof(float) * (size_t)B * 4 * D);
+    if (rc == ORC_OK)
+      rc = mlp_chain(Rin, B, 4 * D, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, -1, out, m->ln_top[m->n_top - 1], nthreads);
+    free(E); free(X); free(Y); free(Rin);
     return rc;
   }
 

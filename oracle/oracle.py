@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libdrs_oracle.so")
 
-MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND = 0, 1, 2, 3
+MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND, MODEL_DIN = 0, 1, 2, 3, 4
 INTERACT_DOT, INTERACT_CAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -51,6 +51,7 @@ class _Model(C.Structure):
         ("bot_Wt", C.POINTER(_f32p)), ("top_Wt", C.POINTER(_f32p)), ("final_Wt", _f32p),
         ("n_task", C.c_int32), ("ln_task", _i32p), ("num_tasks", C.c_int32), ("task_sigmoid", C.c_int32),
         ("task_W", C.POINTER(_f32p)), ("task_b", C.POINTER(_f32p)), ("task_Wt", C.POINTER(_f32p)),
+        ("n_att", C.c_int32), ("ln_att", _i32p), ("att_W", C.POINTER(_f32p)), ("att_b", C.POINTER(_f32p)),
     ]
 
 
@@ -156,8 +157,9 @@ class Model(object):
     """
 
     def __init__(self, kind, tables, ln_bot, bot, ln_top, top, interaction_op=INTERACT_CAT,
-                 itself=False, sigmoid_top=-1, final=None, ln_task=None, tasks=None):
-        """MT-WnD: ln_task = head widths, tasks = list (one per head) of lists of (W, b)."""
+                 itself=False, sigmoid_top=-1, final=None, ln_task=None, tasks=None, ln_att=None, att=None):
+        """MT-WnD: ln_task = head widths, tasks = list (one per head) of lists of (W, b).
+        DIN: ln_att = attention-unit widths, att = list (one per behaviour table) of lists of (W, b)."""
         self.kind = kind
         self.tables = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
         self.D = int(self.tables[0].shape[1])
@@ -218,6 +220,17 @@ class Model(object):
             m.n_task, m.ln_task = self.ln_task.size, self.ln_task.ctypes.data_as(_i32p)
             m.num_tasks, m.task_sigmoid = len(self.tasks), self.sigmoid_top
             m.task_W, m.task_b, m.task_Wt = self._kW, self._kb, self._kWt
+        self.att = None
+        if att is not None:
+            self.ln_att = np.ascontiguousarray(ln_att, dtype=np.int32)
+            self.att = [[(np.ascontiguousarray(W, np.float32), np.ascontiguousarray(b, np.float32)) for W, b in unit]
+                        for unit in att]
+            flat = [wb for unit in self.att for wb in unit]
+            na = len(flat)
+            self._aW = (_f32p * na)(*[W.ctypes.data_as(_f32p) for W, _ in flat])
+            self._ab = (_f32p * na)(*[b.ctypes.data_as(_f32p) for _, b in flat])
+            m.n_att, m.ln_att = self.ln_att.size, self.ln_att.ctypes.data_as(_i32p)
+            m.att_W, m.att_b = self._aW, self._ab
         self._c = m
 
     @property
@@ -230,6 +243,8 @@ class Model(object):
     def num_int(self):
         if self.kind == MODEL_NCF:
             return self.D + int(self.ln_top[-1])
+        if self.kind == MODEL_DIN:
+            return 4 * self.D
         return int(self.ln_top[0])
 
     def forward(self, dense, idx, lengths, bs=None, nthreads=1, want_R=False):

@@ -14,8 +14,10 @@ from oracle import oracle as orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["dlrm_dot_small", "dlrm_dot_itself_small", "dlrm_cat_small", "dlrm_cat_queue_small",
                "dlrm_dot_queue_small", "dlrm_rm1_mini", "dlrm_rm2_mini", "dlrm_rm3_mini", "wnd_mini",
-               "ncf_mini", "mtwnd_mini"]
-NET_CLS = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep}
+               "ncf_mini", "mtwnd_mini", "din_mini"]
+NET_CLS = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep,
+           "din": M.DIN_Net}
+NO_DENSE = ("ncf", "din")     # model types whose queries are sparse features only
 
 
 def sha(a):
@@ -64,6 +66,9 @@ def oracle_model(net):
     if net.kind == M.N.MODEL_NCF:
         return orc.Model(orc.MODEL_NCF, net.emb_w, [0], [], net.ln_top[:-1], net.top_w,
                          final=net.final_w[0])
+    if net.kind == M.N.MODEL_DIN:
+        return orc.Model(orc.MODEL_DIN, net.emb_w, [0], [], net.ln_top, net.top_w, ln_att=net.ln_att,
+                         att=net.att_w)
     if net.kind == M.N.MODEL_MTWND:
         return orc.Model(orc.MODEL_MTWND, net.emb_w, net.ln_bot, [], net.ln_top, net.top_w,
                          sigmoid_top=net.sigmoid_top, ln_task=net.ln_task, tasks=net.task_w)
@@ -110,7 +115,7 @@ def oracle_inference_engine(args, requestQueue=None, engine_id=None, responseQue
             return
         start = time.time()
         bid, bs = request.batch_id, request.batch_size
-        dense = None if args.model_type == "ncf" else lX[bid]
+        dense = None if args.model_type in NO_DENSE else lX[bid]
         out = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, nthreads=1)
         end = time.time()
         responseQueue.put(ServiceResponse(consumer_id=engine_id, epoch=request.epoch, batch_id=bid,

@@ -32,7 +32,7 @@ def test_wrappers_through_the_abi_match_oracle_and_golden(cpu_abi, case):
     args = H.args_from(meta["args"])
     net, lX, lS_l, lS_i, lT = H.materialize(args)
     om = H.oracle_model(net)
-    ncf = args.model_type == "ncf"
+    ncf = args.model_type in H.NO_DENSE
     net.create(lX[0], lS_l[0], lS_i[0], lT[0])
     try:
         net.stage_batches(None if ncf else lX, lS_l, lS_i)

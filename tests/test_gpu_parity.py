@@ -41,7 +41,7 @@ def test_forward_matches_oracle_and_golden(case):
     om = H.oracle_model(net)
     net.create(lX[0], lS_l[0], lS_i[0], lT[0])
     try:
-        net.stage_batches(None if args.model_type == "ncf" else lX, lS_l, lS_i)
+        net.stage_batches(None if args.model_type in H.NO_DENSE else lX, lS_l, lS_i)
         n = len(lS_l[0][0])
         for exact in (1, 0):
             net.engine.set_option("sls_exact", exact)
@@ -49,7 +49,7 @@ def test_forward_matches_oracle_and_golden(case):
                 for bs in sorted({n, 1, max(1, n // 2)}):
                     got = net.run_staged(bid, bs)
                     R = net.engine.fetch_interaction(bs)
-                    dense = None if args.model_type == "ncf" else lX[bid]
+                    dense = None if args.model_type in H.NO_DENSE else lX[bid]
                     exp, R_exp = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, want_R=True)
                     if exact:
                         # pooled embeddings + concat layout + (dot) tril order + bottom MLP: bitwise;
@@ -63,7 +63,7 @@ def test_forward_matches_oracle_and_golden(case):
         full = net.run_staged(0, n)
         assert H.close(full, H.golden_output(meta, z), rtol=H.RTOL_OUT)
         # non-staged inputs (run_queues signature) give the same bits as the staged path
-        again = net.run_queued(lS_i[0], lS_l[0], None if args.model_type == "ncf" else lX[0], n)
+        again = net.run_queued(lS_i[0], lS_l[0], None if args.model_type in H.NO_DENSE else lX[0], n)
         assert np.array_equal(full, again)
     finally:
         net.engine.close()
@@ -290,6 +290,11 @@ FULL_SIZE = {
     # reference models/configs/dlrm_rm2.json (BASELINE config 5): 32 x 500k x 64, 120 lookups per
     # bag, top input 2112 wide (too wide for an LDS slab: the per-layer chain kernel)
     "rm2": dict(kind="dlrm", rows=[500_000] * 32, D=64, L=120, bot="256-128-64", top="128-64-1"),
+    # reference models/configs/din.json as utils/utils.py:132-149 expands it: 254 tables (profile 1M,
+    # 251 behaviour x 100k, ad 10M, context 10M) x 32, 3 lookups, 251 attention units 96-1-32,
+    # top MLP 128-200-80-2
+    "din": dict(kind="din", rows=[1_000_000] + [100_000] * 251 + [10_000_000] * 2, D=32, L=3, bot="1",
+                top="200-80-2"),
 }
 
 
@@ -309,7 +314,7 @@ def test_full_size_reference_shapes_match_oracle(name):
                        numpy_rand_seed=seed, accel_table_init="device", model_type=w["kind"], accel_slots=2)
     np.random.seed(seed)
     net = H.NET_CLS[w["kind"]](args)
-    ncf = w["kind"] == "ncf"
+    ncf = w["kind"] in H.NO_DENSE
     m_den = int(w["bot"].split("-")[0])
     _, lX, lS_l, lS_i = generate_fast_input_data(nb, B, m_den, rows, L, seed)
     dense = (lambda b: None) if ncf else (lambda b: lX[b])

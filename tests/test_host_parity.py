@@ -164,6 +164,12 @@ def test_inputs_and_weights_bitexact_vs_reference(case):
         assert list(net.ln_top) == [z["blob/top:::fc1_w"].shape[1] if "blob/top:::fc1_w" in z.files
                                     else dg["blob/top:::fc1_w"]["shape"][1]] + \
             [int(x) for x in args.arch_mlp_top.split("-")]
+    if args.model_type == "din":
+        # one MLP per attention unit, created in table order (models/din.py:262-277)
+        for u, unit in enumerate(net.att_w):
+            for i, (W, b) in enumerate(unit):
+                assert H.sha(W) == dg["blob/atten:::_fc_%d:::fc%d_w" % (u, i + 1)]["sha256"]
+                assert H.sha(b) == dg["blob/atten:::_fc_%d:::fc%d_b" % (u, i + 1)]["sha256"]
     pre = "mlpfc" if args.model_type == "ncf" else "top"
     for i, (W, b) in enumerate(net.top_w):
         assert H.sha(W) == dg["blob/%s:::fc%d_w" % (pre, i + 1)]["sha256"]

@@ -19,7 +19,7 @@ def test_oracle_forward_matches_golden(case):
     args = H.args_from(meta["args"])
     net, lX, lS_l, lS_i, lT = H.materialize(args)
     om = H.oracle_model(net)
-    dense = None if args.model_type == "ncf" else lX[0]
+    dense = None if args.model_type in H.NO_DENSE else lX[0]
     out, R = om.forward(dense, lS_i[0], lS_l[0], want_R=True)
     exp = H.golden_output(meta, z)
     assert out.shape == exp.shape
@@ -28,7 +28,7 @@ def test_oracle_forward_matches_golden(case):
     # interaction tensor (input of the top MLP) where the fixture has it; RM3's bottom
     # MLP has K=2560 all-positive inputs, so allow cancellation noise relative to max|R|
     key = {"dlrm": "expected/interaction", "wnd": "expected/interaction", "mtwnd": "expected/interaction",
-           "ncf": "expected/feat_int"}[args.model_type]
+           "ncf": "expected/feat_int", "din": "expected/top_fc_in"}[args.model_type]
     if key in z.files:
         assert H.close(R, z[key], rtol=2e-5, atol_scale=2e-6)
 

@@ -26,7 +26,7 @@ import bench
 from deeprecsys_amd import latency_table
 
 MODEL_TO_WORKLOAD = {"rm1": "rmc1_ref", "rm2": "rmc2_ref", "rm3": "rmc3_ref", "rm1_baseline": "rmc1",
-                     "wnd": "wnd", "ncf": "ncf", "mtwnd": "mtwnd"}
+                     "wnd": "wnd", "ncf": "ncf", "mtwnd": "mtwnd", "din": "din"}
 
 
 def main():
@@ -47,7 +47,7 @@ def main():
         bs = 4 ** p
         ids = [i[:bs * L] for i in lS_i[0]]
         lens = [l[:bs] for l in lS_l[0]]
-        x = None if bench.WORKLOADS[opt.workload].get("kind") == "ncf" else lX[0][:bs]
+        x = None if bench.WORKLOADS[opt.workload].get("kind") in bench.NO_DENSE else lX[0][:bs]
         for _ in range(20):
             eng.forward(0, bs)
             eng.forward_inputs(x, ids, lens, bs)

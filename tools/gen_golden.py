@@ -265,7 +265,8 @@ def capture_model(case, ref, argv, queue_requests=None):
     nb, lX, lS_l, lS_i = datagen.generate_input_data()
     nb, lT = datagen.generate_output_data()
     wrapper_cls = {"dlrm": ref["DLRM_Wrapper"], "wnd": ref["Wide_and_Deep_Wrapper"],
-                   "ncf": ref["NCF_Wrapper"], "mtwnd": ref.get("MT_Wide_and_Deep_Wrapper")}[args.model_type]
+                   "ncf": ref["NCF_Wrapper"], "mtwnd": ref.get("MT_Wide_and_Deep_Wrapper"),
+                   "din": ref.get("DIN_Wrapper")}[args.model_type]
     with mock.patch("builtins.print"):
         model = wrapper_cls(args)
         model.create(lX[0], lS_l[0], lS_i[0], lT[0])
@@ -274,7 +275,7 @@ def capture_model(case, ref, argv, queue_requests=None):
                        "(inputs, cli); expected_* are restated by oracle/c2ops.py")
     fx.meta["argv"] = list(argv)
     fx.meta["args"] = jsonable(vars(args))
-    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF", "mtwnd": "MT_Wide_and_Deep"}[args.model_type]
+    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF", "mtwnd": "MT_Wide_and_Deep", "din": "DIN"}[args.model_type]
     ops = [op for op in REC.ops if op["net"] == net_name]
     fx.meta["ops"] = ops
     fx.meta["feed_order"] = [n for n, _ in REC.feeds]
@@ -513,13 +514,27 @@ def main():
         from models.wide_and_deep import Wide_and_Deep_Wrapper
         from models.ncf import NCF_Wrapper
         from models.multi_task_wnd import MT_Wide_and_Deep_Wrapper
+        from models.din import DIN_Wrapper
         from inferenceEngine import inferenceEngine
     finally:
         os.chdir(cwd)
     ref = dict(cli=cli, ServiceRequest=ServiceRequest, DLRMDataGenerator=DLRMDataGenerator,
                DLRM_Wrapper=DLRM_Wrapper, Wide_and_Deep_Wrapper=Wide_and_Deep_Wrapper,
                NCF_Wrapper=NCF_Wrapper, inferenceEngine=inferenceEngine,
-               MT_Wide_and_Deep_Wrapper=MT_Wide_and_Deep_Wrapper)
+               MT_Wide_and_Deep_Wrapper=MT_Wide_and_Deep_Wrapper, DIN_Wrapper=DIN_Wrapper)
+
+    def din():
+        # Deep Interest Network (models/din.py): the shipped widths, shrunk tables, SIX behaviour
+        # tables (cli flags, not the config file: the file would undo the table expansion,
+        # utils/utils.py:132-160)
+        capture_model("din_mini", ref, ["--model_type", "din", "--model_name", "din", "--arch_mlp_bot", "1",
+                                        "--arch_mlp_top", "200-80-2", "--arch_embedding_size", "300-200-400-500",
+                                        "--arch_sparse_feature_size", "32", "--num_indices_per_lookup", "3",
+                                        "--num_indices_per_lookup_fixed", "1", "--arch_interaction_op", "cat",
+                                        "--user_behavior_tables", "5", "--num_batches", "1",
+                                        "--max_mini_batch_size", "8", "--mini_batch_size", "8"])
+    if opt.only == "din_mini":
+        return din()
 
     def mtwnd():
         # multi-task W&D (models/multi_task_wnd.py), shrunk tables, TWO task heads
@@ -580,6 +595,7 @@ def main():
                                     "--max_mini_batch_size", "8", "--mini_batch_size", "8"])
 
     mtwnd()
+    din()
     capture_harness(ref, ref_root)
 
 
