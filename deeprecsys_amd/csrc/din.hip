@@ -1,0 +1,466 @@
+// Deep Interest Network (models/din.py:247-330): the attention units over the pooled behaviour
+// embeddings.  Tables = [user profile | U behaviour tables | candidate ad | context]; per behaviour
+// table i ONE attention unit with its own weights,
+//     y_i = relu(W1_i . Concat(u_i, ad, u_i + ad) + b1_i)      [h]        (models/din.py:262-277)
+//     o_i = relu(W2_i . y_i + b2_i)                             [D]
+//     atten_out = Sum_i o_i                                                (:280)
+//     top MLP input = Concat(profile, atten_out, ad, context)  [4 D]      (:311-318)
+// Not MFMA work: every unit has different weights (K = 3 D, N = h = 1 in the shipped config), the
+// arithmetic is 64 k FLOP per sample next to 97 KB of gathered rows -- the path is HBM-bound on the
+// row gather, so the default launch FUSES gather, units and Concat: the [rows, T * D] pooled
+// tensor (32 KB per sample, a third of the gathered bytes) is never written or re-read.
+#include <hip/hip_ext.h>
+
+#include "drs_internal.h"
+
+namespace drs {
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
+  acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+  return acc;
+}
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ float4 shfl_xor4(const float4& a, int m) {
+  return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m), __shfl_xor(a.w, m));
+}
+
+}  // namespace
+
+// Packed weights of one unit, every piece 16-B aligned (D % 4 == 0):
+//   [ W1 : h x 3D | W2 : D x h | b2 : D | b1 : h, padded to 4 ]
+int64_t din_unit_stride(int D, int h) { return (int64_t)3 * D * h + (int64_t)D * h + D + (h + 3) / 4 * 4; }
+
+namespace {
+
+__global__ __launch_bounds__(256) void din_pack_kernel(const float* const* __restrict__ att, float* __restrict__ packed,
+                                                       int D, int h, int64_t stride) {
+  const int i = blockIdx.x;
+  float* o = packed + (int64_t)i * stride;
+  const float* W1 = att[4 * i + 0];
+  const float* b1 = att[4 * i + 1];
+  const float* W2 = att[4 * i + 2];
+  const float* b2 = att[4 * i + 3];
+  const int n1 = 3 * D * h, n2 = D * h;
+  for (int k = threadIdx.x; k < n1; k += blockDim.x) o[k] = W1[k];
+  for (int k = threadIdx.x; k < n2; k += blockDim.x) o[n1 + k] = W2[k];
+  for (int k = threadIdx.x; k < D; k += blockDim.x) o[n1 + n2 + k] = b2[k];
+  for (int k = threadIdx.x; k < (h + 3) / 4 * 4; k += blockDim.x) o[n1 + n2 + D + k] = k < h ? b1[k] : 0.f;
+}
+
+// The two-launch form (sequential-order mode, and shapes the fused kernel does not cover): T is the
+// gather's pooled tensor [M, Tn * D].  One wave per sample.  Phase 1: lane l evaluates the first
+// layer of units l, l + 64, ... as the oracle's FC does (k-ordered fmaf chain over the Concat,
+// bias after, ReLU); phase 2: lane j < D owns output column j and walks the units IN ORDER (the
+// reference's Sum over fc_outs): second layer = chain over the h hidden values, bias, ReLU.
+// Bit-identical to oracle/drs_oracle.c's DIN branch.
+__global__ __launch_bounds__(256) void din_attention_kernel(const float* __restrict__ T, int64_t ldt, int64_t M,
+                                                            int Tn, int D, int h, const float* __restrict__ packed,
+                                                            int64_t stride, float* __restrict__ R, int64_t ldr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  const int U = Tn - 3;
+  float* sy = smem + (size_t)wave * U * h;          // [U][h] hidden values of this sample
+  if (row >= M) return;                             // whole wave exits together
+  const float* e = T + row * ldt;
+  const float* ad = e + (int64_t)(Tn - 2) * D;
+  const int n1 = 3 * D * h, n2 = D * h;
+  for (int i0 = 0; i0 < U; i0 += 64) {
+    const int i = min(i0 + lane, U - 1);
+    const float* u = e + (int64_t)(1 + i) * D;
+    const float* W1 = packed + (int64_t)i * stride;
+    const float* b1 = W1 + n1 + n2 + D;
+    for (int hh = 0; hh < h; ++hh) {
+      const float* w = W1 + (int64_t)hh * 3 * D;
+      float acc = 0.f;
+      for (int k = 0; k < D; ++k) acc = fmaf(u[k], w[k], acc);
+      for (int k = 0; k < D; ++k) acc = fmaf(ad[k], w[D + k], acc);
+      for (int k = 0; k < D; ++k) acc = fmaf(u[k] + ad[k], w[2 * D + k], acc);
+      const float y = acc + b1[hh];
+      if (i0 + lane < U) sy[i * h + hh] = y > 0.f ? y : 0.f;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  float* out = R + row * ldr;
+  for (int j = lane; j < D; j += 64) {
+    float z = 0.f;
+    for (int i = 0; i < U; ++i) {
+      const float* W2 = packed + (int64_t)i * stride + n1;
+      const float* b2 = W2 + n2;
+      float acc = 0.f;
+      for (int hh = 0; hh < h; ++hh) acc = fmaf(sy[i * h + hh], W2[(int64_t)j * h + hh], acc);
+      float o = acc + b2[j];
+      o = o > 0.f ? o : 0.f;
+      z = i == 0 ? o : z + o;
+    }
+    out[D + j] = z;
+    out[j] = e[j];
+    out[2 * D + j] = ad[j];
+    out[3 * D + j] = e[(int64_t)(Tn - 1) * D + j];
+  }
+}
+
+// Who owns valid-sample number `smp` of a coalesced launch set (select chain over <= 8 entries,
+// wave-uniform: no dynamic indexing of the kernel-argument arrays).
+struct Owner {
+  int b, vrow, ulen;
+  const int32_t* idx;
+  const int32_t* off;
+};
+__device__ __forceinline__ Owner owner_of(const SlsArgs& a, int smp) {
+  Owner o = {smp, a.q.vstart[0] + smp, a.uniform_len[0], a.idx[0], a.off[0]};
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    o.b = in ? smp - a.q.cum[i] : o.b;
+    o.vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : o.vrow;
+    o.ulen = in ? a.uniform_len[i] : o.ulen;
+    o.idx = in ? a.idx[i] : o.idx;
+    o.off = in ? a.off[i] : o.off;
+  }
+  return o;
+}
+
+// FUSED gather + attention units + Concat.  A workgroup of NW waves serves S samples; its waves
+// split into lane groups of G = D / 4 lanes (one 16-B piece of a row each), and lane group gg
+// owns units gg, gg + NGB, ...: it pools the unit's bag for each of the S samples (the bag is
+// summed in index order, like the sequential SparseLengthsSum), applies the unit (weights held in
+// registers across the S samples; first layer = in-lane fmaf chains + a G-lane butterfly, so its
+// summation order differs from the oracle's k-ordered chain -- the default-mode tolerance,
+// tests/test_gpu_parity.py), and keeps a partial Sum.  The partial sums meet in LDS (wave order,
+// then group order: fixed, independent of the launch size).
+// Schedule: the indices (and bag bounds) of a group's NEXT unit are fetched while the rows of the
+// current one are in flight, so a round costs one dependent HBM round trip instead of two; up to
+// S x C row loads per lane are in flight (C = rows per bag covered per round: 3 when no bag of the
+// launch is longer, else 4); loads past a bag's end read the zero page instead of branching.
+// Bytes per sample: T bags of rows + indices in, 4 D floats out.
+template <int G, int S, int H, int C, int NW>
+__global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const float* __restrict__ packed,
+                                                            int64_t stride, const float* __restrict__ zero,
+                                                            float* __restrict__ R, int64_t ldr) {
+  constexpr int NG = 64 / G, NGB = NW * NG, D = 4 * G;
+  static_assert(S <= NW, "wave s finishes sample s");
+  __shared__ float4 s_z[S][NW][G];
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / G, gl = lane - g * G, gg = wave * NG + g;
+  const int n_smp = a.q.cum[a.q.n_q];
+  const int U = a.T - 3;
+  const int col = gl * 4;
+
+  Owner ow[S];
+  bool live[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int smp = blockIdx.x * S + s;
+    live[s] = smp < n_smp;
+    ow[s] = owner_of(a, live[s] ? smp : 0);
+  }
+  bool bad = false;
+
+  // a bag per sample of table t: bounds and the first C indices (fetched one unit ahead)
+  struct Pre {
+    int t;
+    const float* W;          // the table's rows, at this lane's columns
+    uint32_t rows;
+    int beg[S], len[S];
+    uint32_t r[S][C];
+  };
+  bool all_uniform = true;   // (wave-uniform: one scalar branch per unit)
+#pragma unroll
+  for (int s = 0; s < S; ++s) all_uniform = all_uniform && ow[s].ulen >= 0;
+  auto bounds = [&](int t, Pre& p) {
+    p.t = t;
+    // (the table's base and row count travel with the indices: fetched a unit ahead, not in front
+    // of the row loads that need them)
+    p.W = a.tables + a.tab_off[t] + col;
+    p.rows = (uint32_t)a.tab_rows[t];
+    if (all_uniform) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        p.beg[s] = ow[s].b * ow[s].ulen;
+        p.len[s] = live[s] ? ow[s].ulen : 0;
+      }
+    } else {
+      // staged prefix sums: all 2 S loads in flight together
+      int o0[S], o1[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int32_t* offp = ow[s].off + (int64_t)t * a.off_stride + ow[s].b;
+        o0[s] = offp[0];
+        o1[s] = offp[1];
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        // (a fixed-length query coalesced with a ragged one: its prefix sums may never have been
+        // uploaded -- the loads above touch mapped memory, their values are not used)
+        const bool uni = ow[s].ulen >= 0;
+        p.beg[s] = uni ? ow[s].b * ow[s].ulen : o0[s];
+        p.len[s] = !live[s] ? 0 : uni ? ow[s].ulen : o1[s] - o0[s];
+      }
+    }
+  };
+  auto fetch_idx = [&](const Pre& p, int j0, uint32_t (&r)[S][C]) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int32_t* ip = ow[s].idx + (int64_t)p.t * a.idx_stride;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int j = j0 + c;
+        r[s][c] = (uint32_t)ip[j < p.len[s] ? p.beg[s] + j : 0];     // (slot 0 of the table's index block: always mapped)
+      }
+    }
+  };
+  auto prefetch = [&](int t, Pre& p) {
+    bounds(t, p);
+    fetch_idx(p, 0, p.r);
+  };
+  // rows [j0, j0 + C) of the S bags, added in index order
+  const float* zcol = zero + col;
+  auto add_rows = [&](const Pre& p, int j0, const uint32_t (&r)[S][C], float4 (&acc)[S]) {
+    const float* __restrict__ W = p.W;
+    const uint32_t rows = p.rows;
+    float4 v[S][C];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const bool in = j0 + c < p.len[s];
+        uint32_t rr = r[s][c];
+        bad |= in && rr >= rows;
+        rr = rr < rows ? rr : 0u;
+        v[s][c] = ld4(in ? W + (uint64_t)(rr * (uint32_t)D) : zcol);
+      }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < C; ++c) add4(acc[s], v[s][c]);
+  };
+  // everything of a bag beyond its first C rows (only bags longer than C: not the shipped config)
+  auto add_tail = [&](const Pre& p, float4 (&acc)[S]) {
+    int len_max = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) len_max = max(len_max, p.len[s]);
+    for (int j0 = C; j0 < len_max; j0 += C) {
+      uint32_t r[S][C];
+      fetch_idx(p, j0, r);
+      add_rows(p, j0, r, acc);
+    }
+  };
+  auto zero_acc = [&](float4 (&acc)[S]) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  // candidate ad (every lane group needs it) and this group's first unit: indices in flight together
+  Pre pa, pn;
+  prefetch(a.T - 2, pa);
+  const bool has_unit = gg < U;
+  prefetch(has_unit ? 1 + gg : a.T - 2, pn);
+  float4 ad[S];
+  zero_acc(ad);
+  add_rows(pa, 0, pa.r, ad);
+  add_tail(pa, ad);
+
+  // pass-through features of the top MLP's input row: lane group 0 of waves 0..2 takes one each
+  // (profile, candidate ad, context)
+  if (wave < 3 && g == 0) {
+    const int dst = wave == 0 ? 0 : wave == 1 ? 2 * D : 3 * D;
+    float4 pv[S];
+    if (wave == 1) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) pv[s] = ad[s];
+    } else {
+      Pre pp;
+      prefetch(wave == 0 ? 0 : a.T - 1, pp);
+      zero_acc(pv);
+      add_rows(pp, 0, pp.r, pv);
+      add_tail(pp, pv);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (live[s]) *reinterpret_cast<float4*>(R + (int64_t)ow[s].vrow * ldr + dst + col) = pv[s];
+  }
+
+  float4 z[S];
+  zero_acc(z);
+  for (int i = gg; i < U; i += NGB) {
+    const Pre p = pn;
+    float4 u[S];
+    zero_acc(u);
+    // rows of this unit go out first ...
+    const float* __restrict__ W = p.W;
+    const uint32_t rows = p.rows;
+    float4 v[S][C];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const bool in = c < p.len[s];
+        uint32_t rr = p.r[s][c];
+        bad |= in && rr >= rows;
+        rr = rr < rows ? rr : 0u;
+        v[s][c] = ld4(in ? W + (uint64_t)(rr * (uint32_t)D) : zcol);
+      }
+    // ... then the next unit's indices and this unit's weights (this lane's pieces, kept across
+    // the S samples)
+    if (i + NGB < U) prefetch(1 + i + NGB, pn);
+    const float* __restrict__ wp = packed + (int64_t)i * stride;
+    float4 w1u[H], w1a[H], w1s[H];
+    float w2[H][4];
+    float b1[H];
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      w1u[hh] = ld4(wp + hh * 3 * D + col);
+      w1a[hh] = ld4(wp + hh * 3 * D + D + col);
+      w1s[hh] = ld4(wp + hh * 3 * D + 2 * D + col);
+      b1[hh] = wp[3 * D * H + D * H + D + hh];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) w2[hh][j] = wp[3 * D * H + (col + j) * H + hh];
+    const float4 b2 = ld4(wp + 3 * D * H + D * H + col);
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < C; ++c) add4(u[s], v[s][c]);
+    add_tail(p, u);
+
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float4 sum = make_float4(u[s].x + ad[s].x, u[s].y + ad[s].y, u[s].z + ad[s].z, u[s].w + ad[s].w);
+      float y[H];
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        float pd = dot4(u[s], w1u[hh], 0.f);
+        pd = dot4(ad[s], w1a[hh], pd);
+        pd = dot4(sum, w1s[hh], pd);
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) pd += __shfl_xor(pd, m);
+        y[hh] = fmaxf(pd + b1[hh], 0.f);
+      }
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        o.x = fmaf(y[hh], w2[hh][0], o.x); o.y = fmaf(y[hh], w2[hh][1], o.y);
+        o.z = fmaf(y[hh], w2[hh][2], o.z); o.w = fmaf(y[hh], w2[hh][3], o.w);
+      }
+      add4(o, b2);
+      add4(z[s], relu4(o));
+    }
+  }
+  if (bad) atomicOr(a.err, 1);
+  // partial sums: the lane groups of a wave over the cross-lane network, the waves through LDS
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) add4(z[s], shfl_xor4(z[s], m));
+    if (g == 0) s_z[s][wave][gl] = z[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (wave == s && g == 0 && live[s]) {          // wave s finishes sample s (S <= NW)
+      float4 t = s_z[s][0][gl];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) add4(t, s_z[s][w][gl]);
+      *reinterpret_cast<float4*>(R + (int64_t)ow[s].vrow * ldr + D + col) = t;
+    }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
+struct FusedShape { int S, C; };
+// Waves per workgroup.  FIXED for every launch size: it decides which units a lane group sums, i.e.
+// the association of the fp32 Sum over the units -- a query's bits must not depend on how many
+// queries were coalesced with it.  Measured on the din.json shape (254 tables, 3 lookups, D 32),
+// 2048 samples per launch: 4 waves x 4 samples 49 us, 8 x 2 54 us, 8 x 4 62 us, 4 x 2 52 us,
+// 4 x 1 63 us; one query (256 samples): 4 x 1 16 us, 8 x 1 12 us.
+constexpr int kWaves = 4;
+
+template <int G, int S, int H, int C, int NW>
+void launch_fused_k(const SlsArgs& a, const float* packed, int64_t stride, const float* zero, float* R, int64_t ldr,
+                    unsigned grid, hipStream_t s, hipEvent_t stop) {
+  if (stop) hipExtLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW>), dim3(grid), dim3(64 * NW), 0, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
+  else hipLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW>), dim3(grid), dim3(64 * NW), 0, s, a, packed, stride, zero, R, ldr);
+}
+template <int G, int S, int H>
+void launch_fused_c(const FusedShape& f, const SlsArgs& a, const float* packed, int64_t stride, const float* zero,
+                    float* R, int64_t ldr, unsigned grid, hipStream_t s, hipEvent_t stop) {
+  if (f.C == 3) launch_fused_k<G, S, H, 3, kWaves>(a, packed, stride, zero, R, ldr, grid, s, stop);
+  else launch_fused_k<G, S, H, 4, kWaves>(a, packed, stride, zero, R, ldr, grid, s, stop);
+}
+template <int G, int S>
+void launch_fused_h(const FusedShape& f, const SlsArgs& a, int h, const float* packed, int64_t stride, const float* zero,
+                    float* R, int64_t ldr, unsigned grid, hipStream_t s, hipEvent_t stop) {
+  if (h == 1) launch_fused_c<G, S, 1>(f, a, packed, stride, zero, R, ldr, grid, s, stop);
+  else if (h == 2) launch_fused_c<G, S, 2>(f, a, packed, stride, zero, R, ldr, grid, s, stop);
+  else launch_fused_c<G, S, 4>(f, a, packed, stride, zero, R, ldr, grid, s, stop);
+}
+template <int G>
+void launch_fused_s(const FusedShape& f, const SlsArgs& a, int h, const float* packed, int64_t stride, const float* zero,
+                    float* R, int64_t ldr, unsigned grid, hipStream_t s, hipEvent_t stop) {
+  if (f.S == 4) launch_fused_h<G, 4>(f, a, h, packed, stride, zero, R, ldr, grid, s, stop);
+  else if (f.S == 2) launch_fused_h<G, 2>(f, a, h, packed, stride, zero, R, ldr, grid, s, stop);
+  else launch_fused_h<G, 1>(f, a, h, packed, stride, zero, R, ldr, grid, s, stop);
+}
+
+// Samples per workgroup (the units' weights are read once per workgroup; fewer for small launches
+// so that a single query still fills the chip) and rows per round of a launch.
+FusedShape fused_shape(const SlsArgs& a, const Tune& tune) {
+  FusedShape f;
+  const int64_t n_smp = a.q.cum[a.q.n_q];
+  f.S = tune.din_s > 0 ? tune.din_s : (n_smp >= 1024 ? 4 : n_smp >= 512 ? 2 : 1);
+  f.C = 3;
+  for (int i = 0; i < a.q.n_q; ++i)
+    if (a.uniform_len[i] < 0 || a.uniform_len[i] > 3) f.C = 4;
+  return f;
+}
+
+}  // namespace
+
+hipError_t launch_din_pack(const float* const* att, float* packed, int32_t U, int32_t D, int32_t h, hipStream_t s) {
+  hipLaunchKernelGGL(din_pack_kernel, dim3((unsigned)U), dim3(256), 0, s, att, packed, D, h, din_unit_stride(D, h));
+  return hipGetLastError();
+}
+
+hipError_t launch_din_attention(const float* T, int64_t ldt, int64_t M, int32_t Tn, int32_t D, int32_t h,
+                                const float* packed, float* R, int64_t ldr, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  const size_t lds = sizeof(float) * 4 * (size_t)(Tn - 3) * h;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(din_attention_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, s, T, ldt, M, Tn, D, h,
+                     packed, din_unit_stride(D, h), R, ldr);
+  return hipGetLastError();
+}
+
+// Shapes the fused kernel is instantiated for: D = 32 or 64 (8 / 16 lanes x 16 B per row), hidden
+// width 1, 2 or 4.
+bool din_fused_applicable(int32_t D, int32_t h) { return (D == 32 || D == 64) && (h == 1 || h == 2 || h == 4); }
+int64_t din_fused_grid(const SlsArgs& a, const Tune& tune) {
+  const FusedShape f = fused_shape(a, tune);
+  return (a.q.cum[a.q.n_q] + f.S - 1) / f.S;
+}
+
+hipError_t launch_din_fused(const SlsArgs& a, int32_t h, const float* packed, float* R, int64_t ldr, const Tune& tune,
+                            hipStream_t s, hipEvent_t stop) {
+  const int64_t n_smp = a.q.cum[a.q.n_q];
+  if (n_smp <= 0) return hipSuccess;
+  const int64_t stride = din_unit_stride(a.D, h);
+  const FusedShape f = fused_shape(a, tune);
+  const unsigned grid = (unsigned)din_fused_grid(a, tune);
+  if (a.D == 32) launch_fused_s<8>(f, a, h, packed, stride, tune.zero, R, ldr, grid, s, stop);
+  else launch_fused_s<16>(f, a, h, packed, stride, tune.zero, R, ldr, grid, s, stop);
+  return hipGetLastError();
+}
+
+}  // namespace drs

@@ -62,6 +62,7 @@ struct Tune {
                                  // default -- it makes a query's fp32 summation order depend on how many
                                  // queries were coalesced with it (caught by the race hunt), for 0.2 us
   int sls_depth = 0;             // ... explicit-schedule kernel with this many row loads in flight (0 = compiler's schedule)
+  int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 1, mlp_gemm = 1, gemm_tile = 0, mlp_debug = 0;
 };
 // Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs
@@ -184,11 +185,19 @@ hipError_t launch_copy_rows_multi(const XSrc& xs, int32_t m_den, float* out, int
 hipError_t launch_copy_rows(const float* a, int64_t lda, float* out, int64_t ldo, int64_t M,
                             int32_t D, hipStream_t stream);
 
-// DIN attention (models/din.py:247-285): T [M, Tn*D] pooled rows -> R [M, 4*D] =
-// [ profile | Sum_i relu(W2_i relu(W1_i [u_i, ad, u_i+ad] + b1_i) + b2_i) | ad | context ];
-// att: device array of 4 pointers per unit (W1 [h, 3D], b1 [h], W2 [D, h], b2 [D])
+// DIN (din.hip; models/din.py:247-330).  packed: the attention units' weights, one block of
+// din_unit_stride(D, h) floats per unit, built by launch_din_pack from 4 device pointers per unit
+// (W1 [h, 3D], b1 [h], W2 [D, h], b2 [D]).  launch_din_attention: T [M, Tn*D] pooled rows ->
+// R [M, 4*D] = [ profile | Sum_i unit_i(u_i, ad) | ad | context ], bit-identical to the oracle.
+// launch_din_fused: gather + units + Concat in one launch (a: the gather's arguments; a.out unused).
+int64_t din_unit_stride(int D, int h);
+hipError_t launch_din_pack(const float* const* att, float* packed, int32_t U, int32_t D, int32_t h, hipStream_t stream);
 hipError_t launch_din_attention(const float* T, int64_t ldt, int64_t M, int32_t Tn, int32_t D, int32_t h,
-                                const float* const* att, float* R, int64_t ldr, hipStream_t stream);
+                                const float* packed, float* R, int64_t ldr, hipStream_t stream);
+bool din_fused_applicable(int32_t D, int32_t h);
+int64_t din_fused_grid(const SlsArgs& a, const Tune& tune);
+hipError_t launch_din_fused(const SlsArgs& a, int32_t h, const float* packed, float* R, int64_t ldr,
+                            const Tune& tune, hipStream_t stream, hipEvent_t stop);
 
 hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
                                hipStream_t stream);

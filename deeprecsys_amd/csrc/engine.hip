@@ -150,7 +150,10 @@ struct drs_engine {
   Mlp bot, top, fin;
   std::vector<Mlp> tasks;        // MT-WnD task heads
   std::vector<Mlp> att;          // DIN attention units (one small MLP per behaviour table)
-  const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2), uploaded at first forward
+  const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2) ...
+  float* d_att_packed = nullptr; // ... and the units' weights packed for the DIN kernels (din.hip)
+  bool att_dirty = true;         // a unit's weights changed since the last pack
+  int din_fused = 1;             // gather + attention units + Concat in one launch (default mode)
   float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the
   size_t w_arena_floats = 0;     // MLP kernels' per-CU TLBs then hold every weight page)
   size_t w_arena_used = 0;
@@ -544,11 +547,19 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     if ((rc = mlp_ready(e, tk, "task"))) return rc;
   for (auto& au : e->att)
     if ((rc = mlp_ready(e, au, "attention"))) return rc;
-  if (!e->att.empty() && !e->d_att) {
-    std::vector<const float*> hp;
-    for (auto& au : e->att) { hp.push_back(au.layers[0].W); hp.push_back(au.layers[0].b); hp.push_back(au.layers[1].W); hp.push_back(au.layers[1].b); }
-    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att), sizeof(float*) * hp.size()));
-    HIP_TRY(e, hipMemcpy(e->d_att, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice));
+  if (!e->att.empty() && e->att_dirty) {
+    const int U = (int)e->att.size(), h = e->att[0].ln[1];
+    if (!e->d_att) {
+      std::vector<const float*> hp;
+      for (auto& au : e->att) { hp.push_back(au.layers[0].W); hp.push_back(au.layers[0].b); hp.push_back(au.layers[1].W); hp.push_back(au.layers[1].b); }
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att), sizeof(float*) * hp.size()));
+      HIP_TRY(e, hipMemcpy(e->d_att, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice));
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att_packed), sizeof(float) * (size_t)U * din_unit_stride(e->D, h)));
+    }
+    // (drs_set_fc is synchronous; nothing of this engine is in flight while weights change)
+    HIP_TRY(e, launch_din_pack(e->d_att, e->d_att_packed, U, e->D, h, nullptr));
+    HIP_TRY(e, hipStreamSynchronize(nullptr));
+    e->att_dirty = false;
   }
   // layout of the job: zero-sized queries take no rows
   QTable q;
@@ -611,7 +622,10 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   // ... unless the flat variant takes the launch (fixed-length bags of >= 2 rows: several short
   // bags share a wave and all of its row loads are in flight at once)
   const int exact_now = e->sls_exact || (short_bags && !sls_flat_applicable(a, e->tune));
-  s.ts_blocks = prof ? sls_grid_blocks(a, exact_now, e->tune) : 0;
+  // DIN, default mode: the attention units are fused into the gather launch (din.hip)
+  const bool din_fused = e->kind == DRS_MODEL_DIN && !e->sls_exact && e->din_fused &&
+                         din_fused_applicable(e->D, e->att[0].ln[1]);
+  s.ts_blocks = prof ? (din_fused ? din_fused_grid(a, e->tune) : sls_grid_blocks(a, exact_now, e->tune)) : 0;
   if (prof) {
     // algorithmic bytes of THIS launch (rows + int32 indices + length + pooled output
     // per bag), so that achieved GB/s = sum(bytes) / sum(duration) over exactly the timed launches
@@ -620,12 +634,18 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       for (int t = 0; t < e->T; ++t)
         bytes += (int64_t)qb[i]->h_off[(size_t)t * (e->max_batch + 1) + q.bs[i]] * ((int64_t)e->D * 4 + 4) +
                  (int64_t)q.bs[i] * (4 + (int64_t)e->D * 4);
+    // (the fused DIN launch writes the 4 D floats of the top MLP's input row per sample instead
+    // of T pooled vectors)
+    if (din_fused) bytes -= (int64_t)c * (e->T - 4) * e->D * 4;
     s.ts_bytes = bytes;
   }
   // pipelined mode: the event the MLP stream waits for is recorded by the gather dispatch itself
   // (hipExtLaunchKernel's stop event = the packet's completion signal): no marker packet sits
   // between consecutive gathers (a hipEventRecord there costs ~2 us per set)
-  HIP_TRY(e, launch_sls(a, exact_now, e->tune, gstream, piped ? s.ev_sls : nullptr));
+  if (din_fused)
+    HIP_TRY(e, launch_din_fused(a, e->att[0].ln[1], e->d_att_packed, s.R, e->ldR, e->tune, gstream, piped ? s.ev_sls : nullptr));
+  else
+    HIP_TRY(e, launch_sls(a, exact_now, e->tune, gstream, piped ? s.ev_sls : nullptr));
   if (evts) HIP_TRY(e, hipEventRecord(s.ev[1], gstream));
   bool joined = !piped;   // has s.stream been made to wait for the gather yet?
   auto join = [&]() -> hipError_t {
@@ -654,7 +674,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   if (e->kind == DRS_MODEL_DIN) {
     // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
     HIP_TRY(e, join());
-    HIP_TRY(e, launch_din_attention(s.T, e->ldT, Mv, e->T, e->D, e->att[0].ln[1], e->d_att, s.R, e->ldR, s.stream));
+    if (!din_fused)
+      HIP_TRY(e, launch_din_attention(s.T, e->ldT, Mv, e->T, e->D, e->att[0].ln[1], e->d_att_packed, s.R, e->ldR, s.stream));
     if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
   } else if (e->kind == DRS_MODEL_NCF) {
     // mf = Sum(sls0, sls1); mlp = Concat(sls2, sls3) -> MLP; Concat(mf, mlp_out) -> FC+Relu
@@ -1099,6 +1120,7 @@ int32_t drs_destroy(drs_handle e) {
   e->tasks.clear();
   e->att.clear();
   if (e->d_att) (void)hipFree(e->d_att);
+  if (e->d_att_packed) (void)hipFree(e->d_att_packed);
   if (e->w_arena) (void)hipFree(e->w_arena);
   if (e->tables) (void)hipFree(e->tables);
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
@@ -1135,7 +1157,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (!h_W || !h_b) return fail(e, DRS_ERR_BAD_ARG, "null weights");
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
   if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
-  if (mlp >= DRS_MLP_ATT0 && mlp - DRS_MLP_ATT0 < (int)e->att.size()) M = &e->att[mlp - DRS_MLP_ATT0];
+  if (mlp >= DRS_MLP_ATT0 && mlp - DRS_MLP_ATT0 < (int)e->att.size()) { M = &e->att[mlp - DRS_MLP_ATT0]; e->att_dirty = true; }
   if (!M || layer < 0 || layer >= (int)M->layers.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");
@@ -1524,6 +1546,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_flat") && value >= 0 && value <= 2) e->tune.sls_flat = (int)value;
   else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "sls_split")) e->tune.sls_split = value ? 1 : 0;
+  else if (!strcmp(key, "din_fused")) e->din_fused = value ? 1 : 0;
+  else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
   else if (!strcmp(key, "sls_depth") && (value == 0 || value == 6 || value == 8 || value == 10 || value == 12 || value == 14)) e->tune.sls_depth = (int)value;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
@@ -1602,7 +1626,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
       {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},

@@ -799,59 +799,6 @@ __global__ __launch_bounds__(256) void interact_dot_kernel(const float* __restri
     }
 }
 
-// DIN attention units (models/din.py:247-285).  One wave per sample.  Phase 1: lane l evaluates
-// the first layer of units l, l+64, ... (each unit has its own weights: a k-ordered fmaf chain over
-// Concat(u_i, ad, u_i + ad), bias after, ReLU -- exactly the oracle's FC); phase 2: lane j < D
-// owns output column j and walks the units IN ORDER (the reference's Sum over fc_outs), second
-// layer = chain over the h hidden values, bias, ReLU.  Then the top MLP's input row
-// [profile | atten_out | ad | context] is written.  Tiny next to the gather that feeds it
-// (250 units x 161 weights); not MFMA work: every unit has different weights and K = 96 / N = 1.
-__global__ __launch_bounds__(256) void din_attention_kernel(const float* __restrict__ T, int64_t ldt, int64_t M,
-                                                            int Tn, int D, int h, const float* const* __restrict__ att,
-                                                            float* __restrict__ R, int64_t ldr) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  const int U = Tn - 3;
-  float* sy = smem + (size_t)wave * U * h;          // [U][h] hidden values of this sample
-  if (row >= M) return;                             // whole wave exits together
-  const float* e = T + row * ldt;
-  const float* ad = e + (int64_t)(Tn - 2) * D;
-  for (int i0 = 0; i0 < U; i0 += 64) {
-    const int i = min(i0 + lane, U - 1);
-    const float* u = e + (int64_t)(1 + i) * D;
-    const float* W1 = att[4 * i + 0];
-    const float* b1 = att[4 * i + 1];
-    for (int hh = 0; hh < h; ++hh) {
-      const float* w = W1 + (int64_t)hh * 3 * D;
-      float acc = 0.f;
-      for (int k = 0; k < D; ++k) acc = fmaf(u[k], w[k], acc);
-      for (int k = 0; k < D; ++k) acc = fmaf(ad[k], w[D + k], acc);
-      for (int k = 0; k < D; ++k) acc = fmaf(u[k] + ad[k], w[2 * D + k], acc);
-      const float y = acc + b1[hh];
-      if (i0 + lane < U) sy[i * h + hh] = y > 0.f ? y : 0.f;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  float* out = R + row * ldr;
-  for (int j = lane; j < D; j += 64) {
-    float z = 0.f;
-    for (int i = 0; i < U; ++i) {
-      const float* W2 = att[4 * i + 2];
-      const float* b2 = att[4 * i + 3];
-      float acc = 0.f;
-      for (int hh = 0; hh < h; ++hh) acc = fmaf(sy[i * h + hh], W2[(int64_t)j * h + hh], acc);
-      float o = acc + b2[j];
-      o = o > 0.f ? o : 0.f;
-      z = i == 0 ? o : z + o;
-    }
-    out[D + j] = z;
-    out[j] = e[j];
-    out[2 * D + j] = ad[j];
-    out[3 * D + j] = e[(int64_t)(Tn - 1) * D + j];
-  }
-}
-
 __global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                 int64_t ldb, float* __restrict__ o, int64_t ldo, int64_t M, int D) {
   const int64_t n = M * D;
@@ -1255,16 +1202,6 @@ hipError_t launch_interact_dot(const float* T, int64_t ldt, int64_t B, int32_t F
   if (lds > 160 * 1024) return hipErrorInvalidValue;   // (attribute: mlp_set_attrs, per device)
   hipLaunchKernelGGL(interact_dot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, s, T, ldt,
                      B, F, D, itself, R, ldr);
-  return hipGetLastError();
-}
-
-hipError_t launch_din_attention(const float* T, int64_t ldt, int64_t M, int32_t Tn, int32_t D, int32_t h,
-                                const float* const* att, float* R, int64_t ldr, hipStream_t s) {
-  if (M <= 0) return hipSuccess;
-  const size_t lds = sizeof(float) * 4 * (size_t)(Tn - 3) * h;
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(din_attention_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, s, T, ldt, M, Tn, D, h,
-                     att, R, ldr);
   return hipGetLastError();
 }
 

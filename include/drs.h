@@ -250,6 +250,12 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "sls_split"  0 (default) | 1: launches of <= 4096 fixed-length bags (a single query) split each
  *                bag over two waves (0.2 us faster; a query's fp32 summation order then depends on
  *                the size of the launch it was coalesced into)
+ *   "din_fused"  1 (default) DRS_MODEL_DIN with sls_exact 0, D in {32, 64} and hidden width in
+ *                {1, 2, 4}: ONE launch gathers the bags, applies the attention units and writes the top
+ *                MLP's input row (the [rows, T*D] pooled tensor never exists) | 0 gather launch +
+ *                attention launch (what sls_exact 1 always does; bit-identical to the oracle there)
+ *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
+ *                (results do not depend on it)
  *   "sls_depth"  0 (default: the compiler's schedule of the one-bag-per-wave flat kernel) | 6 | 8 |
  *                10 | 12 | 14: the same kernel with exactly that many row loads in flight per lane
  *   "sls_xcd"    1 (default) | 0: several-bags-per-wave flat kernel walks its work list table-major,

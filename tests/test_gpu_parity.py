@@ -428,6 +428,86 @@ def test_engine_ragged_bags_and_device_error_path():
         net.engine.close()
 
 
+@pytest.mark.parametrize("D,h,U,ragged", [(32, 1, 6, False), (32, 1, 70, True), (64, 2, 9, True), (32, 4, 130, False),
+                                          (16, 1, 5, False), (32, 3, 5, True)])
+def test_din_fused_and_two_launch_forms_match_oracle(D, h, U, ragged):
+    """DIN's default launch fuses gather, attention units and Concat (din.hip); "sls_exact" 1 and
+    "din_fused" 0 take the two-launch form.  Both against the oracle: two-launch + sequential
+    gather bitwise on the top MLP's input row, the fused form within the default-mode tolerance
+    -- over ragged bags (incl. empty ones and samples past a workgroup's last), hidden widths
+    with and without a fused instance (3: falls back), D without one (16), more units than one
+    round of lane groups, and 8 coalesced queries whose samples share workgroups."""
+    rng = np.random.RandomState(D + h + U)
+    rows = [500] + [300] * U + [700, 400]
+    T, B, Lmax = len(rows), 150, 5
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_bot=str(h), arch_mlp_top="24-2", arch_interaction_op="cat",
+                       num_indices_per_lookup=Lmax, num_batches=2, max_mini_batch_size=B,
+                       mini_batch_size=B, numpy_rand_seed=3, model_type="din", accel_slots=2)
+    np.random.seed(3)
+    net = H.M.DIN_Net(args)
+    om = H.oracle_model(net)
+    sets = []
+    for b in range(2):
+        if ragged:
+            lens = [rng.randint(0, Lmax + 1, size=B).astype(np.int32) for _ in range(T)]
+            lens[T - 2][:3] = 0
+            lens[1][5:9] = 0
+        else:
+            lens = [np.full(B, 3, dtype=np.int32) for _ in range(T)]
+        idx = [rng.randint(0, rows[t], size=int(lens[t].sum())).astype(np.int64) for t in range(T)]
+        sets.append((idx, lens))
+    net.create(None, sets[0][1], sets[0][0], None)
+    eng = net.engine
+    try:
+        for b, (idx, lens) in enumerate(sets):
+            eng.stage_batch(b, None, idx, lens)
+        ref = {}
+        fused_instance = D in (32, 64) and h in (1, 2, 4)
+        for mode, opts in (("exact", {"sls_exact": 1}), ("two-launch", {"sls_exact": 0, "din_fused": 0}),
+                           ("fused", {"sls_exact": 0, "din_fused": 1})):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            for b, (idx, lens) in enumerate(sets):
+                for bs in (B, 77, 1):
+                    got = net.run_staged(b, bs)
+                    R = eng.fetch_interaction(bs)
+                    exp, R_exp = om.forward(None, idx, lens, bs=bs, want_R=True)
+                    assert R.shape == (bs, 4 * D)
+                    if mode == "exact":
+                        assert np.array_equal(R, R_exp), (mode, b, bs, np.abs(R - R_exp).max())
+                        assert H.close(got, exp, rtol=1e-6, atol=1e-7)
+                    else:
+                        assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (mode, b, bs, np.abs(R - R_exp).max())
+                        assert H.close(got, exp, rtol=H.RTOL_OUT), (mode, b, bs)
+                    # the pass-through features are pooled in index order by every form: bitwise
+                    for lo in (0, 2 * D, 3 * D):
+                        if mode == "exact" or (mode == "fused" and fused_instance):
+                            assert np.array_equal(R[:, lo:lo + D], R_exp[:, lo:lo + D]), (mode, lo)
+                    ref[(mode, b, bs)] = got
+            # a query's bits do not depend on what it was coalesced with, nor on how many samples
+            # share a workgroup
+            if mode == "fused":
+                for S_ in (1, 2, 4):
+                    eng.set_option("din_s", S_)
+                    assert np.array_equal(net.run_staged(1, B), ref[(mode, 1, B)]), S_
+                eng.set_option("din_s", 0)
+            jobs = [(0, B), (1, 77), (0, 1), (1, B), (0, 77), (1, 1), (0, B), (1, B)]
+            outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+            for (b, bs), o in zip(jobs, outs):
+                assert np.array_equal(o, ref[(mode, b, bs)]), (mode, b, bs)
+        # Caffe2's ENFORCE on an index past the table (checked on the host at hand-over; the
+        # kernels' own flag is the backstop for device-resident inputs)
+        bad = [i.copy() for i in sets[0][0]]
+        bad[2][0] = rows[2]
+        with pytest.raises(N.DrsError) as e:
+            net.run_queued(bad, sets[0][1], None, B)
+        assert e.value.code == N.ERR_INDEX_RANGE
+        assert net.run_staged(0, B).shape == (B, 2)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("kind", ["dlrm_dot", "wnd", "ncf"])
 def test_coalesced_queries_equal_individual_queries(kind):
     """drs_forward_multi_async: several queries in one set of launches return exactly the
@@ -749,7 +829,10 @@ def test_options_are_per_handle_and_engines_coexist():
                                    # MLP-bound models: one MLP stream per slot, GEMM + chain launches of
                                    # consecutive sets overlap each other
                                    ["--workload", "rmc3_ref", "--batch", "128"], ["--workload", "wnd", "--batch", "128"],
-                                   ["--set", "sls_exact=1"]])
+                                   ["--set", "sls_exact=1"],
+                                   # DIN: the fused gather + attention launch, 1..8 queries per set (its
+                                   # samples-per-workgroup shape changes with the set size, its bits must not)
+                                   ["--workload", "din", "--batch", "96"]])
 def test_pipelined_engine_race_hunt(extra):
     import os
     import subprocess

@@ -1,12 +1,14 @@
 #!/bin/bash
-# scratch: DIN first light on the GPU
+# scratch: full GPU suite + DIN bench + DIN characterisation
 mkdir -p gpurun_out/din
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "din" > gpurun_out/din/tests.log 2>&1
-echo "tests rc=$?" >> gpurun_out/din/tests.log
-timeout 600 python bench.py --workload din --steps 6 --warmup 2 --queries_per_step 2048 --cpu_seconds 6 > gpurun_out/din/bench.json 2> gpurun_out/din/bench.err
-echo "bench rc=$?" >> gpurun_out/din/bench.err
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/din/prof -o din -- python /root/repo/bench.py --workload din --steps 4 --warmup 2 --queries_per_step 2048 --timed_only > /root/repo/gpurun_out/din/prof.log 2>&1
-cd /root/repo
-f=$(ls gpurun_out/din/prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -12 "$f" > gpurun_out/din/kernel_stats_head.csv
-tail -5 gpurun_out/din/tests.log; cat gpurun_out/din/bench.json; tail -3 gpurun_out/din/bench.err; cat gpurun_out/din/kernel_stats_head.csv
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/din/tests_all.log 2>&1
+echo "tests rc=$?" >> gpurun_out/din/tests_all.log
+tail -6 gpurun_out/din/tests_all.log
+timeout 600 python bench.py --workload din > gpurun_out/din/bench_din.json 2> gpurun_out/din/bench_din.err
+python - <<PY
+import json
+d=json.load(open("gpurun_out/din/bench_din.json"))
+r=d["roofline"]
+print("din", d["value"], "q/s p99", d["latency_ms"]["p99"], "gather us", r["avg_launch_us"], "frac", r["frac"], "single", r["single_query_launch"], "host", d["host_inputs_leg"]["value"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["legs"]["oracle_port"]["value"])
+PY
+timeout 600 python tools/characterize.py --model din --out gpurun_out/accelerator_mi355x/ > gpurun_out/din/char.log 2>&1; tail -8 gpurun_out/din/char.log
