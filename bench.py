@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 HOST_LEG_CALLS = 6         # per-call host-input leg: calls in flight (one per slot)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SLA_MS = 25.0              # run_DeepRecSys.sh:42 target_latency
-NO_DENSE = ("ncf", "din")  # model kinds whose query has no dense input
+NO_DENSE = ("ncf", "din", "dien")  # model kinds whose query has no dense input
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -68,6 +68,10 @@ WORKLOADS = {
     # one attention unit 96-1-32 per behaviour table, top 128-200-80-2 (5.9 GB of tables)
     "din": dict(kind="din", rows=[1_000_000] + [100_000] * 251 + [10_000_000] * 2, T=254, D=32, L=3, bot="1",
                 top="200-80-2", op="cat"),
+    # the reference's models/configs/dien.json: 43 tables (41 x 500k, 2 x 5M) x 32, one lookup; 40
+    # behaviour tables -> two BasicRNN layers 32 -> 64 -> 64 (--hidden_size default), top 160-200-80-2
+    "dien": dict(kind="dien", rows=[500_000] * 41 + [5_000_000] * 2, T=43, D=32, L=1, bot="512", top="200-80-2",
+                 hidden=64, op="cat"),
     # CPU-test size (tests/test_harness.py drives the rank entry through the CPU restatement of the ABI)
     "tiny": dict(rows=1000, T=4, D=16, L=4, bot="16-16", top="32-1", op="cat"),
 }
@@ -131,7 +135,7 @@ def make_model(opt, device):
     np.random.seed(opt.seed)
     args.arch_mlp_tasks, args.num_multi_tasks = w.get("tasks", "4-2-1"), w.get("num_tasks", 1)
     net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep,
-           "din": M.DIN_Net}[kind](args)
+           "din": M.DIN_Net, "dien": M.DIEN_Net}[kind](args)
     m_den = int(w["bot"].split("-")[0])
     nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
     net.create(lX[0], lS_l[0], lS_i[0], None)
@@ -271,6 +275,8 @@ def torch_cpu_leg(opt):
         ln_top = [T * D + ln_bot[0]] + top
     elif kind == "din":
         ln_top = [4 * D] + top
+    elif kind == "dien":
+        ln_top = [w["hidden"] + 3 * D] + top
     else:
         ln_top = top[:-1]            # NCF: MLP branch widths, predictor = last entry
 
@@ -281,6 +287,7 @@ def torch_cpu_leg(opt):
     top_w = mk(ln_top)
     fin_w = mk([D + ln_top[-1], top[-1]]) if kind == "ncf" else []
     att_w = [mk([3 * D] + ln_bot + [D]) for _ in range(T - 3)] if kind == "din" else []
+    rnn_w = [mk([din, w["hidden"]]) + mk([w["hidden"], w["hidden"]]) for din in (D, w["hidden"])] if kind == "dien" else []
     task_w = [mk([int(x) for x in w["tasks"].split("-")]) for _ in range(w.get("num_tasks", 1))] if kind == "mtwnd" else []
     nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, bs, ln_bot[0], rows, L, opt.seed)
     sets = []
@@ -303,6 +310,17 @@ def torch_cpu_leg(opt):
             mf = emb[0] + emb[1]
             z = mlp(torch.cat([emb[2], emb[3]], 1), top_w)
             return mlp(torch.cat([mf, z], 1), fin_w)
+        if kind == "dien":
+            U = T - 3
+            X = torch.stack(emb[1:T - 2], 1).reshape(U, -1, D)     # the reference's Reshape (dien.py:316-320)
+            h0 = torch.zeros(X.shape[1], w["hidden"])
+            h1 = torch.zeros(X.shape[1], w["hidden"])
+            (wi0, bi0), (wg0, bg0) = rnn_w[0]
+            (wi1, bi1), (wg1, bg1) = rnn_w[1]
+            for t in range(U):
+                h0 = torch.tanh(torch.addmm(bg0, h0, wg0.t()) + torch.addmm(bi0, X[t], wi0.t()))
+                h1 = torch.tanh(torch.addmm(bg1, h1, wg1.t()) + torch.addmm(bi1, h0, wi1.t()))
+            return mlp(torch.cat([h1, emb[0], emb[T - 2], emb[T - 1]], 1), top_w)
         if kind == "din":
             ad = emb[T - 2]
             z = None

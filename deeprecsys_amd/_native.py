@@ -15,12 +15,13 @@ LIB_PATH = os.environ.get("DRS_HIP_LIB") or os.path.join(_HERE, "libdrs_hip.so")
 # status codes (include/drs.h)
 OK, ERR_BAD_ARG, ERR_OOM, ERR_HIP, ERR_INDEX_RANGE, ERR_LENGTHS_SUM, ERR_STATE, ERR_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7
-MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND, MODEL_DIN = 0, 1, 2, 3, 4
+MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND, MODEL_DIN, MODEL_DIEN = 0, 1, 2, 3, 4, 5
 INTERACT_DOT, INTERACT_CAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 MLP_BOT, MLP_TOP, MLP_FINAL = 0, 1, 2
 MLP_TASK0 = 16     # + k: task head k (MT-WnD)
 MLP_ATT0 = 1024    # + i: attention unit i (DIN)
+MLP_RNN0, MLP_RNN1 = 32, 33   # the two BasicRNN layers (DIEN): layer 0 = i2h, layer 1 = gates_t
 KERNEL_SLS, KERNEL_MLP, KERNEL_SLS_CLOCK = 0, 1, 2
 
 _f32p = C.POINTER(C.c_float)

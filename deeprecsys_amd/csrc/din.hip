@@ -428,6 +428,356 @@ FusedShape fused_shape(const SlsArgs& a, const Tune& tune) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// DIEN (models/dien.py:308-432): two caffe2 rnn_cell.BasicRNN layers over the behaviour
+// embeddings of a query.  One wave per sample, lane j = hidden unit j (H <= 64): the lane keeps
+// row j of the four weight matrices in registers for all U steps (D + 3 H values), the step's
+// input and the two states are broadcast through 3 x 64 floats of LDS per wave (ds_read_b128 of one
+// address for all lanes; no VALU cross-lane traffic), every product-sum is the oracle's k-ordered
+// fmaf chain with the bias added after it, and the next step's input row is fetched while the
+// current step computes.  VALU work: the recurrence is U = 40 dependent steps of 64-wide
+// mat-vecs per sample -- an MFMA form would tile 16 samples x 16 hidden units per wave and
+// exchange states through LDS with a barrier per step; at 1.1 MFLOP per sample the VALU form
+// already runs a launch set in tens of microseconds, next to ~10 us of gather.
+// Packed weights (dien_pack_kernel), transposed so that lane j's loads coalesce:
+//   [ i2h_0^T : D x H | gates_0^T : H x H | i2h_1^T : H x H | gates_1^T : H x H | 4 biases : 4 x H ]
+namespace {
+
+__global__ __launch_bounds__(256) void dien_pack_kernel(const float* const* __restrict__ w, float* __restrict__ packed,
+                                                        int D, int H) {
+  // w: {i2h_w, i2h_b, gates_w, gates_b} of layer 1, then of layer 2 (row-major [out, in])
+  const int K[4] = {D, H, H, H};
+  const int src[4] = {0, 2, 4, 6};
+  int64_t off = 0;
+  for (int m = 0; m < 4; ++m) {
+    const float* W = w[src[m]];
+    for (int i = threadIdx.x; i < K[m] * H; i += blockDim.x) {
+      const int k = i / H, j = i - k * H;
+      packed[off + i] = W[(int64_t)j * K[m] + k];
+    }
+    off += (int64_t)K[m] * H;
+  }
+  const int bsrc[4] = {1, 3, 5, 7};
+  for (int m = 0; m < 4; ++m)
+    for (int j = threadIdx.x; j < H; j += blockDim.x) packed[off + (int64_t)m * H + j] = w[bsrc[m]][j];
+}
+
+// tanh for the recurrence: 8 values per lane and step in the matrix-core form, where the library
+// tanhf (two divergent paths, ~50 instructions) cost more than the MFMAs.  |x| < 0.25: the odd
+// Taylor polynomial through x^9 (next term < 2e-9 relative); else 1 - 2 / (e^{2|x|} + 1) on
+// v_exp_f32 / v_rcp_f32.  Within ~8 ulp of libm's tanhf (worst near |x| = 0.25); both DIEN kernels
+// use it, so they agree bitwise with each other and with the oracle to the tolerance in
+// tests/test_gpu_parity.py.
+__device__ __forceinline__ float tanh_rnn(float x) {
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);          // e^{2|x|}
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float x2 = ax * ax;
+  float p = fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);        // 62/2835, -17/315
+  p = fmaf(x2, p, 0.13333333333333333f);                                    // 2/15
+  p = fmaf(x2, p, -0.33333333333333331f);
+  p = fmaf(x2, p, 1.0f) * ax;
+  return copysignf(ax < 0.25f ? p : big, x);
+}
+
+template <int K>
+__device__ __forceinline__ float chain_lds(const float* __restrict__ sv, const float (&w)[K]) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k4 = 0; k4 < K / 4; ++k4) {
+    const float4 v = *reinterpret_cast<const float4*>(sv + 4 * k4);
+    acc = fmaf(v.x, w[4 * k4 + 0], acc); acc = fmaf(v.y, w[4 * k4 + 1], acc);
+    acc = fmaf(v.z, w[4 * k4 + 2], acc); acc = fmaf(v.w, w[4 * k4 + 3], acc);
+  }
+  return acc;
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void dien_rnn_kernel(const float* __restrict__ T, int64_t ldt, QTable q, int Tn,
+                                                       const float* __restrict__ packed, float* __restrict__ R,
+                                                       int64_t ldr) {
+  static_assert(D % 4 == 0 && H % 4 == 0 && D <= 64 && H <= 64, "lane j = hidden unit j");
+  __shared__ __attribute__((aligned(16))) float sx[4][64], sh0[4][64], sh1[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int smp = blockIdx.x * 4 + wave;
+  if (smp >= q.cum[q.n_q]) return;                       // (no workgroup barrier below)
+  int b = smp, bs = q.bs[0], v0 = q.vstart[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < q.n_q && smp >= q.cum[i];
+    b = in ? smp - q.cum[i] : b;
+    bs = in ? q.bs[i] : bs;
+    v0 = in ? q.vstart[i] : v0;
+  }
+  const int U = Tn - 3;
+  const int j = min(lane, H - 1);
+  float wi0[D], wg0[H], wi1[H], wg1[H];
+  const float* p = packed;
+#pragma unroll
+  for (int k = 0; k < D; ++k) wi0[k] = p[k * H + j];
+  p += D * H;
+#pragma unroll
+  for (int k = 0; k < H; ++k) wg0[k] = p[k * H + j];
+  p += H * H;
+#pragma unroll
+  for (int k = 0; k < H; ++k) wi1[k] = p[k * H + j];
+  p += H * H;
+#pragma unroll
+  for (int k = 0; k < H; ++k) wg1[k] = p[k * H + j];
+  p += H * H;
+  const float bi0 = p[j], bg0 = p[H + j], bi1 = p[2 * H + j], bg1 = p[3 * H + j];
+
+  // step t of "sample" b reads embedding n % U of sample n / U, n = t * bs + b (the reference's
+  // Reshape of [bs, U*D] to [U, bs, D], models/dien.py:316-320)
+  auto x_of = [&](int t) {
+    const int n = t * bs + b;
+    const int src = n / U, unit = n - src * U;
+    return T[(int64_t)(v0 + src) * ldt + (int64_t)(1 + unit) * D + min(lane, D - 1)];
+  };
+  float* mx = sx[wave];
+  float* m0 = sh0[wave];
+  float* m1 = sh1[wave];
+  m0[lane] = 0.f;                                        // initial_h = 0 (:498-499)
+  m1[lane] = 0.f;
+  float xv = x_of(0), h1 = 0.f;
+  // every weight load has landed before the loop: inside it only the input prefetch is in flight,
+  // and nothing waits for it before the next step's LDS write (with the weights still pending at
+  // the loop header the waitcnt pass put a vmcnt(0) right behind the prefetch: 3 800 cycles a step)
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int t = 0; t < U; ++t) {
+    mx[lane] = xv;
+    __builtin_amdgcn_wave_barrier();
+    xv = x_of(min(t + 1, U - 1));                       // (unconditional: one more read of the last row)
+    // layer 1: Tanh(Sum(FC(h_prev, gates_t), FC(x_t, i2h)))
+    const float a0 = chain_lds<D>(mx, wi0) + bi0;
+    const float g0 = chain_lds<H>(m0, wg0) + bg0;
+    const float h0 = tanh_rnn(g0 + a0);
+    __builtin_amdgcn_wave_barrier();
+    m0[lane] = h0;
+    __builtin_amdgcn_wave_barrier();
+    // layer 2 on layer 1's new state
+    const float a1 = chain_lds<H>(m0, wi1) + bi1;
+    const float g1 = chain_lds<H>(m1, wg1) + bg1;
+    h1 = tanh_rnn(g1 + a1);
+    __builtin_amdgcn_wave_barrier();
+    m1[lane] = h1;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // top MLP input row: [ last state | user profile | candidate ad | context ] (:411-421)
+  float* out = R + (int64_t)(v0 + b) * ldr;
+  const float* e = T + (int64_t)(v0 + b) * ldt;
+  if (lane < H) out[lane] = h1;
+  if (lane < D) {
+    out[H + lane] = e[lane];
+    out[H + D + lane] = e[(int64_t)(Tn - 2) * D + lane];
+    out[H + 2 * D + lane] = e[(int64_t)(Tn - 1) * D + lane];
+  }
+}
+
+// The MFMA form (H a multiple of 16).  A workgroup of H / 16 waves serves 16 samples; wave w owns
+// hidden units [16 w, 16 w + 16) of BOTH layers.  Per step and layer the pre-activations are two
+// v_mfma_f32_16x16x4_f32 chains (bit-for-bit k-ordered fp32 fma chains, as in mlp.hip): A = the
+// wave's 16 weight rows (registers for the whole launch: (D + 3 H) / 4 VGPRs), B = the step's input
+// [k][sample] -- the embeddings straight from the gather's buffer (fetched a step ahead), the
+// states from LDS ([hidden][sample], double-buffered so ONE workgroup barrier per step orders
+// everything) -- D[m = hidden 4 g + q][n = sample r].  Same bits as dien_rnn_kernel.
+// Cost: (D + 3 H) / 4 = 56 MFMAs of 32 cycles per wave and step at D 32 / H 64, 16 samples at a
+// time, against 2 x 112 dependent VALU fmas per SAMPLE in the one-wave-per-sample form.
+// Measured on dien.json's shape (40 steps, 2048 samples per launch = 128 workgroups): 76 us per
+// launch against 112 us; per step 1.9 us = 0.8 MFMA + 0.2 tanh + 0.2 barrier + 0.7 LDS / issue
+// latency that one wave per SIMD cannot hide -- the engine therefore lets the launches of
+// consecutive sets overlap on separate streams (each covers half the chip): 51 k -> 130 k queries/s.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+struct DienW { const float* w[8]; };   // {i2h_w, i2h_b, gates_t_w, gates_t_b} x 2 layers, row-major [out, in]
+
+template <int D, int H>
+__global__ __launch_bounds__(64 * (H / 16)) void dien_rnn_mfma_kernel(const float* __restrict__ T, int64_t ldt, QTable q,
+                                                                      int Tn, DienW W, float* __restrict__ R, int64_t ldr) {
+  static_assert(D % 4 == 0 && H % 16 == 0 && H <= 64, "16 hidden units per wave");
+  constexpr int NW = H / 16;
+  __shared__ float s0[2][H][16], s1[2][H][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n_smp = q.cum[q.n_q];
+  const int smp = min((int)blockIdx.x * 16 + r, n_smp - 1);
+  const bool live = (int)blockIdx.x * 16 + r < n_smp;
+  int b = smp, bs = q.bs[0], v0 = q.vstart[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < q.n_q && smp >= q.cum[i];
+    b = in ? smp - q.cum[i] : b;
+    bs = in ? q.bs[i] : bs;
+    v0 = in ? q.vstart[i] : v0;
+  }
+  const int U = Tn - 3;
+  // A operands: lane (r, g) holds W[16 w + r][4 s + g] of every MFMA step s
+  const int row = 16 * wave + r;
+  float wi0[D / 4], wg0[H / 4], wi1[H / 4], wg1[H / 4];
+#pragma unroll
+  for (int s = 0; s < D / 4; ++s) wi0[s] = W.w[0][row * D + 4 * s + g];
+#pragma unroll
+  for (int s = 0; s < H / 4; ++s) {
+    wg0[s] = W.w[2][row * H + 4 * s + g];
+    wi1[s] = W.w[4][row * H + 4 * s + g];
+    wg1[s] = W.w[6][row * H + 4 * s + g];
+  }
+  // biases of the 4 output rows this lane holds: hidden 16 w + 4 g + qd
+  float bi0[4], bg0[4], bi1[4], bg1[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int hid = 16 * wave + 4 * g + qd;
+    bi0[qd] = W.w[1][hid]; bg0[qd] = W.w[3][hid]; bi1[qd] = W.w[5][hid]; bg1[qd] = W.w[7][hid];
+  }
+  for (int i = threadIdx.x; i < 2 * H * 16; i += 64 * NW) {   // initial_h = 0 (models/dien.py:498-499)
+    (&s0[0][0][0])[i] = 0.f;
+    (&s1[0][0][0])[i] = 0.f;
+  }
+  // B operand of the input product: x_t[sample r][k = 4 s + g]; step t of "sample" b is embedding
+  // n % U of sample n / U, n = t * bs + b (the reference's Reshape, models/dien.py:316-320).
+  // Fetched NB steps ahead into a register ring: a step lasts ~1 us, a load from the gather's
+  // buffer (L2 / MALL / HBM) about as long -- one step of distance left the MFMAs waiting for it.
+  constexpr int NB = 4;
+  float xr[NB][D / 4];
+  auto fetch_x = [&](int t, float (&xb)[D / 4]) {
+    const int tt = min(t, U - 1);
+    const int n = tt * bs + b;
+    const int src = n / U, unit = n - src * U;
+    const float* x = T + (int64_t)(v0 + src) * ldt + (int64_t)(1 + unit) * D + g;
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s) xb[s] = x[4 * s];
+  };
+#pragma unroll
+  for (int j = 0; j < NB; ++j) fetch_x(j, xr[j]);              // slot j % NB holds x_j
+  __syncthreads();
+  // Layer 2 runs one step behind layer 1: an iteration holds layer 2 of step t and layer 1 of step
+  // t + 1, which do not depend on each other -- the tanh (VALU) of one overlaps the MFMA chains of the
+  // other, and ONE barrier per iteration orders the double-buffered state exchange.
+  //   s0[t & 1] = layer-1 state after step t,  s1[t & 1] = layer-2 state after step t
+  f32x4_ h1v = {0.f, 0.f, 0.f, 0.f};
+  {
+    // step 0 of layer 1: its previous state is the zero buffer s0[1]
+    f32x4_ aa = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wi0[s], xr[0][s], aa, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wg0[s], s0[1][4 * s + g][r], ag, 0, 0, 0);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      s0[0][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bg0[qd]) + (aa[qd] + bi0[qd]));
+    fetch_x(NB, xr[0]);
+    __syncthreads();
+  }
+  for (int t0 = 0; t0 < U; t0 += NB) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = t0 + j;
+      if (t >= U) break;                                 // (uniform)
+      const int cur = t & 1, prv = cur ^ 1;
+      float (&xb)[D / 4] = xr[(j + 1) % NB];             // x_{t+1}: t0 is a multiple of NB
+      // layer 2, step t: input = layer-1 state of step t (s0[cur]), previous own state s1[prv];
+      // layer 1, step t + 1: input x_{t+1}, previous state s0[cur]; writes s0[prv].
+      // The four chains are issued round-robin (independent MFMAs back to back).  After the last
+      // step layer 1 computes one step too many into the unused buffer: cheaper than a divergent tail.
+      f32x4_ ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+      f32x4_ aa = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < H / 4; ++s) {
+        const float h0k = s0[cur][4 * s + g][r];
+        ba = __builtin_amdgcn_mfma_f32_16x16x4f32(wi1[s], h0k, ba, 0, 0, 0);
+        bg = __builtin_amdgcn_mfma_f32_16x16x4f32(wg1[s], s1[prv][4 * s + g][r], bg, 0, 0, 0);
+        ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wg0[s], h0k, ag, 0, 0, 0);
+        if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wi0[s], xb[s], aa, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wi0[s], xb[s], aa, 0, 0, 0);
+      fetch_x(t + 1 + NB, xb);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        h1v[qd] = tanh_rnn((bg[qd] + bg1[qd]) + (ba[qd] + bi1[qd]));
+        s1[cur][16 * wave + 4 * g + qd][r] = h1v[qd];
+        s0[prv][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bg0[qd]) + (aa[qd] + bi0[qd]));
+      }
+      __syncthreads();
+    }
+  }
+  // top MLP input rows: [ last state | user profile | candidate ad | context ] (:411-421)
+  if (live) {
+    float* out = R + (int64_t)(v0 + b) * ldr;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) out[16 * wave + 4 * g + qd] = h1v[qd];
+  }
+  for (int i = threadIdx.x; i < 16 * 3 * D; i += 64 * NW) {
+    const int smp_i = (int)blockIdx.x * 16 + i / (3 * D), c = i % (3 * D);
+    if (smp_i >= n_smp) break;
+    int bi = smp_i, vi = q.vstart[0];
+#pragma unroll
+    for (int k = 1; k < DRS_MAX_COALESCE; ++k) {
+      const bool in = k < q.n_q && smp_i >= q.cum[k];
+      bi = in ? smp_i - q.cum[k] : bi;
+      vi = in ? q.vstart[k] : vi;
+    }
+    const int tab = c < D ? 0 : c < 2 * D ? Tn - 2 : Tn - 1;
+    R[(int64_t)(vi + bi) * ldr + H + c] = T[(int64_t)(vi + bi) * ldt + (int64_t)tab * D + c % D];
+  }
+}
+
+template <int D>
+bool launch_dien_mfma_h(const float* T, int64_t ldt, const QTable& q, int Tn, int H, const DienW& W, float* R,
+                        int64_t ldr, unsigned grid, hipStream_t s) {
+  switch (H) {
+    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16>), dim3(grid), dim3(64), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    default: return false;
+  }
+}
+
+template <int D>
+bool launch_dien_h(const float* T, int64_t ldt, const QTable& q, int Tn, int H, const float* packed, float* R,
+                   int64_t ldr, unsigned grid, hipStream_t s) {
+  switch (H) {
+    case 8: hipLaunchKernelGGL((dien_rnn_kernel<D, 8>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, packed, R, ldr); return true;
+    case 16: hipLaunchKernelGGL((dien_rnn_kernel<D, 16>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, packed, R, ldr); return true;
+    case 32: hipLaunchKernelGGL((dien_rnn_kernel<D, 32>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, packed, R, ldr); return true;
+    case 64: hipLaunchKernelGGL((dien_rnn_kernel<D, 64>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, packed, R, ldr); return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+// Shapes the recurrent kernel is instantiated for.
+bool dien_applicable(int32_t D, int32_t H) { return (D == 16 || D == 32 || D == 64) && (H == 8 || H == 16 || H == 32 || H == 64); }
+int64_t dien_packed_floats(int32_t D, int32_t H) { return (int64_t)D * H + 3ll * H * H + 4ll * H; }
+
+hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int32_t H, hipStream_t s) {
+  hipLaunchKernelGGL(dien_pack_kernel, dim3(1), dim3(256), 0, s, w, packed, D, H);
+  return hipGetLastError();
+}
+
+hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t Tn, int32_t D, int32_t H,
+                           const float* packed, const float* const* w, int mfma, float* R, int64_t ldr,
+                           hipStream_t s) {
+  const int64_t n = q.cum[q.n_q];
+  if (n <= 0) return hipSuccess;
+  bool ok = false;
+  if (mfma && H % 16 == 0) {
+    DienW W;
+    for (int i = 0; i < 8; ++i) W.w[i] = w[i];
+    const unsigned g16 = (unsigned)((n + 15) / 16);
+    if (D == 16) ok = launch_dien_mfma_h<16>(T, ldt, q, Tn, H, W, R, ldr, g16, s);
+    else if (D == 32) ok = launch_dien_mfma_h<32>(T, ldt, q, Tn, H, W, R, ldr, g16, s);
+    else if (D == 64) ok = launch_dien_mfma_h<64>(T, ldt, q, Tn, H, W, R, ldr, g16, s);
+    return ok ? hipGetLastError() : hipErrorInvalidValue;
+  }
+  const unsigned grid = (unsigned)((n + 3) / 4);
+  if (D == 16) ok = launch_dien_h<16>(T, ldt, q, Tn, H, packed, R, ldr, grid, s);
+  else if (D == 32) ok = launch_dien_h<32>(T, ldt, q, Tn, H, packed, R, ldr, grid, s);
+  else if (D == 64) ok = launch_dien_h<64>(T, ldt, q, Tn, H, packed, R, ldr, grid, s);
+  if (!ok) return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_din_pack(const float* const* att, float* packed, int32_t U, int32_t D, int32_t h, hipStream_t s) {
   hipLaunchKernelGGL(din_pack_kernel, dim3((unsigned)U), dim3(256), 0, s, att, packed, D, h, din_unit_stride(D, h));
   return hipGetLastError();

@@ -199,6 +199,18 @@ int64_t din_fused_grid(const SlsArgs& a, const Tune& tune);
 hipError_t launch_din_fused(const SlsArgs& a, int32_t h, const float* packed, float* R, int64_t ldr,
                             const Tune& tune, hipStream_t stream, hipEvent_t stop);
 
+// DIEN (din.hip; models/dien.py:308-432).  w: 8 device pointers {i2h_w, i2h_b, gates_t_w, gates_t_b} of
+// layer 1 then layer 2; launch_dien_rnn: T [rows, Tn*D] pooled rows of the coalesced queries q ->
+// R [rows, H + 3*D] = [ last state of layer 2 | profile | ad | context ].
+bool dien_applicable(int32_t D, int32_t H);
+int64_t dien_packed_floats(int32_t D, int32_t H);
+hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int32_t H, hipStream_t stream);
+// (mfma: the 16-samples-per-workgroup matrix-core form when H % 16 == 0, reading the row-major
+// weights w[8] (host array of device pointers); else one wave per sample on `packed`; same bits)
+hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t Tn, int32_t D, int32_t H,
+                           const float* packed, const float* const* w, int mfma, float* R, int64_t ldr,
+                           hipStream_t stream);
+
 hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
                                hipStream_t stream);
 

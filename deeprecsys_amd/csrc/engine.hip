@@ -153,7 +153,9 @@ struct drs_engine {
   const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2) ...
   float* d_att_packed = nullptr; // ... and the units' weights packed for the DIN kernels (din.hip)
   bool att_dirty = true;         // a unit's weights changed since the last pack
+  int dien_mfma = 1;             // DIEN recurrence on the matrix cores (16 samples per workgroup) | 0 one wave per sample
   int din_fused = 1;             // gather + attention units + Concat in one launch (default mode)
+  std::vector<Mlp> rnn;          // DIEN: the two BasicRNN layers, each {i2h, gates_t}; packed into d_att_packed
   float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the
   size_t w_arena_floats = 0;     // MLP kernels' per-CU TLBs then hold every weight page)
   size_t w_arena_used = 0;
@@ -547,6 +549,21 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     if ((rc = mlp_ready(e, tk, "task"))) return rc;
   for (auto& au : e->att)
     if ((rc = mlp_ready(e, au, "attention"))) return rc;
+  for (auto& rn : e->rnn)
+    if ((rc = mlp_ready(e, rn, "rnn"))) return rc;
+  if (!e->rnn.empty() && e->att_dirty) {
+    const int H = e->rnn[0].ln[1];
+    if (!e->d_att) {
+      std::vector<const float*> hp;
+      for (auto& rn : e->rnn) { hp.push_back(rn.layers[0].W); hp.push_back(rn.layers[0].b); hp.push_back(rn.layers[1].W); hp.push_back(rn.layers[1].b); }
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att), sizeof(float*) * hp.size()));
+      HIP_TRY(e, hipMemcpy(e->d_att, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice));
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att_packed), sizeof(float) * (size_t)dien_packed_floats(e->D, H)));
+    }
+    HIP_TRY(e, launch_dien_pack(e->d_att, e->d_att_packed, e->D, H, nullptr));
+    HIP_TRY(e, hipStreamSynchronize(nullptr));
+    e->att_dirty = false;
+  }
   if (!e->att.empty() && e->att_dirty) {
     const int U = (int)e->att.size(), h = e->att[0].ln[1];
     if (!e->d_att) {
@@ -671,7 +688,18 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   memset(&xs, 0, sizeof xs);
   xs.q = q;
   for (int i = 0; i < q.n_q; ++i) xs.x[i] = qb[i]->dense;
-  if (e->kind == DRS_MODEL_DIN) {
+  if (e->kind == DRS_MODEL_DIEN) {
+    // the two recurrent layers over the pooled behaviour rows -> top MLP input R [rows, H + 3D]
+    HIP_TRY(e, join());
+    const float* rw[8];
+    for (int l = 0; l < 2; ++l) {
+      rw[4 * l + 0] = e->rnn[l].layers[0].W; rw[4 * l + 1] = e->rnn[l].layers[0].b;
+      rw[4 * l + 2] = e->rnn[l].layers[1].W; rw[4 * l + 3] = e->rnn[l].layers[1].b;
+    }
+    HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, e->rnn[0].ln[1], e->d_att_packed, rw, e->dien_mfma, s.R,
+                               e->ldR, s.stream));
+    if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
+  } else if (e->kind == DRS_MODEL_DIN) {
     // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
     HIP_TRY(e, join());
     if (!din_fused)
@@ -943,6 +971,23 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       e->n_out = e->top.ln.back();
       break;
     }
+    case DRS_MODEL_DIEN: {
+      if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIEN needs at least 4 embedding tables");
+      if (cfg->n_bot != 2 || e->bot.ln[0] != D || !dien_applicable(D, e->bot.ln[1]))
+        return bail(DRS_ERR_UNSUPPORTED, "DIEN: ln_bot must be [D, hidden_size], D in {16, 32, 64}, hidden_size in {8, 16, 32, 64}");
+      const int H = e->bot.ln[1];
+      e->m_den = 0; e->w0 = 0;
+      e->num_int = H + 3 * D;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
+      e->rnn.resize(2);
+      e->rnn[0].ln = {D, H, H};
+      e->rnn[1].ln = {H, H, H};
+      for (auto& rn : e->rnn) { rn.layers.resize(2); rn.sigmoid_layer = -1; }
+      e->bot.ln = {0}; e->bot.layers.clear();
+      e->top.sigmoid_layer = -1;
+      e->n_out = e->top.ln.back();
+      break;
+    }
     case DRS_MODEL_NCF: {
       if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
       if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
@@ -1078,6 +1123,9 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     double flop = 0;
     for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
       for (size_t i = 0; i + 1 < mm->ln.size(); ++i) flop += 2.0 * mm->ln[i] * (mm->ln[i + 1] > 0 ? mm->ln[i + 1] : 64);
+    // (DIEN: the recurrence, (T - 3) steps of two layers -- 1.1 MFLOP per sample at 40 x 32 -> 64 -> 64,
+    // and its 16-sample workgroups cover half the chip for a full launch set)
+    for (const Mlp& rn : e->rnn) flop += 2.0 * (T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
     const double bytes = (double)T * e->max_lookups * D * 4.0;
     e->mlp_streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
   }
@@ -1119,6 +1167,7 @@ int32_t drs_destroy(drs_handle e) {
     for (auto& l : m->layers) { l.W = l.b = nullptr; }
   e->tasks.clear();
   e->att.clear();
+  e->rnn.clear();
   if (e->d_att) (void)hipFree(e->d_att);
   if (e->d_att_packed) (void)hipFree(e->d_att_packed);
   if (e->w_arena) (void)hipFree(e->w_arena);
@@ -1158,6 +1207,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
   if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
   if (mlp >= DRS_MLP_ATT0 && mlp - DRS_MLP_ATT0 < (int)e->att.size()) { M = &e->att[mlp - DRS_MLP_ATT0]; e->att_dirty = true; }
+  if ((mlp == DRS_MLP_RNN0 || mlp == DRS_MLP_RNN1) && e->rnn.size() == 2) { M = &e->rnn[mlp - DRS_MLP_RNN0]; e->att_dirty = true; }
   if (!M || layer < 0 || layer >= (int)M->layers.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");
@@ -1176,6 +1226,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
       std::vector<Mlp*> all = {&e->bot, &e->top, &e->fin};
       for (auto& tk : e->tasks) all.push_back(&tk);
       for (auto& au : e->att) all.push_back(&au);
+      for (auto& rn : e->rnn) all.push_back(&rn);
       for (Mlp* mm : all)
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
           const size_t out = mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024;
@@ -1439,7 +1490,7 @@ int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R
   const float* src;
   int64_t ld;
   if (e->kind == DRS_MODEL_NCF) { src = s.H2; ld = e->num_int; }
-  else if (e->kind == DRS_MODEL_DIN) { src = s.R; ld = e->ldR; }
+  else if (e->kind == DRS_MODEL_DIN || e->kind == DRS_MODEL_DIEN) { src = s.R; ld = e->ldR; }
   else if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) { src = s.R; ld = e->ldR; }
   else { src = s.T; ld = e->ldT; }
   HIP_TRY(e, hipMemcpy2D(h_R, sizeof(float) * e->num_int, src, sizeof(float) * ld,
@@ -1547,6 +1598,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "sls_split")) e->tune.sls_split = value ? 1 : 0;
   else if (!strcmp(key, "din_fused")) e->din_fused = value ? 1 : 0;
+  else if (!strcmp(key, "dien_mfma")) e->dien_mfma = value ? 1 : 0;
   else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
   else if (!strcmp(key, "sls_depth") && (value == 0 || value == 6 || value == 8 || value == 10 || value == 12 || value == 14)) e->tune.sls_depth = (int)value;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
@@ -1626,7 +1678,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile},
       {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},

@@ -5,6 +5,7 @@
     NCF / NCF_Wrapper                     <- models/ncf.py:140-523
     MT_Wide_and_Deep / ..._Wrapper        <- models/multi_task_wnd.py:160-420
     DIN_Net / DIN_Wrapper                 <- models/din.py:24-470
+    DIEN_Net / DIEN_Wrapper               <- models/dien.py:28-560
 
 Same constructor arguments, the same shape algebra and sys.exit() checks, the same
 numpy RNG consumption order for the weights (embeddings, then bottom MLP, then top
@@ -402,6 +403,65 @@ class DIN_Net(_NoDenseNet):
 
 
 # =====================================================================================
+class DIEN_Net(_NoDenseNet):
+    """Deep Interest Evolution Network (models/dien.py:308-470).  Tables as DIN.  The behaviour
+    embeddings of a query go through two caffe2 rnn_cell.BasicRNN layers (tanh, zero initial state,
+    arch_sparse_feature_size -> hidden_size -> hidden_size); the top MLP (all ReLU) reads
+    Concat(last state of the second layer, user profile, candidate ad, context) (:411-431).
+
+    Reference behaviour kept as it is: the Reshape of the Concat'ed [bs, U*D] embeddings to
+    [U, bs, D] is a row-major reinterpretation (:316-320), so for bs > 1 step t of "sample" b is
+    embedding (t*bs + b) % U of sample (t*bs + b) // U; the FC + Softmax between the two RNNs is
+    dead (the Sum that follows overwrites its output with a copy of the first RNN's states,
+    :336-348) and is not computed.
+
+    Recurrent weights: the reference feeds np.random.randn values (:318-331,350-363) -- drawn here
+    in the same order so the numpy stream stays aligned for the top MLP -- and then create() runs
+    Caffe2's param_init_net (:528), which re-draws them with XavierFill / zero biases from Caffe2's
+    own RNG.  `dien_rnn_init` = "xavier" (default) uses U(+-sqrt(3/fan_in)) weights and zero biases
+    from a RandomState of their own (what a live reference run has, up to the unknowable RNG);
+    "fed" keeps the randn values (the recorded-graph fixture, tests/golden/dien_mini)."""
+    kind = N.MODEL_DIEN
+
+    def __init__(self, cli_args, model=None, tag=None, enable_prof=False, id_qs=None, len_qs=None,
+                 seq_q=None, hid_q=None):
+        self._common_init(cli_args)
+        m_spa = int(cli_args.arch_sparse_feature_size)
+        H = int(cli_args.hidden_size)
+        ln_emb = _ints(cli_args.arch_embedding_size)
+        if ln_emb.size < 4:                         # the reference asserts (:457)
+            sys.exit("ERROR: DIEN needs user profile, user behavior, candidate ad and context tables")
+        self.m_spa, self.ln_emb, self.hidden_size = m_spa, ln_emb, H
+        self.ln_bot = np.array([m_spa, H], dtype=int)
+        self.ln_top = _ints(str(H + 3 * m_spa) + "-" + cli_args.arch_mlp_top)      # :426-429
+        self.arch_interaction_op = "cat"
+        self.arch_interaction_itself = cli_args.arch_interaction_itself
+        self.emb_w = self._make_tables(m_spa, ln_emb)
+
+        def fed(din):   # gates_t_w, gates_t_b, i2h_w, i2h_b (:318-321) -> {i2h: (W, b), gates_t: (W, b)}
+            gw = np.random.randn(H, H).astype(np.float32)
+            gb = np.random.randn(H).astype(np.float32)
+            iw = np.random.randn(H, din).astype(np.float32)
+            ib = np.random.randn(H).astype(np.float32)
+            return [(iw, ib), (gw, gb)]
+        self.rnn_w = [fed(m_spa), fed(H)]
+        if getattr(cli_args, "dien_rnn_init", "xavier") != "fed":
+            rs = np.random.RandomState(int(getattr(cli_args, "numpy_rand_seed", 0)) + 1)
+            z = np.zeros(H, dtype=np.float32)
+            self.rnn_w = [[(rs.uniform(-np.sqrt(3 / din), np.sqrt(3 / din), (H, din)).astype(np.float32), z),
+                           (rs.uniform(-np.sqrt(3 / H), np.sqrt(3 / H), (H, H)).astype(np.float32), z)]
+                          for din in (m_spa, H)]
+        self.top_w = _init_mlp(self.ln_top)
+
+    def _create_engine(self):
+        self.engine = self._build_engine(self.ln_bot, self.ln_top, N.INTERACT_CAT, False, -1)
+        for l, mlp in enumerate((N.MLP_RNN0, N.MLP_RNN1)):
+            for i, (W, b) in enumerate(self.rnn_w[l]):
+                self.engine.set_fc(mlp, i, W, b)
+        for i, (W, b) in enumerate(self.top_w):
+            self.engine.set_fc(N.MLP_TOP, i, W, b)
+
+
 class _Wrapper(object):
     """X_Wrapper(args): .create(...), .run_queues(ids, lengths, fc, batch_size)
     (models/dlrm_s_caffe2.py:79-174).  The 2T+1 Caffe2 BlobsQueues the reference
@@ -446,5 +506,9 @@ class DIN_Wrapper(_Wrapper):
     net_cls, attr = DIN_Net, "din"
 
 
+class DIEN_Wrapper(_Wrapper):
+    net_cls, attr = DIEN_Net, "dien"
+
+
 WRAPPERS = {"dlrm": DLRM_Wrapper, "wnd": Wide_and_Deep_Wrapper, "ncf": NCF_Wrapper,
-            "mtwnd": MT_Wide_and_Deep_Wrapper, "din": DIN_Wrapper}
+            "mtwnd": MT_Wide_and_Deep_Wrapper, "din": DIN_Wrapper, "dien": DIEN_Wrapper}

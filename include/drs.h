@@ -61,6 +61,14 @@ enum {
                          atten_out = Sum over the units; top MLP over Concat(profile, atten_out,
                          ad, context); every activation ReLU.  cfg: ln_bot = the unit's widths
                          [3*D, h, D] (arch_mlp_bot "h"), ln_top = [4*D, ...], no dense input      */
+  ,
+  DRS_MODEL_DIEN = 5  /* models/dien.py:308-432: tables as DIN.  The U behaviour embeddings of a query,
+                         Concat'ed [bs, U*D] and Reshape'd (row-major reinterpretation, as the reference
+                         does it) to [U, bs, D], run through two caffe2 rnn_cell.BasicRNN layers (tanh,
+                         zero initial state, D -> H and H -> H; the FC + Softmax between them is dead in
+                         the reference graph and not computed); top MLP (all ReLU) over Concat(last
+                         state, profile, ad, context).  cfg: ln_bot = [D, H] (--hidden_size),
+                         ln_top = [H + 3*D, ...], no dense input.  H <= 64.                           */
 };
 
 /* feature interaction (models/dlrm_s_caffe2.py:331-365) */
@@ -72,7 +80,10 @@ enum { DRS_ACT_NONE = 0, DRS_ACT_RELU = 1, DRS_ACT_SIGMOID = 2 };
 /* which MLP a layer belongs to in drs_set_fc */
 enum { DRS_MLP_BOT = 0, DRS_MLP_TOP = 1, DRS_MLP_FINAL = 2 /* NCF predictor */,
        DRS_MLP_TASK0 = 16 /* + k: task head k of DRS_MODEL_MTWND */,
-       DRS_MLP_ATT0 = 1024 /* + i: attention unit i of DRS_MODEL_DIN */ };
+       DRS_MLP_ATT0 = 1024 /* + i: attention unit i of DRS_MODEL_DIN */,
+       DRS_MLP_RNN0 = 32 /* DRS_MODEL_DIEN, first BasicRNN: layer 0 = i2h (W [H, D], b [H]), layer 1 =
+                            gates_t (W [H, H], b [H]) */,
+       DRS_MLP_RNN1 = 33 /* second BasicRNN: layer 0 = i2h (W [H, H]), layer 1 = gates_t (W [H, H]) */ };
 
 /* kernels that keep live HIP-event timings (drs_kernel_time) */
 enum {
@@ -254,6 +265,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                {1, 2, 4}: ONE launch gathers the bags, applies the attention units and writes the top
  *                MLP's input row (the [rows, T*D] pooled tensor never exists) | 0 gather launch +
  *                attention launch (what sls_exact 1 always does; bit-identical to the oracle there)
+ *   "dien_mfma"  1 (default) DRS_MODEL_DIEN with hidden_size a multiple of 16: the recurrence runs on the
+ *                matrix cores, 16 samples per workgroup | 0 one wave per sample (same bits)
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
  *   "sls_depth"  0 (default: the compiler's schedule of the one-bag-per-wave flat kernel) | 6 | 8 |

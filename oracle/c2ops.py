@@ -16,7 +16,18 @@ semantics are restated from Caffe2's published operator schemas:
   Flatten(axis=1)         : [B, ...] -> [B, prod(...)]
   BatchGather(DATA, IDX)  : DATA[:, IDX]
   Cast(to=INT32)          : value preserving narrowing
-  Sum(xs...)              : elementwise sum, left to right
+  Sum(xs...)              : elementwise sum, left to right (one input: a copy)
+  Reshape(X, shape)       : row-major reinterpretation (one -1 allowed)
+  Softmax(axis)           : over the dims from `axis` on, flattened
+  FC(axis=k)              : leading k dims are the batch
+  BasicRNN                : caffe2.python.rnn_cell.BasicRNN (BasicRNNCell, forward only):
+      i2h = FC(X [T,B,Din], i2h_w, i2h_b, axis=2); per step gates = FC(h_prev, gates_t_w,
+      gates_t_b, axis=2); gates = Sum(gates, i2h[t]); h = tanh(gates); with seq_lengths,
+      rows whose length <= t keep h_prev.  Outputs: every step's h [T,B,H], the last h [1,B,H]
+An op whose parameter blob does not exist (a brew.fc weight that only Caffe2's param_init_net
+would create) yields an UNAVAILABLE output, which propagates; models/dien.py's FC + Softmax over
+the first RNN's states is such a chain, and it is dead: the Sum that follows overwrites its output
+blob with a copy of the RNN states (models/dien.py:345-348).
   DequeueBlobs            : pops the blob most recently enqueued on that queue
 
 Used only by tools/gen_golden.py (fixture generation) and tests/.  Floating-point
@@ -87,6 +98,41 @@ def batch_gather(data, idx):
     return np.asarray(data)[:, np.asarray(idx, dtype=np.int64)]
 
 
+def reshape(x, shape):
+    return np.asarray(x).reshape(tuple(int(v) for v in shape))
+
+
+def softmax(x, axis=1):
+    x = np.asarray(x, np.float64)
+    flat = x.reshape(int(np.prod(x.shape[:axis])), -1)
+    e = np.exp(flat - flat.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True)).reshape(x.shape).astype(np.float32)
+
+
+def basic_rnn(x, seq_lengths, h0, i2h_w, i2h_b, gates_w, gates_b, activation="tanh"):
+    assert activation == "tanh"
+    x = np.asarray(x, np.float32)
+    steps, B, _ = x.shape
+    H = np.asarray(gates_w).shape[0]
+    i2h = fc(x.reshape(steps * B, -1), i2h_w, i2h_b).reshape(steps, B, H)
+    h = np.asarray(h0, np.float32).reshape(B, H)
+    seq = np.asarray(seq_lengths).reshape(B)
+    every = np.zeros((steps, B, H), np.float32)
+    for t in range(steps):
+        gates = (fc(h, gates_w, gates_b) + i2h[t]).astype(np.float32)
+        hn = np.tanh(gates.astype(np.float64)).astype(np.float32)
+        h = np.where((seq > t)[:, None], hn, h)
+        every[t] = h
+    return every, h.reshape(1, B, H)
+
+
+class _Unavailable(object):
+    pass
+
+
+UNAVAILABLE = _Unavailable()
+
+
 def run_ops(ops, blobs, queues=None):
     """Execute recorded ops in order.  `blobs`: name -> ndarray (weights + fed inputs).
     `queues`: queue blob name -> list of enqueued arrays (queue mode)."""
@@ -94,6 +140,10 @@ def run_ops(ops, blobs, queues=None):
     queues = {k: list(v) for k, v in (queues or {}).items()}
     for op in ops:
         kind, ins, outs, kw = op["type"], op["inputs"], op["outputs"], op.get("kwargs", {})
+        if kind != "DequeueBlobs" and any(i not in ws or ws[i] is UNAVAILABLE for i in ins):
+            for o in outs:
+                ws[o] = UNAVAILABLE
+            continue
         if kind == "DequeueBlobs":
             ws[outs[0]] = queues[ins[0]].pop(0)
         elif kind == "Cast":
@@ -104,7 +154,18 @@ def run_ops(ops, blobs, queues=None):
         elif kind == "SparseLengthsSum":
             ws[outs[0]] = sparse_lengths_sum(ws[ins[0]], ws[ins[1]], ws[ins[2]])
         elif kind == "FC":
-            ws[outs[0]] = fc(ws[ins[0]], ws[ins[1]], ws[ins[2]])
+            x = np.asarray(ws[ins[0]])
+            ax = int(kw.get("axis", 1))
+            y = fc(x.reshape(int(np.prod(x.shape[:ax])), -1), ws[ins[1]], ws[ins[2]])
+            ws[outs[0]] = y.reshape(x.shape[:ax] + (y.shape[1],))
+        elif kind == "Reshape":
+            import ast
+            ws[outs[1]] = np.array(np.asarray(ws[ins[0]]).shape, dtype=np.int64)
+            ws[outs[0]] = reshape(ws[ins[0]], ast.literal_eval(kw["shape"]))
+        elif kind == "Softmax":
+            ws[outs[0]] = softmax(ws[ins[0]], axis=int(kw.get("axis", 1)))
+        elif kind == "BasicRNN":
+            ws[outs[0]], ws[outs[1]] = basic_rnn(*[ws[i] for i in ins], activation=kw.get("activation"))
         elif kind == "Relu":
             ws[outs[0]] = relu(ws[ins[0]])
         elif kind == "Sigmoid":

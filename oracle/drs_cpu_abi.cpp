@@ -53,6 +53,8 @@ typedef struct orc_model {
   const int32_t* ln_att;
   const float* const* att_W;
   const float* const* att_b;
+  int32_t rnn_hidden;
+  const float* rnn_w[8];
 } orc_model;
 int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense, const int64_t* const* idx,
                     const int64_t* n_idx, const int32_t* const* len, float* out, float* R_out,
@@ -104,6 +106,7 @@ struct drs_engine {
   Mlp bot, top, fin;
   std::vector<Mlp> tasks;        // MT-WnD heads
   std::vector<Mlp> att;          // DIN attention units
+  std::vector<Mlp> rnn;          // DIEN: the two BasicRNN layers, each {i2h, gates_t}
   int32_t interaction_op = 0, itself = 0, sigmoid_top = -1;
   int32_t max_batch = 0, max_lookups = 0, n_batches = 0, n_slots = 1;
   int32_t m_den = 0, w0 = 0, num_int = 0, n_out = 0;
@@ -188,7 +191,8 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
   int32_t rc;
   if ((rc = mlp_ready(e, e->bot, "bottom")) || (rc = mlp_ready(e, e->top, "top")) ||
       (rc = mlp_ready(e, e->fin, "final")) || [&] { for (auto& tk : e->tasks) if ((rc = mlp_ready(e, tk, "task"))) return true; return false; }() ||
-      [&] { for (auto& au : e->att) if ((rc = mlp_ready(e, au, "attention"))) return true; return false; }())
+      [&] { for (auto& au : e->att) if ((rc = mlp_ready(e, au, "attention"))) return true; return false; }() ||
+      [&] { for (auto& rn : e->rnn) if ((rc = mlp_ready(e, rn, "rnn"))) return true; return false; }())
     return rc;
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
@@ -226,6 +230,14 @@ int32_t run(drs_engine* e, Slot& s, int n, const Batch* const* bts, const int32_
       for (size_t l = 0; l < au.W.size(); ++l) { aw.push_back(au.W[l].data()); ab.push_back(au.b[l].data()); }
     m.n_att = (int32_t)e->att[0].ln.size(); m.ln_att = e->att[0].ln.data();
     m.att_W = aw.data(); m.att_b = ab.data();
+    m.n_bot = 0; m.ln_bot = nullptr; m.bot_W = nullptr; m.bot_b = nullptr;
+  }
+  if (e->kind == DRS_MODEL_DIEN) {
+    m.rnn_hidden = e->rnn[0].ln[1];
+    for (int l = 0; l < 2; ++l) {
+      m.rnn_w[4 * l + 0] = e->rnn[l].W[0].data(); m.rnn_w[4 * l + 1] = e->rnn[l].b[0].data();
+      m.rnn_w[4 * l + 2] = e->rnn[l].W[1].data(); m.rnn_w[4 * l + 3] = e->rnn[l].b[1].data();
+    }
     m.n_bot = 0; m.ln_bot = nullptr; m.bot_W = nullptr; m.bot_b = nullptr;
   }
   m.interaction_op = e->interaction_op; m.itself = e->itself; m.sigmoid_top = e->sigmoid_top;
@@ -341,6 +353,22 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       e->sigmoid_top = -1;
       e->n_out = e->top.ln.back();
       break;
+    case DRS_MODEL_DIEN: {
+      if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIEN needs at least 4 embedding tables");
+      if (cfg->n_bot != 2 || e->bot.ln[0] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
+        return bail(DRS_ERR_UNSUPPORTED, "DIEN: ln_bot must be [D, hidden_size] with hidden_size <= 64");
+      const int H = e->bot.ln[1];
+      e->m_den = 0; e->w0 = 0;
+      e->num_int = H + 3 * D;
+      if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
+      e->rnn.resize(2);
+      e->rnn[0].ln = {D, H, H};
+      e->rnn[1].ln = {H, H, H};
+      e->bot.ln = {0};
+      e->sigmoid_top = -1;
+      e->n_out = e->top.ln.back();
+      break;
+    }
     case DRS_MODEL_NCF:
       if (T != 4) return bail(DRS_ERR_BAD_ARG, "NCF has 4 embedding tables");
       if (e->top.ln.front() != 2 * D) return bail(DRS_ERR_BAD_ARG, "NCF MLP branch input must be 2*D");
@@ -364,6 +392,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   init_mlp(e->bot); init_mlp(e->top); init_mlp(e->fin);
   for (auto& tk : e->tasks) init_mlp(tk);
   for (auto& au : e->att) init_mlp(au);
+  for (auto& rn : e->rnn) init_mlp(rn);
   e->tables.assign(T, {});
   e->table_set.assign(T, false);
   e->cap = (int64_t)e->max_batch * e->max_lookups;
@@ -407,6 +436,7 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   Mlp* M = mlp == DRS_MLP_BOT ? &e->bot : mlp == DRS_MLP_TOP ? &e->top : mlp == DRS_MLP_FINAL ? &e->fin : nullptr;
   if (mlp >= DRS_MLP_TASK0 && mlp - DRS_MLP_TASK0 < (int)e->tasks.size()) M = &e->tasks[mlp - DRS_MLP_TASK0];
   if (mlp >= DRS_MLP_ATT0 && mlp - DRS_MLP_ATT0 < (int)e->att.size()) M = &e->att[mlp - DRS_MLP_ATT0];
+  if ((mlp == DRS_MLP_RNN0 || mlp == DRS_MLP_RNN1) && e->rnn.size() == 2) M = &e->rnn[mlp - DRS_MLP_RNN0];
   if (!M || layer < 0 || layer >= (int)M->set.size()) return fail(e, DRS_ERR_BAD_ARG, "no such layer");
   if (mlp == DRS_MLP_FINAL && M->ln[1] == 0) {
     if (m <= 0 || m > 1024) return fail(e, DRS_ERR_BAD_ARG, "bad predictor width");

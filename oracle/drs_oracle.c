@@ -54,7 +54,7 @@
 #define ORC_ERR_LENGTHS_SUM (-5)
 #define ORC_ERR_UNSUPPORTED (-7)
 
-enum { ORC_MODEL_DLRM = 0, ORC_MODEL_WND = 1, ORC_MODEL_NCF = 2, ORC_MODEL_MTWND = 3, ORC_MODEL_DIN = 4 };
+enum { ORC_MODEL_DLRM = 0, ORC_MODEL_WND = 1, ORC_MODEL_NCF = 2, ORC_MODEL_MTWND = 3, ORC_MODEL_DIN = 4, ORC_MODEL_DIEN = 5 };
 enum { ORC_INTERACT_DOT = 0, ORC_INTERACT_CAT = 1 };
 enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_SIGMOID = 2 };
 
@@ -291,6 +291,17 @@ typedef struct orc_model {
   const int32_t* ln_att;
   const float* const* att_W;
   const float* const* att_b;
+  /* DIEN (models/dien.py:308-432): tables as DIN.  The U behaviour embeddings of a query are
+   * Concat'ed to [B, U*D] and Reshape'd -- a row-major REINTERPRETATION, not a transpose -- to
+   * [U, B, D] (:316-320): step t of "sample" b is embedding n % U of sample n / U, n = t*B + b.
+   * Two caffe2 rnn_cell.BasicRNN layers (tanh; h_t = tanh((gates_t_w h_{t-1} + gates_t_b) +
+   * (i2h_w x_t + i2h_b)), zero initial state; every step is inside seq_lengths (:495-497,89-90)),
+   * D -> H and H -> H; the second reads the first's states (the FC + Softmax between them is dead:
+   * the Sum after it overwrites its output with a copy of the states, :336-348).  Top input =
+   * Concat(last state of layer 2, user profile, candidate ad, context) [B, H + 3*D] (:411-421); top
+   * MLP all ReLU.  rnn_w = {i2h_w, i2h_b, gates_t_w, gates_t_b} of layer 1 then of layer 2.      */
+  int32_t rnn_hidden;
+  const float* rnn_w[8];
 } orc_model;
 
 static int32_t mlp_chain(const float* in, int64_t B, int64_t ld_in, int32_t n_l,
@@ -405,6 +416,50 @@ int32_t orc_forward(const orc_model* m, int32_t bs, const float* dense,
     if (rc == ORC_OK)
       rc = mlp_chain(Rin, B, 4 * D, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, -1, out, m->ln_top[m->n_top - 1], nthreads);
     free(E); free(X); free(Y); free(Rin);
+    return rc;
+  }
+
+  if (m->model_kind == ORC_MODEL_DIEN) {
+    const int32_t U = T - 3, Hh = m->rnn_hidden, wr = Hh + 3 * D;
+    if (T < 4 || Hh < 1 || m->ln_top[0] != wr) return ORC_ERR_BAD_ARG;
+    for (int i = 0; i < 8; ++i) if (!m->rnn_w[i]) return ORC_ERR_BAD_ARG;
+    const int64_t ldE = (int64_t)T * D;
+    float* E = (float*)malloc(sizeof(float) * (size_t)B * (size_t)ldE);
+    float* X = (float*)malloc(sizeof(float) * (size_t)B * D);
+    float* A = (float*)malloc(sizeof(float) * (size_t)B * Hh);
+    float* G = (float*)malloc(sizeof(float) * (size_t)B * Hh);
+    float* h0 = (float*)calloc((size_t)B * Hh, sizeof(float));
+    float* h1 = (float*)calloc((size_t)B * Hh, sizeof(float));
+    float* Rin = (float*)malloc(sizeof(float) * (size_t)B * wr);
+    if (!E || !X || !A || !G || !h0 || !h1 || !Rin) { free(E); free(X); free(A); free(G); free(h0); free(h1); free(Rin); return ORC_ERR_OOM; }
+    for (int32_t t = 0; t < T && rc == ORC_OK; ++t)
+      rc = sls_impl(m->tables[t], m->rows[t], D, idx[t], NULL, len[t], B, n_idx[t], E + (int64_t)t * D, ldE, nthreads);
+    for (int32_t t = 0; t < U && rc == ORC_OK; ++t) {
+      for (int64_t b = 0; b < B; ++b) {                       /* the Reshape (:319-320) */
+        const int64_t n = (int64_t)t * B + b;
+        memcpy(X + b * D, E + (n / U) * ldE + (1 + n % U) * D, sizeof(float) * D);
+      }
+      /* layer 1: i2h FC, gates FC on the previous state, Sum(gates, i2h), Tanh */
+      rc = fc_impl(X, B, D, D, m->rnn_w[0], NULL, m->rnn_w[1], Hh, ORC_ACT_NONE, A, Hh, nthreads);
+      if (rc == ORC_OK) rc = fc_impl(h0, B, Hh, Hh, m->rnn_w[2], NULL, m->rnn_w[3], Hh, ORC_ACT_NONE, G, Hh, nthreads);
+      if (rc != ORC_OK) break;
+      for (int64_t i = 0; i < B * Hh; ++i) h0[i] = tanhf(G[i] + A[i]);
+      /* layer 2 on layer 1's new state */
+      rc = fc_impl(h0, B, Hh, Hh, m->rnn_w[4], NULL, m->rnn_w[5], Hh, ORC_ACT_NONE, A, Hh, nthreads);
+      if (rc == ORC_OK) rc = fc_impl(h1, B, Hh, Hh, m->rnn_w[6], NULL, m->rnn_w[7], Hh, ORC_ACT_NONE, G, Hh, nthreads);
+      if (rc != ORC_OK) break;
+      for (int64_t i = 0; i < B * Hh; ++i) h1[i] = tanhf(G[i] + A[i]);
+    }
+    if (rc == ORC_OK)
+      for (int64_t b = 0; b < B; ++b) {
+        memcpy(Rin + b * wr, h1 + b * Hh, sizeof(float) * Hh);
+        memcpy(Rin + b * wr + Hh, E + b * ldE, sizeof(float) * D);                                   /* user profile */
+        memcpy(Rin + b * wr + Hh + D, E + b * ldE + (int64_t)(T - 2) * D, sizeof(float) * 2 * D);    /* candidate ad, context */
+      }
+    if (rc == ORC_OK && R_out) memcpy(R_out, Rin, sizeof(float) * (size_t)B * wr);
+    if (rc == ORC_OK)
+      rc = mlp_chain(Rin, B, wr, m->n_top, m->ln_top, m->top_W, m->top_Wt, m->top_b, -1, out, m->ln_top[m->n_top - 1], nthreads);
+    free(E); free(X); free(A); free(G); free(h0); free(h1); free(Rin);
     return rc;
   }
 

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libdrs_oracle.so")
 
-MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND, MODEL_DIN = 0, 1, 2, 3, 4
+MODEL_DLRM, MODEL_WND, MODEL_NCF, MODEL_MTWND, MODEL_DIN, MODEL_DIEN = 0, 1, 2, 3, 4, 5
 INTERACT_DOT, INTERACT_CAT = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -52,6 +52,7 @@ class _Model(C.Structure):
         ("n_task", C.c_int32), ("ln_task", _i32p), ("num_tasks", C.c_int32), ("task_sigmoid", C.c_int32),
         ("task_W", C.POINTER(_f32p)), ("task_b", C.POINTER(_f32p)), ("task_Wt", C.POINTER(_f32p)),
         ("n_att", C.c_int32), ("ln_att", _i32p), ("att_W", C.POINTER(_f32p)), ("att_b", C.POINTER(_f32p)),
+        ("rnn_hidden", C.c_int32), ("rnn_w", _f32p * 8),
     ]
 
 
@@ -157,9 +158,11 @@ class Model(object):
     """
 
     def __init__(self, kind, tables, ln_bot, bot, ln_top, top, interaction_op=INTERACT_CAT,
-                 itself=False, sigmoid_top=-1, final=None, ln_task=None, tasks=None, ln_att=None, att=None):
+                 itself=False, sigmoid_top=-1, final=None, ln_task=None, tasks=None, ln_att=None, att=None,
+                 rnn=None):
         """MT-WnD: ln_task = head widths, tasks = list (one per head) of lists of (W, b).
-        DIN: ln_att = attention-unit widths, att = list (one per behaviour table) of lists of (W, b)."""
+        DIN: ln_att = attention-unit widths, att = list (one per behaviour table) of lists of (W, b).
+        DIEN: rnn = [i2h_w, i2h_b, gates_t_w, gates_t_b] of layer 1 then of layer 2 (8 arrays)."""
         self.kind = kind
         self.tables = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
         self.D = int(self.tables[0].shape[1])
@@ -231,6 +234,13 @@ class Model(object):
             self._ab = (_f32p * na)(*[b.ctypes.data_as(_f32p) for _, b in flat])
             m.n_att, m.ln_att = self.ln_att.size, self.ln_att.ctypes.data_as(_i32p)
             m.att_W, m.att_b = self._aW, self._ab
+        self.rnn = None
+        if rnn is not None:
+            self.rnn = [np.ascontiguousarray(w, np.float32) for w in rnn]
+            assert len(self.rnn) == 8
+            m.rnn_hidden = int(self.rnn[2].shape[0])
+            for i, w in enumerate(self.rnn):
+                m.rnn_w[i] = w.ctypes.data_as(_f32p)
         self._c = m
 
     @property

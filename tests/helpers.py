@@ -14,10 +14,10 @@ from oracle import oracle as orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["dlrm_dot_small", "dlrm_dot_itself_small", "dlrm_cat_small", "dlrm_cat_queue_small",
                "dlrm_dot_queue_small", "dlrm_rm1_mini", "dlrm_rm2_mini", "dlrm_rm3_mini", "wnd_mini",
-               "ncf_mini", "mtwnd_mini", "din_mini"]
+               "ncf_mini", "mtwnd_mini", "din_mini", "dien_mini"]
 NET_CLS = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep,
-           "din": M.DIN_Net}
-NO_DENSE = ("ncf", "din")     # model types whose queries are sparse features only
+           "din": M.DIN_Net, "dien": M.DIEN_Net}
+NO_DENSE = ("ncf", "din", "dien")     # model types whose queries are sparse features only
 
 
 def sha(a):
@@ -43,6 +43,8 @@ def args_from(meta_args, **override):
     args = cli([])
     for k, v in meta_args.items():
         setattr(args, k, v)
+    if meta_args.get("model_type") == "dien":
+        args.dien_rnn_init = "fed"      # the fixtures hold the recurrent weights models/dien.py feeds
     for k, v in override.items():
         setattr(args, k, v)
     return args
@@ -69,6 +71,9 @@ def oracle_model(net):
     if net.kind == M.N.MODEL_DIN:
         return orc.Model(orc.MODEL_DIN, net.emb_w, [0], [], net.ln_top, net.top_w, ln_att=net.ln_att,
                          att=net.att_w)
+    if net.kind == M.N.MODEL_DIEN:
+        rnn = [a for layer in net.rnn_w for a in (layer[0][0], layer[0][1], layer[1][0], layer[1][1])]
+        return orc.Model(orc.MODEL_DIEN, net.emb_w, [0], [], net.ln_top, net.top_w, rnn=rnn)
     if net.kind == M.N.MODEL_MTWND:
         return orc.Model(orc.MODEL_MTWND, net.emb_w, net.ln_bot, [], net.ln_top, net.top_w,
                          sigmoid_top=net.sigmoid_top, ln_task=net.ln_task, tasks=net.task_w)

@@ -51,7 +51,16 @@ def test_forward_matches_oracle_and_golden(case):
                     R = net.engine.fetch_interaction(bs)
                     dense = None if args.model_type in H.NO_DENSE else lX[bid]
                     exp, R_exp = om.forward(dense, lS_i[bid], lS_l[bid], bs=bs, want_R=True)
-                    if exact:
+                    if args.model_type == "dien":
+                        # tanhf: libm vs the device's differ by an ulp, and the fixture's randn
+                        # recurrent weights amplify it over the steps -> tolerance on the states,
+                        # bitwise on the pass-through features (sequential gather)
+                        Hs = args.hidden_size
+                        if exact:
+                            assert np.array_equal(R[:, Hs:], R_exp[:, Hs:]), (case, bid, bs)
+                        assert H.close(R, R_exp, rtol=1e-4, atol=1e-5), (case, bid, bs, np.abs(R - R_exp).max())
+                        assert H.close(got, exp, rtol=H.RTOL_OUT, atol=1e-5), np.abs(got - exp).max()
+                    elif exact:
                         # pooled embeddings + concat layout + (dot) tril order + bottom MLP: bitwise;
                         # outputs: identical fma chains up to the last expf -> a few ulp
                         assert np.array_equal(R, R_exp), (case, bid, bs, np.abs(R - R_exp).max())
@@ -61,7 +70,7 @@ def test_forward_matches_oracle_and_golden(case):
                         assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (case, bid, bs)
                         assert H.close(got, exp, rtol=H.RTOL_OUT)
         full = net.run_staged(0, n)
-        assert H.close(full, H.golden_output(meta, z), rtol=H.RTOL_OUT)
+        assert H.close(full, H.golden_output(meta, z), rtol=H.RTOL_OUT, atol=1e-5 if args.model_type == "dien" else 0.0)
         # non-staged inputs (run_queues signature) give the same bits as the staged path
         again = net.run_queued(lS_i[0], lS_l[0], None if args.model_type in H.NO_DENSE else lX[0], n)
         assert np.array_equal(full, again)
@@ -295,6 +304,10 @@ FULL_SIZE = {
     # top MLP 128-200-80-2
     "din": dict(kind="din", rows=[1_000_000] + [100_000] * 251 + [10_000_000] * 2, D=32, L=3, bot="1",
                 top="200-80-2"),
+    # reference models/configs/dien.json: 43 tables (41 x 500k, 2 x 5M) x 32, one lookup, 40 steps of
+    # two BasicRNN layers 32 -> 64 -> 64, top MLP 160-200-80-2 (tanhf differs by an ulp between
+    # libm and the device: the top MLP's input row is compared with a tolerance, not bitwise)
+    "dien": dict(kind="dien", rows=[500_000] * 41 + [5_000_000] * 2, D=32, L=1, bot="512", top="200-80-2"),
 }
 
 
@@ -332,8 +345,13 @@ def test_full_size_reference_shapes_match_oracle(name):
                 got = net.run_staged(bid, bs)
                 R = eng.fetch_interaction(bs)
                 exp, R_exp = om.forward(dense(bid), lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
-                assert np.array_equal(R, R_exp), (name, bid, bs)
-                assert H.close(got, exp, rtol=1e-6, atol=1e-7), (name, bid, bs, np.abs(got - exp).max())
+                if name == "dien":
+                    assert np.array_equal(R[:, 64:], R_exp[:, 64:]), (name, bid, bs)      # pooled rows: bitwise
+                    assert H.close(R, R_exp, rtol=2e-5, atol=2e-6), (name, bid, bs, np.abs(R - R_exp).max())
+                    assert H.close(got, exp, rtol=H.RTOL_OUT, atol=1e-6), (name, bid, bs, np.abs(got - exp).max())
+                else:
+                    assert np.array_equal(R, R_exp), (name, bid, bs)
+                    assert H.close(got, exp, rtol=1e-6, atol=1e-7), (name, bid, bs, np.abs(got - exp).max())
                 ref[(bid, bs)] = got
         # 8 coalesced queries (one gather launch, one MLP pass) == the same queries served alone
         jobs = [(0, B), (1, 165), (0, 1), (1, B), (0, 165), (1, 1), (0, B), (1, B)]
@@ -350,8 +368,8 @@ def test_full_size_reference_shapes_match_oracle(name):
         got = net.run_staged(0, B)
         R = eng.fetch_interaction(B)
         _, R_exp = om.forward(dense(0), lS_i[0], lS_l[0], bs=B, want_R=True, nthreads=0)
-        assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6)
-        assert H.close(got, ref[(0, B)], rtol=H.RTOL_OUT)
+        assert H.close(R, R_exp, rtol=2e-5 if name == "dien" else 1e-5, atol_scale=2e-6)
+        assert H.close(got, ref[(0, B)], rtol=H.RTOL_OUT, atol=1e-6 if name == "dien" else 0.0)
         assert eng.gather_bytes(0, B) == B * T * (L * D * 4 + L * 4 + 4 + D * 4)
     finally:
         eng.close()
@@ -504,6 +522,59 @@ def test_din_fused_and_two_launch_forms_match_oracle(D, h, U, ragged):
             net.run_queued(bad, sets[0][1], None, B)
         assert e.value.code == N.ERR_INDEX_RANGE
         assert net.run_staged(0, B).shape == (B, 2)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("D,Hs,U,init", [(32, 64, 40, "xavier"), (16, 8, 5, "fed"), (64, 32, 9, "xavier"), (32, 16, 3, "xavier")])
+def test_dien_recurrent_layers_match_oracle(D, Hs, U, init):
+    """DIEN's two BasicRNN layers (din.hip) against the oracle: the pass-through features bitwise,
+    the recurrent state within the tanhf tolerance; query sizes 1 .. B (the reference's Reshape makes
+    a sample's sequence depend on its query's batch size), ragged bags, 8 coalesced queries of
+    different sizes equal to the same queries served alone."""
+    rng = np.random.RandomState(D + Hs + U)
+    rows = [500] + [300] * U + [700, 400]
+    T, B, Lmax = len(rows), 70, 3
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_top="24-2", hidden_size=Hs, arch_interaction_op="cat",
+                       num_indices_per_lookup=Lmax, num_batches=2, max_mini_batch_size=B,
+                       mini_batch_size=B, numpy_rand_seed=3, model_type="dien", accel_slots=2)
+    args.dien_rnn_init = init
+    np.random.seed(3)
+    net = H.M.DIEN_Net(args)
+    om = H.oracle_model(net)
+    sets = []
+    for b in range(2):
+        lens = [rng.randint(0, Lmax + 1, size=B).astype(np.int32) for _ in range(T)]
+        idx = [rng.randint(0, rows[t], size=int(lens[t].sum())).astype(np.int64) for t in range(T)]
+        sets.append((idx, lens))
+    net.create(None, sets[0][1], sets[0][0], None)
+    eng = net.engine
+    # randn weights (the values models/dien.py feeds) make the recurrence chaotic: looser bar
+    rtol, atol = (1e-3, 1e-4) if init == "fed" else (2e-5, 2e-6)
+    try:
+        for b, (idx, lens) in enumerate(sets):
+            eng.stage_batch(b, None, idx, lens)
+        eng.set_option("sls_exact", 1)
+        ref = {}
+        for b, (idx, lens) in enumerate(sets):
+            for bs in (B, 33, 2, 1):
+                got = net.run_staged(b, bs)
+                R = eng.fetch_interaction(bs)
+                exp, R_exp = om.forward(None, idx, lens, bs=bs, want_R=True)
+                assert R.shape == (bs, Hs + 3 * D)
+                assert np.array_equal(R[:, Hs:], R_exp[:, Hs:]), (b, bs)
+                assert H.close(R, R_exp, rtol=rtol, atol=atol), (b, bs, np.abs(R - R_exp).max())
+                assert H.close(got, exp, rtol=max(rtol, H.RTOL_OUT), atol=atol), (b, bs, np.abs(got - exp).max())
+                ref[(b, bs)] = got
+        jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1)]
+        for mfma in (1, 0):
+            # the matrix-core form (16 samples per workgroup; hidden sizes that are multiples of 16)
+            # and the one-wave-per-sample form run the same fma chains: the same bits
+            eng.set_option("dien_mfma", mfma)
+            outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+            for (b, bs), o in zip(jobs, outs):
+                assert np.array_equal(o, ref[(b, bs)]), (mfma, b, bs)
     finally:
         eng.close()
 
@@ -832,7 +903,7 @@ def test_options_are_per_handle_and_engines_coexist():
                                    ["--set", "sls_exact=1"],
                                    # DIN: the fused gather + attention launch, 1..8 queries per set (its
                                    # samples-per-workgroup shape changes with the set size, its bits must not)
-                                   ["--workload", "din", "--batch", "96"]])
+                                   ["--workload", "din", "--batch", "96"], ["--workload", "dien", "--batch", "64"]])
 def test_pipelined_engine_race_hunt(extra):
     import os
     import subprocess

@@ -170,6 +170,12 @@ def test_inputs_and_weights_bitexact_vs_reference(case):
             for i, (W, b) in enumerate(unit):
                 assert H.sha(W) == dg["blob/atten:::_fc_%d:::fc%d_w" % (u, i + 1)]["sha256"]
                 assert H.sha(b) == dg["blob/atten:::_fc_%d:::fc%d_b" % (u, i + 1)]["sha256"]
+    if args.model_type == "dien":
+        # the values models/dien.py feeds for the two BasicRNN layers (:318-331,350-363)
+        for l in (0, 1):
+            (iw, ib), (gw, gb) = net.rnn_w[l]
+            for nm, a in (("i2h_w", iw), ("i2h_b", ib), ("gates_t_w", gw), ("gates_t_b", gb)):
+                assert H.sha(a) == dg["blob/rnn_%d/%s" % (l, nm)]["sha256"], (l, nm)
     pre = "mlpfc" if args.model_type == "ncf" else "top"
     for i, (W, b) in enumerate(net.top_w):
         assert H.sha(W) == dg["blob/%s:::fc%d_w" % (pre, i + 1)]["sha256"]

@@ -28,7 +28,8 @@ def test_oracle_forward_matches_golden(case):
     # interaction tensor (input of the top MLP) where the fixture has it; RM3's bottom
     # MLP has K=2560 all-positive inputs, so allow cancellation noise relative to max|R|
     key = {"dlrm": "expected/interaction", "wnd": "expected/interaction", "mtwnd": "expected/interaction",
-           "ncf": "expected/feat_int", "din": "expected/top_fc_in"}[args.model_type]
+           "ncf": "expected/feat_int", "din": "expected/top_fc_in",
+           "dien": "expected/gru:::concat"}[args.model_type]
     if key in z.files:
         assert H.close(R, z[key], rtol=2e-5, atol_scale=2e-6)
 
@@ -146,3 +147,40 @@ def test_fill_value_is_deterministic_and_in_range():
     W2 = orc.fill_table_uniform(1000, 32, 3, -0.5, 0.25, 12345, nthreads=4)
     assert np.array_equal(W, W2)
     assert not np.array_equal(W, orc.fill_table_uniform(1000, 32, 4, -0.5, 0.25, 12345))
+
+
+def test_oracle_dien_matches_torch_rnn_fp64():
+    """Independent opinion on the DIEN restatement: torch.nn.RNN (tanh; h_t = tanh(W_ih x_t + b_ih +
+    W_hh h_{t-1} + b_hh), the published BasicRNN recurrence) in float64 over the embeddings in the
+    reference's Reshape order (a row-major reinterpretation of [bs, U*D] as [U, bs, D],
+    models/dien.py:316-320), then the top MLP.  Xavier-scale recurrent weights as in a live run."""
+    import torch
+    D, Hs, B = 16, 32, 5
+    rows = [40, 30, 35, 25, 45, 50, 20, 60]           # 5 behaviour tables
+    T, U = len(rows), len(rows) - 3
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_top="12-3", hidden_size=Hs, num_indices_per_lookup=2, model_type="dien",
+                       numpy_rand_seed=7)
+    np.random.seed(7)
+    net = H.M.DIEN_Net(args)
+    om = H.oracle_model(net)
+    rng = np.random.RandomState(1)
+    lens = [np.full(B, 2, dtype=np.int32) for _ in range(T)]
+    idx = [rng.randint(0, rows[t], size=2 * B).astype(np.int64) for t in range(T)]
+    out, R = om.forward(None, idx, lens, want_R=True)
+    emb = [torch.from_numpy(net.emb_w[t].astype(np.float64))[torch.from_numpy(idx[t]).view(B, 2)].sum(1) for t in range(T)]
+    X = torch.stack(emb[1:T - 2], 1).reshape(U, B, D)
+    rnn = torch.nn.RNN(D, Hs, num_layers=2, nonlinearity="tanh").double()
+    with torch.no_grad():
+        for l in (0, 1):
+            (iw, ib), (gw, gb) = net.rnn_w[l]
+            getattr(rnn, "weight_ih_l%d" % l).copy_(torch.from_numpy(iw.astype(np.float64)))
+            getattr(rnn, "bias_ih_l%d" % l).copy_(torch.from_numpy(ib.astype(np.float64)))
+            getattr(rnn, "weight_hh_l%d" % l).copy_(torch.from_numpy(gw.astype(np.float64)))
+            getattr(rnn, "bias_hh_l%d" % l).copy_(torch.from_numpy(gb.astype(np.float64)))
+        _, hn = rnn(X)
+        x = torch.cat([hn[1], emb[0], emb[T - 2], emb[T - 1]], 1)
+        assert H.close(R, x.numpy(), rtol=1e-5, atol=1e-6), np.abs(R - x.numpy()).max()
+        for W, b in net.top_w:
+            x = torch.relu(x @ torch.from_numpy(W.astype(np.float64)).t() + torch.from_numpy(b.astype(np.float64)))
+    assert H.close(out, x.numpy(), rtol=1e-5, atol=1e-6), np.abs(out - x.numpy()).max()

@@ -26,7 +26,7 @@ import bench
 from deeprecsys_amd import latency_table
 
 MODEL_TO_WORKLOAD = {"rm1": "rmc1_ref", "rm2": "rmc2_ref", "rm3": "rmc3_ref", "rm1_baseline": "rmc1",
-                     "wnd": "wnd", "ncf": "ncf", "mtwnd": "mtwnd", "din": "din"}
+                     "wnd": "wnd", "ncf": "ncf", "mtwnd": "mtwnd", "din": "din", "dien": "dien"}
 
 
 def main():

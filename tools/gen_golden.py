@@ -97,7 +97,9 @@ class _Net(object):
         def emit(inputs, outputs=None, **kwargs):
             ins = [inputs] if isinstance(inputs, str) else [str(i) for i in inputs]
             if outputs is None:
-                outs = []
+                # (Caffe2 names an unnamed output itself; ops with no output at all, e.g.
+                # EnqueueBlobs, never have their return value used)
+                outs = ["%s/%s_auto_%d" % (self._name, op_type, len(self._ops))] if op_type == "Flatten" else []
             elif isinstance(outputs, str):
                 outs = [outputs]
             else:
@@ -191,6 +193,45 @@ def _install_caffe2_recorder():
             self.param_init_net = _Net(name + "_init")
 
     model_helper.ModelHelper = ModelHelper
+
+    # caffe2.python.brew / rnn_cell helpers models/dien.py calls (:336-378).  Recorded as single
+    # composite ops with the blob names Caffe2's helpers give their parameters (scope/i2h_w, ...,
+    # which models/dien.py itself spells out when it feeds them, :323-331,355-363); parameters
+    # the helper would create through param_init_net get a "ParamInit" record instead of values.
+    auto = {"n": 0}
+
+    def fresh(prefix):
+        auto["n"] += 1
+        return "%s_auto_%d" % (prefix, auto["n"])
+
+    def brew_fc(model, blob_in, blob_out, dim_in, dim_out, axis=1, **kw):
+        out = blob_out or fresh("fc")
+        w, b = out + "_w", out + "_b"
+        model.param_init_net.XavierFill([], [w], shape=str([dim_out, dim_in]))
+        model.param_init_net.ConstantFill([], [b], shape=str([dim_out]))
+        return model.net.FC([blob_in, w, b], out, axis=axis)
+
+    def brew_softmax(model, blob_in, blob_out=None, axis=1, **kw):
+        return model.net.Softmax(blob_in, blob_out or fresh("softmax"), axis=axis)
+
+    def brew_sum(model, blob_in, blob_out, **kw):
+        # caffe2/python/helpers/algebra.py: sum(model, blob_in, blob_out) = model.net.Sum(blob_in, blob_out)
+        return model.net.Sum(blob_in, blob_out, **kw)
+
+    def basic_rnn(model, input_blob, seq_lengths, initial_states, dim_in, dim_out, scope, activation=None,
+                  forward_only=False, **kw):
+        for nm, shape in (("i2h_w", [dim_out, dim_in]), ("i2h_b", [dim_out]), ("gates_t_w", [dim_out, dim_out]),
+                          ("gates_t_b", [dim_out])):
+            fill = "XavierFill" if nm.endswith("_w") else "ConstantFill"
+            getattr(model.param_init_net, fill)([], [scope + "/" + nm], shape=str(shape))
+        outs = model.net.BasicRNN([input_blob, seq_lengths, initial_states[0], scope + "/i2h_w", scope + "/i2h_b",
+                                   scope + "/gates_t_w", scope + "/gates_t_b"],
+                                  [scope + "/hidden_t_all", scope + "/hidden_t_last"], dim_in=dim_in,
+                                  dim_out=dim_out, activation=activation, forward_only=forward_only)
+        return outs
+
+    python.brew.fc, python.brew.softmax, python.brew.sum = brew_fc, brew_softmax, brew_sum
+    python.rnn_cell.BasicRNN = basic_rnn
     python.core, python.workspace, python.model_helper = core, workspace, model_helper
     python._import_c_extension = cext
     caffe2.proto, caffe2.python, proto.caffe2_pb2 = proto, python, pb2
@@ -266,7 +307,7 @@ def capture_model(case, ref, argv, queue_requests=None):
     nb, lT = datagen.generate_output_data()
     wrapper_cls = {"dlrm": ref["DLRM_Wrapper"], "wnd": ref["Wide_and_Deep_Wrapper"],
                    "ncf": ref["NCF_Wrapper"], "mtwnd": ref.get("MT_Wide_and_Deep_Wrapper"),
-                   "din": ref.get("DIN_Wrapper")}[args.model_type]
+                   "din": ref.get("DIN_Wrapper"), "dien": ref.get("DIEN_Wrapper")}[args.model_type]
     with mock.patch("builtins.print"):
         model = wrapper_cls(args)
         model.create(lX[0], lS_l[0], lS_i[0], lT[0])
@@ -275,9 +316,13 @@ def capture_model(case, ref, argv, queue_requests=None):
                        "(inputs, cli); expected_* are restated by oracle/c2ops.py")
     fx.meta["argv"] = list(argv)
     fx.meta["args"] = jsonable(vars(args))
-    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF", "mtwnd": "MT_Wide_and_Deep", "din": "DIN"}[args.model_type]
+    net_name = {"dlrm": "DLRM", "wnd": "Wide_and_Deep", "ncf": "NCF", "mtwnd": "MT_Wide_and_Deep", "din": "DIN",
+                "dien": "DIEN"}[args.model_type]
     ops = [op for op in REC.ops if op["net"] == net_name]
     fx.meta["ops"] = ops
+    # parameters Caffe2's helpers would (re)initialise when create() runs param_init_net
+    # (models/dien.py:528): their values in the real reference come from Caffe2's own RNG
+    fx.meta["param_init_ops"] = [op for op in REC.ops if op["net"] == net_name + "_init"]
     fx.meta["feed_order"] = [n for n, _ in REC.feeds]
     fx.meta["feed_dtypes"] = {n: str(a.dtype) for n, a in REC.feeds}
     fx.meta["events"] = REC.events
@@ -308,7 +353,8 @@ def capture_model(case, ref, argv, queue_requests=None):
     ws = c2ops.run_ops(run_ops_list, blobs, queues)
     for op in ops:
         for o in op["outputs"]:
-            if o in ws and not o.endswith("_info") and op["type"] not in ("DequeueBlobs",):
+            if o in ws and ws[o] is not c2ops.UNAVAILABLE and not o.endswith("_info") \
+                    and op["type"] not in ("DequeueBlobs",):
                 fx.put("expected/" + o, ws[o])
     fx.meta["output_blob"] = "prob_click"
     if args.model_type == "mtwnd":
@@ -515,13 +561,32 @@ def main():
         from models.ncf import NCF_Wrapper
         from models.multi_task_wnd import MT_Wide_and_Deep_Wrapper
         from models.din import DIN_Wrapper
+        from models.dien import DIEN_Wrapper
         from inferenceEngine import inferenceEngine
     finally:
         os.chdir(cwd)
     ref = dict(cli=cli, ServiceRequest=ServiceRequest, DLRMDataGenerator=DLRMDataGenerator,
                DLRM_Wrapper=DLRM_Wrapper, Wide_and_Deep_Wrapper=Wide_and_Deep_Wrapper,
                NCF_Wrapper=NCF_Wrapper, inferenceEngine=inferenceEngine,
-               MT_Wide_and_Deep_Wrapper=MT_Wide_and_Deep_Wrapper, DIN_Wrapper=DIN_Wrapper)
+               MT_Wide_and_Deep_Wrapper=MT_Wide_and_Deep_Wrapper, DIN_Wrapper=DIN_Wrapper,
+               DIEN_Wrapper=DIEN_Wrapper)
+
+    def dien():
+        # Deep Interest Evolution Network (models/dien.py): the shipped top MLP, shrunk tables, FOUR
+        # behaviour tables, hidden size 8.  The recurrent weights in this fixture are the values
+        # models/dien.py FEEDS (np.random.randn, :318-331,350-363) -- in a live Caffe2 run create()
+        # then runs param_init_net (:528), which re-draws them from Caffe2's own RNG; see
+        # meta["param_init_ops"].  randn weights at hidden size 64 put the recurrence deep in the
+        # chaotic regime, hence the small hidden size here.
+        capture_model("dien_mini", ref, ["--model_type", "dien", "--model_name", "dien", "--arch_mlp_bot", "512",
+                                         "--arch_mlp_top", "200-80-2",
+                                         "--arch_embedding_size", "300-200-250-150-220-400-500",
+                                         "--arch_sparse_feature_size", "32", "--num_indices_per_lookup", "1",
+                                         "--num_indices_per_lookup_fixed", "1", "--arch_interaction_op", "cat",
+                                         "--hidden_size", "8", "--num_batches", "1",
+                                         "--max_mini_batch_size", "6", "--mini_batch_size", "6"])
+    if opt.only == "dien_mini":
+        return dien()
 
     def din():
         # Deep Interest Network (models/din.py): the shipped widths, shrunk tables, SIX behaviour

@@ -64,7 +64,7 @@ def main():
         lens = [np.full(B, L, dtype=np.int32) for _ in range(T)]
         for b in range(nb):
             idx = [per_table[t][b * B * L:(b + 1) * B * L] for t in range(T)]
-            eng.stage_batch(b, None if w.get("kind") in ("ncf", "din") else lX[b], idx, lens)
+            eng.stage_batch(b, None if w.get("kind") in ("ncf", "din", "dien") else lX[b], idx, lens)
             lS_i[b] = idx
     distinct = float(np.mean([np.unique(np.concatenate([lS_i[b][t] for b in range(min(8, nb))])).size
                               for t in range(T)])) / (min(8, nb) * B * L)
