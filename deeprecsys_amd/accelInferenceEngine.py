@@ -56,7 +56,7 @@ def _build_hip_model(args, engine_id):
     ndev = max(_native.device_count(), 1)
     args._drs_device = (int(getattr(args, "accel_device_offset", 0)) + int((engine_id or 0) - first)) % ndev
     if args.model_type not in M.WRAPPERS:
-        raise SystemExit("Model type %r has no accelerator path (dlrm | wnd | ncf)" % args.model_type)
+        raise SystemExit("Model type %r has no accelerator path (%s)" % (args.model_type, " | ".join(sorted(M.WRAPPERS))))
     datagen = DLRMDataGenerator(args)
     nbatches, lX, lS_l, lS_i = datagen.generate_input_data()
     nbatches, lT = datagen.generate_output_data()

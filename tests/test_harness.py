@@ -247,6 +247,28 @@ def test_harness_with_a_real_accelerator_engine(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model_type,extra", [
+    ("din", dict(arch_mlp_bot="1", arch_mlp_top="24-2", arch_embedding_size="300-200-200-200-400-500",
+                 arch_sparse_feature_size=32, num_indices_per_lookup=3)),
+    ("dien", dict(arch_mlp_top="24-2", arch_embedding_size="300-200-200-200-400-500", hidden_size=16,
+                  arch_sparse_feature_size=32, num_indices_per_lookup=1)),
+    ("mtwnd", dict(arch_mlp_bot="16", arch_mlp_top="32-8", arch_mlp_tasks="8-4-1", num_multi_tasks=2,
+                   arch_embedding_size="300-200-400", arch_sparse_feature_size=16, num_indices_per_lookup=1,
+                   arch_interaction_op="cat")),
+])
+def test_harness_serves_every_model_type_on_a_real_accelerator(tmp_path, model_type, extra):
+    """The reference's engines are built per model_type (inferenceEngine.py:100-135); the accelerator
+    engine here serves the same set through the queue harness -- DIN, DIEN and MT-WnD beside the DLRM /
+    W&D / NCF cases above."""
+    a = _args(tmp_path, accel_backend="hip", num_accels=1, model_type=model_type, model_name=model_type,
+              num_indices_per_lookup_fixed=True, **extra)
+    s = DeepRecSys(a, quiet=True)
+    assert s["accel_requests"] == 16 and s["responses"] == 16
+    lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
+    assert all(l["out_batch_size"] == l["batch_size"] for l in lines)
+
+
+@pytest.mark.gpu
 def test_mixed_wnd_ncf_stream_on_a_real_accelerator(tmp_path):
     """W&D and NCF resident on the same GPU, one engine process serving the mixed stream
     (requests coalesce per model, never across models)."""

@@ -309,3 +309,17 @@ def test_trace_profile_and_distribution_equal_reference(tmp_path):
     assert abs(new_share - 0.45) < 0.05
     bags = TG.bags_from_trace(syn, 50, 80)
     assert bags.dtype == np.int64 and bags.size == 4000 and bags.max() < 5000
+
+
+def test_measured_mi355x_tables_load_like_the_reference_tables():
+    """profiles/accelerator_mi355x/ is a drop-in for the reference's accelerator/ directory:
+    GPU_Data reads a results_<model>.txt for EVERY model name it knows (wnd, rm1-3, ncf, mtwnd,
+    din, dien; accelerator/predict_execution.py:49-62) and predict_time interpolates in it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        "accelerator_mi355x") + os.sep
+    gd = latency_table.GPU_Data(root_dir=root, hardware="amd_mi355x")
+    for m in latency_table.MODELS:
+        t = getattr(gd, m + "_exec_time")
+        assert t.shape == (6,) and np.all(t > 0), m
+        mid = float(latency_table.predict_time(m, 32, gd))
+        assert min(t[2], t[3]) <= mid <= max(t[2], t[3]), m     # 16 < 32 < 64
