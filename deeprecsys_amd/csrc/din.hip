@@ -590,17 +590,26 @@ __global__ __launch_bounds__(256) void dien_rnn_kernel(const float* __restrict__
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 struct DienW { const float* w[8]; };   // {i2h_w, i2h_b, gates_t_w, gates_t_b} x 2 layers, row-major [out, in]
 
-template <int D, int H>
-__global__ __launch_bounds__(64 * (H / 16)) void dien_rnn_mfma_kernel(const float* __restrict__ T, int64_t ldt, QTable q,
+template <int D, int H, int GR>
+__global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const float* __restrict__ T, int64_t ldt, QTable q,
                                                                       int Tn, DienW W, float* __restrict__ R, int64_t ldr) {
   static_assert(D % 4 == 0 && H % 16 == 0 && H <= 64, "16 hidden units per wave");
+  // GR groups of H / 16 waves, each group an independent set of 16 samples.  GR = 2 (two waves per
+  // SIMD, one group's MFMA chains under the other's LDS / tanh / barrier latency) was measured: the
+  // launch takes 130 us on half as many CUs instead of 76 us -- 17 % more work per CU and second, but
+  // every query waits longer, and at 3 launch sets in flight the throughput is the same (123 k vs
+  // 125-130 k queries/s); GR = 1 is launched.
   constexpr int NW = H / 16;
-  __shared__ float s0[2][H][16], s1[2][H][16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float s0g[GR][2][H][16], s1g[GR][2][H][16];
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW, grp = (threadIdx.x >> 6) / NW;
+  const int tid_g = threadIdx.x - grp * 64 * NW;         // thread index inside the group
+  float (*s0)[H][16] = s0g[grp];
+  float (*s1)[H][16] = s1g[grp];
   const int r = lane & 15, g = lane >> 4;
   const int n_smp = q.cum[q.n_q];
-  const int smp = min((int)blockIdx.x * 16 + r, n_smp - 1);
-  const bool live = (int)blockIdx.x * 16 + r < n_smp;
+  const int smp_base = ((int)blockIdx.x * GR + grp) * 16;
+  const int smp = min(smp_base + r, n_smp - 1);
+  const bool live = smp_base + r < n_smp;
   int b = smp, bs = q.bs[0], v0 = q.vstart[0];
 #pragma unroll
   for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void dien_rnn_mfma_kernel(const floa
     const int hid = 16 * wave + 4 * g + qd;
     bi0[qd] = W.w[1][hid]; bg0[qd] = W.w[3][hid]; bi1[qd] = W.w[5][hid]; bg1[qd] = W.w[7][hid];
   }
-  for (int i = threadIdx.x; i < 2 * H * 16; i += 64 * NW) {   // initial_h = 0 (models/dien.py:498-499)
+  for (int i = tid_g; i < 2 * H * 16; i += 64 * NW) {         // initial_h = 0 (models/dien.py:498-499)
     (&s0[0][0][0])[i] = 0.f;
     (&s1[0][0][0])[i] = 0.f;
   }
@@ -706,8 +715,8 @@ __global__ __launch_bounds__(64 * (H / 16)) void dien_rnn_mfma_kernel(const floa
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) out[16 * wave + 4 * g + qd] = h1v[qd];
   }
-  for (int i = threadIdx.x; i < 16 * 3 * D; i += 64 * NW) {
-    const int smp_i = (int)blockIdx.x * 16 + i / (3 * D), c = i % (3 * D);
+  for (int i = tid_g; i < 16 * 3 * D; i += 64 * NW) {
+    const int smp_i = smp_base + i / (3 * D), c = i % (3 * D);
     if (smp_i >= n_smp) break;
     int bi = smp_i, vi = q.vstart[0];
 #pragma unroll
@@ -725,9 +734,9 @@ template <int D>
 bool launch_dien_mfma_h(const float* T, int64_t ldt, const QTable& q, int Tn, int H, const DienW& W, float* R,
                         int64_t ldr, unsigned grid, hipStream_t s) {
   switch (H) {
-    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16>), dim3(grid), dim3(64), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 1>), dim3(grid), dim3(64), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 1>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 1>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
     default: return false;
   }
 }

@@ -1,14 +1,18 @@
 #!/bin/bash
-# scratch: full GPU suite + DIEN bench + characterisation
 mkdir -p gpurun_out/dien
-timeout 2700 python -m pytest tests -x -q -m gpu > gpurun_out/dien/tests_all.log 2>&1
-echo "tests rc=$?" >> gpurun_out/dien/tests_all.log
-tail -4 gpurun_out/dien/tests_all.log
-timeout 600 python bench.py --workload dien > gpurun_out/dien/bench_dien.json 2> gpurun_out/dien/bench_dien.err
+timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "dien and not race" > gpurun_out/dien/tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/dien/tests.log
+tail -5 gpurun_out/dien/tests.log
+for sl in 3 4 6; do
+timeout 600 python bench.py --workload dien --steps 6 --warmup 2 --queries_per_step 2048 --no_cpu_baseline --slots $sl > gpurun_out/dien/bench_x.json 2> gpurun_out/dien/bench_x.err
 python - <<PY
 import json
-d=json.load(open("gpurun_out/dien/bench_dien.json"))
+d=json.load(open("gpurun_out/dien/bench_x.json"))
 r=d["roofline"]
-print("dien", d["value"], "q/s p99", d["latency_ms"]["p99"], "gather us", r["avg_launch_us"], "frac", r["frac"], "single", r["single_query_launch"], "host", d["host_inputs_leg"]["value"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["legs"]["oracle_port"]["value"])
+print("slots $sl", d["value"], "q/s p99", d["latency_ms"]["p99"], "gather us", r["avg_launch_us"], "single", r["single_query_launch"]["avg_launch_us"], "set_end", r.get("gather_end_to_set_end_event_us"))
 PY
-timeout 600 python tools/characterize.py --model dien --out gpurun_out/accelerator_mi355x/ > gpurun_out/dien/char.log 2>&1; tail -8 gpurun_out/dien/char.log
+done
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/dien/prof -o dien -- python /root/repo/bench.py --workload dien --steps 4 --warmup 2 --queries_per_step 2048 --timed_only > /root/repo/gpurun_out/dien/prof.log 2>&1
+cd /root/repo
+f=$(find gpurun_out/dien/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -4 "$f" | cut -c1-200
