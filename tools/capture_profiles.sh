@@ -67,7 +67,7 @@ pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
-for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf mtwnd; do
+for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf mtwnd din dien; do
   run 400 python bench.py --workload $w --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 4096 > "$OUT/bench_$w.json" 2>/dev/null
   run 400 python bench.py --workload $w --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 --set shared_stream=1 > "$OUT/bench_${w}_single_stream.json" 2>/dev/null
 done
@@ -75,8 +75,22 @@ run 400 python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --steps 5 
 run 600 python bench.py --workload rmc3 --batch 512 --steps 3 --warmup 1 --queries_per_step 2048 --timed_only > /dev/null 2>&1
 # CPU baseline legs on the MLP-bound shapes as well (port + torch)
 run 600 python bench.py --workload wnd --steps 3 --warmup 1 --queries_per_step 4096 > "$OUT/bench_wnd_cpu.json" 2>/dev/null
+# 5b. DIN (fused gather + attention launch) and DIEN (recurrence on the matrix cores): per-kernel
+#     summaries, HBM traffic of the fused launch, MFMA-busy of the recurrent launch, CPU legs
+DN="python bench.py --workload din --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048"
+DE="python bench.py --workload dien --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048"
+trace din $DN
+trace dien $DE
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  pmc "$OUT/din_pmc_summary.txt" "$pass" $DN
+done
+pmc "$OUT/dien_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $DE
+run 400 python bench.py --workload din --steps 5 --warmup 2 --queries_per_step 4096 --cpu_seconds 6 > "$OUT/bench_din_cpu.json" 2>/dev/null
+run 400 python bench.py --workload dien --steps 5 --warmup 2 --queries_per_step 4096 --cpu_seconds 6 > "$OUT/bench_dien_cpu.json" 2>/dev/null
+run 300 python bench.py --workload din --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048 --set din_fused=0 > "$OUT/bench_din_two_launch.json" 2>/dev/null
+run 300 python bench.py --workload dien --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048 --set dien_mfma=0 > "$OUT/bench_dien_valu.json" 2>/dev/null
 # 6. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
-for m in rm1 rm2 rm3 wnd ncf mtwnd; do
+for m in rm1 rm2 rm3 wnd ncf mtwnd din dien; do
   run 300 python tools/characterize.py --model $m --out "$OUT/accelerator_mi355x/" > "$OUT/characterize_$m.txt" 2>&1
 done
 # 7. the queue harness end to end: one accel engine, RMC1 and the W&D + NCF mixed stream
