@@ -9,7 +9,11 @@
  * What is restated (paths into the reference tree, harvard-acc/DeepRecSys):
  *   - the operator graph emitted by models/dlrm_s_caffe2.py:367-389
  *     (create_emb :281-329, create_mlp :223-279, create_interactions :331-365),
- *     models/wide_and_deep.py:282-305 and models/ncf.py:317-346;
+ *     models/wide_and_deep.py:282-305, models/ncf.py:317-346,
+ *     models/multi_task_wnd.py:286-316, models/din.py:247-330 and
+ *     models/dien.py:308-432 (rnn_cell.BasicRNN = caffe2.python.rnn_cell's
+ *     BasicRNNCell: i2h FC over all steps, per step gates_t FC of the previous
+ *     state, Sum, Tanh);
  *   - the Caffe2 operator arithmetic those builders invoke.  Caffe2 is a
  *     third-party dependency that is NOT in the reference tree (it ships inside
  *     torch==1.4.0+cu92, build/pip_requirements.txt:28), so the operator
@@ -30,13 +34,20 @@
  *   pinned  : SparseLengthsSum / FC arithmetic -- against torch-CPU
  *             embedding_bag(sum) / addmm, the lineal descendants of the Caffe2
  *             kernels (tests/test_oracle.py);
+ *   pinned  : the BasicRNN recurrence -- against torch.nn.RNN in fp64
+ *             (tests/test_oracle.py::test_oracle_dien_matches_torch_rnn_fp64);
  *   UNPINNED: outputs of the reference executing on Caffe2 itself -- Caffe2 is
- *             not installable here, so no reference-run output vector exists.
+ *             not installable here, so no reference-run output vector exists;
+ *   UNPINNED: DIEN's recurrent WEIGHTS in a live reference run -- models/dien.py
+ *             feeds numpy values (:318-331) that create() then overwrites by
+ *             running Caffe2's param_init_net (:528, XavierFill from Caffe2's own
+ *             RNG); the fixture holds the fed values and the list of re-initialised
+ *             blobs.
  *
  * FC accumulation order: the reference's sgemm order (MKL/Eigen) is not
  * observable, so the oracle fixes a definite one -- a k-ordered fp32 fma chain
  * from 0, bias added after -- which is also exactly what the gfx950
- * v_mfma_f32_32x32x2_f32 path computes, making GPU-vs-oracle comparisons
+ * v_mfma_f32_16x16x4_f32 path computes, making GPU-vs-oracle comparisons
  * bitwise up to the final expf.
  */
 #include <math.h>
