@@ -459,7 +459,9 @@ def main():
     bs, nb, slots, co = opt.batch, opt.num_batches, opt.slots, opt.coalesce
     qps_ = max(1, opt.queries_per_step)
     n_timed, n_warm = opt.steps * qps_, opt.warmup * qps_
-    stream_mode = {2: "pipelined (gathers back to back on one stream, MLP launches on a second)",
+    n_mlp = eng.get_option("mlp_streams")
+    stream_mode = {2: "pipelined (gathers back to back on one stream, MLP launches on %s)"
+                      % ("a second" if n_mlp == 1 else "%d more, alternating" % n_mlp),
                    1: "single stream", 0: "one stream per launch set"}[eng.get_option("shared_stream")]
 
     def barrier():

@@ -1128,6 +1128,21 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     for (const Mlp& rn : e->rnn) flop += 2.0 * (T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
     const double bytes = (double)T * e->max_lookups * D * 4.0;
     e->mlp_streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
+    // In between: a gather-bound model whose full launch set (2 048 rows) gathers FASTER than its
+    // latency-bound MLP launch runs -- the reference's own dlrm_rm1.json (D = 32: 175 MB per set,
+    // 33 us, against a 40 us stream-kernel launch that covers half the chip).  Two MLP streams let
+    // consecutive MLP launches overlap and hand the pace back to the gather (measured: RM1
+    // reference JSON 186 k -> 200 k queries/s; RMC1 BASELINE 128 k -> 134 k, within noise; DIN,
+    // whose top MLP is a 20 us launch, 158 k -> 147 k -- hence the estimate instead of a blanket 2).
+    // Estimates fitted to those three launches: gather at 5.5 TB/s, MLP launch 12 us + 1 us per
+    // 4 500 weights.
+    if (e->mlp_streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
+      double weights = 0;
+      for (const Mlp* mm : {&e->bot, &e->top})
+        for (size_t i = 0; i + 1 < mm->ln.size(); ++i) weights += (double)mm->ln[i] * mm->ln[i + 1];
+      const double gather_us = 2048.0 * bytes / 5.5e6, mlp_us = 12.0 + weights / 4500.0;
+      if (mlp_us > gather_us) e->mlp_streams = 2;
+    }
   }
   apply_stream_mode(e);
 #undef CREATE_TRY
