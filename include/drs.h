@@ -286,6 +286,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_gemm"   1 (default) stand-alone wide layers run as the register-blocked gemm_kernel
  *                (gemm.hip) | 0 fc_kernel;  "mlp_gemm_tile" 0 (default: by workgroup count)
  *                | 22 | 12 | 21 | 11 forces the per-wave tile shape
+ *                ("mlp_gemm_min_blocks", default 128: the full 2 x 2 tile is kept while it still gives
+ *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference)
  *   "mlp_stream" 1 (default) chains run as the weight-tile stream kernel (tiles of all layers
  *                requested six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and
  *                the slabs fit | 0 always the per-layer chain kernel.  Same bits either way.
