@@ -583,31 +583,33 @@ __global__ __launch_bounds__(256) void dien_rnn_kernel(const float* __restrict__
 // everything) -- D[m = hidden 4 g + q][n = sample r].  Same bits as dien_rnn_kernel.
 // Cost: (D + 3 H) / 4 = 56 MFMAs of 32 cycles per wave and step at D 32 / H 64, 16 samples at a
 // time, against 2 x 112 dependent VALU fmas per SAMPLE in the one-wave-per-sample form.
-// Measured on dien.json's shape (40 steps, 2048 samples per launch = 128 workgroups): 76 us per
-// launch against 112 us; per step 1.9 us = 0.8 MFMA + 0.2 tanh + 0.2 barrier + 0.7 LDS / issue
-// latency that one wave per SIMD cannot hide -- the engine therefore lets the launches of
-// consecutive sets overlap on separate streams (each covers half the chip): 51 k -> 130 k queries/s.
+// Measured on dien.json's shape (40 steps, 2048 samples per launch = 128 workgroups): every wave
+// running both layers 76 us per launch (the VALU form: 112 us); per step 1.9 us = 0.8 MFMA + 0.2 tanh
+// + 0.2 barrier + 0.7 LDS / issue latency that one wave per SIMD cannot hide.  One wave set per
+// layer (SPLIT, the default: 24 / 32 MFMAs per wave and step, two waves per SIMD): 66 us.  The engine
+// also lets the launches of consecutive sets overlap on separate streams (each covers half the
+// chip): 51 k -> 127 k (both layers per wave) -> 141 k queries/s (SPLIT).
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 struct DienW { const float* w[8]; };   // {i2h_w, i2h_b, gates_t_w, gates_t_b} x 2 layers, row-major [out, in]
 
-template <int D, int H, int GR>
-__global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const float* __restrict__ T, int64_t ldt, QTable q,
-                                                                      int Tn, DienW W, float* __restrict__ R, int64_t ldr) {
+template <int D, int H, int SPLIT>
+__global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma_kernel(const float* __restrict__ T, int64_t ldt,
+                                                                                     QTable q, int Tn, DienW W,
+                                                                                     float* __restrict__ R, int64_t ldr) {
   static_assert(D % 4 == 0 && H % 16 == 0 && H <= 64, "16 hidden units per wave");
-  // GR groups of H / 16 waves, each group an independent set of 16 samples.  GR = 2 (two waves per
-  // SIMD, one group's MFMA chains under the other's LDS / tanh / barrier latency) was measured: the
-  // launch takes 130 us on half as many CUs instead of 76 us -- 17 % more work per CU and second, but
-  // every query waits longer, and at 3 launch sets in flight the throughput is the same (123 k vs
-  // 125-130 k queries/s); GR = 1 is launched.
-  constexpr int NW = H / 16;
-  __shared__ float s0g[GR][2][H][16], s1g[GR][2][H][16];
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW, grp = (threadIdx.x >> 6) / NW;
-  const int tid_g = threadIdx.x - grp * 64 * NW;         // thread index inside the group
-  float (*s0)[H][16] = s0g[grp];
-  float (*s1)[H][16] = s1g[grp];
+  // SPLIT = 1: 2 x H / 16 waves; the first H / 16 run layer 1 (of step t + 1), the others layer 2
+  // (of step t) -- the two layers of an iteration are independent, so the per-step critical path of
+  // a wave is 24 or 32 MFMAs instead of 56, at two waves per SIMD.  SPLIT = 0: every wave runs both
+  // layers of its 16 hidden units (four interleaved chains).  Same bits.
+  // (Two independent 16-sample groups per workgroup, the other way to put two waves on a SIMD, was
+  // measured as well: 130 us on half as many CUs instead of 76 us, no gain in queries/s.)
+  constexpr int NW = H / 16, NT = 64 * (SPLIT ? 2 : 1) * NW;
+  __shared__ float s0[2][H][16], s1[2][H][16];
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW, role = (threadIdx.x >> 6) / NW;
+  const bool do1 = !SPLIT || role == 0, do2 = !SPLIT || role == 1;   // (wave-uniform)
   const int r = lane & 15, g = lane >> 4;
   const int n_smp = q.cum[q.n_q];
-  const int smp_base = ((int)blockIdx.x * GR + grp) * 16;
+  const int smp_base = (int)blockIdx.x * 16;
   const int smp = min(smp_base + r, n_smp - 1);
   const bool live = smp_base + r < n_smp;
   int b = smp, bs = q.bs[0], v0 = q.vstart[0];
@@ -619,25 +621,33 @@ __global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const
     v0 = in ? q.vstart[i] : v0;
   }
   const int U = Tn - 3;
-  // A operands: lane (r, g) holds W[16 w + r][4 s + g] of every MFMA step s
+  // A operands: lane (r, g) holds W[16 w + r][4 s + g] of every MFMA step s -- the i2h and gates_t
+  // rows of the layer(s) this wave runs
   const int row = 16 * wave + r;
-  float wi0[D / 4], wg0[H / 4], wi1[H / 4], wg1[H / 4];
+  float wia[SPLIT ? (D > H ? D : H) / 4 : D / 4], wga[H / 4];      // layer 1 (or, SPLIT role 1, layer 2)
+  float wib[SPLIT ? 1 : H / 4], wgb[SPLIT ? 1 : H / 4];            // layer 2 when one wave runs both
+  float bia[4], bga[4], bib[4], bgb[4];
+  const int la = (SPLIT && role == 1) ? 1 : 0;                       // layer held in the "a" set
+  const int Ka = la == 0 ? D : H;
 #pragma unroll
-  for (int s = 0; s < D / 4; ++s) wi0[s] = W.w[0][row * D + 4 * s + g];
+  for (int s = 0; s < (int)(sizeof(wia) / sizeof(float)); ++s) wia[s] = 4 * s < Ka ? W.w[4 * la + 0][row * Ka + 4 * s + g] : 0.f;
 #pragma unroll
-  for (int s = 0; s < H / 4; ++s) {
-    wg0[s] = W.w[2][row * H + 4 * s + g];
-    wi1[s] = W.w[4][row * H + 4 * s + g];
-    wg1[s] = W.w[6][row * H + 4 * s + g];
+  for (int s = 0; s < H / 4; ++s) wga[s] = W.w[4 * la + 2][row * H + 4 * s + g];
+  if (!SPLIT) {
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) {
+      wib[s] = W.w[4][row * H + 4 * s + g];
+      wgb[s] = W.w[6][row * H + 4 * s + g];
+    }
   }
   // biases of the 4 output rows this lane holds: hidden 16 w + 4 g + qd
-  float bi0[4], bg0[4], bi1[4], bg1[4];
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const int hid = 16 * wave + 4 * g + qd;
-    bi0[qd] = W.w[1][hid]; bg0[qd] = W.w[3][hid]; bi1[qd] = W.w[5][hid]; bg1[qd] = W.w[7][hid];
+    bia[qd] = W.w[4 * la + 1][hid]; bga[qd] = W.w[4 * la + 3][hid];
+    bib[qd] = SPLIT ? 0.f : W.w[5][hid]; bgb[qd] = SPLIT ? 0.f : W.w[7][hid];
   }
-  for (int i = tid_g; i < 2 * H * 16; i += 64 * NW) {         // initial_h = 0 (models/dien.py:498-499)
+  for (int i = threadIdx.x; i < 2 * H * 16; i += NT) {         // initial_h = 0 (models/dien.py:498-499)
     (&s0[0][0][0])[i] = 0.f;
     (&s1[0][0][0])[i] = 0.f;
   }
@@ -648,6 +658,7 @@ __global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const
   constexpr int NB = 4;
   float xr[NB][D / 4];
   auto fetch_x = [&](int t, float (&xb)[D / 4]) {
+    if (!do1) return;
     const int tt = min(t, U - 1);
     const int n = tt * bs + b;
     const int src = n / U, unit = n - src * U;
@@ -659,23 +670,28 @@ __global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const
   for (int j = 0; j < NB; ++j) fetch_x(j, xr[j]);              // slot j % NB holds x_j
   __syncthreads();
   // Layer 2 runs one step behind layer 1: an iteration holds layer 2 of step t and layer 1 of step
-  // t + 1, which do not depend on each other -- the tanh (VALU) of one overlaps the MFMA chains of the
-  // other, and ONE barrier per iteration orders the double-buffered state exchange.
+  // t + 1, which do not depend on each other, and ONE barrier per iteration orders the
+  // double-buffered state exchange.
   //   s0[t & 1] = layer-1 state after step t,  s1[t & 1] = layer-2 state after step t
-  f32x4_ h1v = {0.f, 0.f, 0.f, 0.f};
-  {
-    // step 0 of layer 1: its previous state is the zero buffer s0[1]
+  auto layer1 = [&](int rd, int wr, const float (&xb)[D / 4]) {   // x_t, state s0[rd] -> s0[wr]
     f32x4_ aa = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wi0[s], xr[0][s], aa, 0, 0, 0);
+    for (int s = 0; s < H / 4; ++s) {
+      ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wga[s], s0[rd][4 * s + g][r], ag, 0, 0, 0);
+      if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
+    }
 #pragma unroll
-    for (int s = 0; s < H / 4; ++s) ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wg0[s], s0[1][4 * s + g][r], ag, 0, 0, 0);
+    for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd)
-      s0[0][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bg0[qd]) + (aa[qd] + bi0[qd]));
+      s0[wr][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bga[qd]) + (aa[qd] + bia[qd]));
+  };
+  f32x4_ h1v = {0.f, 0.f, 0.f, 0.f};
+  if (do1) {
+    layer1(1, 0, xr[0]);            // step 0 of layer 1: its previous state is the zero buffer s0[1]
     fetch_x(NB, xr[0]);
-    __syncthreads();
   }
+  __syncthreads();
   for (int t0 = 0; t0 < U; t0 += NB) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -684,38 +700,57 @@ __global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const
       const int cur = t & 1, prv = cur ^ 1;
       float (&xb)[D / 4] = xr[(j + 1) % NB];             // x_{t+1}: t0 is a multiple of NB
       // layer 2, step t: input = layer-1 state of step t (s0[cur]), previous own state s1[prv];
-      // layer 1, step t + 1: input x_{t+1}, previous state s0[cur]; writes s0[prv].
-      // The four chains are issued round-robin (independent MFMAs back to back).  After the last
-      // step layer 1 computes one step too many into the unused buffer: cheaper than a divergent tail.
-      f32x4_ ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-      f32x4_ aa = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f};
+      // layer 1, step t + 1: input x_{t+1}, previous state s0[cur]; writes s0[prv].  (After the last
+      // step layer 1 computes one step too many into the unused buffer: cheaper than a divergent tail.)
+      if (SPLIT) {
+        if (role == 0) {
+          layer1(cur, prv, xb);
+          fetch_x(t + 1 + NB, xb);
+        } else {
+          f32x4_ ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < H / 4; ++s) {
-        const float h0k = s0[cur][4 * s + g][r];
-        ba = __builtin_amdgcn_mfma_f32_16x16x4f32(wi1[s], h0k, ba, 0, 0, 0);
-        bg = __builtin_amdgcn_mfma_f32_16x16x4f32(wg1[s], s1[prv][4 * s + g][r], bg, 0, 0, 0);
-        ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wg0[s], h0k, ag, 0, 0, 0);
-        if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wi0[s], xb[s], aa, 0, 0, 0);
-      }
+          for (int s = 0; s < H / 4; ++s) {
+            ba = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], s0[cur][4 * s + g][r], ba, 0, 0, 0);
+            bg = __builtin_amdgcn_mfma_f32_16x16x4f32(wga[s], s1[prv][4 * s + g][r], bg, 0, 0, 0);
+          }
 #pragma unroll
-      for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wi0[s], xb[s], aa, 0, 0, 0);
-      fetch_x(t + 1 + NB, xb);
+          for (int qd = 0; qd < 4; ++qd) {
+            h1v[qd] = tanh_rnn((bg[qd] + bga[qd]) + (ba[qd] + bia[qd]));
+            s1[cur][16 * wave + 4 * g + qd][r] = h1v[qd];
+          }
+        }
+      } else {
+        // one wave, four chains issued round-robin (independent MFMAs back to back)
+        f32x4_ ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+        f32x4_ aa = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        h1v[qd] = tanh_rnn((bg[qd] + bg1[qd]) + (ba[qd] + bi1[qd]));
-        s1[cur][16 * wave + 4 * g + qd][r] = h1v[qd];
-        s0[prv][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bg0[qd]) + (aa[qd] + bi0[qd]));
+        for (int s = 0; s < H / 4; ++s) {
+          const float h0k = s0[cur][4 * s + g][r];
+          ba = __builtin_amdgcn_mfma_f32_16x16x4f32(wib[s], h0k, ba, 0, 0, 0);
+          bg = __builtin_amdgcn_mfma_f32_16x16x4f32(wgb[s], s1[prv][4 * s + g][r], bg, 0, 0, 0);
+          ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wga[s], h0k, ag, 0, 0, 0);
+          if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
+        fetch_x(t + 1 + NB, xb);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          h1v[qd] = tanh_rnn((bg[qd] + bgb[qd]) + (ba[qd] + bib[qd]));
+          s1[cur][16 * wave + 4 * g + qd][r] = h1v[qd];
+          s0[prv][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bga[qd]) + (aa[qd] + bia[qd]));
+        }
       }
       __syncthreads();
     }
   }
   // top MLP input rows: [ last state | user profile | candidate ad | context ] (:411-421)
-  if (live) {
+  if (live && do2) {
     float* out = R + (int64_t)(v0 + b) * ldr;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) out[16 * wave + 4 * g + qd] = h1v[qd];
   }
-  for (int i = tid_g; i < 16 * 3 * D; i += 64 * NW) {
+  for (int i = threadIdx.x; i < 16 * 3 * D; i += NT) {
     const int smp_i = smp_base + i / (3 * D), c = i % (3 * D);
     if (smp_i >= n_smp) break;
     int bi = smp_i, vi = q.vstart[0];
@@ -732,11 +767,19 @@ __global__ __launch_bounds__(64 * GR * (H / 16)) void dien_rnn_mfma_kernel(const
 
 template <int D>
 bool launch_dien_mfma_h(const float* T, int64_t ldt, const QTable& q, int Tn, int H, const DienW& W, float* R,
-                        int64_t ldr, unsigned grid, hipStream_t s) {
+                        int64_t ldr, unsigned grid, int split, hipStream_t s) {
+  if (split) {
+    switch (H) {
+      case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 1>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+      case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 1>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+      case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 1>), dim3(grid), dim3(512), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+      default: return false;
+    }
+  }
   switch (H) {
-    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 1>), dim3(grid), dim3(64), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 1>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 1>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 0>), dim3(grid), dim3(64), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 0>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 0>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
     default: return false;
   }
 }
@@ -774,9 +817,9 @@ hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t
     DienW W;
     for (int i = 0; i < 8; ++i) W.w[i] = w[i];
     const unsigned g16 = (unsigned)((n + 15) / 16);
-    if (D == 16) ok = launch_dien_mfma_h<16>(T, ldt, q, Tn, H, W, R, ldr, g16, s);
-    else if (D == 32) ok = launch_dien_mfma_h<32>(T, ldt, q, Tn, H, W, R, ldr, g16, s);
-    else if (D == 64) ok = launch_dien_mfma_h<64>(T, ldt, q, Tn, H, W, R, ldr, g16, s);
+    if (D == 16) ok = launch_dien_mfma_h<16>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s);
+    else if (D == 32) ok = launch_dien_mfma_h<32>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s);
+    else if (D == 64) ok = launch_dien_mfma_h<64>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s);
     return ok ? hipGetLastError() : hipErrorInvalidValue;
   }
   const unsigned grid = (unsigned)((n + 3) / 4);

@@ -153,7 +153,7 @@ struct drs_engine {
   const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2) ...
   float* d_att_packed = nullptr; // ... and the units' weights packed for the DIN kernels (din.hip)
   bool att_dirty = true;         // a unit's weights changed since the last pack
-  int dien_mfma = 1;             // DIEN recurrence on the matrix cores (16 samples per workgroup) | 0 one wave per sample
+  int dien_mfma = 2;             // DIEN recurrence on the matrix cores, 16 samples per workgroup: 2 = one wave set per layer | 1 = every wave both layers | 0 one wave per sample (VALU)
   int din_fused = 1;             // gather + attention units + Concat in one launch (default mode)
   std::vector<Mlp> rnn;          // DIEN: the two BasicRNN layers, each {i2h, gates_t}; packed into d_att_packed
   float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the
@@ -1613,7 +1613,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "sls_split")) e->tune.sls_split = value ? 1 : 0;
   else if (!strcmp(key, "din_fused")) e->din_fused = value ? 1 : 0;
-  else if (!strcmp(key, "dien_mfma")) e->dien_mfma = value ? 1 : 0;
+  else if (!strcmp(key, "dien_mfma") && value >= 0 && value <= 2) e->dien_mfma = (int)value;
   else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
   else if (!strcmp(key, "sls_depth") && (value == 0 || value == 6 || value == 8 || value == 10 || value == 12 || value == 14)) e->tune.sls_depth = (int)value;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;

@@ -265,8 +265,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                {1, 2, 4}: ONE launch gathers the bags, applies the attention units and writes the top
  *                MLP's input row (the [rows, T*D] pooled tensor never exists) | 0 gather launch +
  *                attention launch (what sls_exact 1 always does; bit-identical to the oracle there)
- *   "dien_mfma"  1 (default) DRS_MODEL_DIEN with hidden_size a multiple of 16: the recurrence runs on the
- *                matrix cores, 16 samples per workgroup | 0 one wave per sample (same bits)
+ *   "dien_mfma"  2 (default) DRS_MODEL_DIEN with hidden_size a multiple of 16: the recurrence runs on the
+ *                matrix cores, 16 samples per workgroup, one set of waves per layer (layer 2 a step behind
+ *                layer 1) | 1 every wave runs both layers of its 16 hidden units | 0 one wave per sample on
+ *                the VALU.  Same bits in all three.
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
  *   "sls_depth"  0 (default: the compiler's schedule of the one-bag-per-wave flat kernel) | 6 | 8 |

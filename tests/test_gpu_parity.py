@@ -568,7 +568,7 @@ def test_dien_recurrent_layers_match_oracle(D, Hs, U, init):
                 assert H.close(got, exp, rtol=max(rtol, H.RTOL_OUT), atol=atol), (b, bs, np.abs(got - exp).max())
                 ref[(b, bs)] = got
         jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1)]
-        for mfma in (1, 0):
+        for mfma in (1, 2, 0):
             # the matrix-core form (16 samples per workgroup; hidden sizes that are multiples of 16)
             # and the one-wave-per-sample form run the same fma chains: the same bits
             eng.set_option("dien_mfma", mfma)
