@@ -52,6 +52,7 @@ struct Tune {
   const float* zero = nullptr;   // 256 B of zeros on `device`: source of out-of-range float4 loads
   const float* w_arena = nullptr;   // the engine's FC weight arena (biases + weights, one allocation) ...
   uint64_t w_arena_floats = 0;
+  uint64_t w_packed_lo = 0, w_packed_hi = 0;   // float range of the arena whose layers carry a packed twin
   uint32_t w_zero_off = 0;          // ... whose first 64 floats are zeros (float offset of them)
   int sls_u = 0;                 // row loads per register ring and lane (0 = default 4)
   int sls_v_d32 = 4;             // lane width for D == 32 (4 | 2)
@@ -63,7 +64,7 @@ struct Tune {
                                  // queries were coalesced with it (caught by the race hunt), for 0.2 us
   int sls_depth = 0;             // ... explicit-schedule kernel with this many row loads in flight (0 = compiler's schedule)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
-  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 1, mlp_gemm = 1, gemm_tile = 0, gemm_min_blocks = 128, mlp_debug = 0;
+  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_gemm = 1, gemm_tile = 0, gemm_min_blocks = 128, mlp_debug = 0;
 };
 // Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs
 // it (HIP function attributes are per device) and the device's zero page.
@@ -210,6 +211,11 @@ hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int
 hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t Tn, int32_t D, int32_t H,
                            const float* packed, const float* const* w, int mfma, float* R, int64_t ldr,
                            hipStream_t stream);
+
+// Weights of one FC layer (W [N, K] row-major) in the stream kernel's MFMA-operand order (mlp.hip):
+// per 128-column pass and 64-k chunk, per wave (16 columns), four float4 per lane.
+int64_t stream_packed_floats(int K, int N);
+hipError_t launch_pack_stream_weights(const float* W, int32_t K, int32_t N, float* Wp, hipStream_t stream);
 
 hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
                                hipStream_t stream);

@@ -74,6 +74,7 @@ struct Layer {
   float* b = nullptr;
   int32_t m = 0, n = 0;  // W is [m, n]
   bool set = false;
+  bool packed = false;   // a packed twin (MFMA operand order, mlp.hip) follows W in the arena
 };
 
 struct Mlp {
@@ -1232,44 +1233,58 @@ int32_t drs_set_fc(drs_handle e, int32_t mlp, int32_t layer, const float* h_W, c
   if (n != M->ln[layer] || m != M->ln[layer + 1])
     return fail(e, DRS_ERR_BAD_ARG, "layer %d expects W[%d,%d], got [%d,%d]", layer, M->ln[layer + 1], M->ln[layer], m, n);
   Layer& L = M->layers[layer];
-  if (!L.W) {
-    if (!e->w_arena) {
-      // sized for every layer of the three MLPs (the final predictor's width is at most 1024).
-      // All biases sit in front, back to back in layer order (each padded to 4 floats), so a
-      // fused MLP launch can pull every bias it needs into LDS with one flat copy.
-      size_t need = 0, nbias = 0;
-      std::vector<Mlp*> all = {&e->bot, &e->top, &e->fin};
-      for (auto& tk : e->tasks) all.push_back(&tk);
-      for (auto& au : e->att) all.push_back(&au);
-      for (auto& rn : e->rnn) all.push_back(&rn);
-      for (Mlp* mm : all)
+  if (!e->w_arena) {
+    // ONE allocation for every FC layer of the model, laid out up front:
+    //   [64 zeros | all biases, back to back in layer order, each padded to 4 floats (a fused MLP
+    //    launch pulls every bias it needs into LDS with one flat copy) |
+    //    per layer of the bottom / top / final / task MLPs: W [N, K] row-major, then its PACKED twin
+    //    (stream_packed_floats(K, N): the same weights in MFMA-operand order, mlp.hip) |
+    //    per layer of the attention units / recurrent layers: W only ]
+    // (the final predictor's width is known only when it is set: sized for 1024)
+    std::vector<Mlp*> packed = {&e->bot, &e->top, &e->fin}, plain;
+    for (auto& tk : e->tasks) packed.push_back(&tk);
+    for (auto& au : e->att) plain.push_back(&au);
+    for (auto& rn : e->rnn) plain.push_back(&rn);
+    auto width = [](const Mlp* mm, size_t i) { return mm->ln[i] > 0 ? (size_t)mm->ln[i] : (size_t)1024; };
+    auto wsz = [](size_t k, size_t n) { return (k * n + 63) / 64 * 64; };
+    size_t need = 0, nbias = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (Mlp* mm : pass == 0 ? packed : plain)
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
-          const size_t out = mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024;
-          need += ((size_t)mm->ln[i] * out + 63) / 64 * 64;
-          nbias += (out + 3) / 4 * 4;
+          const size_t k = width(mm, i), n = width(mm, i + 1);
+          need += wsz(k, n) + (pass == 0 ? (size_t)stream_packed_floats((int)k, (int)n) : 0);
+          nbias += (n + 3) / 4 * 4;
         }
-      nbias = (nbias + 63) / 64 * 64;
-      const size_t zeros = 64;       // a zero page inside the arena (stream kernel: k beyond a layer's K)
-      need += nbias + zeros;
-      e->w_arena_floats = need < (1u << 20) ? (1u << 20) : need;   // >= 4 MiB
-      HIP_TRY(e, hipMalloc(&e->w_arena, sizeof(float) * e->w_arena_floats));
-      HIP_TRY(e, hipMemset(e->w_arena, 0, sizeof(float) * zeros));
-      e->tune.w_arena = e->w_arena; e->tune.w_arena_floats = e->w_arena_floats; e->tune.w_zero_off = 0;
-      size_t boff = zeros;
-      for (Mlp* mm : all)
+    nbias = (nbias + 63) / 64 * 64;
+    const size_t zeros = 64;       // a zero page inside the arena (stream kernel: k beyond a layer's K)
+    need += nbias + zeros;
+    e->w_arena_floats = need < (1u << 20) ? (1u << 20) : need;   // >= 4 MiB
+    HIP_TRY(e, hipMalloc(&e->w_arena, sizeof(float) * e->w_arena_floats));
+    HIP_TRY(e, hipMemset(e->w_arena, 0, sizeof(float) * zeros));
+    e->tune.w_arena = e->w_arena; e->tune.w_arena_floats = e->w_arena_floats; e->tune.w_zero_off = 0;
+    size_t boff = zeros, woff = zeros + nbias;
+    e->tune.w_packed_lo = woff;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (Mlp* mm : pass == 0 ? packed : plain)
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) {
+          const size_t k = width(mm, i), n = width(mm, i + 1);
           mm->layers[i].b = e->w_arena + boff;
-          boff += ((mm->ln[i + 1] > 0 ? (size_t)mm->ln[i + 1] : 1024) + 3) / 4 * 4;
+          boff += (n + 3) / 4 * 4;
+          mm->layers[i].W = e->w_arena + woff;
+          mm->layers[i].packed = pass == 0;
+          woff += wsz(k, n) + (pass == 0 ? (size_t)stream_packed_floats((int)k, (int)n) : 0);
         }
-      e->w_arena_used = zeros + nbias;
+      if (pass == 0) e->tune.w_packed_hi = woff;
     }
-    const size_t wsz = ((size_t)m * n + 63) / 64 * 64;
-    if (e->w_arena_used + wsz > e->w_arena_floats) return fail(e, DRS_ERR_OOM, "weight arena exhausted");
-    L.W = e->w_arena + e->w_arena_used;
-    e->w_arena_used += wsz;
+    e->w_arena_used = woff;
   }
   HIP_TRY(e, hipMemcpy(L.W, h_W, sizeof(float) * (size_t)m * n, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(L.b, h_b, sizeof(float) * (size_t)m, hipMemcpyHostToDevice));
+  if (L.packed) {
+    // the MFMA-operand-order twin sits right behind W (at W + roundup64(K N): stream_plan relies on it)
+    HIP_TRY(e, launch_pack_stream_weights(L.W, n, m, L.W + ((size_t)m * n + 63) / 64 * 64, nullptr));
+    HIP_TRY(e, hipStreamSynchronize(nullptr));
+  }
   L.m = m; L.n = n; L.set = true;
   return DRS_OK;
 }
@@ -1640,7 +1655,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_stream")) e->tune.mlp_stream = value ? 1 : 0;
+  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 2) e->tune.mlp_stream = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11)) e->tune.gemm_tile = (int)value;

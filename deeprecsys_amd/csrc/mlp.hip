@@ -413,7 +413,8 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
 // LDS; launch_chain2 falls back to chain_kernel otherwise.
 struct SLayer {
   const float* W;          // [N, K] row-major
-  uint32_t w_off, pad0_;   // ... as a float offset from SArgs::wbase (the engine's weight arena)
+  uint32_t w_off, wp_off;  // ... as a float offset from SArgs::wbase (the engine's weight arena);
+                           // wp_off: the packed twin (stream_kernel<true>)
   const float* b;          // [N] or nullptr
   int32_t K, N, act;
   int32_t in_off, in_ld;   // input slab: float offset in LDS, leading dimension
@@ -442,7 +443,7 @@ struct SArgs {
   // dot interaction between the chains (DotArgs): at tile `inter_tile` the T slab (F x D per
   // row) becomes the R slab (D + P per row, zero padded to r_pad) the second chain reads
   int32_t inter_on, inter_tile, F, D, itself, P;
-  int32_t t_off, t_ld, r_off, r_ld, r_pad, pad2_;
+  int32_t t_off, t_ld, r_off, r_ld, r_pad, packed;
   float* g_R;
   int64_t g_ldr;
   int32_t n_bias, bias_off; // all biases: n_bias floats at `bias` -> LDS float offset bias_off
@@ -459,6 +460,13 @@ struct SArgs {
 };
 
 
+// PK = true ("mlp_stream" 2, the default): the weight tiles come from the layers' PACKED twins
+// (pack_stream_kernel below: per pass, chunk and wave, four float4 per lane = the wave's 16 MFMA
+// B operands of the round, k in natural order) straight into the registers the MFMAs read --
+// no LDS staging of W, no stash, and a workgroup barrier only where one layer's outputs become
+// the next layer's inputs (RMC1: 5 barriers instead of 26) instead of one per 64-k chunk.
+// PK = false: the LDS-staged form described above.  Same fma chains, same bits.
+template <bool PK>
 __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = 68;                       // staged W rows: 64 k + 4 pad
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
 
   // ---- fetch iterator: six tiles ahead ----------------------------------------------------
   int f_l = 0, f_n0 = 0, f_c = 0, f_K = a.L[0].K, f_N = a.L[0].N;
-  uint32_t f_woff = a.L[0].w_off;
+  uint32_t f_woff = PK ? a.L[0].wp_off : a.L[0].w_off;
   // The tile loads are issued through inline asm and waited for with an explicit
   // s_waitcnt (DRS_WAIT_TILE): the compiler's own counter model drains the whole ring at
   // the loop header (vmcnt(0) once per trip), which costs a full miss latency every six
@@ -489,6 +497,14 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   // set requested five rounds ago no matter how many stores came in between.
   // One of the four loads of a tile (rows frow + 32 j): scalar base + 32-bit offset.
   auto fetch_part = [&](f32x4 (&rb)[4], int j) {
+    if (PK) {
+      // tile (pass f_n0 / 128, chunk f_c) of the packed twin: 8192 floats; wave w's block of
+      // 1024, float4 j of lane `lane` (always in range: the twin is padded with zeros)
+      const uint32_t tile = (uint32_t)(f_n0 >> 7) * (uint32_t)((f_K + 63) >> 6) + (uint32_t)f_c;
+      const uint32_t boff = (f_woff + tile * 8192u + (uint32_t)wave * 1024u + (uint32_t)j * 256u + (uint32_t)lane * 4u) << 2;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[j]) : "v"(boff), "s"(a.wbase));
+      return;
+    }
     const int k = f_c * 64 + fk;
     const int row = min(f_n0 + frow + 32 * j, f_N - 1);
     uint32_t off = f_woff + (uint32_t)row * (uint32_t)f_K + (uint32_t)k;
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         f_n0 = 0;
         if (f_l + 1 < a.n_layers) {
           ++f_l;
-          f_K = a.L[f_l].K; f_N = a.L[f_l].N; f_woff = a.L[f_l].w_off;
+          f_K = a.L[f_l].K; f_N = a.L[f_l].N; f_woff = PK ? a.L[f_l].wp_off : a.L[f_l].w_off;
         }
       }
     }
@@ -613,8 +629,10 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       if (i0 + tid < a.n_bias) smem[a.bias_off + i0 + tid] = a.bias[i0 + tid];
   }
   TL(3);
-  DRS_WAIT_TILE(rb0, 0);
-  stash(0, rb0);
+  if (!PK) {
+    DRS_WAIT_TILE(rb0, 0);
+    stash(0, rb0);
+  }
   __syncthreads();
   TL(4);
 
@@ -722,6 +740,72 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     TL(14);                                                                                       \
   }
 
+// Packed form: round i waits for ITS set (requested six rounds ago: at most the 5 x 4 loads of the
+// newer sets may still be in flight), reads the 16 activation operands from LDS, runs the
+// dependent chain on the set's registers, and only then re-requests into them (tile i + 6).
+// Every wave issues its 4 loads every round, also when its 16 columns lie beyond the layer's N
+// (zeros in the twin), so the in-order vmcnt arithmetic holds for all of them.
+#define DRS_ROUND_PK(RB)                                                                          \
+  {                                                                                               \
+    if (a.inter_on && c_tile == a.inter_tile) interact();                                         \
+    ++c_tile;                                                                                     \
+    const int col = c_n0 + wave * 16 + r;                                                         \
+    DRS_WAIT_TILE(RB, 20);                                                                        \
+    if (c_n0 + wave * 16 < cl.N) {                                                                \
+      const float* pa = smem + cl.in_off + r * cl.in_ld + c_c * 64 + gs;                          \
+      float av[16];                                                                               \
+      _Pragma("unroll") for (int s = 0; s < 16; ++s) av[s] = pa[4 * s];                           \
+      _Pragma("unroll") for (int s = 0; s < 16; ++s)                                              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], RB[s >> 2][s & 3], acc, 0, 0, 0);       \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) fetch_part(RB, q);                              \
+    fetch_advance();                                                                              \
+    bool layer_done = false;                                                                      \
+    if (c_c == c_nch - 1) {                                                                       \
+      if (col < (cl.out_off >= 0 ? cl.out_pad : cl.N)) {                                          \
+        const float bias_v = smem[cl.b_off + min(col, cl.N - 1)];                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+          const int row = g * 4 + i;                                                              \
+          const float v = col < cl.N ? act_apply(acc[i] + bias_v, cl.act) : 0.f;                  \
+          if (cl.out_off >= 0) smem[cl.out_off + row * cl.out_ld + swz(col + cl.out_col0, row)] = v; \
+          if (cl.g_out && col < cl.N && m0 + row < a.M) {                                         \
+            float* dstg = cl.g_out + (m0 + row) * cl.g_ld + col;                                  \
+            if (cl.g_sc1) __hip_atomic_store(dstg, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\
+            else *dstg = v;                                                                       \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
+      c_c = 0;                                                                                    \
+      c_n0 += 128;                                                                                \
+      if (c_n0 >= cl.N) {                                                                         \
+        c_n0 = 0;                                                                                 \
+        layer_done = true;                                                                        \
+        if (c_l + 1 < a.n_layers) { ++c_l; cl = a.L[c_l]; c_nch = (cl.K + 63) >> 6; }             \
+      }                                                                                           \
+    } else {                                                                                      \
+      ++c_c;                                                                                      \
+    }                                                                                             \
+    /* the only hand-off between waves: a layer's outputs become the next layer's inputs */       \
+    if (layer_done) __syncthreads();                                                              \
+  }
+
+  if (PK) {
+    for (int i = 0; i < a.n_tiles; i += 6) {
+      DRS_ROUND_PK(rb0)
+      if (i + 1 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb1)
+      if (i + 2 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb2)
+      if (i + 3 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb3)
+      if (i + 4 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb4)
+      if (i + 5 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb5)
+    }
+  } else
   for (int i = 0; i < a.n_tiles; i += 6) {
     DRS_ROUND(0, rb0, rb1)
     if (i + 1 >= a.n_tiles) break;
@@ -736,6 +820,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     DRS_ROUND(1, rb5, rb0)
   }
 #undef DRS_ROUND
+#undef DRS_ROUND_PK
 #undef DRS_WAIT_TILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing requests
   TL(20);
@@ -749,6 +834,31 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     g_tl_n = base + n;
   }
 #endif
+}
+
+// The packed twin of a layer's weights (stream_kernel<true>): tile (pass p, chunk c) = 8192 floats,
+// wave w's block = 1024, float4 q of lane (r, g) = { W[128 p + 16 w + r][64 c + 16 q + 4 j + g] : j = 0..3 },
+// i.e. element j of float4 q is the B operand of MFMA step s = 4 q + j (k = 64 c + 4 s + g: natural
+// k order); rows beyond N and k beyond K are zeros.
+__global__ __launch_bounds__(512) void pack_stream_kernel(const float* __restrict__ W, int K, int N,
+                                                          float* __restrict__ Wp) {
+  const int nch = (K + 63) >> 6;
+  const int tile = blockIdx.x, p = tile / nch, c = tile - p * nch;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int row = 128 * p + 16 * wave + r;
+  float* o = Wp + (size_t)tile * 8192 + wave * 1024 + lane * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float4 v;
+    float* vv = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 64 * c + 16 * q + 4 * j + g;
+      vv[j] = (row < N && k < K) ? W[(size_t)row * K + k] : 0.f;
+    }
+    *reinterpret_cast<float4*>(o + q * 256) = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -836,6 +946,18 @@ __global__ void copy_rows_multi_kernel(XSrc xs, int m_den, float* __restrict__ o
 
 }  // namespace
 
+int64_t stream_packed_floats(int K, int N) {
+  if (K <= 0 || N <= 0) return 0;
+  return (int64_t)((N + 127) / 128) * ((K + 63) / 64) * 8192;
+}
+
+hipError_t launch_pack_stream_weights(const float* W, int32_t K, int32_t N, float* Wp, hipStream_t s) {
+  const unsigned tiles = (unsigned)(((N + 127) / 128) * ((K + 63) / 64));
+  if (!tiles) return hipSuccess;
+  hipLaunchKernelGGL(pack_stream_kernel, dim3(tiles), dim3(512), 0, s, W, K, N, Wp);
+  return hipGetLastError();
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 constexpr size_t kLdsBudget = 156 * 1024;
@@ -882,7 +1004,8 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
   DRS_FOR_EACH_KC(SET_ATTR)
 #undef SET_ATTR
-  if (e == hipSuccess) e = set_max_lds(stream_kernel);
+  if (e == hipSuccess) e = set_max_lds(stream_kernel<false>);
+  if (e == hipSuccess) e = set_max_lds(stream_kernel<true>);
   if (e == hipSuccess) e = set_max_lds(interact_dot_kernel);
   return e;
 }
@@ -1020,9 +1143,21 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     for (int l = 0; l < na; ++l) { if (a.b[l] != expect) return false; expect += (a.width[l + 1] + 3) & ~3; }
     for (int l = 0; l < nb; ++l) { if (b->b[l] != expect) return false; expect += (b->width[l + 1] + 3) & ~3; }
   }
-  // LDS layout (floats): [sB 2x128x68][X0][RS][P][Q][biases]
+  // the packed form ("mlp_stream" 2): every layer must carry its packed twin (engine layers of the
+  // bottom / top / final / task MLPs do: drs_set_fc)
+  bool pk = tune.mlp_stream == 2 && tune.w_packed_hi > tune.w_packed_lo;
+  {
+    auto has_twin = [&](const float* w) {
+      const uint64_t o = (uint64_t)(w - tune.w_arena);
+      return o >= tune.w_packed_lo && o < tune.w_packed_hi;
+    };
+    for (int l = 0; l < na; ++l) pk = pk && has_twin(a.W[l]);
+    for (int l = 0; l < nb; ++l) pk = pk && has_twin(b->W[l]);
+  }
+  p.packed = pk ? 1 : 0;
+  // LDS layout (floats): [sB 2x128x68 (LDS-staged form only)][X0][RS][P][Q][biases]
   int off = 0;
-  p.sB_off = off; off += 2 * 128 * 68;
+  p.sB_off = off; off += pk ? 0 : 2 * 128 * 68;
   const int x0_ld = pad64(a.width[0]) + 4;
   const int x0_off = off; off += 16 * x0_ld;
   // RS: what the first chain's last layer writes its dense_out slot into and the pooled rows
@@ -1054,7 +1189,9 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   int which = 0, cur_off = x0_off, cur_ld = x0_ld, n = 0, tiles = 0, boff = bias_off;
   auto add = [&](const ChainArgs& c, int l, bool last_of_chain, bool last_of_all) {
     SLayer& L = p.L[n++];
-    L.W = c.W[l]; L.w_off = (uint32_t)(c.W[l] - tune.w_arena); L.b = c.b[l]; L.K = c.width[l]; L.N = c.width[l + 1]; L.act = c.act[l];
+    L.W = c.W[l]; L.w_off = (uint32_t)(c.W[l] - tune.w_arena);
+    L.wp_off = L.w_off + (uint32_t)(((uint64_t)c.width[l] * c.width[l + 1] + 63) / 64 * 64);   // twin right behind W
+    L.b = c.b[l]; L.K = c.width[l]; L.N = c.width[l + 1]; L.act = c.act[l];
     L.in_off = cur_off; L.in_ld = cur_ld;
     L.out_off = -1; L.out_ld = 0; L.out_pad = L.N; L.out_col0 = 0;
     L.g_out = nullptr; L.g_ld = 0; L.g_sc1 = 0;
@@ -1142,7 +1279,8 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
 #ifdef DRS_TIMELINE
       slds += 8192;
 #endif
-      hipLaunchKernelGGL(stream_kernel, dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
+      if (sp.packed) hipLaunchKernelGGL(stream_kernel<true>, dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
+      else hipLaunchKernelGGL(stream_kernel<false>, dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       return hipGetLastError();
     }
   }

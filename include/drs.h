@@ -290,9 +290,12 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                | 22 | 12 | 21 | 11 forces the per-wave tile shape
  *                ("mlp_gemm_min_blocks", default 128: the full 2 x 2 tile is kept while it still gives
  *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference)
- *   "mlp_stream" 1 (default) chains run as the weight-tile stream kernel (tiles of all layers
+ *   "mlp_stream" 2 (default) chains run as the weight-tile stream kernel (tiles of all layers
  *                requested six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and
- *                the slabs fit | 0 always the per-layer chain kernel.  Same bits either way.
+ *                the slabs fit, the tiles read from the layers' PACKED twins (MFMA operand order,
+ *                built by drs_set_fc) straight into the MFMA operand registers: no LDS staging of
+ *                W, a workgroup barrier per layer instead of per 64-k chunk | 1 the same kernel
+ *                with W staged through LDS | 0 always the per-layer chain kernel.  Same bits.
  *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
  *                LDS in one round instead of streaming it per K chunk
  *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)

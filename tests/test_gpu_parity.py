@@ -359,10 +359,10 @@ def test_full_size_reference_shapes_match_oracle(name):
         for (bid, bs), o in zip(jobs, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, bid, bs)
         # other launch structures of the same arithmetic: bit-identical
-        for key, val in (("mlp_stream", 0), ("mlp_gemm", 0), ("mlp_fuse", 0), ("shared_stream", 1)):
+        for key, val in (("mlp_stream", 0), ("mlp_stream", 1), ("mlp_gemm", 0), ("mlp_fuse", 0), ("shared_stream", 1)):
             eng.set_option(key, val)
-            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, key)
-            eng.set_option(key, {"shared_stream": 2}.get(key, 1))
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, key, val)
+            eng.set_option(key, {"shared_stream": 2, "mlp_stream": 2}.get(key, 1))
         # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
         eng.set_option("sls_exact", 0)
         got = net.run_staged(0, B)
@@ -642,6 +642,9 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
         for name, opts in {
             "stream": dict(mlp_stream=1, mlp_fuse=1, shared_stream=1),
             "chain": dict(mlp_stream=0, mlp_fuse=1, shared_stream=1),
+            "stream_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1),       # weights from the packed twins, no LDS staging
+            "unfused_stream_packed": dict(mlp_stream=2, mlp_fuse=0, shared_stream=1),
+            "pipelined_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=2),
             "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
             "unfused_chain": dict(mlp_stream=0, mlp_fuse=0, shared_stream=1),
             "standalone_layers": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1, mlp_wide_kn=1),
@@ -660,7 +663,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             assert np.array_equal(got, results["stream"]), name
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
         # the interaction tensor the top MLP saw (cat layout / dot triangle), default structure
-        for k, v in dict(mlp_stream=1, mlp_fuse=1, shared_stream=2).items():
+        for k, v in dict(mlp_stream=2, mlp_fuse=1, shared_stream=2).items():
             eng.set_option(k, v)
         eng.forward(1, 37)
         _, R_exp = om.forward(lX[1], lS_i[1], lS_l[1], bs=37, want_R=True, nthreads=0)
@@ -901,6 +904,8 @@ def test_options_are_per_handle_and_engines_coexist():
                                    # consecutive sets overlap each other
                                    ["--workload", "rmc3_ref", "--batch", "128"], ["--workload", "wnd", "--batch", "128"],
                                    ["--set", "sls_exact=1"],
+                                   # the LDS-staged form of the stream kernel (the default reads packed twins)
+                                   ["--set", "mlp_stream=1"],
                                    # DIN: the fused gather + attention launch, 1..8 queries per set (its
                                    # samples-per-workgroup shape changes with the set size, its bits must not)
                                    ["--workload", "din", "--batch", "96"], ["--workload", "dien", "--batch", "64"]])
