@@ -740,6 +740,14 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     TL(14);                                                                                       \
   }
 
+// Where a packed round's time goes (in-kernel timeline, RMC1): the 16 MFMAs of the two waves of a
+// SIMD run as one phase at the pipe's rate (32 MFMAs in ~1 100 cycles) and the per-round
+// bookkeeping of both (~1 000 cycles: tile addresses, iterator state, epilogue tests) as another
+// -- a lone wave issues an fp32 MFMA only every ~75 cycles (also measured in din.hip's
+// recurrence), so skewing the two waves against each other buys nothing (tried: s_sleep on waves
+// 4..7 after every barrier, 0..1 000 cycles: 33.3-33.7 us throughout), and prefetching the next
+// round's activation operands under the MFMAs neither (34.4 us).  The lever left is more MFMAs
+// per round and wave (two column tiles sharing the activation operands) or four waves per SIMD.
 // Packed form: round i waits for ITS set (requested six rounds ago: at most the 5 x 4 loads of the
 // newer sets may still be in flight), reads the 16 activation operands from LDS, runs the
 // dependent chain on the set's registers, and only then re-requests into them (tile i + 6).
@@ -747,10 +755,12 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
 // (zeros in the twin), so the in-order vmcnt arithmetic holds for all of them.
 #define DRS_ROUND_PK(RB)                                                                          \
   {                                                                                               \
+    TL(10);                                                                                       \
     if (a.inter_on && c_tile == a.inter_tile) interact();                                         \
     ++c_tile;                                                                                     \
     const int col = c_n0 + wave * 16 + r;                                                         \
     DRS_WAIT_TILE(RB, 20);                                                                        \
+    TL(11);                                                                                       \
     if (c_n0 + wave * 16 < cl.N) {                                                                \
       const float* pa = smem + cl.in_off + r * cl.in_ld + c_c * 64 + gs;                          \
       float av[16];                                                                               \
@@ -759,8 +769,10 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], RB[s >> 2][s & 3], acc, 0, 0, 0);       \
     }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
+    TL(12);                                                                                       \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) fetch_part(RB, q);                              \
     fetch_advance();                                                                              \
+    TL(13);                                                                                       \
     bool layer_done = false;                                                                      \
     if (c_c == c_nch - 1) {                                                                       \
       if (col < (cl.out_off >= 0 ? cl.out_pad : cl.N)) {                                          \
@@ -789,6 +801,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     }                                                                                             \
     /* the only hand-off between waves: a layer's outputs become the next layer's inputs */       \
     if (layer_done) __syncthreads();                                                              \
+    TL(14);                                                                                       \
   }
 
   if (PK) {
