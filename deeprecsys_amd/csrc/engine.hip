@@ -1656,6 +1656,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 2) e->tune.mlp_stream = (int)value;
+  else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 8 || value == 16)) e->tune.mlp_stream_waves = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11)) e->tune.gemm_tile = (int)value;
@@ -1712,7 +1713,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
-      {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
+      {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)

@@ -466,9 +466,18 @@ struct SArgs {
 // no LDS staging of W, no stash, and a workgroup barrier only where one layer's outputs become
 // the next layer's inputs (RMC1: 5 barriers instead of 26) instead of one per 64-k chunk.
 // PK = false: the LDS-staged form described above.  Same fma chains, same bits.
-template <bool PK>
-__global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs) {
+// NWV = waves per workgroup: 8 (a pass covers 128 output columns), or -- packed form only,
+// "mlp_stream_waves" 16 -- 16 (256 columns per pass, four waves per SIMD, ring of four register
+// sets instead of six to stay inside 128 VGPRs).  The idea was that two waves of a SIMD run their
+// MFMA chains while the other two do the per-round bookkeeping; measured, the launch takes the
+// same time with 8 and 16 waves, so 8 stays the default.
+template <bool PK, int NWV>
+__global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XSrc xs) {
+  static_assert(NWV == 8 || (PK && NWV == 16), "16 waves: packed form only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kThreads = 64 * NWV;           // (shadows the file-scope 512)
+  constexpr int PASSW = 16 * NWV;              // output columns per pass
+  constexpr int RD = NWV == 16 ? 4 : 6;        // ring depth (register sets of weight tiles in flight)
   constexpr int LD = 68;                       // staged W rows: 64 k + 4 pad
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -500,8 +509,12 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     if (PK) {
       // tile (pass f_n0 / 128, chunk f_c) of the packed twin: 8192 floats; wave w's block of
       // 1024, float4 j of lane `lane` (always in range: the twin is padded with zeros)
-      const uint32_t tile = (uint32_t)(f_n0 >> 7) * (uint32_t)((f_K + 63) >> 6) + (uint32_t)f_c;
-      const uint32_t boff = (f_woff + tile * 8192u + (uint32_t)wave * 1024u + (uint32_t)j * 256u + (uint32_t)lane * 4u) << 2;
+      // (16 waves: waves 8..15 take the next 128-column pass of the twin, or -- beyond the layer's
+      // last one, their columns do not exist -- re-read this one: the loads must be issued anyway)
+      int p128 = (f_n0 >> 7) + (wave >> 3);
+      p128 = p128 * 128 < f_N ? p128 : (f_n0 >> 7);
+      const uint32_t tile = (uint32_t)p128 * (uint32_t)((f_K + 63) >> 6) + (uint32_t)f_c;
+      const uint32_t boff = (f_woff + tile * 8192u + (uint32_t)(wave & 7) * 1024u + (uint32_t)j * 256u + (uint32_t)lane * 4u) << 2;
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[j]) : "v"(boff), "s"(a.wbase));
       return;
     }
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     ++f_c;
     if (f_c * 64 >= f_K) {
       f_c = 0;
-      f_n0 += 128;
+      f_n0 += PASSW;
       if (f_n0 >= f_N) {
         f_n0 = 0;
         if (f_l + 1 < a.n_layers) {
@@ -554,7 +567,8 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   // weight tile has five rounds to arrive (the gather of the next launch set runs beside this
   // kernel and pushes L2 misses to several microseconds)
   f32x4 rb0[4], rb1[4], rb2[4], rb3[4], rb4[4], rb5[4];
-  fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3); fetch(rb4); fetch(rb5);   // tiles 0..5 (repeats past the end)
+  fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3);   // tiles 0..RD-1 (repeats past the end)
+  if constexpr (RD == 6) { fetch(rb4); fetch(rb5); }
   TL(2);
   // ---- chain inputs and biases -> LDS ------------------------------------------------------
   // Every load of the prologue -- the six weight tiles above, the 16-row blocks of both chain
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
   // (one per thread); slots [0, n0s) belong to input 0, the rest to input 1, so which input a
   // slot reads is uniform.
   {
-    constexpr int PRE = 8;                       // slots per batch (RMC1 needs 6, RM3's 1024-wide chain 8)
+    constexpr int PRE = NWV == 16 ? 4 : 8;       // slots per batch (512 threads: RMC1 needs 6, RM3's 1024-wide chain 8)
     const SInput in0 = a.in[0];
     const SInput in1 = a.in[a.n_inputs > 1 ? 1 : 0];
     const int n0s = (16 * (in0.cols_pad >> 2) + kThreads - 1) / kThreads;
@@ -753,13 +767,13 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
 // dependent chain on the set's registers, and only then re-requests into them (tile i + 6).
 // Every wave issues its 4 loads every round, also when its 16 columns lie beyond the layer's N
 // (zeros in the twin), so the in-order vmcnt arithmetic holds for all of them.
-#define DRS_ROUND_PK(RB)                                                                          \
+#define DRS_ROUND_PK(RB, NEWER)                                                                   \
   {                                                                                               \
     TL(10);                                                                                       \
     if (a.inter_on && c_tile == a.inter_tile) interact();                                         \
     ++c_tile;                                                                                     \
     const int col = c_n0 + wave * 16 + r;                                                         \
-    DRS_WAIT_TILE(RB, 20);                                                                        \
+    DRS_WAIT_TILE(RB, NEWER);                                                                     \
     TL(11);                                                                                       \
     if (c_n0 + wave * 16 < cl.N) {                                                                \
       const float* pa = smem + cl.in_off + r * cl.in_ld + c_c * 64 + gs;                          \
@@ -790,7 +804,7 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
       }                                                                                           \
       acc = f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
       c_c = 0;                                                                                    \
-      c_n0 += 128;                                                                                \
+      c_n0 += PASSW;                                                                              \
       if (c_n0 >= cl.N) {                                                                         \
         c_n0 = 0;                                                                                 \
         layer_done = true;                                                                        \
@@ -804,19 +818,29 @@ __global__ __launch_bounds__(512) void stream_kernel(SArgs a, Done done, XSrc xs
     TL(14);                                                                                       \
   }
 
-  if (PK) {
-    for (int i = 0; i < a.n_tiles; i += 6) {
-      DRS_ROUND_PK(rb0)
+  if (PK && RD == 4) {
+    for (int i = 0; i < a.n_tiles; i += 4) {
+      DRS_ROUND_PK(rb0, 12)
       if (i + 1 >= a.n_tiles) break;
-      DRS_ROUND_PK(rb1)
+      DRS_ROUND_PK(rb1, 12)
       if (i + 2 >= a.n_tiles) break;
-      DRS_ROUND_PK(rb2)
+      DRS_ROUND_PK(rb2, 12)
       if (i + 3 >= a.n_tiles) break;
-      DRS_ROUND_PK(rb3)
+      DRS_ROUND_PK(rb3, 12)
+    }
+  } else if (PK) {
+    for (int i = 0; i < a.n_tiles; i += 6) {
+      DRS_ROUND_PK(rb0, 20)
+      if (i + 1 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb1, 20)
+      if (i + 2 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb2, 20)
+      if (i + 3 >= a.n_tiles) break;
+      DRS_ROUND_PK(rb3, 20)
       if (i + 4 >= a.n_tiles) break;
-      DRS_ROUND_PK(rb4)
+      DRS_ROUND_PK(rb4, 20)
       if (i + 5 >= a.n_tiles) break;
-      DRS_ROUND_PK(rb5)
+      DRS_ROUND_PK(rb5, 20)
     }
   } else
   for (int i = 0; i < a.n_tiles; i += 6) {
@@ -1017,8 +1041,9 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(chain_kernel<false, KC_>);
   DRS_FOR_EACH_KC(SET_ATTR)
 #undef SET_ATTR
-  if (e == hipSuccess) e = set_max_lds(stream_kernel<false>);
-  if (e == hipSuccess) e = set_max_lds(stream_kernel<true>);
+  if (e == hipSuccess) e = set_max_lds(stream_kernel<false, 8>);
+  if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8>);
+  if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 16>);
   if (e == hipSuccess) e = set_max_lds(interact_dot_kernel);
   return e;
 }
@@ -1167,7 +1192,11 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     for (int l = 0; l < na; ++l) pk = pk && has_twin(a.W[l]);
     for (int l = 0; l < nb; ++l) pk = pk && has_twin(b->W[l]);
   }
-  p.packed = pk ? 1 : 0;
+  // "mlp_stream_waves" 16: sixteen waves, 256-column passes (measured equal to eight on every
+  // model: RMC1's launch 33.7 vs 33.3 us -- kept as an option, not the default)
+  const int nwv = pk && tune.mlp_stream_waves == 16 ? 16 : 8;
+  const int passw = 16 * nwv;
+  p.packed = pk ? (nwv == 16 ? 2 : 1) : 0;
   // LDS layout (floats): [sB 2x128x68 (LDS-staged form only)][X0][RS][P][Q][biases]
   int off = 0;
   p.sB_off = off; off += pk ? 0 : 2 * 128 * 68;
@@ -1222,7 +1251,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
       cur_off = L.out_off; cur_ld = L.out_ld;
       which ^= 1;
     }
-    tiles += ((L.N + 127) / 128) * ((L.K + 63) / 64);
+    tiles += ((L.N + passw - 1) / passw) * ((L.K + 63) / 64);
   };
   for (int l = 0; l < na; ++l) add(a, l, l == na - 1, l == na - 1 && !b);
   for (int l = 0; l < nb; ++l) add(*b, l, l == nb - 1, l == nb - 1);
@@ -1258,7 +1287,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     p.t_off = rs_off; p.t_ld = rs_ld; p.r_off = ri_off; p.r_ld = ri_ld; p.r_pad = pad64(b->width[0]);
     p.g_R = dot->R; p.g_ldr = dot->ldr;
     p.inter_tile = 0;
-    for (int l = 0; l < na; ++l) p.inter_tile += ((a.width[l + 1] + 127) / 128) * ((a.width[l] + 63) / 64);
+    for (int l = 0; l < na; ++l) p.inter_tile += ((a.width[l + 1] + passw - 1) / passw) * ((a.width[l] + 63) / 64);
   }
   return true;
 }
@@ -1292,8 +1321,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
 #ifdef DRS_TIMELINE
       slds += 8192;
 #endif
-      if (sp.packed) hipLaunchKernelGGL(stream_kernel<true>, dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
-      else hipLaunchKernelGGL(stream_kernel<false>, dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
+      if (sp.packed == 2) hipLaunchKernelGGL((stream_kernel<true, 16>), dim3((unsigned)((a.M + 15) / 16)), dim3(1024), slds, s, sp, d, xs);
+      else if (sp.packed) hipLaunchKernelGGL((stream_kernel<true, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
+      else hipLaunchKernelGGL((stream_kernel<false, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       return hipGetLastError();
     }
   }

@@ -296,6 +296,7 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                built by drs_set_fc) straight into the MFMA operand registers: no LDS staging of
  *                W, a workgroup barrier per layer instead of per 64-k chunk | 1 the same kernel
  *                with W staged through LDS | 0 always the per-layer chain kernel.  Same bits.
+ *                ("mlp_stream_waves" 0 / 8 (default) | 16: waves per workgroup of the packed form)
  *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
  *                LDS in one round instead of streaming it per K chunk
  *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)

@@ -645,6 +645,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "stream_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1),       # weights from the packed twins, no LDS staging
             "unfused_stream_packed": dict(mlp_stream=2, mlp_fuse=0, shared_stream=1),
             "pipelined_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=2),
+            "packed_16_waves": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_waves=16),
             "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
             "unfused_chain": dict(mlp_stream=0, mlp_fuse=0, shared_stream=1),
             "standalone_layers": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1, mlp_wide_kn=1),
@@ -659,6 +660,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), name
             results[name] = outs[0]
             eng.set_option("mlp_wide_kn", 512 * 1024)
+            eng.set_option("mlp_stream_waves", 0)
         for name, got in results.items():
             assert np.array_equal(got, results["stream"]), name
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
