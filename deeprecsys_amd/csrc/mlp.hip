@@ -437,6 +437,21 @@ struct SInput {            // 16 x cols block of a global matrix -> LDS slab, ze
   int64_t g_ldd;
 };
 #define DRS_MAX_STREAM_LAYERS (2 * DRS_MAX_CHAIN)
+#define DRS_MAX_STREAM_TILES 96
+// A round of the packed stream kernel, precomputed by the host (stream_plan): which packed tile,
+// where the activation operands sit, how many of the pass's columns exist, what happens after it.
+// The iterator form keeps ~40 scalars of layer / pass / chunk state alive across six unrolled
+// rounds -- they did not fit the SGPR file: the compiled round re-read kernel arguments and
+// shuffled 120 spilled scalars through VGPR lanes, and the bare control flow of RMC1's 26 rounds
+// (MFMAs, loads, LDS reads and barriers removed) took 10.7 of the launch's 34 us.
+struct STile {
+  uint32_t wp_off;         // packed tile (wave 0's slice) as a float offset from SArgs::wbase
+  int32_t a_off;           // activation operands: LDS float offset of (row 0, k = 64 c) in the layer's input slab
+  int32_t in_ld;           // ... and the slab's leading dimension
+  int32_t info;            // bits 0..15: columns of this pass that exist (N - n0, capped); 16: last chunk of the
+                           // pass (epilogue); 17: last round of the layer (barrier); 18: the dot interaction
+                           // runs before this round; 24..31: layer index
+};
 struct SArgs {
   int32_t n_layers, n_tiles, sB_off, n_inputs;
   int32_t dbg, lds_floats;
@@ -457,6 +472,11 @@ struct SArgs {
                            // address); zero_off: zeros INSIDE the arena for k beyond a layer's K
   SLayer L[DRS_MAX_STREAM_LAYERS];
   SInput in[2];
+  // packed form, 8 waves: one descriptor per round, read with ONE scalar load (n_table == n_tiles
+  // when the launch has at most DRS_MAX_STREAM_TILES rounds, else 0: the iterator form below)
+  int32_t n_table, pad4_;
+  int32_t tab_off, lay_off;   // LDS float offsets of the copies of tiles[] and L[] the loop reads
+  STile tiles[DRS_MAX_STREAM_TILES];
 };
 
 
@@ -471,6 +491,7 @@ struct SArgs {
 // sets instead of six to stay inside 128 VGPRs).  The idea was that two waves of a SIMD run their
 // MFMA chains while the other two do the per-round bookkeeping; measured, the launch takes the
 // same time with 8 and 16 waves, so 8 stays the default.
+static_assert(sizeof(SArgs) + sizeof(Done) + sizeof(XSrc) <= 4096, "kernel arguments: 4 KB");
 template <bool PK, int NWV>
 __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XSrc xs) {
   static_assert(NWV == 8 || (PK && NWV == 16), "16 waves: packed form only");
@@ -480,9 +501,14 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   constexpr int RD = NWV == 16 ? 4 : 6;        // ring depth (register sets of weight tiles in flight)
   constexpr int LD = 68;                       // staged W rows: 64 k + 4 pad
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // `wave` as a SCALAR: everything derived from it (the wave's columns, "is my tile inside N",
+  // the wave's slice of a packed tile) then runs on the scalar unit.  The per-round bookkeeping
+  // was ~150 VALU instructions per wave (21 of them 32-bit multiplies), which two waves per SIMD
+  // issue back to back: with MFMAs and weight loads removed the launch still took 25.6 of 34 us.
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int gs = swz(g, r);
+  const uint32_t lane16 = (uint32_t)lane * 16u;   // byte offset of this lane's float4 inside a 1-KB operand block
   const int64_t m0 = (int64_t)blockIdx.x * 16;
   float* sB = smem + a.sB_off;
 #ifdef DRS_TIMELINE
@@ -514,8 +540,12 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
       int p128 = (f_n0 >> 7) + (wave >> 3);
       p128 = p128 * 128 < f_N ? p128 : (f_n0 >> 7);
       const uint32_t tile = (uint32_t)p128 * (uint32_t)((f_K + 63) >> 6) + (uint32_t)f_c;
-      const uint32_t boff = (f_woff + tile * 8192u + (uint32_t)(wave & 7) * 1024u + (uint32_t)j * 256u + (uint32_t)lane * 4u) << 2;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[j]) : "v"(boff), "s"(a.wbase));
+      // scalar base of the wave's 4-KB slice, constant per-lane offset, float4 j as the immediate
+      const float* sb = a.wbase + (f_woff + tile * 8192u + (uint32_t)(wave & 7) * 1024u);
+      if (j == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[0]) : "v"(lane16), "s"(sb));
+      else if (j == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(rb[1]) : "v"(lane16), "s"(sb));
+      else if (j == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(rb[2]) : "v"(lane16), "s"(sb));
+      else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(rb[3]) : "v"(lane16), "s"(sb));
       return;
     }
     const int k = f_c * 64 + fk;
@@ -567,8 +597,47 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   // weight tile has five rounds to arrive (the gather of the next launch set runs beside this
   // kernel and pushes L2 misses to several microseconds)
   f32x4 rb0[4], rb1[4], rb2[4], rb3[4], rb4[4], rb5[4];
-  fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3);   // tiles 0..RD-1 (repeats past the end)
-  if constexpr (RD == 6) { fetch(rb4); fetch(rb5); }
+  // (table form: the tile's packed offset comes from its descriptor)
+  const bool use_table = PK && NWV == 8 && a.n_table > 0;          // uniform
+  // The round descriptors and the layer records are COPIED from the kernel-argument segment into
+  // LDS by the prologue and read from there: a scalar load of a kernel argument the wave has not
+  // touched yet is a cold miss all the way to HBM (the segment is written by the host for every
+  // launch), and the loop touched a new 64-B line of it every few rounds -- the bare control flow of
+  // RMC1's 26 rounds cost 10 us of a 34 us launch that way (0.4 us per round with every MFMA, load,
+  // LDS read and barrier removed; with the arguments in HOST memory, HIP_FORCE_DEV_KERNARG=0, 49 us).
+  const int n_table = a.n_table;
+  const uint32_t* s_tab = reinterpret_cast<const uint32_t*>(smem + a.tab_off);
+  const uint32_t* s_lay = reinterpret_cast<const uint32_t*>(smem + a.lay_off);
+  auto lds_tile = [&](int i) {
+    const uint4 v = *reinterpret_cast<const uint4*>(s_tab + 4 * min(i, n_table - 1));
+    STile t;
+    t.wp_off = __builtin_amdgcn_readfirstlane(v.x); t.a_off = __builtin_amdgcn_readfirstlane(v.y);
+    t.in_ld = __builtin_amdgcn_readfirstlane(v.z); t.info = __builtin_amdgcn_readfirstlane(v.w);
+    return t;
+  };
+  auto lds_wp = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane(s_tab[4 * min(i, n_table - 1)]); };
+  auto lds_layer = [&](int l) {
+    SLayer L;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&L);
+    const uint32_t* src = s_lay + l * (int)(sizeof(SLayer) / 4);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SLayer) / 4); ++i) d[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    return L;
+  };
+  auto fetch_tile_wp = [&](f32x4 (&rb)[4], uint32_t wp) {
+    const float* sb = a.wbase + (wp + (uint32_t)wave * 1024u);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[0]) : "v"(lane16), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(rb[1]) : "v"(lane16), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(rb[2]) : "v"(lane16), "s"(sb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(rb[3]) : "v"(lane16), "s"(sb));
+  };
+  auto fetch_tile = [&](f32x4 (&rb)[4], int i) { fetch_tile_wp(rb, a.tiles[min(i, a.n_table - 1)].wp_off); };   // (prologue: straight from the arguments)
+  if (use_table) {
+    fetch_tile(rb0, 0); fetch_tile(rb1, 1); fetch_tile(rb2, 2); fetch_tile(rb3, 3); fetch_tile(rb4, 4); fetch_tile(rb5, 5);
+  } else {
+    fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3);   // tiles 0..RD-1 (repeats past the end)
+    if constexpr (RD == 6) { fetch(rb4); fetch(rb5); }
+  }
   TL(2);
   // ---- chain inputs and biases -> LDS ------------------------------------------------------
   // Every load of the prologue -- the six weight tiles above, the 16-row blocks of both chain
@@ -641,6 +710,13 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
       if (tid + j * kThreads < a.n_bias) smem[a.bias_off + tid + j * kThreads] = bias_v[j];
     for (int i0 = 2 * kThreads; i0 < a.n_bias; i0 += kThreads)     // (more than 1024 bias words: not on any shipped config)
       if (i0 + tid < a.n_bias) smem[a.bias_off + i0 + tid] = a.bias[i0 + tid];
+  }
+  if (use_table) {
+    const uint32_t* kp = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();   // SArgs is argument 0 (constant -> generic address space)
+    uint32_t* dt = reinterpret_cast<uint32_t*>(smem + a.tab_off);
+    uint32_t* dl = reinterpret_cast<uint32_t*>(smem + a.lay_off);
+    for (int i = tid; i < 4 * a.n_table; i += kThreads) dt[i] = kp[offsetof(SArgs, tiles) / 4 + i];
+    for (int i = tid; i < a.n_layers * (int)(sizeof(SLayer) / 4); i += kThreads) dl[i] = kp[offsetof(SArgs, L) / 4 + i];
   }
   TL(3);
   if (!PK) {
@@ -754,6 +830,15 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
     TL(14);                                                                                       \
   }
 
+// Decomposition of the packed launch by removal (RMC1, 2 048 rows, 34 us): no round loop at all
+// (prologue + hand-off only) 14 us; rounds with MFMAs, weight loads, LDS reads and barriers removed
+// +10 us; MFMAs + weight loads +9 us; LDS reads + barriers +1 us.  Tried against the +10 us, each
+// with no change of the total: the wave index as a scalar and the operand row hoisted per layer
+// (fewer VALU), the table-driven rounds above with the rare blocks out of line (68 instructions
+// between two MFMA groups instead of 700), the descriptors and layer records in LDS instead of
+// the kernel-argument segment (kept: with the arguments in HOST memory, HIP_FORCE_DEV_KERNARG=0,
+// the launch takes 49 us, so argument reads are not free), sixteen waves, skewing, prefetching
+// the activation operands.
 // Where a packed round's time goes (in-kernel timeline, RMC1): the 16 MFMAs of the two waves of a
 // SIMD run as one phase at the pipe's rate (32 MFMAs in ~1 100 cycles) and the per-round
 // bookkeeping of both (~1 000 cycles: tile addresses, iterator state, epilogue tests) as another
@@ -776,7 +861,7 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
     DRS_WAIT_TILE(RB, NEWER);                                                                     \
     TL(11);                                                                                       \
     if (c_n0 + wave * 16 < cl.N) {                                                                \
-      const float* pa = smem + cl.in_off + r * cl.in_ld + c_c * 64 + gs;                          \
+      const float* pa = pa_layer + c_c * 64;                                                      \
       float av[16];                                                                               \
       _Pragma("unroll") for (int s = 0; s < 16; ++s) av[s] = pa[4 * s];                           \
       _Pragma("unroll") for (int s = 0; s < 16; ++s)                                              \
@@ -809,6 +894,7 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
         c_n0 = 0;                                                                                 \
         layer_done = true;                                                                        \
         if (c_l + 1 < a.n_layers) { ++c_l; cl = a.L[c_l]; c_nch = (cl.K + 63) >> 6; }             \
+        pa_layer = smem + cl.in_off + r * cl.in_ld + gs;                                          \
       }                                                                                           \
     } else {                                                                                      \
       ++c_c;                                                                                      \
@@ -818,6 +904,64 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
     TL(14);                                                                                       \
   }
 
+  const float* pa_layer = smem + cl.in_off + r * cl.in_ld + gs;   // (iterator form: per layer, not per round)
+  // ---- packed form, table-driven: one scalar descriptor load per round ---------------------
+#define DRS_ROUND_T(RB)                                                                           \
+  {                                                                                               \
+    const STile tn = lds_tile(ti + 1);                         /* next round's descriptor */       \
+    if (__builtin_expect((t.info & (1 << 18)) != 0, 0)) interact();                               \
+    const int ncols = t.info & 0xffff;                                                            \
+    DRS_WAIT_TILE(RB, 20);                                                                        \
+    if (__builtin_expect(wave * 16 < ncols, 1)) {                                                 \
+      const float* pa = smem + t.a_off + r * t.in_ld + gs;                                        \
+      float av[16];                                                                               \
+      _Pragma("unroll") for (int s = 0; s < 16; ++s) av[s] = pa[4 * s];                           \
+      _Pragma("unroll") for (int s = 0; s < 16; ++s)                                              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], RB[s >> 2][s & 3], acc, 0, 0, 0);       \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    fetch_tile_wp(RB, lds_wp(ti + 6));                                                            \
+    if (__builtin_expect((t.info & (1 << 16)) != 0, 0)) {      /* last chunk of the pass */        \
+      const SLayer el = lds_layer((t.info >> 24) & 0xff);                                         \
+      const int col = el.N - ncols + wave * 16 + r;                                               \
+      if (col < (el.out_off >= 0 ? el.out_pad : el.N)) {                                          \
+        const float bias_v = smem[el.b_off + min(col, el.N - 1)];                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+          const int row = g * 4 + i;                                                              \
+          const float v = col < el.N ? act_apply(acc[i] + bias_v, el.act) : 0.f;                  \
+          if (el.out_off >= 0) smem[el.out_off + row * el.out_ld + swz(col + el.out_col0, row)] = v; \
+          if (el.g_out && col < el.N && m0 + row < a.M) {                                         \
+            float* dstg = el.g_out + (m0 + row) * el.g_ld + col;                                  \
+            if (el.g_sc1) __hip_atomic_store(dstg, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\
+            else *dstg = v;                                                                       \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
+    }                                                                                             \
+    if (__builtin_expect((t.info & (1 << 17)) != 0, 0)) __syncthreads();   /* a layer's outputs -> the next layer's inputs */ \
+    t = tn;                                                                                       \
+    ++ti;                                                                                         \
+  }
+  if (use_table) {
+    int ti = 0;
+    STile t = lds_tile(0);
+    for (int i = 0; i < n_table; i += 6) {
+      DRS_ROUND_T(rb0)
+      if (i + 1 >= n_table) break;
+      DRS_ROUND_T(rb1)
+      if (i + 2 >= n_table) break;
+      DRS_ROUND_T(rb2)
+      if (i + 3 >= n_table) break;
+      DRS_ROUND_T(rb3)
+      if (i + 4 >= n_table) break;
+      DRS_ROUND_T(rb4)
+      if (i + 5 >= n_table) break;
+      DRS_ROUND_T(rb5)
+    }
+  } else
+#undef DRS_ROUND_T
+  // this lane's activation operand row inside the current layer's input slab (per layer, not per round)
   if (PK && RD == 4) {
     for (int i = 0; i < a.n_tiles; i += 4) {
       DRS_ROUND_PK(rb0, 12)
@@ -1224,6 +1368,9 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   const int bias_off = off;
   for (int l = 0; l < na; ++l) off += (a.width[l + 1] + 3) & ~3;
   for (int l = 0; l < nb; ++l) off += (b->width[l + 1] + 3) & ~3;
+  off = (off + 3) & ~3;
+  p.tab_off = off; off += pk ? 4 * DRS_MAX_STREAM_TILES : 0;
+  p.lay_off = off; off += pk ? (int)(sizeof(SLayer) / 4) * DRS_MAX_STREAM_LAYERS : 0;
   if (sizeof(float) * (size_t)off > kLdsBudget) return false;
   *lds_bytes = sizeof(float) * (size_t)off;
   p.lds_floats = off;
@@ -1257,6 +1404,30 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   for (int l = 0; l < nb; ++l) add(*b, l, l == nb - 1, l == nb - 1);
   p.n_layers = n;
   p.n_tiles = tiles;
+  p.n_table = 0;
+  if (pk && nwv == 8 && tiles <= DRS_MAX_STREAM_TILES) {
+    int ti = 0, inter_at = -1;
+    if (dot) {
+      inter_at = 0;
+      for (int l = 0; l < na; ++l) inter_at += ((a.width[l + 1] + 127) / 128) * ((a.width[l] + 63) / 64);
+    }
+    for (int l = 0; l < n; ++l) {
+      const SLayer& L = p.L[l];
+      const int nch = (L.K + 63) / 64, npass = (L.N + 127) / 128;
+      for (int ps = 0; ps < npass; ++ps)
+        for (int c = 0; c < nch; ++c) {
+          STile& t = p.tiles[ti];
+          t.wp_off = L.wp_off + (uint32_t)(ps * nch + c) * 8192u;
+          t.a_off = L.in_off + c * 64;
+          t.in_ld = L.in_ld;
+          const int ncols = L.N - ps * 128;
+          t.info = (ncols > 0xffff ? 0xffff : ncols) | (c == nch - 1 ? 1 << 16 : 0) |
+                   (c == nch - 1 && ps == npass - 1 ? 1 << 17 : 0) | (ti == inter_at ? 1 << 18 : 0) | (l << 24);
+          ++ti;
+        }
+    }
+    p.n_table = ti;
+  }
   p.n_bias = boff - bias_off;
   p.bias_off = bias_off;
   p.bias = a.b[0];
