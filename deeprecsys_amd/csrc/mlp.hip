@@ -615,7 +615,6 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
     t.in_ld = __builtin_amdgcn_readfirstlane(v.z); t.info = __builtin_amdgcn_readfirstlane(v.w);
     return t;
   };
-  auto lds_wp = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane(s_tab[4 * min(i, n_table - 1)]); };
   auto lds_layer = [&](int l) {
     SLayer L;
     uint32_t* d = reinterpret_cast<uint32_t*>(&L);
@@ -908,19 +907,41 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   // ---- packed form, table-driven: one scalar descriptor load per round ---------------------
 #define DRS_ROUND_T(RB)                                                                           \
   {                                                                                               \
-    const STile tn = lds_tile(ti + 1);                         /* next round's descriptor */       \
+    /* The control chain of a round (descriptor of the next round, packed offset of the tile six  */ \
+    /* ahead: LDS read -> readfirstlane -> scalar address) is issued INSIDE the MFMA chain, in     */ \
+    /* the ~60 idle issue cycles between two dependent MFMAs: a wave issues in order, so behind    */ \
+    /* the chain it costs its full latency every round.                                            */ \
+    const uint4 tn_raw = *reinterpret_cast<const uint4*>(s_tab + 4 * min(ti + 1, n_table - 1));   \
+    const uint32_t wp_raw = s_tab[4 * min(ti + 6, n_table - 1)];                                  \
     if (__builtin_expect((t.info & (1 << 18)) != 0, 0)) interact();                               \
     const int ncols = t.info & 0xffff;                                                            \
+    const bool act_now = wave * 16 < ncols;                                                       \
     DRS_WAIT_TILE(RB, 20);                                                                        \
-    if (__builtin_expect(wave * 16 < ncols, 1)) {                                                 \
+    float av[16];                                                                                 \
+    if (__builtin_expect(act_now, 1)) {                                                           \
       const float* pa = smem + t.a_off + r * t.in_ld + gs;                                        \
-      float av[16];                                                                               \
       _Pragma("unroll") for (int s = 0; s < 16; ++s) av[s] = pa[4 * s];                           \
-      _Pragma("unroll") for (int s = 0; s < 16; ++s)                                              \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                               \
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], RB[s >> 2][s & 3], acc, 0, 0, 0);       \
     }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    fetch_tile_wp(RB, lds_wp(ti + 6));                                                            \
+    const uint32_t wp6 = (uint32_t)__builtin_amdgcn_readfirstlane(wp_raw);                        \
+    STile tn;                                                                                     \
+    tn.wp_off = __builtin_amdgcn_readfirstlane(tn_raw.x); tn.a_off = __builtin_amdgcn_readfirstlane(tn_raw.y); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (__builtin_expect(act_now, 1)) {                                                           \
+      _Pragma("unroll") for (int s = 4; s < 8; ++s)                                               \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], RB[s >> 2][s & 3], acc, 0, 0, 0);       \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    tn.in_ld = __builtin_amdgcn_readfirstlane(tn_raw.z); tn.info = __builtin_amdgcn_readfirstlane(tn_raw.w); \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (__builtin_expect(act_now, 1)) {                                                           \
+      _Pragma("unroll") for (int s = 8; s < 16; ++s)                                              \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], RB[s >> 2][s & 3], acc, 0, 0, 0);       \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    fetch_tile_wp(RB, wp6);                                                                       \
     if (__builtin_expect((t.info & (1 << 16)) != 0, 0)) {      /* last chunk of the pass */        \
       const SLayer el = lds_layer((t.info >> 24) & 0xff);                                         \
       const int col = el.N - ncols + wave * 16 + r;                                               \
