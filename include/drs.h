@@ -148,6 +148,10 @@ int32_t drs_set_table(drs_handle h, int32_t t, const float* h_W /*[rows,D]*/, in
 /* device-side fill for benchmark-sized tables; value(t,i) is a pure function
  * of (seed, t, i) restated bit-exactly in oracle/               */
 int32_t drs_fill_table_uniform(drs_handle h, int32_t t, float lo, float hi, uint64_t seed);
+/* drs_set_fc copies W [m, n] (row-major, as the reference feeds it) and b [m] into the engine's
+ * weight arena and, for the bottom / top / final / task MLPs, builds the layer's packed twin (the
+ * same weights in MFMA-operand order, read by the MLP stream kernel): weights take ~2x their size
+ * in HBM.  Synchronous; may be called again to replace a layer's weights.                         */
 int32_t drs_set_fc(drs_handle h, int32_t mlp, int32_t layer /*0-based*/,
                    const float* h_W /*[m,n] row-major, NOT transposed*/,
                    const float* h_b /*[m]*/, int32_t m, int32_t n);
