@@ -838,6 +838,12 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
 // the kernel-argument segment (kept: with the arguments in HOST memory, HIP_FORCE_DEV_KERNARG=0,
 // the launch takes 49 us, so argument reads are not free), sixteen waves, skewing, prefetching
 // the activation operands.
+// 32-row workgroups (two activation tiles per weight operand set, two accumulators per wave) were
+// built and measured as well: bit-identical, but the launch takes 60 us on 64 CUs instead of 33 us
+// on 128 -- a round's time follows its MFMA count, i.e. with two waves per SIMD the rounds run at
+// ~37 cycles per MFMA and SIMD, close to the pipe's 32; RMC1 -19 %, NCF -17 %, only RM3 at batch
+// 512 +2 %.  What bounds the launch is 16 rows per CU on half the CUs plus ~14 us of fixed cost,
+// not the round.
 // Where a packed round's time goes (in-kernel timeline, RMC1): the 16 MFMAs of the two waves of a
 // SIMD run as one phase at the pipe's rate (32 MFMAs in ~1 100 cycles) and the per-round
 // bookkeeping of both (~1 000 cycles: tile addresses, iterator state, epilogue tests) as another
