@@ -29,6 +29,11 @@ Two provenance classes, recorded in every fixture's `provenance` field:
       reference's; the *expected outputs* stored next to them are computed by
       oracle/c2ops.py (numpy restatement of the published Caffe2 op semantics) and
       are labelled "restated", never "reference output".
+      models/dien.py additionally calls caffe2.python helpers (brew.fc / softmax / sum,
+      rnn_cell.BasicRNN): the stand-in records each as one composite op with the parameter
+      blob names the helper gives them, and notes which blobs Caffe2's param_init_net would
+      (re)initialise (`meta["param_init_ops"]`) -- see DESIGN.md 3.9 for what that means for
+      the recurrent weights.
 """
 import argparse
 import hashlib
