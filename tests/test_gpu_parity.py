@@ -823,6 +823,38 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
         eng.close()
 
 
+@pytest.mark.parametrize("case", ["din_mini", "dien_mini", "ncf_mini"])
+def test_per_call_inputs_of_the_sparse_only_models(case):
+    """DIN / DIEN / NCF take no dense input: run_queues' id / length arrays alone, as 2-D arrays or
+    per-table lists, read in place from pinned memory or copied (modes 0-3), several calls in
+    flight, ragged prefix sizes -- the bits of the staged path."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"], accel_slots=3)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    eng = net.engine
+    try:
+        net.stage_batches(None, lS_l, lS_i)
+        n = len(lS_l[0][0])
+        L = int(args.num_indices_per_lookup)
+        ids2 = np.stack([np.asarray(i, dtype=np.int64) for i in lS_i[0]])
+        len2 = np.stack([np.asarray(l, dtype=np.int32) for l in lS_l[0]])
+        for bs in sorted({n, max(1, n // 2), 1}):
+            ref = net.run_staged(0, bs)
+            ids, lens = ids2[:, :bs * L], len2[:, :bs]
+            for workers, mode in ((0, 3), (1, 1), (3, 2), (-1, 0)):
+                eng.set_option("host_threads", workers)
+                eng.set_option("zero_copy_inputs", mode)
+                assert np.array_equal(eng.forward_inputs(None, ids, lens, bs), ref), (case, bs, workers, mode)
+                assert np.array_equal(eng.forward_inputs(None, list(ids), list(lens), bs), ref), (case, bs, mode)
+            for s_ in range(3):
+                eng.forward_inputs_async(None, ids, lens, bs, slot=s_)
+            for s_ in range(3):
+                assert np.array_equal(eng.wait(s_, bs), ref), (case, bs, s_)
+    finally:
+        eng.close()
+
+
 def test_enable_profiling_prints_the_per_operator_type_table(capsys):
     """run(..., enable_prof=True) prints what the reference's benchmark_net prints per operator
     type, in the layout experiments/operator_breakdown/sweep_p.py:21-28 parses."""
