@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 HOST_LEG_CALLS = 6         # per-call host-input leg: calls in flight (one per slot)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SLA_MS = 25.0              # run_DeepRecSys.sh:42 target_latency
+SPAWN_PREFIX = [os.path.join(ROOT, "bench.py")]   # how a rank of `--gpus N` is re-launched (tests/cpu_abi_entry.py sets its own)
 NO_DENSE = ("ncf", "din", "dien")  # model kinds whose query has no dense input
 
 WORKLOADS = {
@@ -369,7 +370,7 @@ def spawn_ranks(opt, argv):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(opt.gpus),
                     "LOCAL_WORLD_SIZE": str(opt.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable] + SPAWN_PREFIX + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=r == 0 or None))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]

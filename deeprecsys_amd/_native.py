@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DRS_HIP_LIB") or os.path.join(_HERE, "libdrs_hip.so")
+LIB_PATH = os.path.join(_HERE, "libdrs_hip.so")   # the one library this package binds (no override)
 
 # status codes (include/drs.h)
 OK, ERR_BAD_ARG, ERR_OOM, ERR_HIP, ERR_INDEX_RANGE, ERR_LENGTHS_SUM, ERR_STATE, ERR_UNSUPPORTED = \
@@ -31,6 +31,7 @@ _i64p = C.POINTER(C.c_int64)
 # every symbol include/drs.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("drs_abi_version", C.c_int32, []),
+    ("drs_backend", C.c_char_p, []),
     ("drs_device_count", C.c_int32, [_i32p]),
     ("drs_last_error", C.c_char_p, [C.c_void_p]),
     ("drs_create", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -113,6 +114,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        backend = L.drs_backend() or b""
+        if not backend.startswith(b"hip:"):
+            raise ImportError("%s identifies itself as %r: deeprecsys_amd binds the HIP build only "
+                              "(the CPU restatement of the ABI is test infrastructure)" % (LIB_PATH, backend))
         _lib = L
     return _lib
 
@@ -154,6 +159,8 @@ class Engine(object):
         self.T = int(self._rows.size)
         self.D = int(sparse_dim)
         self.max_batch = int(max_batch)
+        # width of a query's dense rows (drs_create's shape algebra): DLRM / W&D / MT-WnD feed ln_bot[0]
+        self.m_den = int(self._ln_bot[0]) if kind in (MODEL_DLRM, MODEL_WND, MODEL_MTWND) else 0
         self.num_slots = int(num_slots)
         self.device = int(device)
 
@@ -285,6 +292,12 @@ class Engine(object):
                 lengths.strides[1] == 4 and lengths.shape[0] == idx.shape[0] == self.T and
                 (dense is None or (type(dense) is np.ndarray and dense.dtype == np.float32 and dense.flags.c_contiguous))):
             # the reference feeder's arrays as they are: two base pointers and two row strides
+            # (the C side reads lengths[t][0 .. bs) and bs dense rows: check them here, a short array
+            # must be a Python error, not a host out-of-bounds read)
+            if bs < 0 or bs > lengths.shape[1]:
+                raise ValueError("bs=%d but lengths has %d columns" % (bs, lengths.shape[1]))
+            if dense is not None and (dense.ndim != 2 or dense.shape[0] < bs or dense.shape[1] != self.m_den):
+                raise ValueError("bs=%d, dense width %d, but dense has shape %r" % (bs, self.m_den, dense.shape))
             self._check(lib().drs_run_queues_async(self._h, slot, bs, None if dense is None else dense.ctypes.data,
                                                    idx.ctypes.data, idx.strides[0] // 8, idx.shape[1],
                                                    lengths.ctypes.data, lengths.strides[0] // 4),

@@ -863,6 +863,7 @@ int32_t check_handle(drs_engine* e) {
 extern "C" {
 
 int32_t drs_abi_version(void) { return DRS_ABI_VERSION; }
+const char* drs_backend(void) { return "hip:gfx950"; }
 
 int32_t drs_device_count(int32_t* out_count) {
   if (!out_count) return DRS_ERR_BAD_ARG;
@@ -962,6 +963,10 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIN needs at least 4 embedding tables");
       if (cfg->n_bot != 3 || e->bot.ln[0] != 3 * D || e->bot.ln[2] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
         return bail(DRS_ERR_UNSUPPORTED, "DIN attention unit must be 3*D -> h -> D with 1 <= h <= 64");
+      // the two-launch attention kernel (the only path for sls_exact = 1 and for shapes the fused launch is
+      // not instantiated for) keeps 4 samples x (T - 3) units x h hidden values in 64 KB of LDS
+      if ((int64_t)(T - 3) * e->bot.ln[1] > 4096)
+        return bail(DRS_ERR_UNSUPPORTED, "DIN: (num_tables - 3) * hidden width must not exceed 4096");
       e->m_den = 0; e->w0 = 0;
       e->num_int = 4 * D;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
@@ -1144,6 +1149,13 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       const double gather_us = 2048.0 * bytes / 5.5e6, mlp_us = 12.0 + weights / 4500.0;
       if (mlp_us > gather_us) e->mlp_streams = 2;
     }
+    // Gather-bound DLRM whose MLP launch hides under the next set's gather (RMC1 BASELINE: one MLP
+    // stream): what matters there is how little the MLP launch takes from the gather beside it.
+    // stream3_kernel with four waves per workgroup (half the waves, a third of the LDS traffic, the
+    // launch itself within 3 % of the 8-wave forms) leaves the gather at 0.75-0.77 of peak instead of
+    // 0.68-0.70 (measured round 3, same session A/B: 127 k -> 132 k queries/s).  MLP-bound models keep
+    // the 8-wave packed form, which is faster alone (NCF 43 vs 53 us).
+    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; }
   }
   apply_stream_mode(e);
 #undef CREATE_TRY
@@ -1460,7 +1472,9 @@ int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const f
     const size_t used = dense_bytes + sizeof(int32_t) * ((size_t)(e->T - 1) * e->cap + (size_t)n_idx[e->T - 1]);
     const size_t idx_bytes = sizeof(int32_t) * (size_t)e->T * e->cap;
     HIP_TRY(e, hipMemcpyAsync(s.d_stage, s.h_stage, used, hipMemcpyHostToDevice, gstream));
-    if (s.dc.uniform_len < 0)   // ragged bags: the kernels read the prefix sums as well
+    // ragged bags -- or "sls_uniform" 0, which makes enqueue_forward hand the kernels uniform_len = -1
+    // for fixed-length bags too: the kernels then read the prefix sums as well (same predicate)
+    if (!e->sls_uniform || s.dc.uniform_len < 0)
       HIP_TRY(e, hipMemcpyAsync(s.d_stage + dense_bytes + idx_bytes, static_cast<char*>(s.h_stage) + dense_bytes + idx_bytes,
                                 sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1), hipMemcpyHostToDevice, gstream));
     if (gstream != s.stream) {   // the MLP side reads the dense rows: order it behind the copy
@@ -1655,8 +1669,9 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 2) e->tune.mlp_stream = (int)value;
-  else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 8 || value == 16)) e->tune.mlp_stream_waves = (int)value;
+  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 3) e->tune.mlp_stream = (int)value;
+  else if (!strcmp(key, "mlp_ring") && value == 2) e->tune.mlp_ring = (int)value;
+  else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 4 || value == 8 || value == 16)) e->tune.mlp_stream_waves = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11)) e->tune.gemm_tile = (int)value;
@@ -1713,7 +1728,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
-      {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
+      {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRS_ABI_VERSION 2
+#define DRS_ABI_VERSION 3
 
 typedef struct drs_engine* drs_handle;
 
@@ -129,6 +129,12 @@ typedef struct drs_model_cfg {
 
 /* ---- library / device ------------------------------------------------------ */
 int32_t drs_abi_version(void);
+/* which implementation of this header a loaded library is: "hip:gfx950" for libdrs_hip.so (the
+ * product).  The CPU restatement that tests/ drive the host code with (oracle/drs_cpu_abi.cpp)
+ * answers "cpu:oracle"; the product binding (deeprecsys_amd/_native.py) refuses to bind anything
+ * whose answer does not start with "hip:" -- no environment variable or path can put the
+ * arithmetic of a served query on the CPU.  Static string, never NULL.                        */
+const char* drs_backend(void);
 int32_t drs_device_count(int32_t* out_count);
 /* last error text of this handle (or of the failed drs_create when h == NULL);
  * owned by the library, valid until the next call on the same thread */

@@ -278,6 +278,7 @@ int32_t finish(drs_engine* e, Slot& s, float* h_out, int64_t h_cap = -1) {
 extern "C" {
 
 int32_t drs_abi_version(void) { return DRS_ABI_VERSION; }
+const char* drs_backend(void) { return "cpu:oracle"; }
 
 int32_t drs_device_count(int32_t* out_count) {
   if (!out_count) return DRS_ERR_BAD_ARG;
@@ -344,6 +345,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIN needs at least 4 embedding tables");
       if (cfg->n_bot != 3 || e->bot.ln[0] != 3 * D || e->bot.ln[2] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
         return bail(DRS_ERR_UNSUPPORTED, "DIN attention unit must be 3*D -> h -> D with 1 <= h <= 64");
+      if ((int64_t)(T - 3) * e->bot.ln[1] > 4096)   // same limit as the HIP engine (its attention kernel's LDS)
+        return bail(DRS_ERR_UNSUPPORTED, "DIN: (num_tables - 3) * hidden width must not exceed 4096");
       e->m_den = 0; e->w0 = 0;
       e->num_int = 4 * D;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");

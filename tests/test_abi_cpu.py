@@ -20,7 +20,7 @@ def test_cpu_abi_restates_every_entry_point_of_the_header(cpu_abi):
     assert declared == bound, declared ^ bound          # the binding covers the whole header ...
     for name in declared:
         assert hasattr(cpu_abi, name), name              # ... and so does the CPU restatement
-    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 2
+    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 3 and cpu_abi.drs_backend() == b"cpu:oracle"
 
 
 @pytest.mark.parametrize("case", H.MODEL_CASES)
@@ -178,9 +178,33 @@ def test_hip_library_loads_and_exports_every_symbol_of_the_header():
     assert len(declared) >= 28
     for name in declared:
         assert hasattr(L, name), "libdrs_hip.so does not export %s" % name
-    assert N.lib().drs_abi_version() == 2
+    assert N.lib().drs_abi_version() == 3 and N.lib().drs_backend() == b"hip:gfx950"
     if N.device_count() == 0:
         with pytest.raises(N.DrsError) as ei:
             N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
                      max_batch=4, max_lookups=2, num_staged_batches=1, num_slots=1)
         assert ei.value.code == N.ERR_HIP and "no CPU fallback" in str(ei.value)
+
+
+def test_product_binding_refuses_anything_but_the_hip_build(monkeypatch):
+    """no environment variable or path puts a served query's arithmetic on the CPU.
+    DRS_HIP_LIB is not read any more, and a library that answers drs_backend() with anything but
+    "hip:*" -- the CPU restatement exports the same symbol set, drs_abi_version included -- is
+    refused by the binding itself."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpu_so = os.path.join(root, "oracle", "_build", "libdrs_cpu.so")
+    assert os.path.exists(cpu_so)
+    monkeypatch.setenv("DRS_HIP_LIB", cpu_so)
+    import importlib
+    fresh = importlib.reload(N)
+    try:
+        assert fresh.LIB_PATH.endswith(os.path.join("deeprecsys_amd", "libdrs_hip.so"))   # the env var is ignored
+        monkeypatch.setattr(fresh, "LIB_PATH", cpu_so)
+        monkeypatch.setattr(fresh, "_lib", None)
+        with pytest.raises(ImportError) as ei:
+            fresh.lib()
+        assert "cpu:oracle" in str(ei.value) and fresh._lib is None
+    finally:
+        monkeypatch.undo()
+        importlib.reload(N)

@@ -646,6 +646,10 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "unfused_stream_packed": dict(mlp_stream=2, mlp_fuse=0, shared_stream=1),
             "pipelined_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=2),
             "packed_16_waves": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_waves=16),
+            "stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=8),   # 8 waves x 2 tiles, b128 operands
+            "stream3_4_waves": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4),   # 4 waves x 4 tiles
+            "unfused_stream3": dict(mlp_stream=3, mlp_fuse=0, shared_stream=1),
+            "pipelined_stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=2),
             "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
             "unfused_chain": dict(mlp_stream=0, mlp_fuse=0, shared_stream=1),
             "standalone_layers": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1, mlp_wide_kn=1),

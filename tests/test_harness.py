@@ -140,16 +140,25 @@ def test_multi_rank_stats_allreduce_gloo():
     assert p99 == pytest.approx(np.percentile(lat, 99, method="higher") * 1e3, rel=0.01)
 
 
-def _bench(extra, env_extra=None, timeout=600):
-    import json
-    import subprocess
+def _bench_cmd(cpu_abi):
+    """bench.py as the driver starts it -- or, for the CPU tests of its rank entry, through
+    tests/cpu_abi_entry.py, which binds the CPU restatement of the C ABI first (the product binding
+    has no override for that: deeprecsys_amd/_native.py)."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if cpu_abi:
+        return [sys.executable, os.path.join(root, "tests", "cpu_abi_entry.py"), "bench.py"]
+    return [sys.executable, os.path.join(root, "bench.py")]
+
+
+def _bench(extra, env_extra=None, timeout=600, cpu_abi=False):
+    import json
+    import subprocess
     env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DRS_HIP_LIB"):
         env.pop(k, None)
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True,
+    r = subprocess.run(_bench_cmd(cpu_abi) + extra, env=env, capture_output=True,
                        text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -168,8 +177,8 @@ def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
     collective on gloo), and rank 0 prints one line for the whole job."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # one OpenMP thread per rank: two oracle-backed ranks spinning on all cores starve each other
-    cpu = {"DRS_HIP_LIB": os.path.join(root, "oracle", "_build", "libdrs_cpu.so"), "OMP_NUM_THREADS": "1"}
-    two = _bench(["--gpus", "2", "--collective", "gloo", "--allow_device_sharing"] + _TINY, cpu)
+    cpu = {"OMP_NUM_THREADS": "1"}
+    two = _bench(["--gpus", "2", "--collective", "gloo", "--allow_device_sharing"] + _TINY, cpu, cpu_abi=True)
     assert two["n_gpus"] == 2 and two["steps"] == 3 and two["warmup"] == 1 and two["scaling"] == "weak"
     assert two["config"]["queries_per_step"] == 20 and two["config"]["timed_queries_per_gpu"] == 60
     assert two["latency_ms"]["queries"] == 120                      # both ranks' histograms, summed
@@ -178,10 +187,10 @@ def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
     assert two["ms_per_step"] == pytest.approx(two["config"]["timed_seconds"] / 3 * 1e3, rel=0.15)
     # default --collective rccl above a library without RCCL: the run still produces its line, the
     # statistics are combined over gloo and the line says why
-    fb = _bench(["--gpus", "2", "--allow_device_sharing"] + _TINY, cpu)
+    fb = _bench(["--gpus", "2", "--allow_device_sharing"] + _TINY, cpu, cpu_abi=True)
     assert fb["n_gpus"] == 2 and fb["latency_ms"]["queries"] == 120
     assert "RCCL communicator did not come up" in fb["config"]["collective"]
-    one = _bench(["--gpus", "1"] + _TINY, cpu)
+    one = _bench(["--gpus", "1"] + _TINY, cpu, cpu_abi=True)
     assert one["n_gpus"] == 1 and one["latency_ms"]["queries"] == 60 and one["config"]["collective"] is None
     # identical line structure at N = 1 and N = 2
     assert set(one) == set(two) and set(one["roofline"]) == set(two["roofline"])
@@ -191,10 +200,10 @@ def test_bench_refuses_more_ranks_than_devices():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import subprocess
     import sys
-    env = dict(os.environ, DRS_HIP_LIB=os.path.join(root, "oracle", "_build", "libdrs_cpu.so"), OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective", "gloo"] + _TINY,
+    r = subprocess.run(_bench_cmd(True) + ["--gpus", "2", "--collective", "gloo"] + _TINY,
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "device 1 of 1" in r.stderr and not r.stdout.strip()
 

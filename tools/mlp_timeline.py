@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the MLP kernels (GPU box; needs `make -C deeprecsys_amd/csrc timeline`
-and DRS_HIP_LIB=deeprecsys_amd/libdrs_hip_tl.so).  Prints, for workgroup 0 / wave 0, the
+; binds deeprecsys_amd/libdrs_hip_tl.so, the same HIP library built with -DDRS_TIMELINE).  Prints, for workgroup 0 / wave 0, the
 shader-clock cycles spent in each phase of every K-chunk round of one forward."""
 import ctypes as C
 import os
@@ -13,15 +13,18 @@ import bench
 
 NAMES = {1: "pass start", 2: "fetch0 issued", 3: "stash0 done", 4: "barrier0", 10: "round start",
          11: "fetch issued", 12: "mfma done", 13: "stash done", 14: "barrier", 20: "loop end", 21: "signal done"}
+# (stream3_kernel: 2 = inputs requested, 3 = ring requested + inputs in LDS, 10 = step start (previous step's
+# epilogue / barrier before it), 12 = the step's MFMA stream issued, 14 = epilogue + barrier)
 
 
 def main():
     argv = sys.argv[1:]
     sys.argv = ["bench.py", "--num_batches", "8"] + argv
+    from deeprecsys_amd import _native as N
+    N.LIB_PATH = os.path.join(os.path.dirname(N.LIB_PATH), "libdrs_hip_tl.so")   # before anything binds it
     opt = bench.parse()
     args, net, data = bench.make_model(opt, 0)
     eng = net.engine
-    from deeprecsys_amd import _native as N
     L = N.lib()
     L.drs_debug_timeline.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int]
     for kv in opt.set:
@@ -49,7 +52,7 @@ def main():
         a[1] += 1
     for name, (tot, cnt) in agg.items():
         print("%-14s n=%3d total=%8d ticks avg=%7.1f" % (name, cnt, tot, tot / cnt))
-    print("first 60 deltas:", [(a[:6], int(b)) for a, b in rows[:60]])
+    print("deltas:", [(a[:6], int(b)) for a, b in rows[:int(os.environ.get("TL_ROWS", "60"))]])
     eng.close()
 
 
