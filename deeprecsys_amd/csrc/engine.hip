@@ -258,9 +258,14 @@ class HostPool {
   void run(int n, const std::function<void(int)>& fn) {
     if (n <= 0) return;
     if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    fn_ = &fn; n_ = n;
-    next_.store(0, std::memory_order_relaxed);
+    // a worker of the PREVIOUS job may still be between its last pending_ decrement and its next
+    // next_ increment inside work(): re-arming fn_ / n_ / next_ under it would be a data race, and a
+    // worker that grabs an item before pending_ is stored would leave run() spinning forever
+    // (ADVICE r2).  Wait until nobody is inside work(), then arm pending_ BEFORE next_.
+    while (active_.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    fn_ = &fn; n_.store(n, std::memory_order_relaxed);
     pending_.store(n, std::memory_order_relaxed);
+    next_.store(0, std::memory_order_release);
     {
       std::lock_guard<std::mutex> l(mu_);     // pairs with the sleepers' predicate check
       gen_.fetch_add(1, std::memory_order_release);
@@ -268,16 +273,19 @@ class HostPool {
     if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
     work();
     while (pending_.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    next_.store(1 << 30, std::memory_order_release);   // closed: a worker that wakes up late finds no item
   }
 
  private:
   void work() {
+    active_.fetch_add(1, std::memory_order_acq_rel);
     for (;;) {
       const int i = next_.fetch_add(1, std::memory_order_acq_rel);
-      if (i >= n_) return;
+      if (i >= n_.load(std::memory_order_relaxed)) break;
       (*fn_)(i);
       pending_.fetch_sub(1, std::memory_order_acq_rel);
     }
+    active_.fetch_sub(1, std::memory_order_acq_rel);
   }
   void loop() {
     uint64_t seen = gen_.load(std::memory_order_acquire);
@@ -303,9 +311,9 @@ class HostPool {
   std::mutex mu_;
   std::condition_variable cv_;
   std::atomic<uint64_t> gen_{0};
-  std::atomic<int> next_{0}, pending_{0}, sleepers_{0};
+  std::atomic<int> next_{1 << 30}, pending_{0}, sleepers_{0}, active_{0};   // (next_ past any n_ while idle)
   const std::function<void(int)>* fn_ = nullptr;
-  int n_ = 0;
+  std::atomic<int> n_{0};
   bool stop_ = false;
 };
 
@@ -1457,7 +1465,7 @@ int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const f
   // how the converted inputs reach the kernels: 1 = read in place from the pinned block over PCIe
   // (no copy: best for small queries, kernel-issued PCIe reads top out near 20 GB/s), 2 = ONE
   // DMA copy of the packed block into its HBM twin (the copy engine moves it at PCIe rate beside
-  // the kernels of the other slots), 3 (default) = 2 when the query carries >= 128 KB, else 1
+  // the kernels of the other slots), 3 = 2 when the query carries >= 128 KB, else 1 (default: 1)
   int mode = e->zero_copy_inputs;
   if (mode == 3) {
     int64_t bytes = (int64_t)bs * e->m_den * 4;

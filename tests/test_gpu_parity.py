@@ -308,6 +308,19 @@ FULL_SIZE = {
     # two BasicRNN layers 32 -> 64 -> 64, top MLP 160-200-80-2 (tanhf differs by an ulp between
     # libm and the device: the top MLP's input row is compared with a tolerance, not bitwise)
     "dien": dict(kind="dien", rows=[500_000] * 41 + [5_000_000] * 2, D=32, L=1, bot="512", top="200-80-2"),
+    # reference models/configs/dlrm_rm1.json -- SURVEY 8d's "parity run": 8 x 4M x 32, 80 lookups (the
+    # D = 32 instance of the one-bag-per-wave flat gather on 4 M-row tables; the fused launch on 288-wide rows)
+    "rmc1_ref": dict(kind="dlrm", rows=[4_000_000] * 8, D=32, L=80, bot="128-64-32", top="256-64-1"),
+    # reference models/configs/dlrm_rm3.json: 10 x 2M x 32, 20 lookups, bottom 2560-1024-256-32 (two GEMM
+    # launches + a chain), top 352-512-256-1, two bags per wave in the gather
+    "rmc3_ref": dict(kind="dlrm", rows=[2_000_000] * 10, D=32, L=20, bot="2560-1024-256-32", top="512-256-1"),
+    # reference models/configs/mtwnd.json: 43 tables (41 x 500k, 2 x 5M) x 32, one lookup, shared top
+    # 1888-1024-512 (all ReLU, two GEMM launches), task heads 512-256-128 -- one head (num_multi_tasks
+    # default) and two heads (the last head's launch carries the hand-off)
+    "mtwnd": dict(kind="mtwnd", rows=[500_000] * 41 + [5_000_000] * 2, D=32, L=1, bot="512", top="1024-512",
+                  tasks="512-256-128", num_tasks=1),
+    "mtwnd_2_heads": dict(kind="mtwnd", rows=[500_000] * 41 + [5_000_000] * 2, D=32, L=1, bot="512", top="1024-512",
+                          tasks="512-256-128", num_tasks=2),
 }
 
 
@@ -325,6 +338,8 @@ def test_full_size_reference_shapes_match_oracle(name):
                        arch_mlp_bot=w["bot"], arch_mlp_top=w["top"], arch_interaction_op="cat",
                        num_indices_per_lookup=L, num_batches=nb, max_mini_batch_size=B, mini_batch_size=B,
                        numpy_rand_seed=seed, accel_table_init="device", model_type=w["kind"], accel_slots=2)
+    if "tasks" in w:
+        args.arch_mlp_tasks, args.num_multi_tasks = w["tasks"], w["num_tasks"]
     np.random.seed(seed)
     net = H.NET_CLS[w["kind"]](args)
     ncf = w["kind"] in H.NO_DENSE
@@ -359,10 +374,14 @@ def test_full_size_reference_shapes_match_oracle(name):
         for (bid, bs), o in zip(jobs, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, bid, bs)
         # other launch structures of the same arithmetic: bit-identical
-        for key, val in (("mlp_stream", 0), ("mlp_stream", 1), ("mlp_gemm", 0), ("mlp_fuse", 0), ("shared_stream", 1)):
-            eng.set_option(key, val)
-            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, key, val)
-            eng.set_option(key, {"shared_stream": 2, "mlp_stream": 2}.get(key, 1))
+        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_fuse", "shared_stream")}
+        for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=3, mlp_stream_waves=8),
+                     dict(mlp_stream=3, mlp_stream_waves=4), dict(mlp_gemm=0), dict(mlp_fuse=0), dict(shared_stream=1)):
+            for key, val in opts.items():
+                eng.set_option(key, val)
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, opts)
+            for key in opts:
+                eng.set_option(key, defaults[key])
         # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
         eng.set_option("sls_exact", 0)
         got = net.run_staged(0, B)
@@ -812,6 +831,20 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
                 eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=s_)
             for s_ in range(3):
                 assert np.array_equal(eng.wait(s_, bs), ref)
+            # "sls_uniform" 0: the kernels read the prefix sums even for fixed-length bags, so every
+            # copy mode has to ship them (the one-DMA-copy modes used to skip that upload)
+            eng.set_option("sls_uniform", 0)
+            for mode in (0, 1, 2, 3):
+                eng.set_option("zero_copy_inputs", mode)
+                for s_ in range(3):
+                    eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=s_)
+                for s_ in range(3):
+                    assert np.array_equal(eng.wait(s_, bs), ref), (bs, mode, "sls_uniform=0")
+            eng.set_option("sls_uniform", 1)
+        with pytest.raises(ValueError):          # lengths narrower than bs: a Python error, not a host out-of-bounds read
+            eng.forward_inputs(dense, big_ids[:, :B * L], big_len[:, :B - 1], B)
+        with pytest.raises(ValueError):          # dense rows of the wrong width
+            eng.forward_inputs(dense[:, :8].copy(), big_ids[:, :B * L], big_len[:, :B], B)
         bad = big_ids[:, :B * L].copy()
         bad[5, 17] = rows            # table 5 ...
         bad[2, 9000] = -1            # ... and table 2: the lower table reports, like a sequential pass
@@ -874,6 +907,16 @@ def test_enable_profiling_prints_the_per_operator_type_table(capsys):
                 ops[line.rstrip().split()[3]] = float(line.rstrip().split()[0])
         assert set(ops) == {"SparseLengthsSum", "FC"} and all(0 < v < 50 for v in ops.values()), ops
         assert H.close(net.fetch_output(), z["expected/prob_click"], rtol=H.RTOL_OUT)
+    finally:
+        net.engine.close()
+    # the sparse-only models (NCF / DIN / DIEN) print the table too
+    meta, z = H.load_fixture("ncf_mini")
+    net, lX, lS_l, lS_i, lT = H.materialize(H.args_from(meta["args"]))
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    try:
+        net.run(lX[0], lS_l[0], lS_i[0], enable_prof=True)
+        lines = [l for l in capsys.readouterr().out.splitlines() if "ms." in l]
+        assert {l.rstrip().split()[3] for l in lines} == {"SparseLengthsSum", "FC"}
     finally:
         net.engine.close()
 

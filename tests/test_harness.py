@@ -211,9 +211,10 @@ def test_bench_refuses_more_ranks_than_devices():
 # ---- the real thing ------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_stats_allreduce_over_rccl_through_the_c_abi():
-    """drs_stats_allreduce on real RCCL: world size 1 in-process (identity), and two ranks that
-    share GPU 0 when the box has a single device (RCCL refuses duplicate devices on some
-    versions: that refusal must surface as a DrsError, not a hang)."""
+    """drs_stats_allreduce on real RCCL through the C ABI: a communicator of world size 1, created and
+    used in-process (ncclCommInitRank, the grouped all-reduce = identity, drs_comm_barrier).  The
+    box has one GPU: nothing with more than one rank can run here (the N > 1 path is covered by the
+    world-size-2 gloo runs of bench.py's rank entry on CPU)."""
     from deeprecsys_amd import _native as N
     uid = N.Comm.unique_id()
     assert len(uid) == N.COMM_ID_BYTES
@@ -328,3 +329,25 @@ def test_two_real_accel_engines_share_the_queue(tmp_path):
     lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
     assert sorted((l["epoch"], l["batch_id"]) for l in lines) == sorted((e, b) for e in range(a.nepochs) for b in range(a.num_batches))
     assert {l["consumer_id"] for l in lines} <= {0, 1}
+
+
+def test_bench_cpu_baseline_has_the_reference_serving_shape_leg(tmp_path):
+    """beside the closed-loop legs, cpu_baseline times the CPU path the way the reference
+    serves -- `cores` engines on one queue, run_DeepRecSys.sh's query sizes cut into
+    sub_task_batch_size = 32 pieces, per-query latency, queries/s at p99 <= 25 ms -- and emits the
+    reference's `***` table; `kind` / `leg` name the leg whose value is reported."""
+    tab = str(tmp_path / "results_rm1.txt")
+    out = _bench(["--workload", "tiny", "--steps", "1", "--warmup", "1", "--queries_per_step", "8", "--batch", "4",
+                  "--num_batches", "2", "--cpu_seconds", "1.2", "--cpu_table", tab], {"OMP_NUM_THREADS": "2"}, cpu_abi=True)
+    c = out["cpu_baseline"]
+    assert c["kind"] in ("port", "torch") and c["leg"] in ("oracle_port", "torch_cpu")
+    assert (c["kind"] == "port") == (c["leg"] == "oracle_port")
+    s = c["legs"]["serving_shape"]
+    assert s["sub_task_batch_size"] == 32 and s["engines"] == c["cores"] and s["tables"] == "one shared copy"
+    assert s["saturation_closed_loop"]["queries"] > 0 and s["open_loop_runs"]
+    if s["at"] is not None:
+        assert s["at"]["p99_ms"] <= 25.0 and s["value"] == s["at"]["qps"]
+    assert list(s["ms_per_iter_one_engine"]) == ["1", "4", "16", "64", "256", "1024"]
+    from deeprecsys_amd.latency_table import parse_results
+    rows = parse_results(tab)
+    assert len(rows) == 6 and all(r[5] > 0 for r in rows)      # six batch sizes, ms/iter in the column GPU_Data reads

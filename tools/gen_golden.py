@@ -666,6 +666,7 @@ def main():
 
     mtwnd()
     din()
+    dien()
     capture_harness(ref, ref_root)
 
 
