@@ -89,8 +89,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
     ap.add_argument("--slots", type=int, default=3)
-    ap.add_argument("--coalesce", type=int, default=8,
-                    help="queries per launch set (the engine coalesces requests that are already queued)")
+    ap.add_argument("--coalesce", type=int, default=0,
+                    help="queries per launch set (the engine coalesces requests that are already queued); "
+                         "0 = the engine's own preference for the model: 8, or 16 for the MLP-bound ones")
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of each cpu_baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -618,7 +619,8 @@ def main():
             comm = None
             comm_note = "gloo (RCCL communicator did not come up: %s)" % (err or "on another rank")
             print("bench.py rank %d: %s" % (rank, comm_note), file=sys.stderr)
-    bs, nb, slots, co = opt.batch, opt.num_batches, opt.slots, opt.coalesce
+    bs, nb, slots = opt.batch, opt.num_batches, opt.slots
+    co = opt.coalesce if opt.coalesce > 0 else max(1, int(eng.get_option("preferred_coalesce")))
     qps_ = max(1, opt.queries_per_step)
     n_timed, n_warm = opt.steps * qps_, opt.warmup * qps_
     n_mlp = eng.get_option("mlp_streams")
@@ -671,7 +673,7 @@ def main():
     state_after = gpu_state(local) if rank == 0 else None
 
     extra = not opt.timed_only and rank == 0
-    ev_ms = ev_n = ev_bytes = mlp_ms = mlp_n = one_ms = one_n = one_bytes = 0
+    ev_ms = ev_n = ev_bytes = mlp_ms = mlp_n = one_ms = one_n = one_bytes = alone_ms = alone_n = alone_bytes = 0
     if extra:
         # cross-check leg (not part of `value`): HIP events recorded around the gather launch on the
         # stream it is launched on; they bracket several us of packet processing as well
@@ -689,6 +691,18 @@ def main():
         eng.set_profiling(0)
         one_ms, one_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
         one_bytes = eng.kernel_bytes(N.KERNEL_SLS_CLOCK)
+        # ... and full launch sets with the chip to itself: one stream, every kernel alone (what the
+        # gather reaches when nothing runs beside it; BASELINE config 3 names this figure)
+        prev_mode = eng.get_option("shared_stream")
+        eng.set_option("shared_stream", 1)
+        run_queries(eng, 64 * co, bs, nb, slots, coalesce=co)
+        eng.reset_kernel_time()
+        eng.set_profiling(1)
+        run_queries(eng, min(n_timed, 256 * co), bs, nb, slots, coalesce=co)
+        eng.set_profiling(0)
+        alone_ms, alone_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
+        alone_bytes = eng.kernel_bytes(N.KERNEL_SLS_CLOCK)
+        eng.set_option("shared_stream", prev_mode)
     # PCIe-inclusive leg (never `value`): the same queries handed over as HOST arrays per call --
     # int64 ids / int32 lengths / fp32 dense, the reference's run_queues signature -- through
     # drs_forward_inputs_async with `slots` calls in flight
@@ -734,8 +748,10 @@ def main():
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("workload") == opt.workload and tj.get("batch") == bs and tj.get("queries_per_launch") == co:
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+            # one entry per workload the counters were taken on (tools/publish_profiles.py)
+            te = tj.get("by_workload", {}).get(opt.workload) or tj
+            if te.get("workload") == opt.workload and te.get("batch") == bs and te.get("queries_per_launch") == co:
+                traffic, traffic_src = te["hbm_bytes_per_launch"], te["source"]
         except (OSError, ValueError, KeyError):
             pass
         gbps = lambda by, ms: None if not ms else by / (ms * 1e-3) / 1e9   # noqa: E731
@@ -786,6 +802,10 @@ def main():
                          "sustained_over_timed_region": {
                              "GBps": round(sls_bytes / elapsed / 1e9, 1),
                              "frac": round(sls_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+                         "gather_alone": None if not alone_n else {
+                             "what": "the same launch sets on ONE stream: the gather has the chip to itself",
+                             "avg_launch_us": round(alone_ms / alone_n * 1e3, 3), "launches": alone_n,
+                             "frac": round(gbps(alone_bytes, alone_ms) / HBM_PEAK_GBS, 4)},
                          "single_query_launch": None if not one_n else {
                              "bytes": int(one_bytes / one_n), "avg_launch_us": round(one_ms / one_n * 1e3, 3),
                              "frac": round(one / HBM_PEAK_GBS, 4)}},

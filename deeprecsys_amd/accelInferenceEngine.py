@@ -13,7 +13,7 @@ signature, same queue protocol --
 stream every CPU engine uses, inferenceEngine.py:72-88), keeps all `num_batches` input
 sets resident in HBM, runs the query through libdrs_hip.so and stamps
 inference_end_time when the result is on the host.  Requests that are already waiting
-in the queue when the engine comes back for work (up to --accel_coalesce, max 8) are
+in the queue when the engine comes back for work (up to --accel_coalesce, max 16; 0 = what the engine prefers for the model) are
 served by ONE set of launches (drs_forward_multi_async): the gather then runs long
 enough to amortise its start-up and tail, which is worth ~15% HBM efficiency.  Up to
 --accel_slots (default 3) such sets are in flight at a time: the library runs the gather
@@ -102,7 +102,12 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
         sys.exit(1)
 
     inferenceEngineReadyQueue.put(True)
-    coalesce = max(1, min(int(getattr(args, "accel_coalesce", 8)), 8)) if model is not None else 1
+    # --accel_coalesce n: up to n (<= 16) queued requests per launch set; 0: what the engine prefers for the
+    # model (16 for the MLP-bound ones, whose 16-row MLP workgroups then cover all 256 CUs; 8 otherwise)
+    coalesce = 1
+    if model is not None:
+        want = int(getattr(args, "accel_coalesce", 8))
+        coalesce = max(1, min(want, 16)) if want > 0 else min(m.net.engine.get_option("preferred_coalesce") for m in models)
     n_slots = model.net.engine.num_slots if model is not None else 1
     n_models = len(models) if model is not None else 1
     free = [list(range(n_slots)) for _ in range(n_models)]   # per model: slots with nothing in flight

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void din_attention_kernel(const float* __restr
   }
 }
 
-// Who owns valid-sample number `smp` of a coalesced launch set (select chain over <= 8 entries,
+// Who owns valid-sample number `smp` of a coalesced launch set (select chain over <= DRS_MAX_COALESCE entries,
 // wave-uniform: no dynamic indexing of the kernel-argument arrays).
 struct Owner {
   int b, vrow, ulen;

@@ -11,7 +11,7 @@ namespace drs {
 // Up to this many queries can be coalesced into one set of launches.  A query q owns the
 // virtual rows [vstart[q], vstart[q] + bs[q]) of the slot's activation buffers; vstart[]
 // is kept a multiple of 64 so a 16- or 64-row MLP block never straddles two queries.
-#define DRS_MAX_COALESCE 8
+// (DRS_MAX_COALESCE: include/drs.h)
 struct QTable {
   int32_t n_q;
   int32_t vstart[DRS_MAX_COALESCE + 1];   // virtual first row per query; [n_q] = total virtual rows

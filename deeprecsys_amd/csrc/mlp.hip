@@ -1697,7 +1697,7 @@ __global__ void add_rows_kernel(const float* __restrict__ a, int64_t lda, const 
   }
 }
 
-// Dense rows of up to 8 coalesced queries (one staged array per query) -> their virtual rows
+// Dense rows of up to DRS_MAX_COALESCE coalesced queries (one staged array per query) -> their virtual rows
 // of the concat buffer, in ONE launch (W&D has no bottom MLP: models/wide_and_deep.py:271-281).
 __global__ void copy_rows_multi_kernel(XSrc xs, int m_den, float* __restrict__ o, int64_t ldo) {
   const int64_t Mv = xs.q.vstart[xs.q.n_q];

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   const bool bag_ok = bag < n_bags;
   const int smp = bag_ok ? (int)(bag / a.T) : 0;            // valid-sample number over all queries
   const int t = bag_ok ? (int)(bag - (int64_t)smp * a.T) : 0;
-  // which coalesced query owns this sample: select chain over <= 8 entries (no dynamic
+  // which coalesced query owns this sample: select chain over <= DRS_MAX_COALESCE entries (no dynamic
   // indexing of the kernel-argument arrays)
   int b = smp, vrow = a.q.vstart[0] + smp, ulen = a.uniform_len[0];
   const int32_t* qidx = a.idx[0];

@@ -186,12 +186,13 @@ int32_t drs_forward(drs_handle h, int32_t batch_id, int32_t bs, float* h_out);
  * pinned buffer; drs_wait blocks for that slot and copies to h_out (may be NULL
  * to only wait).  Slots are independent HIP streams and may overlap.           */
 int32_t drs_forward_async(drs_handle h, int32_t slot, int32_t batch_id, int32_t bs);
-/* Query coalescing: n (1..8) queries -- query i = first bs[i] samples of staged batch
+/* Query coalescing: n (1..16) queries -- query i = first bs[i] samples of staged batch
  * batch_ids[i] -- run as ONE set of launches (one gather over all their bags, one MLP
  * pass over all their rows).  This is what the engine does when several requests are
  * already waiting in its queue; drs_wait then returns the n results back to back,
  * [sum(bs), n_out].  drs_forward_async is the n == 1 case.                         */
-#define DRS_MAX_COALESCE 8
+#define DRS_MAX_COALESCE 16   /* (8 until round 3: sets of 16 x 256 rows give the 16-row MLP workgroups of the
+                                   MLP-bound models all 256 CUs; drs_get_option "preferred_coalesce" says what a model wants) */
 int32_t drs_forward_multi_async(drs_handle h, int32_t slot, int32_t n, const int32_t* batch_ids,
                                 const int32_t* bs);
 /* h_out_floats: capacity of h_out in floats; must hold sum(bs) * n_out of what was submitted

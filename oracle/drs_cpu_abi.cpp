@@ -583,7 +583,7 @@ int32_t drs_interact_dot(drs_handle e, const float* d_T, int64_t B, int32_t F, i
 }
 
 // tuning / measurement knobs have no meaning on the CPU: accepted and ignored
-int32_t drs_set_option(drs_handle e, const char* key, int64_t) {
+int32_t drs_set_option(drs_handle e, const char* key, int64_t) {   // (options tune the HIP kernels: accepted, ignored)
   if (!e || !key) return DRS_ERR_BAD_ARG;
   return DRS_OK;
 }
@@ -601,7 +601,7 @@ int32_t drs_kernel_bytes(drs_handle e, int32_t, int64_t* bytes) {
 }
 int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   if (!e || !key || !value) return DRS_ERR_BAD_ARG;
-  *value = 0;
+  *value = !strcmp(key, "preferred_coalesce") ? 8 : 0;
   return DRS_OK;
 }
 // the collective is RCCL over xGMI: no CPU restatement (the CPU suite combines ranks over gloo)

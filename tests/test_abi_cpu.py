@@ -91,7 +91,7 @@ def test_abi_status_codes_surface_as_DrsError(cpu_abi):
             e.forward(0, 5)
         assert ei.value.code == N.ERR_BAD_ARG
         with pytest.raises(N.DrsError):
-            e.forward_multi_async(0, [0] * 9, [1] * 9)  # DRS_MAX_COALESCE
+            e.forward_multi_async(0, [0] * 17, [1] * 17)  # DRS_MAX_COALESCE
         assert e.gather_bytes(0, 4) == 4 * 2 * (2 * 8 * 4 + 2 * 4 + 4 + 8 * 4)
     finally:
         e.close()

@@ -373,6 +373,11 @@ def test_full_size_reference_shapes_match_oracle(name):
         outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
         for (bid, bs), o in zip(jobs, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, bid, bs)
+        # ... and 16 (DRS_MAX_COALESCE: 4 096 rows give the 16-row MLP workgroups all 256 CUs)
+        jobs16 = jobs + jobs[::-1]
+        outs = net.run_staged_multi([b for b, _ in jobs16], [n for _, n in jobs16])
+        for (bid, bs), o in zip(jobs16, outs):
+            assert np.array_equal(o, ref[(bid, bs)]), (name, "16 coalesced", bid, bs)
         # other launch structures of the same arithmetic: bit-identical
         defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_fuse", "shared_stream")}
         for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=3, mlp_stream_waves=8),
@@ -626,7 +631,7 @@ def test_coalesced_queries_equal_individual_queries(kind):
             eng.set_option("mlp_fuse", 1)
             eng.set_option("mlp_split", 1)
         with pytest.raises(N.DrsError):
-            eng.forward_multi_async(0, [0] * 9, [1] * 9)
+            eng.forward_multi_async(0, [0] * 17, [1] * 17)
     finally:
         net.engine.close()
 

@@ -30,7 +30,7 @@ def main():
     for kv in opt.set:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    co = opt.coalesce
+    co = opt.coalesce or 8
     bench.run_queries(eng, 200, opt.batch, opt.num_batches, 1, coalesce=co)
     buf = np.zeros(16384, dtype=np.uint64)
     L.drs_debug_timeline(buf.ctypes.data_as(C.POINTER(C.c_uint64)), 16384, 1)

@@ -32,29 +32,45 @@ def main(tag, prefix):
         shutil.rmtree(out, ignore_errors=True)
         shutil.copytree(acc, out)
         print("profiles/accelerator_mi355x/")
-    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-    co = bench["config"]["queries_per_launch"]
-    # gather launches of the timed region are the biggest sls_kernel grid in the PMC passes
-    vals = {}
-    for line in open(os.path.join(src, "pmc_summary.txt")):
-        m = re.match(r"sls_\w+kernel\S*(?:\s\S+)*?\s+grid=(\d+)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=(\d+)\s+avg=([\d.]+)", line)
-        if m:
-            g, c, n, avg = int(m.group(1)), m.group(2), int(m.group(3)), float(m.group(4))
-            if c not in vals or g > vals[c][0]:
-                vals[c] = (g, n, avg)
-    fetch_kb, write_kb = vals["FETCH_SIZE"][2], vals["WRITE_SIZE"][2]
-    # MI355X_MICROARCH.md, HBM section: both counters are in KB; on gfx950 FETCH_SIZE counts the
-    # 128-B requests of 16-B/lane reads at 64 B -> x2 (calibrated against TCC_MISS x 128 B)
-    hbm = int(round(fetch_kb * 1024 * 2 + write_kb * 1024))
-    tj = {"workload": "rmc1", "batch": 256, "queries_per_launch": co,
-          "kernel": "sls_flatc_kernel (gather)", "grid": vals["FETCH_SIZE"][0], "launches": vals["FETCH_SIZE"][1],
-          "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-          "hbm_bytes_per_launch": hbm,
-          "algorithmic_bytes_per_launch": bench["roofline"]["bytes_per_launch"],
-          "ratio": round(hbm / bench["roofline"]["bytes_per_launch"], 4),
-          "source": "profiles/%s_pmc_summary.txt: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes "
-                    "over `python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048`; KB units, FETCH_SIZE x2 on "
-                    "gfx950 (MI355X_MICROARCH.md HBM section)" % prefix}
+    # one traffic entry per workload whose PMC passes were taken: (bench line, summary file, its command)
+    jobs = [("rmc1", "bench.json", "pmc_summary.txt",
+             "python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048"),
+            ("rmc3", "rmc3_bench_single_stream.json", "rmc3_pmc_summary.txt",
+             "python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --timed_only --steps 3 --warmup 1 "
+             "--queries_per_step 2048 --set shared_stream=1"),
+            ("din", "bench_din.json", "din_pmc_summary.txt",
+             "python bench.py --workload din --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048")]
+    by = {}
+    for wl, bench_file, pmc_file, cmd in jobs:
+        try:
+            bench = json.loads(open(os.path.join(src, bench_file)).read().strip().splitlines()[-1])
+            lines = open(os.path.join(src, pmc_file)).read().splitlines()
+        except (OSError, ValueError, IndexError):
+            continue
+        co = bench["config"]["queries_per_launch"]
+        # the gather launches of the timed region are the biggest grid of a gather kernel in the PMC passes
+        vals = {}
+        for line in lines:
+            m = re.match(r"(sls_\w+kernel|din_fused_kernel)\S*(?:\s\S+)*?\s+grid=(\d+)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=(\d+)\s+avg=([\d.]+)", line)
+            if m:
+                k, g, c, n, avg = m.group(1), int(m.group(2)), m.group(3), int(m.group(4)), float(m.group(5))
+                if c not in vals or g > vals[c][0]:
+                    vals[c] = (g, n, avg, k)
+        if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals or not bench["roofline"].get("bytes_per_launch"):
+            continue
+        fetch_kb, write_kb = vals["FETCH_SIZE"][2], vals["WRITE_SIZE"][2]
+        # MI355X_MICROARCH.md, HBM section: both counters are in KB; on gfx950 FETCH_SIZE counts the
+        # 128-B requests of 16-B/lane reads at 64 B -> x2 (calibrated against TCC_MISS x 128 B)
+        hbm = int(round(fetch_kb * 1024 * 2 + write_kb * 1024))
+        batch = int(re.search(r"batch (\d+)", bench["config"]["workload"]).group(1))
+        by[wl] = {"workload": wl, "batch": batch, "queries_per_launch": co,
+                  "kernel": vals["FETCH_SIZE"][3] + " (gather)", "grid": vals["FETCH_SIZE"][0], "launches": vals["FETCH_SIZE"][1],
+                  "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "hbm_bytes_per_launch": hbm,
+                  "algorithmic_bytes_per_launch": bench["roofline"]["bytes_per_launch"],
+                  "ratio": round(hbm / bench["roofline"]["bytes_per_launch"], 4),
+                  "source": "profiles/%s_%s: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over `%s`; "
+                            "KB units, FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section)" % (prefix, pmc_file, cmd)}
+    tj = {"by_workload": by}
     with open(os.path.join(dst, "traffic.json"), "w") as f:
         json.dump(tj, f, indent=1)
         f.write("\n")

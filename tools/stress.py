@@ -57,7 +57,7 @@ def main():
         slot = int(rng.randint(slots))
         if inflight[slot] is not None:
             check(slot)
-        k = int(rng.randint(1, 9))
+        k = int(rng.randint(1, 17))          # 1 .. DRS_MAX_COALESCE queries per launch set
         jobs = [(int(rng.randint(nb)), int(sizes[rng.randint(len(sizes))])) for _ in range(k)]
         eng.forward_multi_async(slot, [b for b, _ in jobs], [s for _, s in jobs])
         inflight[slot] = jobs

@@ -68,7 +68,7 @@ def main():
             lS_i[b] = idx
     distinct = float(np.mean([np.unique(np.concatenate([lS_i[b][t] for b in range(min(8, nb))])).size
                               for t in range(T)])) / (min(8, nb) * B * L)
-    co, slots, q = opt.coalesce, opt.slots, 8192
+    co, slots, q = opt.coalesce or 8, opt.slots, 8192
     bench.run_queries(eng, q, B, nb, slots, coalesce=co)
     eng.reset_kernel_time()
     eng.set_profiling(1)
