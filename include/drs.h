@@ -301,13 +301,19 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                | 22 | 12 | 21 | 11 forces the per-wave tile shape
  *                ("mlp_gemm_min_blocks", default 128: the full 2 x 2 tile is kept while it still gives
  *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference)
- *   "mlp_stream" 2 (default) chains run as the weight-tile stream kernel (tiles of all layers
- *                requested six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and
- *                the slabs fit, the tiles read from the layers' PACKED twins (MFMA operand order,
- *                built by drs_set_fc) straight into the MFMA operand registers: no LDS staging of
- *                W, a workgroup barrier per layer instead of per 64-k chunk | 1 the same kernel
- *                with W staged through LDS | 0 always the per-layer chain kernel.  Same bits.
- *                ("mlp_stream_waves" 0 / 8 (default) | 16: waves per workgroup of the packed form)
+ *   "mlp_stream" 2 (default for MLP-bound models) chains run as the weight-tile stream kernel
+ *                (tiles of all layers requested six rounds ahead, inputs resident in LDS) when every
+ *                K % 4 == 0 and the slabs fit, the tiles read from the layers' PACKED twins (MFMA
+ *                operand order, built by drs_set_fc) straight into the MFMA operand registers: no LDS
+ *                staging of W, a workgroup barrier per layer instead of per 64-k chunk | 3 (default
+ *                for gather-bound DLRM, with "mlp_stream_waves" 4) stream3_kernel: the same packed
+ *                twins, activation operands as four ds_read_b128 per 64-k chunk, accumulators in fixed
+ *                AGPRs, weight loads spread through the MFMA stream (EXEC-masked for tiles a wave does
+ *                not own), one-round-trip prologue; "mlp_stream_waves" 4: four waves x up to four
+ *                tiles (half the waves and LDS traffic beside a gather) | 8: eight waves x up to two |
+ *                1 the first kernel with W staged through LDS | 0 always the per-layer chain kernel.
+ *                Same bits in every form.
+ *                ("mlp_stream_waves" with "mlp_stream" 2: 0 / 8 (default) | 16 waves per workgroup)
  *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
  *                LDS in one round instead of streaming it per K chunk
  *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)
@@ -334,6 +340,12 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                work item, the dense rows' copy one more) beside the calling thread:
  *                -1 (default) min(T, 7) | 0 the caller alone | n.  They spin ~50 us after a call and
  *                then sleep; they do not exist until the first per-call-input query.
+ *   "launch_thread" 0 (default) | 1: per-call inputs: the caller converts a query's arrays (they are
+ *                consumed before the call returns) and hands the HIP calls -- DMA copy, events,
+ *                launches -- to a launcher thread; errors of those calls surface at drs_wait.  Cuts
+ *                the caller's time per call from 20 to 14 us; throughput is PCIe-bound either way.
+ *   "preferred_coalesce" (read only) queries per launch set the engine asks its feeder for: 8, or 16
+ *                (DRS_MAX_COALESCE) for MLP-bound models
  *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
  *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
  *                MLP launches of consecutive small sets overlap each other

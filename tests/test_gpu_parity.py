@@ -826,11 +826,21 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
             assert not ids.flags["C_CONTIGUOUS"] or bs == 2 * B
             eng.stage_batch(0, dense[:bs], [r.copy() for r in ids], [r.copy() for r in lens])
             ref = eng.forward(0, bs)
-            for workers, mode in ((0, 3), (1, 1), (3, 2), (-1, 0), (-1, 3)):
+            for workers, mode, lt in ((0, 3, 1), (1, 1, 0), (3, 2, 1), (-1, 0, 0), (-1, 3, 1), (-1, 1, 1), (-1, 2, 0)):
                 eng.set_option("host_threads", workers)
                 eng.set_option("zero_copy_inputs", mode)
-                assert np.array_equal(eng.forward_inputs(dense[:bs], ids, lens, bs), ref), (bs, workers, mode)
+                eng.set_option("launch_thread", lt)      # launches on the calling thread (0) or handed to the launcher thread (1)
+                assert np.array_equal(eng.forward_inputs(dense[:bs], ids, lens, bs), ref), (bs, workers, mode, lt)
                 assert np.array_equal(eng.forward_inputs(dense[:bs], list(ids), list(lens), bs), ref)
+            eng.set_option("launch_thread", 1)
+            # calls handed to the launcher thread, mixed with staged submits on the other slots (every
+            # other entry point first lets that thread finish)
+            for rep in range(20):
+                eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=0)
+                eng.forward_async(1, 0, bs)
+                eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=2)
+                for s_ in (1, 0, 2):
+                    assert np.array_equal(eng.wait(s_, bs), ref), (bs, rep, s_)
             # three calls in flight on three slots
             for s_ in range(3):
                 eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=s_)

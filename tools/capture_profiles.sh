@@ -33,7 +33,8 @@ trace() { # name, command...
 }
 
 # 1. the bench line exactly as the driver runs it (N=1), with the CPU baseline legs
-run 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+mkdir -p "$OUT/cpu_host/raw_data"
+run 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu_table "$OUT/cpu_host/raw_data/results_rm1.txt" > "$OUT/bench.json" 2> "$OUT/bench.err"
 # 2. rocprofv3's per-kernel summary of the same warm-up + timed region (--timed_only: none of the
 #    extra legs, so every gather launch in the trace is a launch of the benchmark itself)
 trace bench python bench.py --gpus 1 --steps 20 --warmup 5 --timed_only
@@ -67,6 +68,8 @@ pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
+# the 8-wave packed MLP launch in place of stream3_kernel's 4-wave form (what it costs the gather beside it)
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=2 > "$OUT/bench_mlp_stream2.json" 2>/dev/null
 for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf mtwnd din dien; do
   run 400 python bench.py --workload $w --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 4096 > "$OUT/bench_$w.json" 2>/dev/null
   run 400 python bench.py --workload $w --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 --set shared_stream=1 > "$OUT/bench_${w}_single_stream.json" 2>/dev/null

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Only the per-call host-input loop (profiling target): python tools/host_leg.py [mode] [slots] [n]"""
+"""Only the per-call host-input loop (profiling target):
+    python tools/host_leg.py [--mode 1] [--slots 6] [--n 4000] [--set key=value ...]
+prints queries/s and the split between submit (drs_run_queues_async) and wait per query."""
+import argparse
 import os
 import sys
 import time
@@ -9,28 +12,40 @@ import numpy as np
 
 import bench
 
-mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-slots = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-n = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
-sys.argv = ["bench.py", "--num_batches", "4", "--slots", str(slots)]
+ap = argparse.ArgumentParser()
+ap.add_argument("--mode", type=int, default=1)
+ap.add_argument("--slots", type=int, default=6)
+ap.add_argument("--n", type=int, default=4000)
+ap.add_argument("--set", action="append", default=[])
+o = ap.parse_args()
+sys.argv = ["bench.py", "--num_batches", "4", "--slots", str(o.slots)]
 opt = bench.parse()
 args, net, (lX, lS_l, lS_i) = bench.make_model(opt, 0)
 eng = net.engine
-eng.set_option("zero_copy_inputs", mode)
+eng.set_option("zero_copy_inputs", o.mode)
+for kv in o.set:
+    k, v = kv.split("=")
+    eng.set_option(k, int(v))
 bs, L = opt.batch, bench.WORKLOADS[opt.workload]["L"]
 sets = [(np.stack([np.asarray(t[:bs * L], dtype=np.int64) for t in lS_i[b]]),
          np.stack([np.asarray(t[:bs], dtype=np.int32) for t in lS_l[b]]), np.ascontiguousarray(lX[b][:bs])) for b in range(4)]
 for rep in range(2):
-    busy = [False] * slots
+    busy = [False] * o.slots
+    t_sub = t_wait = 0.0
     t0 = time.perf_counter()
-    for i in range(n):
-        s = i % slots
+    for i in range(o.n):
+        s = i % o.slots
         if busy[s]:
+            ta = time.perf_counter()
             eng.wait(s)
+            t_wait += time.perf_counter() - ta
         ids, lens, x = sets[i % 4]
+        ta = time.perf_counter()
         eng.forward_inputs_async(x, ids, lens, bs, slot=s)
+        t_sub += time.perf_counter() - ta
         busy[s] = True
     eng.sync()
     el = time.perf_counter() - t0
-print("mode %d slots %d: %.1f us/query = %.0f queries/s" % (mode, slots, el / n * 1e6, n / el))
+print("mode %d slots %d %s: %.1f us/query = %.0f queries/s (submit %.1f us, wait %.1f us per query)"
+      % (o.mode, o.slots, " ".join(o.set), el / o.n * 1e6, o.n / el, t_sub / o.n * 1e6, t_wait / o.n * 1e6))
 eng.close()

@@ -26,12 +26,13 @@ def main(tag, prefix):
             continue
         shutil.copy(p, os.path.join(dst, "%s_%s" % (prefix, f)))
         print("profiles/%s_%s" % (prefix, f))
-    acc = os.path.join(src, "accelerator_mi355x")
-    if os.path.isdir(acc):
-        out = os.path.join(dst, "accelerator_mi355x")
-        shutil.rmtree(out, ignore_errors=True)
-        shutil.copytree(acc, out)
-        print("profiles/accelerator_mi355x/")
+    for sub in ("accelerator_mi355x", "cpu_host"):       # latency tables in the reference's "***" format
+        acc = os.path.join(src, sub)
+        if os.path.isdir(acc):
+            out = os.path.join(dst, sub)
+            shutil.rmtree(out, ignore_errors=True)
+            shutil.copytree(acc, out)
+            print("profiles/%s/" % sub)
     # one traffic entry per workload whose PMC passes were taken: (bench line, summary file, its command)
     jobs = [("rmc1", "bench.json", "pmc_summary.txt",
              "python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048"),
