@@ -115,13 +115,24 @@ struct Owner {
 __device__ __forceinline__ Owner owner_of(const SlsArgs& a, int smp) {
   Owner o = {smp, a.q.vstart[0] + smp, a.uniform_len[0], a.idx[0], a.off[0]};
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < a.q.n_q && smp >= a.q.cum[i];
     o.b = in ? smp - a.q.cum[i] : o.b;
     o.vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : o.vrow;
     o.ulen = in ? a.uniform_len[i] : o.ulen;
     o.idx = in ? a.idx[i] : o.idx;
     o.off = in ? a.off[i] : o.off;
+  }
+  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      o.b = in ? smp - a.q.cum[i] : o.b;
+      o.vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : o.vrow;
+      o.ulen = in ? a.uniform_len[i] : o.ulen;
+      o.idx = in ? a.idx[i] : o.idx;
+      o.off = in ? a.off[i] : o.off;
+    }
   }
   return o;
 }
@@ -605,11 +616,20 @@ __global__ __launch_bounds__(256) void dien_rnn_kernel(const float* __restrict__
   if (smp >= q.cum[q.n_q]) return;                       // (no workgroup barrier below)
   int b = smp, bs = q.bs[0], v0 = q.vstart[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < q.n_q && smp >= q.cum[i];
     b = in ? smp - q.cum[i] : b;
     bs = in ? q.bs[i] : bs;
     v0 = in ? q.vstart[i] : v0;
+  }
+  if (q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < q.n_q && smp >= q.cum[i];
+      b = in ? smp - q.cum[i] : b;
+      bs = in ? q.bs[i] : bs;
+      v0 = in ? q.vstart[i] : v0;
+    }
   }
   const int U = Tn - 3;
   const int j = min(lane, H - 1);
@@ -716,11 +736,20 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
   const bool live = smp_base + r < n_smp;
   int b = smp, bs = q.bs[0], v0 = q.vstart[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < q.n_q && smp >= q.cum[i];
     b = in ? smp - q.cum[i] : b;
     bs = in ? q.bs[i] : bs;
     v0 = in ? q.vstart[i] : v0;
+  }
+  if (q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < q.n_q && smp >= q.cum[i];
+      b = in ? smp - q.cum[i] : b;
+      bs = in ? q.bs[i] : bs;
+      v0 = in ? q.vstart[i] : v0;
+    }
   }
   const int U = Tn - 3;
   // A operands: lane (r, g) holds W[16 w + r][4 s + g] of every MFMA step s -- the i2h and gates_t
@@ -857,10 +886,18 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
     if (smp_i >= n_smp) break;
     int bi = smp_i, vi = q.vstart[0];
 #pragma unroll
-    for (int k = 1; k < DRS_MAX_COALESCE; ++k) {
+    for (int k = 1; k < 8; ++k) {
       const bool in = k < q.n_q && smp_i >= q.cum[k];
       bi = in ? smp_i - q.cum[k] : bi;
       vi = in ? q.vstart[k] : vi;
+    }
+    if (q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+      for (int k = 8; k < DRS_MAX_COALESCE; ++k) {
+        const bool in = k < q.n_q && smp_i >= q.cum[k];
+        bi = in ? smp_i - q.cum[k] : bi;
+        vi = in ? q.vstart[k] : vi;
+      }
     }
     const int tab = c < D ? 0 : c < 2 * D ? Tn - 2 : Tn - 1;
     R[(int64_t)(vi + bi) * ldr + H + c] = T[(int64_t)(vi + bi) * ldt + (int64_t)tab * D + c % D];

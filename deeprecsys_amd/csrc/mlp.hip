@@ -1709,11 +1709,20 @@ __global__ void copy_rows_multi_kernel(XSrc xs, int m_den, float* __restrict__ o
     const float* p = xs.x[0];
     int lo = xs.q.vstart[0], nb = xs.q.bs[0];
 #pragma unroll
-    for (int k = 1; k < DRS_MAX_COALESCE; ++k) {
+    for (int k = 1; k < 8; ++k) {
       const bool in = k < xs.q.n_q && v >= xs.q.vstart[k];
       p = in ? xs.x[k] : p;
       lo = in ? xs.q.vstart[k] : lo;
       nb = in ? xs.q.bs[k] : nb;
+    }
+    if (xs.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+      for (int k = 8; k < DRS_MAX_COALESCE; ++k) {
+        const bool in = k < xs.q.n_q && v >= xs.q.vstart[k];
+        p = in ? xs.x[k] : p;
+        lo = in ? xs.q.vstart[k] : lo;
+        nb = in ? xs.q.bs[k] : nb;
+      }
     }
     const int64_t r = v - lo;
     if (r < nb) o[v * ldo + d] = p[r * m_den + d];

@@ -192,11 +192,20 @@ __device__ __forceinline__ void resolve_src(const XSrc& xs, const float* x, int6
     const float* p = xs.x[0];
     int lo = xs.q.vstart[0], n = xs.q.bs[0];
 #pragma unroll
-    for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    for (int i = 1; i < 8; ++i) {
       const bool in = i < xs.q.n_q && m0 >= xs.q.vstart[i];
       p = in ? xs.x[i] : p;
       lo = in ? xs.q.vstart[i] : lo;
       n = in ? xs.q.bs[i] : n;
+    }
+    if (xs.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+      for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+        const bool in = i < xs.q.n_q && m0 >= xs.q.vstart[i];
+        p = in ? xs.x[i] : p;
+        lo = in ? xs.q.vstart[i] : lo;
+        n = in ? xs.q.bs[i] : n;
+      }
     }
     *base = p; *row0 = m0 - lo; *rows = n;
   }

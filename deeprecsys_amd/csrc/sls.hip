@@ -120,13 +120,24 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   const int32_t* qidx = a.idx[0];
   const int32_t* qoff = a.off[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < a.q.n_q && smp >= a.q.cum[i];
     b = in ? smp - a.q.cum[i] : b;
     vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
     ulen = in ? a.uniform_len[i] : ulen;
     qidx = in ? a.idx[i] : qidx;
     qoff = in ? a.off[i] : qoff;
+  }
+  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      b = in ? smp - a.q.cum[i] : b;
+      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+      ulen = in ? a.uniform_len[i] : ulen;
+      qidx = in ? a.idx[i] : qidx;
+      qoff = in ? a.off[i] : qoff;
+    }
   }
 
   // fixed-length bags (every shipped reference config: num_indices_per_lookup_fixed) need
@@ -286,11 +297,20 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
   int b = smp, vrow = a.q.vstart[0] + smp;
   const int32_t* qidx = a.idx[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < a.q.n_q && smp >= a.q.cum[i];
     b = in ? smp - a.q.cum[i] : b;
     vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
     qidx = in ? a.idx[i] : qidx;
+  }
+  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      b = in ? smp - a.q.cum[i] : b;
+      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+      qidx = in ? a.idx[i] : qidx;
+    }
   }
   const int R = BPW * L;
   const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
@@ -422,11 +442,20 @@ __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
   int b = smp, vrow = a.q.vstart[0] + smp;
   const int32_t* qidx = a.idx[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < a.q.n_q && smp >= a.q.cum[i];
     b = in ? smp - a.q.cum[i] : b;
     vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
     qidx = in ? a.idx[i] : qidx;
+  }
+  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      b = in ? smp - a.q.cum[i] : b;
+      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+      qidx = in ? a.idx[i] : qidx;
+    }
   }
   const int R = BPW * L;
   const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
@@ -535,11 +564,20 @@ __global__ __launch_bounds__(64) void sls_flatx_kernel(SlsArgs a, int L) {
   int b = smp, vrow = a.q.vstart[0] + smp;
   const int32_t* qidx = a.idx[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < a.q.n_q && smp >= a.q.cum[i];
     b = in ? smp - a.q.cum[i] : b;
     vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
     qidx = in ? a.idx[i] : qidx;
+  }
+  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      b = in ? smp - a.q.cum[i] : b;
+      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+      qidx = in ? a.idx[i] : qidx;
+    }
   }
   const int R = L;
   const uint32_t Du = (uint32_t)a.D;
@@ -629,11 +667,20 @@ __global__ __launch_bounds__(64 * WV) void sls_flatc2_kernel(SlsArgs a, int L) {
   int b = smp, vrow = a.q.vstart[0] + smp;
   const int32_t* qidx = a.idx[0];
 #pragma unroll
-  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+  for (int i = 1; i < 8; ++i) {
     const bool in = i < a.q.n_q && smp >= a.q.cum[i];
     b = in ? smp - a.q.cum[i] : b;
     vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
     qidx = in ? a.idx[i] : qidx;
+  }
+  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      b = in ? smp - a.q.cum[i] : b;
+      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+      qidx = in ? a.idx[i] : qidx;
+    }
   }
   const int R = L;
   const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
