@@ -46,8 +46,13 @@ struct GArgs {
 // TM x TN MFMA tiles (16 x 16) per wave; the 8 waves sit 2 x 4, so a workgroup owns
 // 32 TM rows x 64 TN columns.  (2,2) is the full-rate shape; the smaller ones exist so a
 // launch with few rows (one query: 256) or few columns still covers the chip.
-template <int TM, int TN>
-__global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) {
+// RING: register sets of chunks in flight (4, or 2 to fit 128 VGPRs); OCC: waves per SIMD the kernel is
+// compiled for.  <2, 1, 2, 4> is the shape TWO workgroups of which share a CU (64 x 64 tiles, 70 KB of
+// LDS, <= 128 VGPRs): their per-chunk barriers and bookkeeping are not in phase, so one workgroup's
+// MFMAs run while the other's waves sit between two runs -- what the two waves of a SIMD inside ONE
+// workgroup, locked to each other by the chunk barrier, cannot do for each other.
+template <int TM, int TN, int RING = 4, int OCC = 2>
+__global__ __launch_bounds__(512, OCC) void gemm_kernel(GArgs a, Done done, XSrc xs) {
   constexpr int GBM = 32 * TM, GBN = 64 * TN;
   constexpr int NA = TM, NB = 2 * TN;            // float4 per thread per chunk
   constexpr int NQ = 2 * (NA + NB);              // ds_write_b64 per stashed chunk
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
   // explicit wait for one register set: "at most 3 newer chunks outstanding" (vmcnt retires
   // in order); the registers are tied to the asm so no use can be scheduled above it
   auto gwait = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
-    constexpr int n = 3 * (NA + NB);
+    constexpr int n = (RING - 1) * (NA + NB);
     if constexpr (NA == 2 && NB == 4)
       asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(n));
     else if constexpr (NA == 1 && NB == 4)
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
 #define DRS_GWAIT(RA, RB, N_) gwait(RA, RB)
 
   f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB], ra2[NA], rb2[NB], ra3[NA], rb3[NB];
-  fetch(ra0, rb0); fetch(ra1, rb1); fetch(ra2, rb2); fetch(ra3, rb3);   // chunks 0..3
+  fetch(ra0, rb0); fetch(ra1, rb1);                                     // chunks 0 .. RING-1
+  if constexpr (RING == 4) { fetch(ra2, rb2); fetch(ra3, rb3); }
   DRS_GWAIT(ra0, rb0, 18);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) stash_part(0, ra0, rb0, q);
@@ -202,14 +208,22 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
     __builtin_amdgcn_sched_barrier(0);                                                            \
   }
 
-  for (int c = 0; c < nch; c += 4) {
-    DRS_GROUND(0, ra0, rb0, ra1, rb1)
-    if (c + 1 >= nch) break;
-    DRS_GROUND(1, ra1, rb1, ra2, rb2)
-    if (c + 2 >= nch) break;
-    DRS_GROUND(0, ra2, rb2, ra3, rb3)
-    if (c + 3 >= nch) break;
-    DRS_GROUND(1, ra3, rb3, ra0, rb0)
+  if constexpr (RING == 4) {
+    for (int c = 0; c < nch; c += 4) {
+      DRS_GROUND(0, ra0, rb0, ra1, rb1)
+      if (c + 1 >= nch) break;
+      DRS_GROUND(1, ra1, rb1, ra2, rb2)
+      if (c + 2 >= nch) break;
+      DRS_GROUND(0, ra2, rb2, ra3, rb3)
+      if (c + 3 >= nch) break;
+      DRS_GROUND(1, ra3, rb3, ra0, rb0)
+    }
+  } else {
+    for (int c = 0; c < nch; c += 2) {
+      DRS_GROUND(0, ra0, rb0, ra1, rb1)
+      if (c + 1 >= nch) break;
+      DRS_GROUND(1, ra1, rb1, ra0, rb0)
+    }
   }
 #undef DRS_GROUND
 #undef DRS_GWAIT
@@ -243,7 +257,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(GArgs a, Done done, XSrc xs) 
 // per device (device_init, engine.hip)
 hipError_t gemm_set_attrs() {
   for (const void* k : {reinterpret_cast<const void*>(gemm_kernel<2, 2>), reinterpret_cast<const void*>(gemm_kernel<1, 2>),
-                        reinterpret_cast<const void*>(gemm_kernel<2, 1>), reinterpret_cast<const void*>(gemm_kernel<1, 1>)}) {
+                        reinterpret_cast<const void*>(gemm_kernel<2, 1>), reinterpret_cast<const void*>(gemm_kernel<1, 1>),
+                        reinterpret_cast<const void*>(gemm_kernel<2, 1, 2, 4>)}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -269,7 +284,13 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   // weight panel is the shared operand, re-read once per row block)
   auto blocks = [&](int tm, int tn) { return ((M + 32 * tm - 1) / (32 * tm)) * (int64_t)((N + 64 * tn - 1) / (64 * tn)); };
   int tm = 2, tn = 2;
-  if (tune.gemm_tile) { tm = tune.gemm_tile / 10; tn = tune.gemm_tile % 10; }
+  bool two_per_cu = false;       // "mlp_gemm_tile" 214: the 64 x 64 shape compiled for two workgroups per CU
+  if (tune.gemm_tile == 214) { tm = 2; tn = 1; two_per_cu = true; }
+  else if (tune.gemm_tile) { tm = tune.gemm_tile / 10; tn = tune.gemm_tile % 10; }
+  // two 64 x 64 workgroups per CU once they fill the chip twice over ("mlp_gemm_2cu", set per model by
+  // drs_create): W&D 84.8 k -> 89.2 k queries/s, RM3 config 3 29.5 k -> 30.9 k (= 65 % of the fp32-MFMA
+  // peak), RM3 reference JSON 59.2 k -> 62.5 k; MT-WnD loses 5 % with it and keeps the 2 x 2 shape
+  else if (tune.gemm_2cu && blocks(2, 1) >= 512) { tm = 2; tn = 1; two_per_cu = true; }
   // (2,2) already when it covers half the chip: in the pipelined engine other launches (the next
   // set's gather, the other MLP streams' GEMMs and chains) fill the remaining CUs, and a 2 x 2
   // wave tile does twice the MFMAs per operand read (measured: RM3 +4 %, W&D +2 % queries/s)
@@ -281,7 +302,8 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   const size_t lds = sizeof(float) * 2 * (32 * tm + 64 * tn) * GLD;
 #define DRS_GLAUNCH(TM_, TN_) \
   if (tm == TM_ && tn == TN_) hipLaunchKernelGGL((gemm_kernel<TM_, TN_>), grid, dim3(kGThreads), lds, s, a, d, xs);
-  DRS_GLAUNCH(2, 2) DRS_GLAUNCH(1, 2) DRS_GLAUNCH(2, 1) DRS_GLAUNCH(1, 1)
+  if (two_per_cu) hipLaunchKernelGGL((gemm_kernel<2, 1, 2, 4>), grid, dim3(kGThreads), lds, s, a, d, xs);
+  else { DRS_GLAUNCH(2, 2) DRS_GLAUNCH(1, 2) DRS_GLAUNCH(2, 1) DRS_GLAUNCH(1, 1) }
 #undef DRS_GLAUNCH
   *err = hipGetLastError();
   return true;

@@ -298,7 +298,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                | 0 one launch per MLP;  "mlp_fuse_rows": fuse only from this many rows on
  *   "mlp_gemm"   1 (default) stand-alone wide layers run as the register-blocked gemm_kernel
  *                (gemm.hip) | 0 fc_kernel;  "mlp_gemm_tile" 0 (default: by workgroup count)
- *                | 22 | 12 | 21 | 11 forces the per-wave tile shape
+ *                | 22 | 12 | 21 | 11 forces the per-wave tile shape, 214 = the 2 x 1 shape compiled for TWO
+ *                workgroups per CU (ring of two chunks, <= 128 VGPRs, 70 KB of LDS);
+ *                "mlp_gemm_2cu" 1 (default for DLRM and W&D) | 0: take that shape by itself whenever
+ *                it gives >= 512 workgroups (W&D +5 %, RM3 +5 %; MT-WnD -5 %: off there)
  *                ("mlp_gemm_min_blocks", default 128: the full 2 x 2 tile is kept while it still gives
  *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference)
  *   "mlp_stream" 2 (default for MLP-bound models) chains run as the weight-tile stream kernel

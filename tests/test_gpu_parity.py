@@ -194,7 +194,7 @@ def test_fc_matches_oracle_chain(op_engine, M, K, N_, act):
         assert np.array_equal(got, exp)   # MFMA == k-ordered fmaf chain, bit for bit
 
 
-@pytest.mark.parametrize("tile", [22, 12, 21, 11, 0])
+@pytest.mark.parametrize("tile", [22, 12, 21, 11, 214, 0])   # 214: the 2 x 1 shape compiled for two workgroups per CU
 @pytest.mark.parametrize("M,K,N_", [(300, 896, 1024), (65, 68, 130), (2048, 1024, 512), (31, 132, 64), (129, 64, 200)])
 def test_gemm_kernel_every_tile_shape_is_bitwise(op_engine, tile, M, K, N_):
     """gemm.hip: each per-wave tile shape (2x2, 1x2, 2x1, 1x1 MFMA tiles; 0 = chosen by block
@@ -379,9 +379,10 @@ def test_full_size_reference_shapes_match_oracle(name):
         for (bid, bs), o in zip(jobs16, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, "16 coalesced", bid, bs)
         # other launch structures of the same arithmetic: bit-identical
-        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_fuse", "shared_stream")}
+        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_gemm_2cu", "mlp_fuse", "shared_stream")}
         for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=3, mlp_stream_waves=8),
-                     dict(mlp_stream=3, mlp_stream_waves=4), dict(mlp_gemm=0), dict(mlp_fuse=0), dict(shared_stream=1)):
+                     dict(mlp_stream=3, mlp_stream_waves=4), dict(mlp_gemm=0), dict(mlp_gemm_2cu=0), dict(mlp_gemm_2cu=1),
+                     dict(mlp_fuse=0), dict(shared_stream=1)):
             for key, val in opts.items():
                 eng.set_option(key, val)
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, opts)

@@ -24,9 +24,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--tile", type=int, default=0, help="mlp_gemm_tile (0 auto | 22 | 12 | 21 | 11 | 214)")
     o = ap.parse_args()
     eng = N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
                    max_batch=4, max_lookups=2, num_staged_batches=1, num_slots=1)
+    eng.set_option("mlp_gemm_tile", o.tile)
     dev = torch.device("cuda", 0)
     M = o.rows
     print("%-16s %6s %6s %6s %10s %10s %8s" % ("layer", "M", "K", "N", "us/launch", "TFLOP/s", "of peak"))
