@@ -1294,6 +1294,10 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; }
     // wide layers as two 64 x 64 GEMM workgroups per CU (gemm.hip) where that measured faster
     e->tune.gemm_2cu = e->kind == DRS_MODEL_DLRM || e->kind == DRS_MODEL_WND;
+    // ... and the packed stream kernel in its 128-VGPR form, two workgroups per CU, for every model whose
+    // MLP launches overlap each other (measured with 16-query sets: DIEN +8 %, W&D +5 %, MT-WnD +4 %, DIN +3 %,
+    // RM3 +2 %; NCF -2 %: its launch is bound by its own 512 KB of outputs crossing PCIe)
+    e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF;
   }
   apply_stream_mode(e);
 #undef CREATE_TRY
@@ -1804,6 +1808,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 3) e->tune.mlp_stream = (int)value;
+  else if (!strcmp(key, "mlp_stream_2cu") && (value == 0 || value == 1)) e->tune.mlp_stream_2cu = (int)value;
   else if (!strcmp(key, "mlp_gemm_2cu") && (value == 0 || value == 1)) e->tune.gemm_2cu = (int)value;
   else if (!strcmp(key, "launch_thread") && (value == 0 || value == 1)) e->launch_thread = (int)value;
   else if (!strcmp(key, "mlp_ring") && value == 2) e->tune.mlp_ring = (int)value;
@@ -1863,7 +1868,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : 8}, {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};

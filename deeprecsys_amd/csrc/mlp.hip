@@ -514,14 +514,19 @@ __device__ __forceinline__ void kernarg_burst() {
 #undef S3_KL
 }
 
-template <bool PK, int NWV>
-__global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XSrc xs) {
+// RD3: the table-driven packed form with a ring of THREE register sets instead of six, compiled for 128
+// VGPRs (four waves per SIMD): two of its workgroups share a CU, so the launches of two overlapping
+// sets (MLP-bound models run one MLP stream per slot) interleave on the same SIMDs instead of
+// queueing for whole CUs -- what gemm_kernel<2, 1, 2, 4> does for the wide layers.
+template <bool PK, int NWV, bool RD3 = false>
+__global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, Done done, XSrc xs) {
   static_assert(NWV == 8 || (PK && NWV == 16), "16 waves: packed form only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   kernarg_burst();
   constexpr int kThreads = 64 * NWV;           // (shadows the file-scope 512)
   constexpr int PASSW = 16 * NWV;              // output columns per pass
-  constexpr int RD = NWV == 16 ? 4 : 6;        // ring depth (register sets of weight tiles in flight)
+  constexpr int RD = RD3 ? 3 : NWV == 16 ? 4 : 6;   // ring depth (register sets of weight tiles in flight)
+  static_assert(!RD3 || (PK && NWV == 8), "the 3-deep ring: table-driven packed form only");
   constexpr int LD = 68;                       // staged W rows: 64 k + 4 pad
   const int tid = threadIdx.x;
   // `wave` as a SCALAR: everything derived from it (the wave's columns, "is my tile inside N",
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   // kernel and pushes L2 misses to several microseconds)
   f32x4 rb0[4], rb1[4], rb2[4], rb3[4], rb4[4], rb5[4];
   // (table form: the tile's packed offset comes from its descriptor)
-  const bool use_table = PK && NWV == 8 && a.n_table > 0;          // uniform
+  const bool use_table = RD3 || (PK && NWV == 8 && a.n_table > 0);          // uniform
   // The round descriptors and the layer records are COPIED from the kernel-argument segment into
   // LDS by the prologue and read from there: a scalar load of a kernel argument the wave has not
   // touched yet is a cold miss all the way to HBM (the segment is written by the host for every
@@ -655,7 +660,8 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   };
   auto fetch_tile = [&](f32x4 (&rb)[4], int i) { fetch_tile_wp(rb, a.tiles[min(i, a.n_table - 1)].wp_off); };   // (prologue: straight from the arguments)
   if (use_table) {
-    fetch_tile(rb0, 0); fetch_tile(rb1, 1); fetch_tile(rb2, 2); fetch_tile(rb3, 3); fetch_tile(rb4, 4); fetch_tile(rb5, 5);
+    fetch_tile(rb0, 0); fetch_tile(rb1, 1); fetch_tile(rb2, 2);
+    if constexpr (RD == 6) { fetch_tile(rb3, 3); fetch_tile(rb4, 4); fetch_tile(rb5, 5); }
   } else {
     fetch(rb0); fetch(rb1); fetch(rb2); fetch(rb3);   // tiles 0..RD-1 (repeats past the end)
     if constexpr (RD == 6) { fetch(rb4); fetch(rb5); }
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   // (one per thread); slots [0, n0s) belong to input 0, the rest to input 1, so which input a
   // slot reads is uniform.
   {
-    constexpr int PRE = NWV == 16 ? 4 : 8;       // slots per batch (512 threads: RMC1 needs 6, RM3's 1024-wide chain 8)
+    constexpr int PRE = (NWV == 16 || RD3) ? 4 : 8;   // slots per batch (512 threads: RMC1 needs 6, RM3's 1024-wide chain 8)
     const SInput in0 = a.in[0];
     const SInput in1 = a.in[a.n_inputs > 1 ? 1 : 0];
     const int n0s = (16 * (in0.cols_pad >> 2) + kThreads - 1) / kThreads;
@@ -941,11 +947,11 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
     /* the ~60 idle issue cycles between two dependent MFMAs: a wave issues in order, so behind    */ \
     /* the chain it costs its full latency every round.                                            */ \
     const uint4 tn_raw = *reinterpret_cast<const uint4*>(s_tab + 4 * min(ti + 1, n_table - 1));   \
-    const uint32_t wp_raw = s_tab[4 * min(ti + 6, n_table - 1)];                                  \
+    const uint32_t wp_raw = s_tab[4 * min(ti + RD, n_table - 1)];                                 \
     if (__builtin_expect((t.info & (1 << 18)) != 0, 0)) interact();                               \
     const int ncols = t.info & 0xffff;                                                            \
     const bool act_now = wave * 16 < ncols;                                                       \
-    DRS_WAIT_TILE(RB, 20);                                                                        \
+    if constexpr (RD == 3) { DRS_WAIT_TILE(RB, 8); } else { DRS_WAIT_TILE(RB, 20); }            \
     float av[16];                                                                                 \
     if (__builtin_expect(act_now, 1)) {                                                           \
       const float* pa = smem + t.a_off + r * t.in_ld + gs;                                        \
@@ -996,12 +1002,13 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
   if (use_table) {
     int ti = 0;
     STile t = lds_tile(0);
-    for (int i = 0; i < n_table; i += 6) {
+    for (int i = 0; i < n_table; i += RD) {
       DRS_ROUND_T(rb0)
       if (i + 1 >= n_table) break;
       DRS_ROUND_T(rb1)
       if (i + 2 >= n_table) break;
       DRS_ROUND_T(rb2)
+      if constexpr (RD == 3) continue;
       if (i + 3 >= n_table) break;
       DRS_ROUND_T(rb3)
       if (i + 4 >= n_table) break;
@@ -1009,6 +1016,8 @@ __global__ __launch_bounds__(64 * NWV) void stream_kernel(SArgs a, Done done, XS
       if (i + 5 >= n_table) break;
       DRS_ROUND_T(rb5)
     }
+  } else if constexpr (RD3) {
+    // (launched only with a table)
   } else
 #undef DRS_ROUND_T
   // this lane's activation operand row inside the current layer's input slab (per layer, not per round)
@@ -1791,6 +1800,7 @@ hipError_t mlp_set_attrs() {
 #undef SET_ATTR
   if (e == hipSuccess) e = set_max_lds(stream_kernel<false, 8>);
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8>);
+  if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8, true>);
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 16>);
   if (e == hipSuccess) e = set_max_lds(stream3_kernel<4, 2>);
   if (e == hipSuccess) e = set_max_lds(stream3_kernel<2, 2>);
@@ -2170,6 +2180,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
       if (sp.packed == 4) hipLaunchKernelGGL((stream3_kernel<4, 2>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 3) hipLaunchKernelGGL((stream3_kernel<2, 2>), g3, dim3(512), slds, s, sp, d, xs);
       else if (sp.packed == 2) hipLaunchKernelGGL((stream_kernel<true, 16>), dim3((unsigned)((a.M + 15) / 16)), dim3(1024), slds, s, sp, d, xs);
+      else if (sp.packed && tune.mlp_stream_2cu && sp.n_table > 0) hipLaunchKernelGGL((stream_kernel<true, 8, true>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else if (sp.packed) hipLaunchKernelGGL((stream_kernel<true, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else hipLaunchKernelGGL((stream_kernel<false, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       return hipGetLastError();

@@ -316,7 +316,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                tiles (half the waves and LDS traffic beside a gather) | 8: eight waves x up to two |
  *                1 the first kernel with W staged through LDS | 0 always the per-layer chain kernel.
  *                Same bits in every form.
- *                ("mlp_stream_waves" with "mlp_stream" 2: 0 / 8 (default) | 16 waves per workgroup)
+ *                ("mlp_stream_waves" with "mlp_stream" 2: 0 / 8 (default) | 16 waves per workgroup;
+ *                "mlp_stream_2cu" 1 (default, except NCF) | 0: "mlp_stream" 2 with a ring of three
+ *                register sets instead of six, compiled for 128 VGPRs, so that two of its workgroups
+ *                share a CU and overlapping launches interleave on the same SIMDs)
  *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
  *                LDS in one round instead of streaming it per K chunk
  *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)

@@ -671,6 +671,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "unfused_stream_packed": dict(mlp_stream=2, mlp_fuse=0, shared_stream=1),
             "pipelined_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=2),
             "packed_16_waves": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_waves=16),
+            "packed_ring3_2_per_cu": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),   # 128 VGPRs: two workgroups per CU
             "stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=8),   # 8 waves x 2 tiles, b128 operands
             "stream3_4_waves": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4),   # 4 waves x 4 tiles
             "unfused_stream3": dict(mlp_stream=3, mlp_fuse=0, shared_stream=1),
@@ -690,6 +691,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             results[name] = outs[0]
             eng.set_option("mlp_wide_kn", 512 * 1024)
             eng.set_option("mlp_stream_waves", 0)
+            eng.set_option("mlp_stream_2cu", 0)
         for name, got in results.items():
             assert np.array_equal(got, results["stream"]), name
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
