@@ -350,8 +350,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                consumed before the call returns) and hands the HIP calls -- DMA copy, events,
  *                launches -- to a launcher thread; errors of those calls surface at drs_wait.  Cuts
  *                the caller's time per call from 20 to 14 us; throughput is PCIe-bound either way.
- *   "preferred_coalesce" (read only) queries per launch set the engine asks its feeder for: 8, or 16
- *                (DRS_MAX_COALESCE) for MLP-bound models
+ *   "preferred_coalesce" (read only) queries per launch set the engine asks its feeder for: 12
+ *                for gather-bound DLRM (the gap between two gather launches is amortised over
+ *                more bytes), 8 for DIN, 16 (DRS_MAX_COALESCE) for MLP-bound models
  *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
  *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
  *                MLP launches of consecutive small sets overlap each other

@@ -237,7 +237,9 @@ def test_bench_self_spawn_n1_equals_plain_n1_line_shape():
                   "--no_cpu_baseline", "--timed_only"])
     r = out["roofline"]
     assert out["n_gpus"] == 1 and out["config"]["timed_queries_per_gpu"] == 2002
-    assert r["launches_timed"] == (2002 + 7) // 8                    # 250 full sets + one of 2 queries
+    co = out["config"]["queries_per_launch"]                         # the engine's preference for RMC1
+    assert co == 12
+    assert r["launches_timed"] == (2002 + co - 1) // co              # full sets + one partial set
     assert r["bytes_timed"] == 2002 * 43130880                       # RMC1: 43.13 MB per query, exactly
     assert r["frac"] == pytest.approx(r["bytes_timed"] / (r["avg_launch_us"] * 1e-6 * r["launches_timed"]) / 8e12, rel=2e-3)
     assert 0.3 < r["frac"] < 0.8                                       # above the copy ceiling = accounting bug

@@ -33,8 +33,8 @@ trace() { # name, command...
 }
 
 # 1. the bench line exactly as the driver runs it (N=1), with the CPU baseline legs
-mkdir -p "$OUT/cpu_host/raw_data"
-run 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu_table "$OUT/cpu_host/raw_data/results_rm1.txt" > "$OUT/bench.json" 2> "$OUT/bench.err"
+mkdir -p "$OUT/cpu_epyc9575f/raw_data"
+run 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu_table "$OUT/cpu_epyc9575f/raw_data/results_rm1.txt" > "$OUT/bench.json" 2> "$OUT/bench.err"
 # 2. rocprofv3's per-kernel summary of the same warm-up + timed region (--timed_only: none of the
 #    extra legs, so every gather launch in the trace is a launch of the benchmark itself)
 trace bench python bench.py --gpus 1 --steps 20 --warmup 5 --timed_only

@@ -26,7 +26,7 @@ def main(tag, prefix):
             continue
         shutil.copy(p, os.path.join(dst, "%s_%s" % (prefix, f)))
         print("profiles/%s_%s" % (prefix, f))
-    for sub in ("accelerator_mi355x", "cpu_host"):       # latency tables in the reference's "***" format
+    for sub in ("accelerator_mi355x", "cpu_epyc9575f"):       # latency tables in the reference's "***" format
         acc = os.path.join(src, sub)
         if os.path.isdir(acc):
             out = os.path.join(dst, sub)
