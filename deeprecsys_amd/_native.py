@@ -52,6 +52,8 @@ SYMBOLS = [
                                        C.POINTER(_i32p), _f32p]),
     ("drs_run_queues_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_int64, C.c_void_p, C.c_int64]),
+    ("drs_run_queues_multi_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i32p, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), _i64p, _i64p, C.POINTER(C.c_void_p), _i64p]),
     ("drs_fetch_interaction", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
     ("drs_out_width", C.c_int32, [C.c_void_p, _i32p]),
     ("drs_interaction_width", C.c_int32, [C.c_void_p, _i32p]),
@@ -310,6 +312,48 @@ class Engine(object):
             dp = dense.ctypes.data_as(_f32p)
         self._check(lib().drs_forward_inputs_async(self._h, slot, bs, dp, ip, n_idx.ctypes.data_as(_i64p), lp),
                     "drs_forward_inputs_async")
+
+    def run_queues_multi_async(self, queries, slot=0):
+        """Several waiting requests as ONE launch set: `queries` is a list of (dense, ids, lengths, bs)
+        with the arrays as the reference's feeder holds them (ids [T, n] int64, lengths [T, >= bs]
+        int32, dense [>= bs, m_den] float32 or None; row slices of bigger arrays are fine).
+        wait(slot, sum(bs)) returns the outputs back to back.  The arrays are consumed before this
+        returns."""
+        n = len(queries)
+        bsa = np.empty(n, dtype=np.int32)
+        ids_stride = np.empty(n, dtype=np.int64)
+        len_stride = np.empty(n, dtype=np.int64)
+        n_idx = np.empty(n, dtype=np.int64)
+        dp = (C.c_void_p * n)()
+        ip = (C.c_void_p * n)()
+        lp = (C.c_void_p * n)()
+        keep = []
+        for i, (dense, idx, lengths, bs) in enumerate(queries):
+            if not (type(idx) is np.ndarray and idx.ndim == 2 and idx.dtype == np.int64 and idx.strides[1] == 8):
+                idx = np.ascontiguousarray(idx, dtype=np.int64)
+            if not (type(lengths) is np.ndarray and lengths.ndim == 2 and lengths.dtype == np.int32 and lengths.strides[1] == 4):
+                lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+            if idx.ndim != 2 or lengths.ndim != 2 or idx.shape[0] != self.T or lengths.shape[0] != self.T:
+                raise ValueError("query %d: ids / lengths must be [T=%d, ...] arrays" % (i, self.T))
+            if bs < 0 or bs > lengths.shape[1]:
+                raise ValueError("query %d: bs=%d but lengths has %d columns" % (i, bs, lengths.shape[1]))
+            if dense is not None:
+                if not (type(dense) is np.ndarray and dense.dtype == np.float32 and dense.flags.c_contiguous):
+                    dense = np.ascontiguousarray(dense, dtype=np.float32)
+                if dense.ndim != 2 or dense.shape[0] < bs or dense.shape[1] != self.m_den:
+                    raise ValueError("query %d: bs=%d, dense width %d, but dense has shape %r" % (i, bs, self.m_den, dense.shape))
+            keep.append((dense, idx, lengths))
+            bsa[i] = bs
+            ids_stride[i] = idx.strides[0] // 8
+            len_stride[i] = lengths.strides[0] // 4
+            n_idx[i] = idx.shape[1]
+            dp[i] = None if dense is None else dense.ctypes.data
+            ip[i] = idx.ctypes.data
+            lp[i] = lengths.ctypes.data
+        self._check(lib().drs_run_queues_multi_async(self._h, slot, n, bsa.ctypes.data_as(_i32p), dp, ip,
+                                                     ids_stride.ctypes.data_as(_i64p), n_idx.ctypes.data_as(_i64p),
+                                                     lp, len_stride.ctypes.data_as(_i64p)),
+                    "drs_run_queues_multi_async")
 
     def fetch_interaction(self, bs, slot=0):
         R = np.empty((bs, self.num_int), dtype=np.float32)

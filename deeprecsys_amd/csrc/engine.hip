@@ -133,6 +133,13 @@ struct Slot {
   int32_t q_vstart[DRS_MAX_COALESCE] = {0};
   bool busy = false;
   bool polled = false;       // completion arrives through the host flag
+  // per-call inputs of a whole launch set (drs_run_queues_multi_async; allocated on first use):
+  // DRS_MAX_COALESCE blocks [dense | idx | off] back to back in ONE pinned allocation and their
+  // twins in ONE HBM allocation, so that a set's inputs cross the bus in one DMA copy
+  char* h_multi = nullptr;
+  char* d_multi = nullptr;
+  size_t multi_block = 0;    // bytes from one block to the next
+  std::vector<Batch> mq;     // block i viewed as a batch (device pointers into d_multi)
   int32_t launch_rc = 0;     // status of the launches the launcher thread made for the job in flight
   std::string launch_err;
 };
@@ -175,6 +182,7 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+  hipStream_t stream_h2d = nullptr; // input copies of drs_run_queues_multi_async (created on first use)
   int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
   int zero_copy_inputs = 1;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 by size
@@ -357,34 +365,61 @@ static int64_t narrow_checked(const int64_t* s, int64_t n, int64_t r, int32_t* d
 }
 
 // Validate (the Caffe2 ENFORCEs) and narrow int64 -> int32 (the Cast op,
-// models/dlrm_s_caffe2.py:308-309) into caller-provided host buffers.
+// models/dlrm_s_caffe2.py:308-309) into caller-provided host buffers: one table of one query ...
+struct ConvRes { int32_t code = DRS_OK; int32_t bag = 0; int64_t pos = 0, val = 0, total = 0; bool same = true; };
+void convert_table(const drs_engine* e, int32_t n, int t, const int64_t* idx_t, int64_t n_idx_t,
+                   const int32_t* len_t, int32_t* idx32_t /*[cap]*/, int32_t* off_t /*[max_batch+1]*/, ConvRes& r) {
+  r = ConvRes();
+  if (!idx_t && n_idx_t > 0) { r.code = DRS_ERR_BAD_ARG; r.pos = -1; return; }
+  if (!len_t) { r.code = DRS_ERR_BAD_ARG; r.pos = -2; return; }
+  if (n_idx_t < 0 || n_idx_t > e->cap) { r.code = DRS_ERR_BAD_ARG; r.pos = -3; return; }
+  int64_t total = 0;
+  off_t[0] = 0;
+  const int32_t L0 = n > 0 ? len_t[0] : 0;
+  bool same = true;
+  for (int b = 0; b < n; ++b) {
+    if (len_t[b] < 0) { r.code = DRS_ERR_LENGTHS_SUM; r.bag = b; r.pos = -1; return; }
+    same = same && len_t[b] == L0;
+    total += len_t[b];
+    if (total > n_idx_t) break;
+    off_t[b + 1] = (int32_t)total;
+  }
+  r.total = total;
+  r.same = same;
+  if (total != n_idx_t) { r.code = DRS_ERR_LENGTHS_SUM; r.pos = 0; return; }
+  for (int b = n; b < e->max_batch; ++b) off_t[b + 1] = (int32_t)total;
+  const int64_t j = narrow_checked(idx_t, n_idx_t, e->rows[t], idx32_t);
+  if (j >= 0) { r.code = DRS_ERR_INDEX_RANGE; r.pos = j; r.val = idx_t[j]; }
+}
+// ... and what the lowest failing table of a query reports (what a sequential pass would have hit first)
+int32_t convert_report(drs_engine* e, const ConvRes* res, const int64_t* n_idx, const char* who = "") {
+  for (int t = 0; t < e->T; ++t) {
+    const ConvRes& r = res[t];
+    if (r.code == DRS_OK) continue;
+    if (r.code == DRS_ERR_BAD_ARG) {
+      if (r.pos == -1) return fail(e, DRS_ERR_BAD_ARG, "%sh_idx[%d] is NULL", who, t);
+      if (r.pos == -2) return fail(e, DRS_ERR_BAD_ARG, "%sh_len[%d] is NULL", who, t);
+      return fail(e, DRS_ERR_BAD_ARG, "%stable %d: %lld indices exceed staging capacity %lld", who, t,
+                  (long long)n_idx[t], (long long)e->cap);
+    }
+    if (r.code == DRS_ERR_LENGTHS_SUM) {
+      if (r.pos == -1) return fail(e, DRS_ERR_LENGTHS_SUM, "%stable %d bag %d: negative length", who, t, r.bag);
+      return fail(e, DRS_ERR_LENGTHS_SUM, "%stable %d: sum(lengths)=%lld != len(indices)=%lld", who, t,
+                  (long long)r.total, (long long)n_idx[t]);
+    }
+    return fail(e, DRS_ERR_INDEX_RANGE, "%stable %d: index %lld at position %lld outside [0, %lld)", who, t,
+                (long long)r.val, (long long)r.pos, (long long)e->rows[t]);
+  }
+  return DRS_OK;
+}
+
 int32_t convert_inputs(drs_engine* e, int32_t n, const int64_t* const* h_idx, const int64_t* n_idx,
                        const int32_t* const* h_len, int32_t* idx32 /*[T][cap]*/,
                        int32_t* off /*[T][max_batch+1]*/, HostPool* pool = nullptr,
                        const std::function<void()>* also = nullptr /*one more independent work item*/) {
-  // per table: status + where it went wrong; the lowest failing table reports (what a
-  // sequential pass would have hit first)
-  struct Res { int32_t code = DRS_OK; int32_t bag = 0; int64_t pos = 0, val = 0, total = 0; };
-  std::vector<Res> res((size_t)e->T);
+  std::vector<ConvRes> res((size_t)e->T);
   auto one = [&](int t) {
-    Res& r = res[t];
-    if (!h_idx[t] && n_idx[t] > 0) { r.code = DRS_ERR_BAD_ARG; r.pos = -1; return; }
-    if (!h_len[t]) { r.code = DRS_ERR_BAD_ARG; r.pos = -2; return; }
-    if (n_idx[t] < 0 || n_idx[t] > e->cap) { r.code = DRS_ERR_BAD_ARG; r.pos = -3; return; }
-    int32_t* o = off + (size_t)t * (e->max_batch + 1);
-    int64_t total = 0;
-    o[0] = 0;
-    for (int b = 0; b < n; ++b) {
-      if (h_len[t][b] < 0) { r.code = DRS_ERR_LENGTHS_SUM; r.bag = b; r.pos = -1; return; }
-      total += h_len[t][b];
-      if (total > n_idx[t]) break;
-      o[b + 1] = (int32_t)total;
-    }
-    r.total = total;
-    if (total != n_idx[t]) { r.code = DRS_ERR_LENGTHS_SUM; r.pos = 0; return; }
-    for (int b = n; b < e->max_batch; ++b) o[b + 1] = (int32_t)total;
-    const int64_t j = narrow_checked(h_idx[t], n_idx[t], e->rows[t], idx32 + (size_t)t * e->cap);
-    if (j >= 0) { r.code = DRS_ERR_INDEX_RANGE; r.pos = j; r.val = h_idx[t][j]; }
+    convert_table(e, n, t, h_idx[t], n_idx[t], h_len[t], idx32 + (size_t)t * e->cap, off + (size_t)t * (e->max_batch + 1), res[t]);
   };
   int64_t work = 0;
   for (int t = 0; t < e->T; ++t) work += n_idx[t] > 0 ? n_idx[t] : 0;
@@ -392,24 +427,7 @@ int32_t convert_inputs(drs_engine* e, int32_t n, const int64_t* const* h_idx, co
   const int n_items = e->T + (also ? 1 : 0);
   if (pool && work >= 32768) pool->run(n_items, item);
   else for (int i = 0; i < n_items; ++i) item(i);
-  for (int t = 0; t < e->T; ++t) {
-    const Res& r = res[t];
-    if (r.code == DRS_OK) continue;
-    if (r.code == DRS_ERR_BAD_ARG) {
-      if (r.pos == -1) return fail(e, DRS_ERR_BAD_ARG, "h_idx[%d] is NULL", t);
-      if (r.pos == -2) return fail(e, DRS_ERR_BAD_ARG, "h_len[%d] is NULL", t);
-      return fail(e, DRS_ERR_BAD_ARG, "table %d: %lld indices exceed staging capacity %lld", t,
-                  (long long)n_idx[t], (long long)e->cap);
-    }
-    if (r.code == DRS_ERR_LENGTHS_SUM) {
-      if (r.pos == -1) return fail(e, DRS_ERR_LENGTHS_SUM, "table %d bag %d: negative length", t, r.bag);
-      return fail(e, DRS_ERR_LENGTHS_SUM, "table %d: sum(lengths)=%lld != len(indices)=%lld", t,
-                  (long long)r.total, (long long)n_idx[t]);
-    }
-    return fail(e, DRS_ERR_INDEX_RANGE, "table %d: index %lld at position %lld outside [0, %lld)", t,
-                (long long)r.val, (long long)r.pos, (long long)e->rows[t]);
-  }
-  return DRS_OK;
+  return convert_report(e, res.data(), n_idx);
 }
 
 int32_t mlp_ready(drs_engine* e, const Mlp& m, const char* name) {
@@ -1310,7 +1328,11 @@ int32_t drs_destroy(drs_handle e) {
   e->launcher.reset();           // (finishes the jobs it holds, then joins)
   (void)hipSetDevice(e->device);
   if (e->stream_g) { (void)hipStreamSynchronize(e->stream_g); (void)hipStreamDestroy(e->stream_g); }
+  if (e->stream_h2d) { (void)hipStreamSynchronize(e->stream_h2d); (void)hipStreamDestroy(e->stream_h2d); }
   for (auto& s : e->slots) {
+    if (s.h_multi) (void)hipHostFree(s.h_multi);
+    if (s.d_multi) (void)hipFree(s.d_multi);
+    s.mq.clear();
     if (s.own_stream) { (void)hipStreamSynchronize(s.own_stream); (void)hipStreamDestroy(s.own_stream); }
     if (s.ev_sls) (void)hipEventDestroy(s.ev_sls);
     if (s.ev_in) (void)hipEventDestroy(s.ev_in);
@@ -1594,7 +1616,6 @@ int32_t drs_forward_inputs_async(drs_handle e, int32_t slot, int32_t bs, const f
   if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
   Slot& s = e->slots[slot];
   if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
-  const Batch* bt;
   // the copies below must go on the stream the job's MLP side will use
   if (bs >= 0) s.stream = job_stream(e, s, ((int64_t)bs + 63) / 64 * 64);
   // how the converted inputs reach the kernels: 1 = read in place from the pinned block over PCIe
@@ -1651,6 +1672,114 @@ int32_t drs_run_queues_async(drs_handle e, int32_t slot, int32_t bs, const float
     ni[t] = n_idx_per_table;
   }
   return drs_forward_inputs_async(e, slot, bs, h_dense, ip, ni, lp);
+}
+
+// n queries' per-call arrays as ONE launch set: every query is narrowed / ENFORCE-checked into its
+// own block of the slot's multi-block pinned allocation, the blocks cross the bus in one DMA copy on
+// a copy stream of their own (so the copy of this set runs under the gathers of the sets before it),
+// and the set is launched like a coalesced set of staged batches.
+int32_t drs_run_queues_multi_async(drs_handle e, int32_t slot, int32_t n, const int32_t* bs,
+                                   const float* const* h_dense, const int64_t* const* h_ids,
+                                   const int64_t* ids_row_stride, const int64_t* n_idx_per_table,
+                                   const int32_t* const* h_lengths, const int64_t* len_row_stride) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  if (n < 1 || n > DRS_MAX_COALESCE) return fail(e, DRS_ERR_BAD_ARG, "1..%d queries per launch", DRS_MAX_COALESCE);
+  if (!bs || !h_dense || !h_ids || !ids_row_stride || !n_idx_per_table || !h_lengths || !len_row_stride || e->T > 256)
+    return fail(e, DRS_ERR_BAD_ARG, "bad per-query array tables");
+  Slot& s = e->slots[slot];
+  if (s.busy && (rc = wait_slot(e, s, nullptr))) return rc;
+  const size_t dense_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1);
+  const size_t idx_bytes = sizeof(int32_t) * (size_t)e->T * e->cap;
+  const size_t off_bytes = sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1);
+  if (!s.h_multi) {
+    s.multi_block = (size_t)round_up((int64_t)(dense_bytes + idx_bytes + off_bytes), 256);
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&s.h_multi), s.multi_block * DRS_MAX_COALESCE, hipHostMallocDefault));
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&s.d_multi), s.multi_block * DRS_MAX_COALESCE));
+    s.mq.assign(DRS_MAX_COALESCE, Batch());
+    for (int i = 0; i < DRS_MAX_COALESCE; ++i) {
+      char* d = s.d_multi + (size_t)i * s.multi_block;
+      s.mq[i].dense = reinterpret_cast<float*>(d);
+      s.mq[i].idx = reinterpret_cast<int32_t*>(d + dense_bytes);
+      s.mq[i].off = reinterpret_cast<int32_t*>(d + dense_bytes + idx_bytes);
+      s.mq[i].h_off.assign((size_t)e->T * (e->max_batch + 1), 0);
+    }
+  }
+  if (!e->stream_h2d) HIP_TRY(e, hipStreamCreateWithFlags(&e->stream_h2d, hipStreamNonBlocking));
+  // host pass: ONE fork-join over the tables (and dense rows) of every query of the set
+  for (int i = 0; i < n; ++i) {
+    if (bs[i] < 0 || bs[i] > e->max_batch) return fail(e, DRS_ERR_BAD_ARG, "query %d: n_samples=%d exceeds max_batch=%d", i, bs[i], e->max_batch);
+    if (!h_ids[i] || !h_lengths[i] || n_idx_per_table[i] < 0) return fail(e, DRS_ERR_BAD_ARG, "bad 2-D input arrays of query %d", i);
+    if (e->m_den > 0 && !h_dense[i] && bs[i] > 0) return fail(e, DRS_ERR_BAD_ARG, "query %d: null dense input", i);
+  }
+  if (!e->pool) {
+    int w = e->host_threads >= 0 ? e->host_threads : (e->T < 7 ? e->T : 7);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && w > hw - 1) w = hw - 1;
+    e->pool.reset(new HostPool(w < 0 ? 0 : w));
+  }
+  const int T = e->T, per_q = T + 1;
+  std::vector<ConvRes> res((size_t)n * T);
+  auto item = [&](int k) {
+    const int i = k / per_q, t = k % per_q;
+    char* blk = s.h_multi + (size_t)i * s.multi_block;
+    if (t == T) {   // the dense rows
+      if (e->m_den > 0 && bs[i] > 0) memcpy(blk, h_dense[i], sizeof(float) * (size_t)bs[i] * e->m_den);
+      return;
+    }
+    int32_t* off_t = reinterpret_cast<int32_t*>(blk + dense_bytes + idx_bytes) + (size_t)t * (e->max_batch + 1);
+    convert_table(e, bs[i], t, h_ids[i] + (int64_t)t * ids_row_stride[i], n_idx_per_table[i],
+                  h_lengths[i] + (int64_t)t * len_row_stride[i],
+                  reinterpret_cast<int32_t*>(blk + dense_bytes) + (size_t)t * e->cap, off_t, res[(size_t)i * T + t]);
+    memcpy(s.mq[i].h_off.data() + (size_t)t * (e->max_batch + 1), off_t, sizeof(int32_t) * (size_t)(e->max_batch + 1));
+  };
+  e->pool->run(n * per_q, item);
+  const Batch* bts[DRS_MAX_COALESCE];
+  int64_t Mv = 0;
+  size_t used_sum = 0, used[DRS_MAX_COALESCE];
+  bool need_off = false;
+  for (int i = 0; i < n; ++i) {
+    Batch& b = s.mq[i];
+    int64_t ni[256];
+    for (int t = 0; t < T; ++t) ni[t] = n_idx_per_table[i];
+    char who[32];
+    snprintf(who, sizeof who, "query %d: ", i);
+    if ((rc = convert_report(e, res.data() + (size_t)i * T, ni, who))) {
+      for (int k = 0; k < n; ++k) { s.mq[k].staged = false; s.mq[k].n_samples = 0; }
+      return rc;
+    }
+    b.n_samples = bs[i];
+    b.staged = true;
+    b.uniform_len = -1;
+    if (bs[i] > 0) {
+      const int32_t L0 = h_lengths[i][0];
+      bool same = true;
+      for (int t = 0; t < T && same; ++t) same = res[(size_t)i * T + t].same && h_lengths[i][(int64_t)t * len_row_stride[i]] == L0;
+      if (same) b.uniform_len = L0;
+    }
+    bts[i] = &b;
+    Mv += ((int64_t)bs[i] + 63) / 64 * 64;
+    used[i] = dense_bytes + sizeof(int32_t) * ((size_t)(T - 1) * e->cap + (size_t)n_idx_per_table[i]);
+    used_sum += used[i];
+    need_off = need_off || !e->sls_uniform || b.uniform_len < 0;
+  }
+  if (Mv > e->max_rows) return fail(e, DRS_ERR_BAD_ARG, "%lld coalesced rows exceed the slot capacity %lld", (long long)Mv, (long long)e->max_rows);
+  // one copy of the n blocks when they are mostly full (and always when the prefix sums are needed:
+  // they sit at the end of a block); else the used prefix of each
+  if (need_off || 2 * used_sum >= (size_t)n * s.multi_block) {
+    const size_t bytes = need_off ? (size_t)n * s.multi_block : (size_t)(n - 1) * s.multi_block + used[n - 1];
+    HIP_TRY(e, hipMemcpyAsync(s.d_multi, s.h_multi, bytes, hipMemcpyHostToDevice, e->stream_h2d));
+  } else {
+    for (int i = 0; i < n; ++i)
+      HIP_TRY(e, hipMemcpyAsync(s.d_multi + (size_t)i * s.multi_block, s.h_multi + (size_t)i * s.multi_block, used[i],
+                                hipMemcpyHostToDevice, e->stream_h2d));
+  }
+  HIP_TRY(e, hipEventRecord(s.ev_in, e->stream_h2d));
+  const hipStream_t ms = job_stream(e, s, Mv), gs = job_gather_stream(e, s, Mv);
+  HIP_TRY(e, hipStreamWaitEvent(gs, s.ev_in, 0));
+  if (ms != gs) HIP_TRY(e, hipStreamWaitEvent(ms, s.ev_in, 0));   // the MLP side reads the dense rows
+  return enqueue_forward(e, s, n, bts, bs);
 }
 
 int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,

@@ -155,6 +155,21 @@ class _HipNet(object):
         self._out = self.engine.forward_inputs(fc, ids, lengths, int(batch_size))
         return self._out
 
+    def run_queued_multi(self, requests, slot=0):
+        """run_queues for every request an engine found waiting in its queue, as ONE launch set
+        (drs_run_queues_multi_async): `requests` is a list of (ids, lengths, fc, batch_size) in
+        run_queues' argument order; returns the list of their [bs_i, n_out] outputs."""
+        no_dense = self.engine.m_den == 0
+        qs = [(None if no_dense else fc, np.asarray(ids) if not isinstance(ids, np.ndarray) else ids,
+               np.asarray(lengths) if not isinstance(lengths, np.ndarray) else lengths, int(bs))
+              for ids, lengths, fc, bs in requests]
+        self.engine.run_queues_multi_async(qs, slot=slot)
+        sizes = [q[3] for q in qs]
+        out = self.engine.wait(slot, sum(sizes))
+        outs = np.split(out, np.cumsum(sizes)[:-1], axis=0)
+        self._out = outs[-1]
+        return outs
+
     def stage_batches(self, lX, lS_l, lS_i):
         for j in range(len(lS_l)):
             self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
@@ -487,6 +502,10 @@ class _Wrapper(object):
 
     def run_queues(self, ids, lengths, fc, batch_size):
         return self.net.run_queued(ids, lengths, fc, batch_size)
+
+    def run_queues_multi(self, requests, slot=0):
+        """Several queued requests, each in run_queues' argument order, as one launch set."""
+        return self.net.run_queued_multi(requests, slot=slot)
 
 
 class DLRM_Wrapper(_Wrapper):

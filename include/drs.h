@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRS_ABI_VERSION 3
+#define DRS_ABI_VERSION 4
 
 typedef struct drs_engine* drs_handle;
 
@@ -220,6 +220,20 @@ int32_t drs_forward_inputs_async(drs_handle h, int32_t slot, int32_t bs,
 int32_t drs_run_queues_async(drs_handle h, int32_t slot, int32_t bs, const float* h_dense,
                              const int64_t* h_ids, int64_t ids_row_stride, int64_t n_idx_per_table,
                              const int32_t* h_lengths, int64_t len_row_stride);
+/* Several queued requests' arrays as ONE launch set -- what an engine process does with the
+ * requests it finds waiting in its queue (inferenceEngine.py:195-215 takes one request per turn
+ * and slices its arrays; accelInferenceEngine.py drains the queue): query i is (bs[i],
+ * h_dense[i] [bs, m_den], h_ids[i] [T, n_idx_per_table[i]] int64, h_lengths[i] [T, bs] int32, rows
+ * ids_row_stride[i] / len_row_stride[i] ELEMENTS apart), n in 1..DRS_MAX_COALESCE.  Every query
+ * is narrowed and ENFORCE-checked like a drs_run_queues_async call (the lowest failing query
+ * reports; nothing is launched then); the converted inputs of the whole set cross PCIe in one
+ * DMA copy that overlaps the kernels of the sets before it.  drs_wait returns the n results back
+ * to back, [sum(bs), n_out], exactly as for drs_forward_multi_async, and a query's bits do not
+ * depend on what it was coalesced with.  All arrays are consumed before the call returns. */
+int32_t drs_run_queues_multi_async(drs_handle h, int32_t slot, int32_t n, const int32_t* bs,
+                                   const float* const* h_dense, const int64_t* const* h_ids,
+                                   const int64_t* ids_row_stride, const int64_t* n_idx_per_table,
+                                   const int32_t* const* h_lengths, const int64_t* len_row_stride);
 /* read back the interaction tensor R [bs, num_int] (the top MLP's input) of the last forward
  * on `slot` (parity tests).  Rows are the slot's virtual rows: a single query starts at row 0,
  * coalesced query i at the sum of round_up(bs_j, 64) over j < i; bs may span several queries. */

@@ -527,6 +527,30 @@ int32_t drs_run_queues_async(drs_handle e, int32_t slot, int32_t bs, const float
   return drs_forward_inputs_async(e, slot, bs, h_dense, ip.data(), ni.data(), lp.data());
 }
 
+int32_t drs_run_queues_multi_async(drs_handle e, int32_t slot, int32_t n, const int32_t* bs,
+                                   const float* const* h_dense, const int64_t* const* h_ids,
+                                   const int64_t* ids_row_stride, const int64_t* n_idx_per_table,
+                                   const int32_t* const* h_lengths, const int64_t* len_row_stride) {
+  int32_t rc = check_handle(e);
+  if (rc) return rc;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  if (n < 1 || n > DRS_MAX_COALESCE) return fail(e, DRS_ERR_BAD_ARG, "1..%d queries per launch", DRS_MAX_COALESCE);
+  if (!bs || !h_dense || !h_ids || !ids_row_stride || !n_idx_per_table || !h_lengths || !len_row_stride)
+    return fail(e, DRS_ERR_BAD_ARG, "bad per-query array tables");
+  std::vector<Batch> b(n);
+  const Batch* bts[DRS_MAX_COALESCE];
+  for (int i = 0; i < n; ++i) {
+    if (!h_ids[i] || !h_lengths[i] || n_idx_per_table[i] < 0) return fail(e, DRS_ERR_BAD_ARG, "bad 2-D input arrays of query %d", i);
+    std::vector<const int64_t*> ip(e->T);
+    std::vector<const int32_t*> lp(e->T);
+    std::vector<int64_t> ni(e->T, n_idx_per_table[i]);
+    for (int t = 0; t < e->T; ++t) { ip[t] = h_ids[i] + (int64_t)t * ids_row_stride[i]; lp[t] = h_lengths[i] + (int64_t)t * len_row_stride[i]; }
+    if ((rc = store_batch(e, b[i], bs[i], h_dense[i], ip.data(), ni.data(), lp.data()))) return rc;
+    bts[i] = &b[i];
+  }
+  return run(e, e->slots[slot], n, bts, bs);
+}
+
 int32_t drs_forward_inputs(drs_handle e, int32_t slot, int32_t bs, const float* h_dense,
                            const int64_t* const* h_idx, const int64_t* n_idx,
                            const int32_t* const* h_len, float* h_out) {

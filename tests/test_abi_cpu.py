@@ -20,7 +20,7 @@ def test_cpu_abi_restates_every_entry_point_of_the_header(cpu_abi):
     assert declared == bound, declared ^ bound          # the binding covers the whole header ...
     for name in declared:
         assert hasattr(cpu_abi, name), name              # ... and so does the CPU restatement
-    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 3 and cpu_abi.drs_backend() == b"cpu:oracle"
+    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 4 and cpu_abi.drs_backend() == b"cpu:oracle"
 
 
 @pytest.mark.parametrize("case", H.MODEL_CASES)
@@ -48,6 +48,16 @@ def test_wrappers_through_the_abi_match_oracle_and_golden(cpu_abi, case):
         outs = net.run_staged_multi([0, len(lS_l) - 1, 0], [n, 1, max(1, n // 2)])
         assert [o.shape[0] for o in outs] == [n, 1, max(1, n // 2)]
         assert np.array_equal(outs[1], net.run_staged(len(lS_l) - 1, 1))
+        # several waiting requests' arrays as one launch set (drs_run_queues_multi_async)
+        L_ = int(args.num_indices_per_lookup)
+        reqs = []
+        for bid, bs in ((0, n), (len(lS_l) - 1, 1), (0, max(1, n // 2))):
+            ids2 = np.stack([np.asarray(i, dtype=np.int64) for i in lS_i[bid]])
+            len2 = np.stack([np.asarray(l, dtype=np.int32) for l in lS_l[bid]])
+            fc = None if ncf else np.asarray(lX[bid], dtype=np.float32)[:bs]
+            reqs.append((ids2[:, :bs * L_], len2[:, :bs], fc, bs))
+        outs_q = net.run_queued_multi(reqs)
+        assert all(np.array_equal(a_, b_) for a_, b_ in zip(outs_q, outs))
         # the reference's stand-alone run(X, S_lengths, S_indices) signature: per-call host inputs
         net.run(None if ncf else lX[0], lS_l[0], lS_i[0])
         assert np.array_equal(net.fetch_output(), net.run_staged(0, n))
@@ -178,7 +188,7 @@ def test_hip_library_loads_and_exports_every_symbol_of_the_header():
     assert len(declared) >= 28
     for name in declared:
         assert hasattr(L, name), "libdrs_hip.so does not export %s" % name
-    assert N.lib().drs_abi_version() == 3 and N.lib().drs_backend() == b"hip:gfx950"
+    assert N.lib().drs_abi_version() == 4 and N.lib().drs_backend() == b"hip:gfx950"
     if N.device_count() == 0:
         with pytest.raises(N.DrsError) as ei:
             N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,

@@ -878,6 +878,124 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
         eng.close()
 
 
+def test_per_call_inputs_of_a_whole_launch_set():
+    """drs_run_queues_multi_async: the arrays of several waiting requests (inferenceEngine.py:195-215:
+    slices of the pre-generated sets) as ONE launch set -- every query's bits are those of the same
+    query served alone through the staged path, whatever it is coalesced with (1..16 queries, mixed
+    prefix sizes, ragged bags, several sets in flight); the ENFORCEs name the failing query's table
+    and nothing is launched then."""
+    T, rows, D, L, B = 8, 100_000, 64, 80, 256
+    rng = np.random.RandomState(33)
+    eng = N.Engine(N.MODEL_DLRM, [rows] * T, D, [16, D], [D * (T + 1), 8, 1], N.INTERACT_CAT, sigmoid_top=2,
+                   max_batch=B, max_lookups=L, num_staged_batches=4, num_slots=3)
+    try:
+        for t in range(T):
+            eng.fill_table_uniform(t, -0.1, 0.1, 3)
+        eng.set_fc(N.MLP_BOT, 0, rng.randn(D, 16).astype(np.float32), rng.randn(D).astype(np.float32))
+        eng.set_fc(N.MLP_TOP, 0, rng.randn(8, D * (T + 1)).astype(np.float32) * 0.05, np.zeros(8, np.float32))
+        eng.set_fc(N.MLP_TOP, 1, rng.randn(1, 8).astype(np.float32), np.zeros(1, np.float32))
+        nb = 4
+        sets = []
+        for k in range(nb):
+            ids = rng.randint(0, rows, size=(T, B * L)).astype(np.int64)
+            lens = np.full((T, B), L, dtype=np.int32)
+            dense = rng.rand(B, 16).astype(np.float32)
+            eng.stage_batch(k, dense, list(ids), list(lens))
+            sets.append((dense, ids, lens))
+        alone = {}
+        def ref(k, bs):
+            if (k, bs) not in alone:
+                alone[(k, bs)] = eng.forward(k, bs)
+            return alone[(k, bs)]
+        def query(k, bs):
+            dense, ids, lens = sets[k]
+            return (dense[:bs], ids[:, :bs * L], lens[:, :bs], bs)       # strided slices, as the feeder makes them
+        for n, sizes in ((1, (B,)), (2, (165, B)), (5, (1, 64, 65, B, 17)), (8, (B,) * 8), (12, (B,) * 12), (16, (B, 200) * 8), (3, (0, 7, 0))):
+            qs = [query(i % nb, sizes[i % len(sizes)]) for i in range(n)]
+            for workers in (-1, 0):
+                eng.set_option("host_threads", workers)
+                eng.run_queues_multi_async(qs, slot=0)
+                out = eng.wait(0, sum(q[3] for q in qs))
+                o = 0
+                for i, q in enumerate(qs):
+                    assert np.array_equal(out[o:o + q[3]], ref(i % nb, q[3])), (n, i, q[3], workers)
+                    o += q[3]
+        # three sets in flight, mixed with a staged set and a single per-call query
+        eng.set_option("host_threads", -1)
+        for rep in range(10):
+            qa = [query((rep + i) % nb, B) for i in range(8)]
+            qb = [query((rep + i + 1) % nb, 165) for i in range(3)]
+            eng.run_queues_multi_async(qa, slot=0)
+            eng.forward_multi_async(1, [0, 1], [B, 99])
+            eng.run_queues_multi_async(qb, slot=2)
+            out = eng.wait(0, 8 * B)
+            for i in range(8):
+                assert np.array_equal(out[i * B:(i + 1) * B], ref((rep + i) % nb, B)), (rep, i)
+            out = eng.wait(1, B + 99)
+            assert np.array_equal(out[:B], ref(0, B)) and np.array_equal(out[B:], ref(1, 99))
+            out = eng.wait(2, 3 * 165)
+            for i in range(3):
+                assert np.array_equal(out[i * 165:(i + 1) * 165], ref((rep + i + 1) % nb, 165)), (rep, i)
+            d, i_, l_, _ = query(rep % nb, B)
+            assert np.array_equal(eng.forward_inputs(d, i_, l_, B, slot=0), ref(rep % nb, B))
+        # ragged bags: the prefix sums travel with the set (every table: a permutation of the same lengths)
+        base = rng.randint(0, L + 1, size=B).astype(np.int32)
+        lens_r = np.stack([rng.permutation(base) for _ in range(T)]).astype(np.int32)
+        n_r = int(base.sum())
+        ids_r = rng.randint(0, rows, size=(T, n_r)).astype(np.int64)
+        eng.stage_batch(3, sets[3][0], list(ids_r), list(lens_r))
+        want = eng.forward(3, B)
+        eng.run_queues_multi_async([(sets[3][0], ids_r, lens_r, B), query(0, B)], slot=1)
+        out = eng.wait(1, 2 * B)
+        assert np.array_equal(out[:B], want) and np.array_equal(out[B:], ref(0, B))
+        # ENFORCEs: query 1 of the set is bad
+        bad = sets[1][1].copy()
+        bad[4, 123] = rows
+        with pytest.raises(N.DrsError) as ei:
+            eng.run_queues_multi_async([query(0, B), (sets[1][0], bad, sets[1][2], B), query(2, B)], slot=0)
+        assert ei.value.code == N.ERR_INDEX_RANGE and "table 4" in ei.value.detail
+        eng.run_queues_multi_async([query(2, B)], slot=0)                         # the slot is usable afterwards
+        assert np.array_equal(eng.wait(0, B), ref(2, B))
+        with pytest.raises(ValueError):
+            eng.run_queues_multi_async([(sets[0][0], sets[0][1], sets[0][2][:, :10], B)], slot=0)
+        with pytest.raises(N.DrsError):
+            eng.run_queues_multi_async([query(0, B)] * 17, slot=0)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("case", ["din_mini", "dien_mini", "ncf_mini", "wnd_mini"])
+def test_per_call_launch_sets_of_the_other_models(case):
+    """The same call on DIN / DIEN / NCF (no dense input) and W&D: a set of per-call queries gives
+    the bits of each query served alone from staged inputs."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"], accel_slots=2)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    eng = net.engine
+    try:
+        net.stage_batches(lX if eng.m_den else None, lS_l, lS_i)
+        n = len(lS_l[0][0])
+        L = int(args.num_indices_per_lookup)
+        nb = len(lS_l)
+        qs, want = [], []
+        for k in range(min(nb, 5)):
+            ids2 = np.stack([np.asarray(i, dtype=np.int64) for i in lS_i[k]])
+            len2 = np.stack([np.asarray(l, dtype=np.int32) for l in lS_l[k]])
+            bs = max(1, n - 3 * k)
+            dense = np.asarray(lX[k], dtype=np.float32) if eng.m_den else None
+            qs.append((None if dense is None else dense[:bs], ids2[:, :bs * L], len2[:, :bs], bs))
+            want.append(net.run_staged(k, bs))
+        eng.run_queues_multi_async(qs, slot=1)
+        out = eng.wait(1, sum(q[3] for q in qs))
+        o = 0
+        for q, w in zip(qs, want):
+            assert np.array_equal(out[o:o + q[3]], w), (case, q[3])
+            o += q[3]
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("case", ["din_mini", "dien_mini", "ncf_mini"])
 def test_per_call_inputs_of_the_sparse_only_models(case):
     """DIN / DIEN / NCF take no dense input: run_queues' id / length arrays alone, as 2-D arrays or
