@@ -1309,7 +1309,15 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // launch itself within 3 % of the 8-wave forms) leaves the gather at 0.75-0.77 of peak instead of
     // 0.68-0.70 (measured round 3, same session A/B: 127 k -> 132 k queries/s).  MLP-bound models keep
     // the 8-wave packed form, which is faster alone (NCF 43 vs 53 us).
-    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; }
+    // Later in round 3: stream4_kernel, the same four waves with every (layer, pass) run by one
+    // hand-laid instruction stream -- the launch alone 30.6 instead of 33-36 us, one query per
+    // launch set 52.8 k instead of 50.1 k queries/s; beside a full set's gather it costs the gather
+    // 1.5-4 % more than stream3_kernel does (same-session A/B on two boxes), so it takes the small
+    // launch sets only ("mlp_s4_rows").
+    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; e->tune.mlp_s4_rows = 1024; }
+    // W&D and DIEN: their stream launches (512-256-1 tail; top MLP) as stream4_kernel compiled for two
+    // workgroups per CU: 95.1 k -> 96.2 k and 168 k -> 172 k queries/s (MT-WnD -4 %, NCF -9 %, DIN, RM3: +-0)
+    if (e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
     // wide layers as two 64 x 64 GEMM workgroups per CU (gemm.hip) where that measured faster
     e->tune.gemm_2cu = e->kind == DRS_MODEL_DLRM || e->kind == DRS_MODEL_WND;
     // ... and the packed stream kernel in its 128-VGPR form, two workgroups per CU, for every model whose
@@ -1936,7 +1944,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 3) e->tune.mlp_stream = (int)value;
+  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 4) e->tune.mlp_stream = (int)value;
   else if (!strcmp(key, "mlp_stream_2cu") && (value == 0 || value == 1)) e->tune.mlp_stream_2cu = (int)value;
   else if (!strcmp(key, "mlp_gemm_2cu") && (value == 0 || value == 1)) e->tune.gemm_2cu = (int)value;
   else if (!strcmp(key, "launch_thread") && (value == 0 || value == 1)) e->launch_thread = (int)value;
@@ -1946,6 +1954,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214)) e->tune.gemm_tile = (int)value;
   else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
+  else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
@@ -1999,7 +2008,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
+      {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }

@@ -1621,6 +1621,358 @@ __global__ __launch_bounds__(1024 / NT) void stream3_kernel(SArgs a, Done done, 
 #endif
 }
 
+// stream4_kernel ("mlp_stream" 4): the 4-wave form with every SEGMENT -- all 64-k chunks of one
+// (layer, pass) for the 1 / 2 / 4 tiles a wave owns -- run by ONE asm statement (seg_asm.inc, generated
+// by tools/gen_seg_asm.py): an unbroken run of MFMAs with the weight reloads, the operand prefetch and
+// the loop control between them, no per-step descriptor decode, no EXEC masks (a tile a wave does not
+// own is requested from the address of one it owns and its results are dropped by the epilogue).  The
+// ring, the operands and the accumulators live in AGPRs under fixed names; the C++ around the
+// statements (prologue, epilogues, interaction, hand-off) never touches an AGPR -- the Makefile checks
+// the generated ISA for that.  Chunk 0 of the NEXT segment is requested while a segment's last chunk
+// runs, so a layer boundary costs an epilogue and a barrier, not a memory round trip.
+#include "seg_asm.inc"
+// SUM1: the second input is the sum of two column blocks (NCF) -- a template parameter because the third
+// staging array costs 32 VGPRs, and at 280 registers per wave instead of 312 a SIMD that hosts one of
+// this kernel's waves still has room for two of the gather's (104 each) instead of one.
+// TWO: compiled for 256 registers per wave (the input staging arrays halved), so that two workgroups
+// share a CU -- what the MLP-bound models want (see stream_kernel's RD3 form).
+template <bool SUM1, bool TWO>
+__global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done done, XSrc xs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kThreads = 256;
+  kernarg_burst();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+#ifdef DRS_TIMELINE
+  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(smem + a.lds_floats);
+  if (threadIdx.x == 0) g_tl_lds[0] = 0;
+#endif
+  TL(1);
+  const float* zero = a.zero;
+  const int n_table = a.n_table;
+  const uint32_t* s_tab = reinterpret_cast<const uint32_t*>(smem + a.tab_off);
+  const uint32_t* s_lay = reinterpret_cast<const uint32_t*>(smem + a.lay_off);
+  const float* const wbase = a.wbase;
+  // A wave's tiles in a segment: byte offsets (from the arena) of their 4-KB blocks in chunk 0, + 16 lane;
+  // nex = how many of its tpw tiles exist in the twin (the others are requested from tile 0's address)
+  struct Seg { uint32_t off[4]; int nex, tpw, nch; };
+  auto seg_of = [&](uint32_t wp_off, int pstride, int info) {
+    Seg q;
+    q.tpw = (info >> S3_TPW_SHIFT) & 7;
+    q.nch = pstride >> 13;
+    const int tile0 = info & 0xff, ntl = (info >> 8) & 0xff;
+    const int t0 = tile0 + q.tpw * wave;
+    q.nex = min(max(ntl - t0, 0), q.tpw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = q.nex > 0 ? t0 + min(j, q.nex - 1) : 0;
+      q.off[j] = (wp_off + (uint32_t)(t >> 3) * (uint32_t)pstride + (uint32_t)(t & 7) * 1024u) * 4u + (uint32_t)lane * 16u;
+    }
+    return q;
+  };
+  auto prefetch = [&](const Seg& q, int slot) {
+    if (slot)
+      asm volatile(SEG_PREFETCH1_ASM :: "v"(q.off[0]), "v"(q.off[1]), "v"(q.off[2]), "v"(q.off[3]), "s"(wbase)
+                   : "memory", SEG_AGPR_CLOBBER);
+    else
+      asm volatile(SEG_PREFETCH0_ASM :: "v"(q.off[0]), "v"(q.off[1]), "v"(q.off[2]), "v"(q.off[3]), "s"(wbase)
+                   : "memory", SEG_AGPR_CLOBBER);
+  };
+  // ---- prologue: ONE memory round trip.  The chain inputs (the critical path: cold misses all the
+  // way to HBM), the biases and the descriptor table are requested first, the weights of the first
+  // RD steps right behind them; nothing is waited for before all of it is in flight.
+  // A thread's role in the input copies is fixed: row tid / TPR, columns 4 (tid % TPR) + CG j -- no
+  // division, one 64-bit row pointer per input.
+  constexpr int TPR = kThreads / 16, CG = 4 * TPR;   // threads per row; columns one pass of them covers (64 | 128)
+  constexpr int PB = (TWO ? 256 : 512) / CG;                   // column groups per input and batch (512 columns)
+  const int prow = tid / TPR, pk0 = (tid % TPR) * 4;
+  const SInput& in0 = a.in[0];
+  const SInput& in1 = a.in[a.n_inputs > 1 ? 1 : 0];
+  const int nj0 = (in0.cols_pad + CG - 1) / CG, nj1 = a.n_inputs > 1 ? (in1.cols_pad + CG - 1) / CG : 0;
+  const float* base0 = in0.src;
+  int64_t row00 = m0, rows0 = a.M;
+  if (in0.use_xs) resolve_src(xs, in0.src, a.M, m0, &base0, &row00, &rows0);
+  const float* const rp0 = base0 + min(row00 + prow, rows0 - 1) * in0.ld + in0.col0;
+  const float* const rp1 = in1.src + min(m0 + prow, a.M - 1) * in1.ld + in1.col0;
+  const float* const rp2 = in1.src + min(m0 + prow, a.M - 1) * in1.ld + (in1.col2 >= 0 ? in1.col2 : in1.col0);
+  const int cols0 = in0.cols, cols1 = in1.cols, cpad0 = in0.cols_pad, cpad1 = in1.cols_pad;
+  constexpr bool sum1 = SUM1;
+  float* const ld0 = smem + in0.lds_off + prow * in0.lds_ld;
+  float* const ld1 = smem + in1.lds_off + prow * in1.lds_ld;
+  const int lc0 = in0.lds_col0 + pk0, lc1 = in1.lds_col0 + pk0;
+  float* const gd1 = in1.g_dst && m0 + prow < a.M ? in1.g_dst + (m0 + prow) * in1.g_ldd : nullptr;
+  // (a load beyond the block's real columns reads the zero page: an address select keeps it unconditional)
+  auto issue = [&](const float* rp, int cols, int jb, int nj, float4 (&v)[PB]) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      if (jb + j < nj) {                         // uniform
+        const int k = pk0 + CG * (jb + j);
+        int64_t off = k < cols ? (int64_t)k : (int64_t)(zero - rp);   // (offset, not pointer, select: the load stays a global_load)
+        asm("" : "+v"(off));
+        v[j] = *reinterpret_cast<const float4*>(rp + off);
+      }
+  };
+  auto store = [&](float* ld, int lc, int cpad, int jb, int nj, const float4 (&v)[PB]) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      if (jb + j < nj) {
+        const int k = pk0 + CG * (jb + j);
+        if (k < cpad) {
+          // columns c .. c+3 (c a multiple of 4) sit 4 floats apart inside their 16-column block
+          const int c = lc + CG * (jb + j);
+          float* dst = ld + ((c & ~15) | ((c >> 2) & 3));
+          dst[0] = v[j].x; dst[4] = v[j].y; dst[8] = v[j].z; dst[12] = v[j].w;
+        }
+      }
+  };
+  const uint32_t* kp = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();   // SArgs is argument 0
+  uint32_t* dt = reinterpret_cast<uint32_t*>(smem + a.tab_off);
+  uint32_t* dl = reinterpret_cast<uint32_t*>(smem + a.lay_off);
+  const int n_tab_w = 4 * n_table, n_lay_w = a.n_layers * (int)(sizeof(SLayer) / 4);
+  float4 pv0[PB], pv1[PB], pv2[PB];
+  issue(rp0, cols0, 0, nj0, pv0);
+  issue(rp1, cols1, 0, nj1, pv1);
+  if constexpr (sum1) issue(rp2, cols1, 0, nj1, pv2);
+  // biases, descriptors and layer records ride on the same round trip
+  constexpr int NBV = 1024 / kThreads, NTV = 512 / kThreads;
+  float bias_v[NBV];
+  uint32_t tabv[NTV], layv[NTV];
+#pragma unroll
+  for (int j = 0; j < NBV; ++j) bias_v[j] = a.bias[min(tid + j * kThreads, a.n_bias - 1)];
+#pragma unroll
+  for (int j = 0; j < NTV; ++j) {
+    tabv[j] = kp[offsetof(SArgs, tiles) / 4 + min(tid + j * kThreads, n_tab_w - 1)];
+    layv[j] = kp[offsetof(SArgs, L) / 4 + min(tid + j * kThreads, n_lay_w - 1)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  TL(2);
+  // L2 warm-up (see stream3_kernel): one slice of the launch's packed weights per workgroup, fire and
+  // forget, into the odd ring slot's registers (every later request retires after these)
+  {
+    const uint32_t nx = (gridDim.x + 7u) >> 3, rank = blockIdx.x >> 3;
+    const uint32_t bytes = (uint32_t)a.warm_bytes;               // a multiple of 4096
+    const uint32_t slice = ((bytes / nx) + 4095u) & ~4095u;
+    const uint32_t o0 = rank * slice + (uint32_t)tid * 16u, last = bytes - 16u;
+    const float* wb = wbase + a.warm_off;
+#define S4_WARM(R, I)                                                                             \
+    { const uint32_t o_ = min(o0 + (I) * 4096u, last);                                            \
+      asm volatile("global_load_dwordx4 " R ", %0, %1" :: "v"(o_), "s"(wb) : "memory", SEG_AGPR_CLOBBER); }
+    S4_WARM("a[80:83]", 0) S4_WARM("a[84:87]", 1) S4_WARM("a[88:91]", 2) S4_WARM("a[92:95]", 3)
+    S4_WARM("a[96:99]", 4) S4_WARM("a[100:103]", 5) S4_WARM("a[104:107]", 6) S4_WARM("a[108:111]", 7)
+    S4_WARM("a[112:115]", 8) S4_WARM("a[116:119]", 9) S4_WARM("a[120:123]", 10) S4_WARM("a[124:127]", 11)
+    S4_WARM("a[128:131]", 12) S4_WARM("a[132:135]", 13) S4_WARM("a[136:139]", 14) S4_WARM("a[140:143]", 15)
+#undef S4_WARM
+  }
+  // chunk 0 of the first segment (descriptor straight from the arguments: its LDS copy is not there yet)
+  {
+    const STile e0 = a.tiles[0];
+    prefetch(seg_of(e0.wp_off, e0.in_ld, e0.info), 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  store(ld0, lc0, cpad0, 0, nj0, pv0);
+  if constexpr (sum1) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      pv1[j] = make_float4(pv1[j].x + pv2[j].x, pv1[j].y + pv2[j].y, pv1[j].z + pv2[j].z, pv1[j].w + pv2[j].w);
+  }
+  store(ld1, lc1, cpad1, 0, nj1, pv1);
+  if (gd1) {                                     // NCF: the summed block is also kept in global memory
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      if (j < nj1 && pk0 + CG * j < cols1) *reinterpret_cast<float4*>(gd1 + pk0 + CG * j) = pv1[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NBV; ++j)
+    if (tid + j * kThreads < a.n_bias) smem[a.bias_off + tid + j * kThreads] = bias_v[j];
+#pragma unroll
+  for (int j = 0; j < NTV; ++j) {
+    if (tid + j * kThreads < n_tab_w) dt[tid + j * kThreads] = tabv[j];
+    if (tid + j * kThreads < n_lay_w) dl[tid + j * kThreads] = layv[j];
+  }
+  // (inputs wider than 8 x 64 columns: further batches, one round trip each)
+  for (int jb = PB; jb < nj0; jb += PB) { issue(rp0, cols0, jb, nj0, pv0); store(ld0, lc0, cpad0, jb, nj0, pv0); }
+  for (int jb = PB; jb < nj1; jb += PB) {
+    issue(rp1, cols1, jb, nj1, pv1);
+    if constexpr (sum1) {
+      issue(rp2, cols1, jb, nj1, pv2);
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        pv1[j] = make_float4(pv1[j].x + pv2[j].x, pv1[j].y + pv2[j].y, pv1[j].z + pv2[j].z, pv1[j].w + pv2[j].w);
+    }
+    store(ld1, lc1, cpad1, jb, nj1, pv1);
+    if (gd1) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        if (jb + j < nj1 && pk0 + CG * (jb + j) < cols1) *reinterpret_cast<float4*>(gd1 + pk0 + CG * (jb + j)) = pv1[j];
+    }
+  }
+  for (int i0 = 1024; i0 < a.n_bias; i0 += kThreads)     // (more than 1024 bias words: not on any shipped config)
+    if (i0 + tid < a.n_bias) smem[a.bias_off + i0 + tid] = a.bias[i0 + tid];
+  for (int i = tid + 512; i < n_lay_w; i += kThreads) dl[i] = kp[offsetof(SArgs, L) / 4 + i];
+  TL(3);
+  __syncthreads();
+  TL(4);
+
+  // dot interaction between the chains: as stream_kernel's, on this form's slab layout
+  auto interact = [&]() {
+    const float* Ts = smem + a.t_off;
+    float* Rs = smem + a.r_off;
+    const int D = a.D, W = a.r_pad, off = a.itself ? 1 : 0;
+    for (int o = tid; o < 16 * W; o += kThreads) {
+      const int row = o / W, c = o - row * W;
+      const float* t = Ts + row * a.t_ld;
+      float v = 0.f;
+      if (c < D) {
+        v = t[lpos(c)];
+      } else if (c < D + a.P) {
+        const int p = c - D;
+        int i = off ? 0 : 1;
+        while ((i + 1) * (i + off * 2) / 2 <= p) ++i;
+        const int j = p - i * (i - 1 + 2 * off) / 2;
+        const int bi = i * D, bj = j * D;
+        for (int k = 0; k < D; ++k) v = fmaf(t[lpos(bi + k)], t[lpos(bj + k)], v);
+      }
+      Rs[row * a.r_ld + lpos(c)] = v;
+      if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
+    }
+    __syncthreads();
+  };
+
+  // the fields of a layer record the epilogue needs, from its LDS copy
+  struct Epi { int N, act, out_off, out_ld, out_pad, out_col0, b_off, g_sc1; float* g_out; int64_t g_ld; };
+  auto lds_epi = [&](int l) {
+    const uint32_t* src = s_lay + l * (int)(sizeof(SLayer) / 4);
+    auto w = [&](size_t byte_off) { return (int)__builtin_amdgcn_readfirstlane(src[byte_off / 4]); };
+    Epi e;
+    e.N = w(offsetof(SLayer, N)); e.act = w(offsetof(SLayer, act));
+    e.out_off = w(offsetof(SLayer, out_off)); e.out_ld = w(offsetof(SLayer, out_ld));
+    e.out_pad = w(offsetof(SLayer, out_pad)); e.out_col0 = w(offsetof(SLayer, out_col0));
+    e.b_off = w(offsetof(SLayer, b_off)); e.g_sc1 = w(offsetof(SLayer, g_sc1));
+    const uint64_t glo = (uint32_t)w(offsetof(SLayer, g_out)), ghi = (uint32_t)w(offsetof(SLayer, g_out) + 4);
+    e.g_out = reinterpret_cast<float*>(glo | (ghi << 32));
+    const uint64_t llo = (uint32_t)w(offsetof(SLayer, g_ld)), lhi = (uint32_t)w(offsetof(SLayer, g_ld) + 4);
+    e.g_ld = (int64_t)(llo | (lhi << 32));
+    return e;
+  };
+  // Epilogue of one tile: bias + activation -> the next layer's slab (columns past N inside the pad
+  // are zero filled) and / or global memory.  `lim`: columns that exist in the slab; `dst`: this lane's
+  // slab address of (row 4 g, its column); the four rows of a lane are out_ld apart.
+  auto epilogue = [&](const Epi& el, const float (&acc)[4], float bias_v, int col, int lim, float* dst) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = acc[i] + bias_v;
+    if (el.act == DRS_ACT_RELU) {                // (uniform)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (el.act == DRS_ACT_SIGMOID) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], DRS_ACT_SIGMOID);
+    }
+    if (el.out_off >= 0 && col < lim) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i * el.out_ld] = col < el.N ? v[i] : 0.f;
+    }
+    if (el.g_out && col < el.N) {                // the last layer of a chain
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t row = m0 + g * 4 + i;
+        if (row < a.M) {
+          float* dstg = el.g_out + row * el.g_ld + col;
+          if (el.g_sc1) __hip_atomic_store(dstg, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dstg = v[i];
+        }
+      }
+    }
+  };
+
+#define S4_ACC_READ(DST, A0, A1, A2, A3)                                                          \
+  asm volatile("v_accvgpr_read_b32 %0, " A0 "\n\tv_accvgpr_read_b32 %1, " A1 "\n\t"               \
+               "v_accvgpr_read_b32 %2, " A2 "\n\tv_accvgpr_read_b32 %3, " A3                      \
+               : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]) :: SEG_AGPR_CLOBBER)
+  auto desc = [&](int i) {
+    const uint4 d = *reinterpret_cast<const uint4*>(s_tab + 4 * i);
+    STile t;
+    t.wp_off = __builtin_amdgcn_readfirstlane(d.x); t.a_off = __builtin_amdgcn_readfirstlane(d.y);
+    t.in_ld = __builtin_amdgcn_readfirstlane(d.z); t.info = __builtin_amdgcn_readfirstlane(d.w);
+    return t;
+  };
+  int ti = 0, par = 0;          // par: the ring slot this wave's chunk 0 of the segment was requested into
+  while (ti < n_table) {
+    const STile cur = desc(ti);
+    const Seg sg = seg_of(cur.wp_off, cur.in_ld, cur.info);
+    const int nti = ti + sg.nch;
+    const int last_info = __builtin_amdgcn_readfirstlane(s_tab[4 * (nti - 1) + 3]);
+    const STile nx = desc(min(nti, n_table - 1));
+    const Seg sn = seg_of(nx.wp_off, nx.in_ld, nx.info);
+    if (__builtin_expect((cur.info & S3_INTERACT) != 0, 0)) interact();
+    TL(10);
+    if (sg.nex > 0) {
+      uint32_t aaddr = (uint32_t)(((cur.a_off & 0xffff) + r * (cur.a_off >> 16) + g * 4) * 4);
+      int rem = sg.nch;
+      uint32_t r0 = sg.off[0] + 32768u, r1 = sg.off[1] + 32768u, r2 = sg.off[2] + 32768u, r3 = sg.off[3] + 32768u;
+      float c0[4], c1[4], c2[4], c3[4];
+      if (sg.tpw == 4) {
+        asm volatile(SEG_ASM_T4 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(aaddr), "+s"(rem)
+                     : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
+                     : "memory", "scc", SEG_AGPR_CLOBBER);
+      } else if (sg.tpw == 2) {
+        asm volatile(SEG_ASM_T2 : "+v"(r0), "+v"(r1), "+v"(aaddr), "+s"(rem)
+                     : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
+                     : "memory", "scc", SEG_AGPR_CLOBBER);
+      } else {
+        asm volatile(SEG_ASM_T1 : "+v"(r0), "+v"(aaddr), "+s"(rem)
+                     : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
+                     : "memory", "scc", SEG_AGPR_CLOBBER);
+      }
+      TL(12);
+      S4_ACC_READ(c0, "a0", "a1", "a2", "a3"); S4_ACC_READ(c1, "a4", "a5", "a6", "a7");
+      S4_ACC_READ(c2, "a8", "a9", "a10", "a11"); S4_ACC_READ(c3, "a12", "a13", "a14", "a15");
+      const Epi el = lds_epi((last_info >> 24) & 0xff);
+      const int tpw = sg.tpw;
+      const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;
+      const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;
+      float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);
+      const float b0 = smem[el.b_off + min(col0, el.N - 1)], b1 = smem[el.b_off + min(col0 + 16, el.N - 1)];
+      const float b2 = smem[el.b_off + min(col0 + 32, el.N - 1)], b3 = smem[el.b_off + min(col0 + 48, el.N - 1)];
+      if (tpw == 4) { epilogue(el, c2, b2, col0 + 32, lim, dst + 32); epilogue(el, c3, b3, col0 + 48, lim, dst + 48); }
+      epilogue(el, c0, b0, col0, lim, dst);
+      if (tpw >= 2) epilogue(el, c1, b1, col0 + 16, lim, dst + 16);
+    } else {
+      // this wave sits the segment out -- but it still has to request the next one's chunk 0
+      const int tpw = sg.tpw;
+      const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;
+      // (columns of the pad that no twin tile covers: the slab wants zeros there)
+      const Epi el = lds_epi((last_info >> 24) & 0xff);
+      const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;
+      if (el.out_off >= 0) {
+        float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);
+        for (int t = 0; t < tpw; ++t)
+          if (col0 + 16 * t < lim)
+            for (int i = 0; i < 4; ++i) dst[16 * t + i * el.out_ld] = 0.f;
+      }
+      prefetch(sn, par);
+    }
+    if (sg.nex > 0) par = (par + sg.nch) & 1;
+    if (last_info & S3_BARRIER) { TL(13); __syncthreads(); TL(14); }
+    ti = nti;
+  }
+#undef S4_ACC_READ
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory", SEG_AGPR_CLOBBER);   // the trailing request
+  TL(20);
+  signal_done(done, gridDim.x, smem);
+#ifdef DRS_TIMELINE
+  TL(21);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned n = (unsigned)g_tl_lds[0];
+    unsigned base = g_tl_n;
+    for (unsigned i = 0; i < n && base + i < 16384; ++i) g_tl[base + i] = g_tl_lds[i + 1];
+    g_tl_n = base + n;
+  }
+#endif
+}
+
 // The packed twin of a layer's weights (stream_kernel<true>): tile (pass p, chunk c) = 8192 floats,
 // wave w's block = 1024, float4 q of lane (r, g) = { W[128 p + 16 w + r][64 c + 16 q + 4 j + g] : j = 0..3 },
 // i.e. element j of float4 q is the B operand of MFMA step s = 4 q + j (k = 64 c + 4 s + g: natural
@@ -1804,6 +2156,9 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 16>);
   if (e == hipSuccess) e = set_max_lds(stream3_kernel<4, 2>);
   if (e == hipSuccess) e = set_max_lds(stream3_kernel<2, 2>);
+  if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false>);
+  if (e == hipSuccess) e = set_max_lds(stream4_kernel<true, false>);
+  if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, true>);
   if (e == hipSuccess) e = set_max_lds(interact_dot_kernel);
   return e;
 }
@@ -1956,7 +2311,11 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   // "mlp_stream" 3 (default): stream3_kernel -- two tiles per wave, b128 activation operands; its
   // steps must fit the descriptor table
   // stream3_kernel: 4 waves x up to 4 tiles ("mlp_stream_waves" 4) or 8 waves x up to 2 tiles (default)
-  const int nt3 = tune.mlp_stream_waves == 4 ? 4 : 2, nw3 = 16 / nt3;   // tiles per wave at most; waves (4 | 8)
+  // stream4_kernel: the 4-wave step table, run segment by segment ("mlp_stream" 4; with "mlp_stream" 3
+  // on four waves: launches of up to tune.mlp_s4_rows rows -- a single query -- where the launch's own
+  // latency counts, not what it takes from a gather beside it)
+  const bool f4 = tune.mlp_stream == 4 || (tune.mlp_stream == 3 && tune.mlp_stream_waves == 4 && a.M <= tune.mlp_s4_rows);
+  const int nt3 = (f4 || tune.mlp_stream_waves == 4) ? 4 : 2, nw3 = 16 / nt3;   // tiles per wave at most; waves (4 | 8)
   auto tpw3 = [&](int N, int out_pad) {       // tiles per wave of a layer: 1 / 2 (/ 4): a pass covers nw3 * tpw tiles
     const int etl = ((out_pad > N ? out_pad : N) + 15) / 16;
     int t = 1;
@@ -1967,7 +2326,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     const int etl = ((out_pad > N ? out_pad : N) + 15) / 16, tpp = nw3 * tpw3(N, out_pad);
     return ((etl + tpp - 1) / tpp) * ((K + 63) / 64);
   };
-  bool f3 = pk && tune.mlp_stream == 3 && tune.mlp_stream_waves != 16;
+  bool f3 = pk && ((tune.mlp_stream == 3 && tune.mlp_stream_waves != 16) || f4);
   if (f3) {
     int st = 0;
     for (int l = 0; l < na; ++l) {
@@ -1983,7 +2342,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   if (sum && !f3 && pad64(b->width[0]) - sum->cols > ((d_out + 127) / 128) * 128) return false;   // zero pad must fall in an existing pass
   const int nwv = pk && !f3 && tune.mlp_stream_waves == 16 ? 16 : 8;
   const int passw = 16 * nwv;
-  p.packed = f3 ? (nt3 == 4 ? 4 : 3) : pk ? (nwv == 16 ? 2 : 1) : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves
+  p.packed = f3 ? (f4 ? 5 : nt3 == 4 ? 4 : 3) : pk ? (nwv == 16 ? 2 : 1) : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves | 5: stream4
   const int lpad = f3 ? 8 : 4;      // slab rows: 64 m + 8 floats apart in the b128 form, 64 m + 4 else
   // LDS layout (floats): [sB 2x128x68 (LDS-staged form only)][X0][RS][P][Q][biases]
   int off = 0;
@@ -2178,6 +2537,9 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
 #endif
       const dim3 g3((unsigned)((a.M + 15) / 16));
       if (sp.packed == 4) hipLaunchKernelGGL((stream3_kernel<4, 2>), g3, dim3(256), slds, s, sp, d, xs);
+      else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs);
+      else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs);
+      else if (sp.packed == 5) hipLaunchKernelGGL((stream4_kernel<false, false>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 3) hipLaunchKernelGGL((stream3_kernel<2, 2>), g3, dim3(512), slds, s, sp, d, xs);
       else if (sp.packed == 2) hipLaunchKernelGGL((stream_kernel<true, 16>), dim3((unsigned)((a.M + 15) / 16)), dim3(1024), slds, s, sp, d, xs);
       else if (sp.packed && tune.mlp_stream_2cu && sp.n_table > 0) hipLaunchKernelGGL((stream_kernel<true, 8, true>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);

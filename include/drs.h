@@ -322,8 +322,12 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                (tiles of all layers requested six rounds ahead, inputs resident in LDS) when every
  *                K % 4 == 0 and the slabs fit, the tiles read from the layers' PACKED twins (MFMA
  *                operand order, built by drs_set_fc) straight into the MFMA operand registers: no LDS
- *                staging of W, a workgroup barrier per layer instead of per 64-k chunk | 3 (default
- *                for gather-bound DLRM, with "mlp_stream_waves" 4) stream3_kernel: the same packed
+ *                staging of W, a workgroup barrier per layer instead of per 64-k chunk | 4 (default
+ *                for gather-bound DLRM) stream4_kernel: four waves, every (layer, 64-column-per-wave
+ *                pass) run by ONE hand-laid instruction stream (csrc/seg_asm.inc): MFMAs back to
+ *                back with the weight reloads, operand prefetch and loop control between them, ring
+ *                and accumulators in AGPRs under fixed names, the next segment's first chunk
+ *                requested while the last one runs | 3 stream3_kernel: the same packed
  *                twins, activation operands as four ds_read_b128 per 64-k chunk, accumulators in fixed
  *                AGPRs, weight loads spread through the MFMA stream (EXEC-masked for tiles a wave does
  *                not own), one-round-trip prologue; "mlp_stream_waves" 4: four waves x up to four

@@ -673,7 +673,12 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "packed_16_waves": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_waves=16),
             "packed_ring3_2_per_cu": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),   # 128 VGPRs: two workgroups per CU
             "stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=8),   # 8 waves x 2 tiles, b128 operands
-            "stream3_4_waves": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4),   # 4 waves x 4 tiles
+            "stream3_4_waves": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4, mlp_s4_rows=0),   # 4 waves x 4 tiles
+            "stream3_4_waves_small_sets_stream4": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4, mlp_s4_rows=1 << 20),
+            "stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1),               # 4 waves, one asm statement per (layer, pass)
+            "unfused_stream4": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1),
+            "stream4_2_per_cu": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),
+            "pipelined_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2),
             "unfused_stream3": dict(mlp_stream=3, mlp_fuse=0, shared_stream=1),
             "pipelined_stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=2),
             "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
@@ -692,6 +697,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             eng.set_option("mlp_wide_kn", 512 * 1024)
             eng.set_option("mlp_stream_waves", 0)
             eng.set_option("mlp_stream_2cu", 0)
+            eng.set_option("mlp_s4_rows", 0)
         for name, got in results.items():
             assert np.array_equal(got, results["stream"]), name
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)

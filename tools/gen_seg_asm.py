@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generates deeprecsys_amd/csrc/seg_asm.inc: the instruction streams of stream4_kernel (mlp.hip).
+
+One asm statement runs a whole SEGMENT -- every 64-k chunk of one (layer, pass) for the T = 4 / 2 / 1
+column tiles a wave owns -- as an unbroken run of MFMAs with the weight reloads, the operand prefetch
+and the loop control placed between them.  Everything it touches lives in accumulation registers
+under fixed names (the kernel's C++ never uses AGPRs; the build checks that):
+
+    a[0:15]     accumulators, tile j = a[4j:4j+3]
+    a[16:79]    S0: weight slot 0     tile j, k-group q = base + 16 j + 4 q
+    a[80:143]   S1: weight slot 1
+    a[144:159]  A0: activation operands that go with slot 0 (k-group q = base + 4 q)
+    a[160:175]  A1: ... with slot 1
+Chunk c of a segment that starts in slot p uses slot (p + c) % 2; while the LAST chunk runs, chunk 0 of
+the NEXT segment is requested into the other slot, which that segment then starts in (`par`).
+
+Operands of a segment statement (T tiles): %0..%(T-1) R_j (in/out: byte offset from the weight arena
+of tile j's 4-KB block in the chunk the next reload fetches, + 16 lane), then a_addr (in/out: this
+lane's LDS byte address of the next operand read), rem (in/out: chunks left), N_0..N_3 (offsets of the
+next segment's chunk 0, all four tiles), wbase (64-bit scalar), par (scalar: the slot chunk 0 sits in).
+
+    python tools/gen_seg_asm.py > deeprecsys_amd/csrc/seg_asm.inc
+"""
+
+ACC, SB, AB = 0, (16, 80), (144, 160)
+CHUNK_BYTES = 32768
+
+
+def areg(b, n=4):
+    return "a[%d:%d]" % (b, b + n - 1)
+
+
+def gen(T):
+    oR = list(range(T))                 # %0..%T-1
+    oA, oREM = T, T + 1
+    oN = [T + 2 + j for j in range(4)]
+    oW, oPAR = T + 6, T + 7
+    L = []
+    e = L.append
+
+    def S(base, j, q):
+        return base + 16 * j + 4 * q
+
+    def loads(base, offs, tiles, q_list=(0, 1, 2, 3)):
+        for q in q_list:
+            for j in range(tiles):
+                e("global_load_dwordx4 %s, %%%d, %%%d offset:%d" % (areg(S(base, j, q)), offs[j], oW, 1024 * q))
+
+    def read_a(base):
+        for q in range(4):
+            e("ds_read_b128 %s, %%%d offset:%d" % (areg(base + 4 * q), oA, 64 * q))
+        e("v_add_u32 %%%d, 256, %%%d" % (oA, oA))
+
+    def mfmas(sb, ab, q):
+        for s in range(4):
+            for j in range(T):
+                e("v_mfma_f32_16x16x4_f32 %s, a%d, a%d, %s" % (areg(4 * j), ab + 4 * q + s, S(sb, j, q) + s, areg(4 * j)))
+
+    def body(kind, sb, ab, sbo, abo):
+        # kind: steady | penult_w | penult_nw | last_w | last_nw;  sb / ab: this chunk's slot and operand
+        # set, sbo / abo: the other ones
+        if kind == "last_w":
+            e("s_waitcnt vmcnt(0)")
+        if kind == "penult_w":
+            e("s_waitcnt vmcnt(%d)" % (4 * T))
+        e("s_waitcnt lgkmcnt(0)")
+        if kind.startswith("last"):
+            loads(sbo, oN, 4)                      # the next segment's chunk 0 (all four tiles) -> the free slot
+        else:
+            read_a(abo)
+        for q in range(4):
+            if kind == "steady":
+                e("s_waitcnt vmcnt(%d)" % (7 * T))
+            mfmas(sb, ab, q)
+            if kind == "steady":
+                loads(sb, oR, T, (q,))
+        if kind == "steady":
+            for j in range(T):
+                e("v_add_u32 %%%d, 0x%x, %%%d" % (oR[j], CHUNK_BYTES, oR[j]))
+            e("s_sub_u32 %%%d, %%%d, 1" % (oREM, oREM))
+
+    def variant(p):
+        X, Y = (SB[p], AB[p]), (SB[1 - p], AB[1 - p])     # chunk 0 sits in slot p
+        t = "P%d" % p
+        read_a(X[1])
+        for i in range(4 * T):
+            e("v_accvgpr_write_b32 a%d, 0" % i)
+        e("s_cmp_eq_u32 %%%d, 1" % oREM)
+        e("s_cbranch_scc1 LE1%s_%%=" % t)
+        loads(Y[0], oR, T)
+        for j in range(T):
+            e("v_add_u32 %%%d, 0x%x, %%%d" % (oR[j], CHUNK_BYTES, oR[j]))
+        e("s_cmp_eq_u32 %%%d, 2" % oREM)
+        e("s_cbranch_scc1 LE2%s_%%=" % t)
+        e("LLOOP%s_%%=:" % t)
+        body("steady", X[0], X[1], Y[0], Y[1])
+        e("s_cmp_le_u32 %%%d, 2" % oREM)
+        e("s_cbranch_scc1 LTODD%s_%%=" % t)
+        body("steady", Y[0], Y[1], X[0], X[1])
+        e("s_cmp_gt_u32 %%%d, 2" % oREM)
+        e("s_cbranch_scc1 LLOOP%s_%%=" % t)
+        body("penult_w", X[0], X[1], Y[0], Y[1])
+        body("last_w", Y[0], Y[1], X[0], X[1])
+        e("s_branch LDONE_%=")
+        e("LTODD%s_%%=:" % t)
+        body("penult_w", Y[0], Y[1], X[0], X[1])
+        body("last_w", X[0], X[1], Y[0], Y[1])
+        e("s_branch LDONE_%=")
+        e("LE2%s_%%=:" % t)
+        body("penult_nw", X[0], X[1], Y[0], Y[1])
+        body("last_w", Y[0], Y[1], X[0], X[1])
+        e("s_branch LDONE_%=")
+        e("LE1%s_%%=:" % t)
+        body("last_nw", X[0], X[1], Y[0], Y[1])
+
+    # ---- entry: chunk 0 of this segment was requested into slot `par` by the segment before
+    e("s_waitcnt vmcnt(0)")
+    e("s_cmp_eq_u32 %%%d, 0" % oPAR)
+    e("s_cbranch_scc0 LPAR1_%=")
+    variant(0)
+    e("s_branch LDONE_%=")
+    e("LPAR1_%=:")
+    variant(1)
+    e("LDONE_%=:")
+    e("s_nop 15")
+    e("s_nop 7")
+    return L
+
+
+def emit(name, lines):
+    print("#define %s \\" % name)
+    for i, l in enumerate(lines):
+        print('  "%s\\n\\t"%s' % (l, " \\" if i + 1 < len(lines) else ""))
+    print()
+
+
+def main():
+    print("// GENERATED by tools/gen_seg_asm.py -- do not edit.  See that file for the register map.")
+    for T in (4, 2, 1):
+        emit("SEG_ASM_T%d" % T, gen(T))
+    # stand-alone request of a segment's chunk 0 into slot 0 / 1 (kernel prologue; waves that sit a
+    # segment out): %0..%3 offsets of the four tiles, %4 wbase
+    for p in (0, 1):
+        pf = []
+        for q in range(4):
+            for j in range(4):
+                pf.append("global_load_dwordx4 %s, %%%d, %%4 offset:%d" % (areg(SB[p] + 16 * j + 4 * q), j, 1024 * q))
+        emit("SEG_PREFETCH%d_ASM" % p, pf)
+    regs = ", ".join('"a%d"' % i for i in range(176))
+    print("#define SEG_AGPR_CLOBBER %s" % regs)
+
+
+if __name__ == "__main__":
+    main()
