@@ -29,6 +29,7 @@ trace() { # name, command...
   [ -n "$S" ] && cp "$S" "$OUT/${n}_rocprofv3_kernel_stats.csv"
   [ -n "$T" ] && run 120 python tools/trace_stats.py "$T" > "$OUT/${n}_kernel_trace_by_grid.txt"
   [ -n "$T" ] && run 120 python tools/trace_overlap.py "$T" > "$OUT/${n}_kernel_overlap.txt"
+  [ -n "$T" ] && run 120 python tools/trace_timeline.py "$T" 30 > "$OUT/${n}_kernel_timeline.txt"
   rm -rf "$d"
 }
 
@@ -41,6 +42,7 @@ trace bench python bench.py --gpus 1 --steps 20 --warmup 5 --timed_only
 mv "$OUT/bench_rocprofv3_kernel_stats.csv" "$OUT/rocprofv3_kernel_stats.csv" 2>/dev/null
 mv "$OUT/bench_kernel_trace_by_grid.txt" "$OUT/kernel_trace_by_grid.txt" 2>/dev/null
 mv "$OUT/bench_kernel_overlap.txt" "$OUT/kernel_overlap.txt" 2>/dev/null
+mv "$OUT/bench_kernel_timeline.txt" "$OUT/kernel_timeline.txt" 2>/dev/null
 mv "$OUT/bench_traced.json" "$OUT/bench_traced.json" 2>/dev/null
 # 3. PMC passes on RMC1 (the headline workload), each in its own run
 B1="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048"
@@ -68,8 +70,20 @@ pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
-# the 8-wave packed MLP launch in place of stream3_kernel's 4-wave form (what it costs the gather beside it)
+# the 8-wave packed MLP launch / stream4_kernel in place of stream3_kernel's 4-wave form (what each costs
+# the gather beside it), and launch sets of 8 instead of 12 queries
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=2 > "$OUT/bench_mlp_stream2.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=4 > "$OUT/bench_mlp_stream4.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 8 > "$OUT/bench_coalesce8.json" 2>/dev/null
+# the MLP launch ALONE (one stream, 8-query sets = 128 workgroups) in its three forms: durations from
+# rocprofv3, MFMA counters, and the in-kernel timeline of stream4_kernel (needs libdrs_hip_tl.so: make timeline)
+MA="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --coalesce 8 --set shared_stream=1 --set mlp_s4_rows=0"
+trace mlp_alone_stream4 $MA --set mlp_stream=4
+trace mlp_alone_stream3 $MA --set mlp_stream=3 --set mlp_stream_waves=4
+trace mlp_alone_stream2 $MA --set mlp_stream=2 --set mlp_stream_2cu=0
+pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $MA --set mlp_stream=4
+pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" $MA --set mlp_stream=4
+[ -f deeprecsys_amd/libdrs_hip_tl.so ] && TL_ROWS=40 run 200 python tools/mlp_timeline.py --coalesce 8 --set mlp_stream=4 --set shared_stream=1 > "$OUT/mlp_timeline_stream4.txt" 2>&1
 for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf mtwnd din dien; do
   run 400 python bench.py --workload $w --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 4096 > "$OUT/bench_$w.json" 2>/dev/null
   run 400 python bench.py --workload $w --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 --set shared_stream=1 > "$OUT/bench_${w}_single_stream.json" 2>/dev/null
