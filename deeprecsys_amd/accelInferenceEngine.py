@@ -106,7 +106,7 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
     # model (16 for the MLP-bound ones, whose 16-row MLP workgroups then cover all 256 CUs; 8 otherwise)
     coalesce = 1
     if model is not None:
-        want = int(getattr(args, "accel_coalesce", 8))
+        want = int(getattr(args, "accel_coalesce", 0))
         coalesce = max(1, min(want, 16)) if want > 0 else min(m.net.engine.get_option("preferred_coalesce") for m in models)
     n_slots = model.net.engine.num_slots if model is not None else 1
     n_models = len(models) if model is not None else 1
