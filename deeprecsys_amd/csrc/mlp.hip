@@ -1899,25 +1899,35 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     return t;
   };
   int ti = 0, par = 0;          // par: the ring slot this wave's chunk 0 of the segment was requested into
+  STile cur = desc(0);
+  Seg sg = seg_of(cur.wp_off, cur.in_ld, cur.info);
   while (ti < n_table) {
-    const STile cur = desc(ti);
-    const Seg sg = seg_of(cur.wp_off, cur.in_ld, cur.info);
     const int nti = ti + sg.nch;
     const int last_info = __builtin_amdgcn_readfirstlane(s_tab[4 * (nti - 1) + 3]);
+    // the next segment's descriptor now (its chunk 0 is requested from inside this segment's statement),
+    // and everything the epilogue needs from LDS -- layer record, biases -- BEFORE the statement: the
+    // reads complete under its MFMAs instead of after them
     const STile nx = desc(min(nti, n_table - 1));
     const Seg sn = seg_of(nx.wp_off, nx.in_ld, nx.info);
     if (__builtin_expect((cur.info & S3_INTERACT) != 0, 0)) interact();
     TL(10);
+    const Epi el = lds_epi((last_info >> 24) & 0xff);
+    const int tpw = sg.tpw;
+    const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;
+    const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;
+    float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);
     if (sg.nex > 0) {
+      const float b0 = smem[el.b_off + min(col0, el.N - 1)], b1 = smem[el.b_off + min(col0 + 16, el.N - 1)];
+      const float b2 = smem[el.b_off + min(col0 + 32, el.N - 1)], b3 = smem[el.b_off + min(col0 + 48, el.N - 1)];
       uint32_t aaddr = (uint32_t)(((cur.a_off & 0xffff) + r * (cur.a_off >> 16) + g * 4) * 4);
       int rem = sg.nch;
       uint32_t r0 = sg.off[0] + 32768u, r1 = sg.off[1] + 32768u, r2 = sg.off[2] + 32768u, r3 = sg.off[3] + 32768u;
       float c0[4], c1[4], c2[4], c3[4];
-      if (sg.tpw == 4) {
+      if (tpw == 4) {
         asm volatile(SEG_ASM_T4 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(aaddr), "+s"(rem)
                      : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
                      : "memory", "scc", SEG_AGPR_CLOBBER);
-      } else if (sg.tpw == 2) {
+      } else if (tpw == 2) {
         asm volatile(SEG_ASM_T2 : "+v"(r0), "+v"(r1), "+v"(aaddr), "+s"(rem)
                      : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
                      : "memory", "scc", SEG_AGPR_CLOBBER);
@@ -1929,34 +1939,24 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       TL(12);
       S4_ACC_READ(c0, "a0", "a1", "a2", "a3"); S4_ACC_READ(c1, "a4", "a5", "a6", "a7");
       S4_ACC_READ(c2, "a8", "a9", "a10", "a11"); S4_ACC_READ(c3, "a12", "a13", "a14", "a15");
-      const Epi el = lds_epi((last_info >> 24) & 0xff);
-      const int tpw = sg.tpw;
-      const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;
-      const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;
-      float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);
-      const float b0 = smem[el.b_off + min(col0, el.N - 1)], b1 = smem[el.b_off + min(col0 + 16, el.N - 1)];
-      const float b2 = smem[el.b_off + min(col0 + 32, el.N - 1)], b3 = smem[el.b_off + min(col0 + 48, el.N - 1)];
       if (tpw == 4) { epilogue(el, c2, b2, col0 + 32, lim, dst + 32); epilogue(el, c3, b3, col0 + 48, lim, dst + 48); }
       epilogue(el, c0, b0, col0, lim, dst);
       if (tpw >= 2) epilogue(el, c1, b1, col0 + 16, lim, dst + 16);
+      par = (par + sg.nch) & 1;
     } else {
-      // this wave sits the segment out -- but it still has to request the next one's chunk 0
-      const int tpw = sg.tpw;
-      const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;
-      // (columns of the pad that no twin tile covers: the slab wants zeros there)
-      const Epi el = lds_epi((last_info >> 24) & 0xff);
-      const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;
+      // this wave sits the segment out -- but it still has to request the next one's chunk 0, and
+      // the columns of the pad that no twin tile covers want zeros in the slab
       if (el.out_off >= 0) {
-        float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);
         for (int t = 0; t < tpw; ++t)
           if (col0 + 16 * t < lim)
             for (int i = 0; i < 4; ++i) dst[16 * t + i * el.out_ld] = 0.f;
       }
       prefetch(sn, par);
     }
-    if (sg.nex > 0) par = (par + sg.nch) & 1;
     if (last_info & S3_BARRIER) { TL(13); __syncthreads(); TL(14); }
     ti = nti;
+    cur = nx;
+    sg = sn;
   }
 #undef S4_ACC_READ
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory", SEG_AGPR_CLOBBER);   // the trailing request

@@ -78,7 +78,7 @@ run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 8 > "$
 # the MLP launch ALONE (one stream, 8-query sets = 128 workgroups) in its three forms: durations from
 # rocprofv3, MFMA counters, and the in-kernel timeline of stream4_kernel (needs libdrs_hip_tl.so: make timeline)
 MA="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --coalesce 8 --set shared_stream=1 --set mlp_s4_rows=0"
-trace mlp_alone_stream4 $MA --set mlp_stream=4
+trace mlp_alone_stream4 $MA --set mlp_stream=4 --set mlp_stream_2cu=0
 trace mlp_alone_stream3 $MA --set mlp_stream=3 --set mlp_stream_waves=4
 trace mlp_alone_stream2 $MA --set mlp_stream=2 --set mlp_stream_2cu=0
 pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $MA --set mlp_stream=4
