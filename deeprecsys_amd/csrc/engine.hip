@@ -1318,6 +1318,11 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // W&D and DIEN: their stream launches (512-256-1 tail; top MLP) as stream4_kernel compiled for two
     // workgroups per CU: 95.1 k -> 96.2 k and 168 k -> 172 k queries/s (MT-WnD -4 %, NCF -9 %, DIN, RM3: +-0)
     if (e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
+    // MLP-bound DLRM (RM3): the same, and launches of >= 8 192 rows (a 16-query set at batch 512) with 32
+    // rows per workgroup -- two 16-row halves share every weight operand, 256 workgroups still cover the
+    // chip: RM3 config 3's 416-512-256-1 top chain 80 -> 67 us, 31.5 k -> 32.1 k queries/s.  At 4 096 rows
+    // (128 workgroups) the form loses: W&D 96.1 k -> 94.5 k.
+    if (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1) { e->tune.mlp_stream = 4; e->tune.mlp_rows32 = 8192; }
     // wide layers as two 64 x 64 GEMM workgroups per CU (gemm.hip) where that measured faster
     e->tune.gemm_2cu = e->kind == DRS_MODEL_DLRM || e->kind == DRS_MODEL_WND;
     // ... and the packed stream kernel in its 128-VGPR form, two workgroups per CU, for every model whose
@@ -1955,6 +1960,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214)) e->tune.gemm_tile = (int)value;
   else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
   else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
+  else if (!strcmp(key, "mlp_rows32") && value >= 0) e->tune.mlp_rows32 = value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
@@ -2008,7 +2014,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
+      {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }

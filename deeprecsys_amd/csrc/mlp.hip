@@ -1636,7 +1636,10 @@ __global__ __launch_bounds__(1024 / NT) void stream3_kernel(SArgs a, Done done, 
 // this kernel's waves still has room for two of the gather's (104 each) instead of one.
 // TWO: compiled for 256 registers per wave (the input staging arrays halved), so that two workgroups
 // share a CU -- what the MLP-bound models want (see stream_kernel's RD3 form).
-template <bool SUM1, bool TWO>
+// R: 16-row slabs per workgroup (1 | 2).  R = 2: a workgroup owns 32 rows as two halves that share every
+// weight operand -- twice the MFMAs per byte of weights streamed from L2 and per fixed cost of a
+// workgroup; taken for launches of many rows whose slabs still fit LDS ("mlp_rows32").
+template <bool SUM1, bool TWO, int R = 1>
 __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done done, XSrc xs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kThreads = 256;
@@ -1644,7 +1647,8 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  static_assert(R == 1 || (R == 2 && !TWO && !SUM1), "32-row form: one workgroup per CU, no summed input");
+  const int64_t m0 = (int64_t)blockIdx.x * (16 * R);
 #ifdef DRS_TIMELINE
   unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(smem + a.lds_floats);
   if (threadIdx.x == 0) g_tl_lds[0] = 0;
@@ -1673,7 +1677,14 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     return q;
   };
   auto prefetch = [&](const Seg& q, int slot) {
-    if (slot)
+    if constexpr (R == 2) {
+      if (slot)
+        asm volatile(SEG2_PREFETCH1_ASM :: "v"(q.off[0]), "v"(q.off[1]), "v"(q.off[2]), "v"(q.off[3]), "s"(wbase)
+                     : "memory", SEG2_AGPR_CLOBBER);
+      else
+        asm volatile(SEG2_PREFETCH0_ASM :: "v"(q.off[0]), "v"(q.off[1]), "v"(q.off[2]), "v"(q.off[3]), "s"(wbase)
+                     : "memory", SEG2_AGPR_CLOBBER);
+    } else if (slot)
       asm volatile(SEG_PREFETCH1_ASM :: "v"(q.off[0]), "v"(q.off[1]), "v"(q.off[2]), "v"(q.off[3]), "s"(wbase)
                    : "memory", SEG_AGPR_CLOBBER);
     else
@@ -1685,7 +1696,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   // RD steps right behind them; nothing is waited for before all of it is in flight.
   // A thread's role in the input copies is fixed: row tid / TPR, columns 4 (tid % TPR) + CG j -- no
   // division, one 64-bit row pointer per input.
-  constexpr int TPR = kThreads / 16, CG = 4 * TPR;   // threads per row; columns one pass of them covers (64 | 128)
+  constexpr int TPR = kThreads / (16 * R), CG = 4 * TPR;   // threads per row; columns one pass of them covers (64 | 128)
   constexpr int PB = (TWO ? 256 : 512) / CG;                   // column groups per input and batch (512 columns)
   const int prow = tid / TPR, pk0 = (tid % TPR) * 4;
   const SInput& in0 = a.in[0];
@@ -1820,7 +1831,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     const float* Ts = smem + a.t_off;
     float* Rs = smem + a.r_off;
     const int D = a.D, W = a.r_pad, off = a.itself ? 1 : 0;
-    for (int o = tid; o < 16 * W; o += kThreads) {
+    for (int o = tid; o < 16 * R * W; o += kThreads) {
       const int row = o / W, c = o - row * W;
       const float* t = Ts + row * a.t_ld;
       float v = 0.f;
@@ -1859,7 +1870,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   // Epilogue of one tile: bias + activation -> the next layer's slab (columns past N inside the pad
   // are zero filled) and / or global memory.  `lim`: columns that exist in the slab; `dst`: this lane's
   // slab address of (row 4 g, its column); the four rows of a lane are out_ld apart.
-  auto epilogue = [&](const Epi& el, const float (&acc)[4], float bias_v, int col, int lim, float* dst) {
+  auto epilogue = [&](const Epi& el, const float (&acc)[4], float bias_v, int col, int lim, float* dst, int rowoff = 0) {
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = acc[i] + bias_v;
@@ -1877,7 +1888,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     if (el.g_out && col < el.N) {                // the last layer of a chain
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int64_t row = m0 + g * 4 + i;
+        const int64_t row = m0 + rowoff + g * 4 + i;
         if (row < a.M) {
           float* dstg = el.g_out + row * el.g_ld + col;
           if (el.g_sc1) __hip_atomic_store(dstg, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1890,7 +1901,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
 #define S4_ACC_READ(DST, A0, A1, A2, A3)                                                          \
   asm volatile("v_accvgpr_read_b32 %0, " A0 "\n\tv_accvgpr_read_b32 %1, " A1 "\n\t"               \
                "v_accvgpr_read_b32 %2, " A2 "\n\tv_accvgpr_read_b32 %3, " A3                      \
-               : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]) :: SEG_AGPR_CLOBBER)
+               : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]))
   auto desc = [&](int i) {
     const uint4 d = *reinterpret_cast<const uint4*>(s_tab + 4 * i);
     STile t;
@@ -1923,6 +1934,45 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       int rem = sg.nch;
       uint32_t r0 = sg.off[0] + 32768u, r1 = sg.off[1] + 32768u, r2 = sg.off[2] + 32768u, r3 = sg.off[3] + 32768u;
       float c0[4], c1[4], c2[4], c3[4];
+      if constexpr (R == 2) {
+        uint32_t aaddr1 = aaddr + (uint32_t)(16 * (cur.a_off >> 16) * 4);       // rows 16 .. 31 of the slab
+        float d0[4], d1[4], d2[4], d3[4];
+        if (tpw == 4) {
+          asm volatile(SEG2_ASM_T4 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(aaddr), "+v"(aaddr1), "+s"(rem)
+                       : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
+                       : "memory", "scc", SEG2_AGPR_CLOBBER);
+        } else if (tpw == 2) {
+          asm volatile(SEG2_ASM_T2 : "+v"(r0), "+v"(r1), "+v"(aaddr), "+v"(aaddr1), "+s"(rem)
+                       : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
+                       : "memory", "scc", SEG2_AGPR_CLOBBER);
+        } else {
+          asm volatile(SEG2_ASM_T1 : "+v"(r0), "+v"(aaddr), "+v"(aaddr1), "+s"(rem)
+                       : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
+                       : "memory", "scc", SEG2_AGPR_CLOBBER);
+        }
+        TL(12);
+        // accumulators: tile j of half h at a[4 (j + tpw h) ...]
+        float* const dsth = dst + 16 * el.out_ld;
+        if (tpw == 4) {
+          S4_ACC_READ(c0, "a0", "a1", "a2", "a3"); S4_ACC_READ(c1, "a4", "a5", "a6", "a7");
+          S4_ACC_READ(c2, "a8", "a9", "a10", "a11"); S4_ACC_READ(c3, "a12", "a13", "a14", "a15");
+          S4_ACC_READ(d0, "a16", "a17", "a18", "a19"); S4_ACC_READ(d1, "a20", "a21", "a22", "a23");
+          S4_ACC_READ(d2, "a24", "a25", "a26", "a27"); S4_ACC_READ(d3, "a28", "a29", "a30", "a31");
+          epilogue(el, c2, b2, col0 + 32, lim, dst + 32); epilogue(el, c3, b3, col0 + 48, lim, dst + 48);
+          epilogue(el, d2, b2, col0 + 32, lim, dsth + 32, 16); epilogue(el, d3, b3, col0 + 48, lim, dsth + 48, 16);
+          epilogue(el, c1, b1, col0 + 16, lim, dst + 16); epilogue(el, d0, b0, col0, lim, dsth, 16);
+          epilogue(el, d1, b1, col0 + 16, lim, dsth + 16, 16);
+        } else if (tpw == 2) {
+          S4_ACC_READ(c0, "a0", "a1", "a2", "a3"); S4_ACC_READ(c1, "a4", "a5", "a6", "a7");
+          S4_ACC_READ(d0, "a8", "a9", "a10", "a11"); S4_ACC_READ(d1, "a12", "a13", "a14", "a15");
+          epilogue(el, c1, b1, col0 + 16, lim, dst + 16); epilogue(el, d0, b0, col0, lim, dsth, 16);
+          epilogue(el, d1, b1, col0 + 16, lim, dsth + 16, 16);
+        } else {
+          S4_ACC_READ(c0, "a0", "a1", "a2", "a3"); S4_ACC_READ(d0, "a4", "a5", "a6", "a7");
+          epilogue(el, d0, b0, col0, lim, dsth, 16);
+        }
+        epilogue(el, c0, b0, col0, lim, dst);
+      } else {
       if (tpw == 4) {
         asm volatile(SEG_ASM_T4 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(aaddr), "+s"(rem)
                      : "v"(sn.off[0]), "v"(sn.off[1]), "v"(sn.off[2]), "v"(sn.off[3]), "s"(wbase), "s"(par)
@@ -1942,14 +1992,16 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       if (tpw == 4) { epilogue(el, c2, b2, col0 + 32, lim, dst + 32); epilogue(el, c3, b3, col0 + 48, lim, dst + 48); }
       epilogue(el, c0, b0, col0, lim, dst);
       if (tpw >= 2) epilogue(el, c1, b1, col0 + 16, lim, dst + 16);
+      }
       par = (par + sg.nch) & 1;
     } else {
       // this wave sits the segment out -- but it still has to request the next one's chunk 0, and
       // the columns of the pad that no twin tile covers want zeros in the slab
       if (el.out_off >= 0) {
-        for (int t = 0; t < tpw; ++t)
-          if (col0 + 16 * t < lim)
-            for (int i = 0; i < 4; ++i) dst[16 * t + i * el.out_ld] = 0.f;
+        for (int h = 0; h < R; ++h)
+          for (int t = 0; t < tpw; ++t)
+            if (col0 + 16 * t < lim)
+              for (int i = 0; i < 4; ++i) dst[16 * t + (16 * h + i) * el.out_ld] = 0.f;
       }
       prefetch(sn, par);
     }
@@ -2159,6 +2211,7 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<true, false>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, true>);
+  if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false, 2>);
   if (e == hipSuccess) e = set_max_lds(interact_dot_kernel);
   return e;
 }
@@ -2342,20 +2395,41 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   if (sum && !f3 && pad64(b->width[0]) - sum->cols > ((d_out + 127) / 128) * 128) return false;   // zero pad must fall in an existing pass
   const int nwv = pk && !f3 && tune.mlp_stream_waves == 16 ? 16 : 8;
   const int passw = 16 * nwv;
-  p.packed = f3 ? (f4 ? 5 : nt3 == 4 ? 4 : 3) : pk ? (nwv == 16 ? 2 : 1) : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves | 5: stream4
+  p.packed = f3 ? (f4 ? 5 : nt3 == 4 ? 4 : 3) : pk ? (nwv == 16 ? 2 : 1) : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves | 5: stream4 (6: its 32-row form, set below)
   const int lpad = f3 ? 8 : 4;      // slab rows: 64 m + 8 floats apart in the b128 form, 64 m + 4 else
+  // rows per workgroup: 16, or 32 for stream4_kernel's two-halves form ("mlp_rows32": launches of at
+  // least that many rows, no summed input, slabs that still fit LDS)
+  int SR = 16;
+  if (f3 && f4 && !sum && tune.mlp_rows32 > 0 && a.M >= tune.mlp_rows32) {
+    size_t fl = 32 * (size_t)(pad64(a.width[0]) + lpad);
+    if (b) {
+      const int rc = dot ? dot->F * dot->D : b->width[0];
+      fl += 32 * (size_t)(pad64(rc) + lpad);
+      if (dot) fl += 32 * (size_t)(pad64(b->width[0]) + lpad);
+    }
+    int w0 = 0, w1 = 0, wh = 0;
+    auto note = [&](int n) { int& w = wh ? w1 : w0; w = pad64(n) > w ? pad64(n) : w; wh ^= 1; };
+    for (int l = 0; l < na; ++l) if (!(l == na - 1)) note(a.width[l + 1]);
+    for (int l = 0; l < nb; ++l) if (!(l == nb - 1)) note(b->width[l + 1]);
+    const bool q_in_x0 = !b && w1 && w1 <= pad64(a.width[0]);     // (see the Q slab below)
+    fl += (w0 ? 32 * (size_t)(w0 + lpad) : 0) + (w1 && !q_in_x0 ? 32 * (size_t)(w1 + lpad) : 0);
+    for (int l = 0; l < na; ++l) fl += (a.width[l + 1] + 3) & ~3;
+    for (int l = 0; l < nb; ++l) fl += (b->width[l + 1] + 3) & ~3;
+    fl += 4 + 4 * DRS_MAX_STREAM_TILES + (sizeof(SLayer) / 4) * DRS_MAX_STREAM_LAYERS;
+    if (sizeof(float) * fl <= kLdsBudget) SR = 32;
+  }
   // LDS layout (floats): [sB 2x128x68 (LDS-staged form only)][X0][RS][P][Q][biases]
   int off = 0;
   p.sB_off = off; off += pk ? 0 : 2 * 128 * 68;
   const int x0_ld = pad64(a.width[0]) + lpad;
-  const int x0_off = off; off += 16 * x0_ld;
+  const int x0_off = off; off += SR * x0_ld;
   // RS: what the first chain's last layer writes its dense_out slot into and the pooled rows
   // are pulled beside: the second chain's input (cat) or the interaction's T slab (dot)
   int rs_off = -1, rs_ld = 0, rs_cols = 0, ri_off = -1, ri_ld = 0;
   if (b) {
     rs_cols = dot ? dot->F * dot->D : b->width[0];
-    rs_ld = pad64(rs_cols) + lpad; rs_off = off; off += 16 * rs_ld;
-    if (dot) { ri_ld = pad64(b->width[0]) + lpad; ri_off = off; off += 16 * ri_ld; }
+    rs_ld = pad64(rs_cols) + lpad; rs_off = off; off += SR * rs_ld;
+    if (dot) { ri_ld = pad64(b->width[0]) + lpad; ri_off = off; off += SR * ri_ld; }
   }
   // ping-pong widths
   int wP = 0, wQ = 0;
@@ -2366,8 +2440,12 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     for (int l = 0; l < nb; ++l) if (!(l == nb - 1)) note(b->width[l + 1]);
   }
   const int p_ld = wP + lpad, q_ld = wQ + lpad;
-  const int p_off = off; off += wP ? 16 * p_ld : 0;
-  const int q_off = off; off += wQ ? 16 * q_ld : 0;
+  const int p_off = off; off += wP ? SR * p_ld : 0;
+  // 32-row form, single chain: the input slab is dead once layer 0 has run (the barrier behind it), and Q
+  // is first written by layer 1 -- Q lives in X0's space when it fits there (RM3's 416-512-256-1 top
+  // chain: 164 KB -> 130 KB)
+  const bool q_in_x0 = SR == 32 && !b && wQ && q_ld <= x0_ld;
+  const int q_off = q_in_x0 ? x0_off : off; off += wQ && !q_in_x0 ? SR * q_ld : 0;
   const int bias_off = off;
   for (int l = 0; l < na; ++l) off += (a.width[l + 1] + 3) & ~3;
   for (int l = 0; l < nb; ++l) off += (b->width[l + 1] + 3) & ~3;
@@ -2377,6 +2455,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   if (sizeof(float) * (size_t)off > kLdsBudget) return false;
   *lds_bytes = sizeof(float) * (size_t)off;
   p.lds_floats = off;
+  if (SR == 32) p.packed = 6;
 
   int which = 0, cur_off = x0_off, cur_ld = x0_ld, n = 0, tiles = 0, boff = bias_off;
   auto add = [&](const ChainArgs& c, int l, bool last_of_chain, bool last_of_all) {
@@ -2536,7 +2615,8 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
       slds += 8192;
 #endif
       const dim3 g3((unsigned)((a.M + 15) / 16));
-      if (sp.packed == 4) hipLaunchKernelGGL((stream3_kernel<4, 2>), g3, dim3(256), slds, s, sp, d, xs);
+      if (sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2>), dim3((unsigned)((a.M + 31) / 32)), dim3(256), slds, s, sp, d, xs);
+      else if (sp.packed == 4) hipLaunchKernelGGL((stream3_kernel<4, 2>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5) hipLaunchKernelGGL((stream4_kernel<false, false>), g3, dim3(256), slds, s, sp, d, xs);

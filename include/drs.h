@@ -327,7 +327,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                pass) run by ONE hand-laid instruction stream (csrc/seg_asm.inc): MFMAs back to
  *                back with the weight reloads, operand prefetch and loop control between them, ring
  *                and accumulators in AGPRs under fixed names, the next segment's first chunk
- *                requested while the last one runs | 3 stream3_kernel: the same packed
+ *                requested while the last one runs ("mlp_rows32" n: its launches of >= n rows take 32 rows per
+ *                workgroup -- two halves sharing the weight operands; default 8192 for MLP-bound DLRM,
+ *                else 0 = never; "mlp_s4_rows" n: with "mlp_stream" 3 on four waves, launches of up to n
+ *                rows take stream4_kernel; default 1024 for gather-bound DLRM) | 3 stream3_kernel: the same packed
  *                twins, activation operands as four ds_read_b128 per 64-k chunk, accumulators in fixed
  *                AGPRs, weight loads spread through the MFMA stream (EXEC-masked for tiles a wave does
  *                not own), one-round-trip prologue; "mlp_stream_waves" 4: four waves x up to four

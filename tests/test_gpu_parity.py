@@ -678,6 +678,9 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1),               # 4 waves, one asm statement per (layer, pass)
             "unfused_stream4": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1),
             "stream4_2_per_cu": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),
+            "stream4_32_rows": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_rows32=1),         # 32 rows per workgroup: two halves share the weight operands
+            "unfused_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1, mlp_rows32=1),
+            "pipelined_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_rows32=1),
             "pipelined_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2),
             "unfused_stream3": dict(mlp_stream=3, mlp_fuse=0, shared_stream=1),
             "pipelined_stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=2),
@@ -698,6 +701,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             eng.set_option("mlp_stream_waves", 0)
             eng.set_option("mlp_stream_2cu", 0)
             eng.set_option("mlp_s4_rows", 0)
+            eng.set_option("mlp_rows32", 0)
         for name, got in results.items():
             assert np.array_equal(got, results["stream"]), name
         assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)

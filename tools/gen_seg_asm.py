@@ -11,6 +11,8 @@ under fixed names (the kernel's C++ never uses AGPRs; the build checks that):
     a[80:143]   S1: weight slot 1
     a[144:159]  A0: activation operands that go with slot 0 (k-group q = base + 4 q)
     a[160:175]  A1: ... with slot 1
+(32 rows per workgroup, SEG2_*: accumulators a[0:31] -- tile j of half h = a[4 (j + T h) ...] --, slots at
+a[32:95] / a[96:159], operand sets of slot p, half h at a[160 + 32 p + 16 h ...]: 224 registers.)
 Chunk c of a segment that starts in slot p uses slot (p + c) % 2; while the LAST chunk runs, chunk 0 of
 the NEXT segment is requested into the other slot, which that segment then starts in (`par`).
 
@@ -22,7 +24,12 @@ next segment's chunk 0, all four tiles), wbase (64-bit scalar), par (scalar: the
     python tools/gen_seg_asm.py > deeprecsys_amd/csrc/seg_asm.inc
 """
 
-ACC, SB, AB = 0, (16, 80), (144, 160)
+# register maps by rows per workgroup: R = 1 (16 rows) and R = 2 (32 rows: two 16-row halves that share
+# every weight operand -- twice the MFMAs per byte of weights)
+MAPS = {
+    1: dict(SB=(16, 80), AB=((144,), (160,)), NREG=176),
+    2: dict(SB=(32, 96), AB=((160, 176), (192, 208)), NREG=224),
+}
 CHUNK_BYTES = 32768
 
 
@@ -30,11 +37,13 @@ def areg(b, n=4):
     return "a[%d:%d]" % (b, b + n - 1)
 
 
-def gen(T):
+def gen(T, R=1):
+    SB, AB = MAPS[R]["SB"], MAPS[R]["AB"]
     oR = list(range(T))                 # %0..%T-1
-    oA, oREM = T, T + 1
-    oN = [T + 2 + j for j in range(4)]
-    oW, oPAR = T + 6, T + 7
+    oAs = [T + h for h in range(R)]     # a_addr of each 16-row half
+    oREM = T + R
+    oN = [T + R + 1 + j for j in range(4)]
+    oW, oPAR = T + R + 5, T + R + 6
     L = []
     e = L.append
 
@@ -46,15 +55,19 @@ def gen(T):
             for j in range(tiles):
                 e("global_load_dwordx4 %s, %%%d, %%%d offset:%d" % (areg(S(base, j, q)), offs[j], oW, 1024 * q))
 
-    def read_a(base):
-        for q in range(4):
-            e("ds_read_b128 %s, %%%d offset:%d" % (areg(base + 4 * q), oA, 64 * q))
-        e("v_add_u32 %%%d, 256, %%%d" % (oA, oA))
+    def read_a(bases):
+        for h in range(R):
+            for q in range(4):
+                e("ds_read_b128 %s, %%%d offset:%d" % (areg(bases[h] + 4 * q), oAs[h], 64 * q))
+        for h in range(R):
+            e("v_add_u32 %%%d, 256, %%%d" % (oAs[h], oAs[h]))
 
     def mfmas(sb, ab, q):
         for s in range(4):
-            for j in range(T):
-                e("v_mfma_f32_16x16x4_f32 %s, a%d, a%d, %s" % (areg(4 * j), ab + 4 * q + s, S(sb, j, q) + s, areg(4 * j)))
+            for h in range(R):
+                for j in range(T):
+                    acc = areg(4 * (j + T * h))
+                    e("v_mfma_f32_16x16x4_f32 %s, a%d, a%d, %s" % (acc, ab[h] + 4 * q + s, S(sb, j, q) + s, acc))
 
     def body(kind, sb, ab, sbo, abo):
         # kind: steady | penult_w | penult_nw | last_w | last_nw;  sb / ab: this chunk's slot and operand
@@ -83,7 +96,7 @@ def gen(T):
         X, Y = (SB[p], AB[p]), (SB[1 - p], AB[1 - p])     # chunk 0 sits in slot p
         t = "P%d" % p
         read_a(X[1])
-        for i in range(4 * T):
+        for i in range(4 * T * R):
             e("v_accvgpr_write_b32 a%d, 0" % i)
         e("s_cmp_eq_u32 %%%d, 1" % oREM)
         e("s_cbranch_scc1 LE1%s_%%=" % t)
@@ -136,18 +149,20 @@ def emit(name, lines):
 
 def main():
     print("// GENERATED by tools/gen_seg_asm.py -- do not edit.  See that file for the register map.")
-    for T in (4, 2, 1):
-        emit("SEG_ASM_T%d" % T, gen(T))
-    # stand-alone request of a segment's chunk 0 into slot 0 / 1 (kernel prologue; waves that sit a
-    # segment out): %0..%3 offsets of the four tiles, %4 wbase
-    for p in (0, 1):
-        pf = []
-        for q in range(4):
-            for j in range(4):
-                pf.append("global_load_dwordx4 %s, %%%d, %%4 offset:%d" % (areg(SB[p] + 16 * j + 4 * q), j, 1024 * q))
-        emit("SEG_PREFETCH%d_ASM" % p, pf)
-    regs = ", ".join('"a%d"' % i for i in range(176))
-    print("#define SEG_AGPR_CLOBBER %s" % regs)
+    for R in (1, 2):
+        tag = "SEG" if R == 1 else "SEG2"
+        for T in (4, 2, 1):
+            emit("%s_ASM_T%d" % (tag, T), gen(T, R))
+        # stand-alone request of a segment's chunk 0 into slot 0 / 1 (kernel prologue; waves that sit a
+        # segment out): %0..%3 offsets of the four tiles, %4 wbase
+        for p in (0, 1):
+            pf = []
+            for q in range(4):
+                for j in range(4):
+                    pf.append("global_load_dwordx4 %s, %%%d, %%4 offset:%d" % (areg(MAPS[R]["SB"][p] + 16 * j + 4 * q), j, 1024 * q))
+            emit("%s_PREFETCH%d_ASM" % (tag, p), pf)
+        regs = ", ".join('"a%d"' % i for i in range(MAPS[R]["NREG"]))
+        print("#define %s_AGPR_CLOBBER %s" % (tag, regs))
 
 
 if __name__ == "__main__":
