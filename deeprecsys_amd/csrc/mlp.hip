@@ -411,6 +411,42 @@ __global__ __launch_bounds__(512) void chain_kernel(ChainArgs a0, ChainArgs a1, 
 // With a DotArgs the DLRM dot interaction runs between the two chains, in LDS (interact()).
 // Requires K % 4 == 0 and 16-B aligned operands on every layer and the slabs to fit in
 // LDS; launch_chain2 falls back to chain_kernel otherwise.
+// The pairwise dots of the fused dot interaction on the matrix cores (north_star: "the feature-interaction
+// batched dot ... use MFMA"): for one sample Z = T T^t with T the sample's F x D feature block; a wave
+// takes a sample, lane (r, g) feeds T[r][4 s + g] as BOTH operands of MFMA step s (rows r >= F feed
+// zeros), D / 4 dependent steps = one k-ordered fma chain per pair from 0, like the oracle's and like
+// interact_dot_kernel's.  Lane (r, g) then holds Z[4 g + i][r], i = 0..3, and writes the pairs of the
+// (strictly) lower triangle in BatchGather order behind the D dense columns.  pos(c, row) maps a column
+// of a slab row to its LDS position (the kernels keep different column permutations).  The accumulator
+// is a VGPR quad through inline asm: stream4_kernel must not have the compiler allocate AGPRs.
+template <typename POS>
+__device__ __forceinline__ void interact_pairs_mfma(const float* Ts, int t_ld, float* Rs, int r_ld, int rows, int F,
+                                                    int D, int itself, float* g_R, int64_t g_ldr, int64_t m0,
+                                                    int64_t M, int n_waves, int wave, int lane, POS pos) {
+  const int r = lane & 15, g = lane >> 4, off = itself ? 1 : 0;
+  for (int row = wave; row < rows; row += n_waves) {
+    const float* t = Ts + row * t_ld;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int base = (r < F ? r : 0) * D + g;
+    for (int k0 = 0; k0 < D; k0 += 4) {
+      float v = t[pos(base + k0, row)];
+      v = r < F ? v : 0.f;
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(v));   // (s_nop: v was just written by a VALU op the compiler cannot see the consumer of)
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));      // the last step's results
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int fi = 4 * g + i, fj = r;
+      if (fi < F && (fj < fi || (off && fj == fi))) {
+        const int c = D + fi * (fi - 1 + 2 * off) / 2 + fj;
+        const float v = acc[i];
+        Rs[row * r_ld + pos(c, row)] = v;
+        if (g_R && m0 + row < M) g_R[(m0 + row) * g_ldr + c] = v;
+      }
+    }
+  }
+}
+
 struct SLayer {
   const float* W;          // [N, K] row-major
   uint32_t w_off, wp_off;  // ... as a float offset from SArgs::wbase (the engine's weight arena);
@@ -767,6 +803,7 @@ __global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, 
       if (c < D) {
         v = t[swz(c, row)];
       } else if (c < D + a.P) {
+        if (a.F <= 16) continue;                  // the pairs: on the matrix cores, below
         // BatchGather order: row i of the (strictly) lower triangle starts at i(i-1)/2 (+ i with itself)
         const int p = c - D;
         int i = off ? 0 : 1;
@@ -778,6 +815,9 @@ __global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, 
       Rs[row * a.r_ld + swz(c, row)] = v;
       if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
+    if (a.F <= 16)
+      interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+                          tid >> 6, tid & 63, [](int c, int row) { return swz(c, row); });
     __syncthreads();
   };
 
@@ -1373,6 +1413,7 @@ __global__ __launch_bounds__(1024 / NT) void stream3_kernel(SArgs a, Done done, 
       if (c < D) {
         v = t[lpos(c)];
       } else if (c < D + a.P) {
+        if (a.F <= 16) continue;                  // the pairs: on the matrix cores, below
         const int p = c - D;
         int i = off ? 0 : 1;
         while ((i + 1) * (i + off * 2) / 2 <= p) ++i;
@@ -1383,6 +1424,9 @@ __global__ __launch_bounds__(1024 / NT) void stream3_kernel(SArgs a, Done done, 
       Rs[row * a.r_ld + lpos(c)] = v;
       if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
+    if (a.F <= 16)
+      interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+                          tid >> 6, tid & 63, [](int c, int) { return lpos(c); });
     __syncthreads();
   };
 
@@ -1838,6 +1882,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       if (c < D) {
         v = t[lpos(c)];
       } else if (c < D + a.P) {
+        if (a.F <= 16) continue;                  // the pairs: on the matrix cores, below
         const int p = c - D;
         int i = off ? 0 : 1;
         while ((i + 1) * (i + off * 2) / 2 <= p) ++i;
@@ -1848,6 +1893,9 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       Rs[row * a.r_ld + lpos(c)] = v;
       if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
+    if (a.F <= 16)
+      interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16 * R, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+                          tid >> 6, tid & 63, [](int c, int) { return lpos(c); });
     __syncthreads();
   };
 
