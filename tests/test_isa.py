@@ -20,3 +20,13 @@ def test_stream4_kernel_keeps_agprs_to_its_asm_statements():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("AGPR uses outside asm: 0") == 4 and "occupancy 2" in r.stdout      # three instantiations, one of them two per CU
+
+
+def test_generated_segment_streams_wait_for_exactly_what_they_consume():
+    """tools/check_seg_asm.py interprets every generated statement of stream4_kernel (1 / 2 / 4 tiles,
+    16 / 32 rows, segments of 1..7 chunks, either entry slot) with in-order retirement of loads and LDS
+    reads: every MFMA must find operands that have retired and hold the data of its place in the
+    k-ordered chain, and the next segment's first chunk must be requested into the slot left free."""
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_seg_asm.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "84 cases" in r.stdout
