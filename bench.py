@@ -853,6 +853,26 @@ def main():
                         "per launch set, %d calls in flight; h2d_GBps counts the bytes on the bus, "
                         "h2d_GBps_caller_bytes the caller's"
                         % (host_bytes // 1024, "min(T,7)+1", bus_bytes // 1024, hslots)}
+        # MLP-bound workloads: the FC layers' arithmetic end to end against the fp32-MFMA peak (the gather
+        # stays the `roofline` kernel of the line; this is the figure BASELINE.md quotes for RM3 / W&D)
+        fc_mac = 0
+        for name in ("ln_bot", "ln_top"):
+            ln = getattr(net, name, None)
+            if ln is not None:
+                fc_mac += sum(int(ln[i]) * int(ln[i + 1]) for i in range(len(ln) - 1))
+        if getattr(net, "ln_task", None) is not None:
+            lt = net.ln_task
+            fc_mac += int(getattr(net, "num_tasks", 1)) * sum(int(lt[i]) * int(lt[i + 1]) for i in range(len(lt) - 1))
+        if fc_mac and WORKLOADS[opt.workload].get("kind", "dlrm") in ("dlrm", "wnd", "mtwnd"):
+            fpq = 2.0 * bs * fc_mac
+            tf = out["value"] * fpq / 1e12
+            out["roofline"]["mlp_end_to_end"] = {
+                "bound": "mfma", "achieved": round(tf, 2), "peak": round(157.3 * world, 1), "unit": "TFLOP/s",
+                "frac": round(tf / (157.3 * world), 4),
+                "flop_per_query": int(fpq),
+                "what": "2 x batch x MACs of the bottom / top (/ task) FC layers x queries/s, all %d GPU(s); "
+                        "peak = dense fp32 MFMA (v_mfma_f32_16x16x4_f32) of one MI355X x n_gpus" % world,
+            }
         out["gpu_state"] = {"device": local, "before_warmup": state_before, "after_timed_region": state_after}
         if not opt.no_cpu_baseline and not opt.timed_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt, net, data, opt.cpu_seconds)

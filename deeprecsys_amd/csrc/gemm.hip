@@ -1,4 +1,4 @@
-// Wide FC layers (K*N >= "mlp_wide_kn" weights: RM3's 2560x1024, W&D's 896x1024 and
+// Wide FC layers (K*N >= "mlp_wide_kn" weights: RM3's 2560x1024, W&D's 1376x1024 and
 // 1024x512) as a register-blocked GEMM on the fp32 matrix cores.
 //
 // Replaces the same FC + Relu|Sigmoid operator pair as mlp.hip (reference
@@ -7,7 +7,7 @@
 // oracle/drs_oracle.c.
 //
 // Why a second kernel: fc_kernel gives a workgroup 16 rows x 128 columns, so every 16-row
-// slab streams the whole weight panel (2 048 rows x 896x1024: 470 MB through L2 for one
+// slab streams the whole weight panel (2 048 rows x 1376x1024: 720 MB through L2 for one
 // layer) and each wave owns ONE accumulator -- 16 dependent MFMAs per K chunk.  Here a
 // workgroup owns 64 rows x 128 columns and each of its 8 waves a 32 x 32 block held in
 // FOUR independent accumulators (2 x 2 MFMA tiles): an operand read from LDS feeds two

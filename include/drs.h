@@ -307,7 +307,7 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_split"  1 (default) a layer with K*N >= "mlp_wide_kn" weights (RM3's 2560x1024)
  *                runs as its own 2-D launch | 0 chain everything that fits LDS
  *   "mlp_wide_kn" that threshold (default 256K weights: RM3's 2560x1024 and 1024x256, W&D's
- *                896x1024 and 1024x512)
+ *                1376x1024 and 1024x512)
  *   "mlp_fuse"   1 (default) DLRM/"cat": bottom and top MLP of a 16-row slab in ONE launch
  *                | 0 one launch per MLP;  "mlp_fuse_rows": fuse only from this many rows on
  *   "mlp_gemm"   1 (default) stand-alone wide layers run as the register-blocked gemm_kernel

@@ -15,7 +15,7 @@ import torch
 
 from deeprecsys_amd import _native as N
 
-SHAPES = [("RM3 bottom L1", 2560, 1024), ("RM3 bottom L2", 1024, 256), ("W&D top L1", 896, 1024),
+SHAPES = [("RM3 bottom L1", 2560, 1024), ("RM3 bottom L2", 1024, 256), ("W&D top L1", 1376, 1024),
           ("W&D top L2", 1024, 512), ("W&D top L3", 512, 256), ("RM1 top L1", 576, 256)]
 PEAK = 157.3e12
 
