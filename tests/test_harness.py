@@ -243,6 +243,9 @@ def test_bench_self_spawn_n1_equals_plain_n1_line_shape():
     assert r["bytes_timed"] == 2002 * 43130880                       # RMC1: 43.13 MB per query, exactly
     assert r["frac"] == pytest.approx(r["bytes_timed"] / (r["avg_launch_us"] * 1e-6 * r["launches_timed"]) / 8e12, rel=2e-3)
     assert 0.3 < r["frac"] < 0.8                                       # above the copy ceiling = accounting bug
+    m = r["mlp_end_to_end"]                                            # RMC1: 2 x 256 x 176 192 MACs per query
+    assert m["flop_per_query"] == 2 * 256 * (128 * 64 + 64 * 64 + 576 * 256 + 256 * 64 + 64) and m["peak"] == 157.3
+    assert m["achieved"] == pytest.approx(out["value"] * m["flop_per_query"] / 1e12, rel=1e-2)
 
 
 
