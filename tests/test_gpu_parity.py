@@ -1006,6 +1006,41 @@ def test_per_call_launch_sets_of_the_other_models(case):
         eng.close()
 
 
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_stream4_forms_on_every_model_kind(case):
+    """stream4_kernel is an option on every model (the default on some): its one- and two-per-CU
+    instantiations, the summed-input one NCF takes and the 32-row form give the bits of the model's
+    default launch structure, alone and coalesced."""
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"], accel_slots=2)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    eng = net.engine
+    try:
+        net.stage_batches(lX if eng.m_den else None, lS_l, lS_i)
+        n = len(lS_l[0][0])
+        nb = len(lS_l)
+        ids, sizes = [k % nb for k in range(5)], [n, 1, max(1, n // 2), n, max(1, n - 1)]
+        def run():
+            outs = [net.run_staged(0, n).copy()]
+            outs += [o.copy() for o in net.run_staged_multi(ids, sizes, slot=1)]
+            return outs
+        eng.set_option("mlp_stream", 2)
+        eng.set_option("mlp_stream_2cu", 0)
+        want = run()
+        for opts in (dict(mlp_stream=4, mlp_stream_2cu=0), dict(mlp_stream=4, mlp_stream_2cu=1),
+                     dict(mlp_stream=4, mlp_stream_2cu=0, mlp_rows32=1), dict(mlp_stream=3, mlp_stream_waves=4, mlp_s4_rows=1 << 20)):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            got = run()
+            assert all(np.array_equal(a_, b_) for a_, b_ in zip(got, want)), (case, opts)
+            eng.set_option("mlp_rows32", 0)
+            eng.set_option("mlp_s4_rows", 0)
+            eng.set_option("mlp_stream_waves", 0)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("case", ["din_mini", "dien_mini", "ncf_mini"])
 def test_per_call_inputs_of_the_sparse_only_models(case):
     """DIN / DIEN / NCF take no dense input: run_queues' id / length arrays alone, as 2-D arrays or
