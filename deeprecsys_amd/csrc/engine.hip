@@ -266,7 +266,7 @@ class HostPool {
   ~HostPool() {
     {
       std::lock_guard<std::mutex> l(mu_);
-      stop_ = true;
+      stop_.store(true, std::memory_order_release);
       gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
@@ -307,7 +307,11 @@ class HostPool {
     active_.fetch_sub(1, std::memory_order_acq_rel);
   }
   void loop() {
-    uint64_t seen = gen_.load(std::memory_order_acquire);
+    // gen_ is 0 when the constructor starts the workers: a worker that gets its first time slice only
+    // after run() -- or the destructor -- has already bumped gen_ must still notice that bump (reading
+    // gen_ here instead left such a worker asleep for ever and the destructor's join() with it: pools
+    // that are created and destroyed without work in between, small models on a busy host)
+    uint64_t seen = 0;
     for (;;) {
       // spin ~50 us for the next job, then sleep
       bool got = false;
@@ -322,7 +326,7 @@ class HostPool {
         sleepers_.fetch_sub(1, std::memory_order_acq_rel);
       }
       seen = gen_.load(std::memory_order_acquire);
-      if (stop_) return;
+      if (stop_.load(std::memory_order_acquire)) return;
       work();
     }
   }
@@ -333,7 +337,7 @@ class HostPool {
   std::atomic<int> next_{1 << 30}, pending_{0}, sleepers_{0}, active_{0};   // (next_ past any n_ while idle)
   const std::function<void(int)>* fn_ = nullptr;
   std::atomic<int> n_{0};
-  bool stop_ = false;
+  std::atomic<bool> stop_{false};
 };
 
 // int64 -> int32 with the range ENFORCE, branch-free so it vectorises (AVX2 where the host has
@@ -1338,15 +1342,23 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
 
 int32_t drs_destroy(drs_handle e) {
   if (!e) return DRS_OK;
+  const bool trc = getenv("DRS_TRACE_DESTROY") != nullptr;
+#define DTR(x) do { if (trc) { fprintf(stderr, "destroy %p: %s\n", (void*)e, x); fflush(stderr); } } while (0)
+  DTR("begin");
   e->launcher.reset();           // (finishes the jobs it holds, then joins)
+  DTR("launcher gone");
   (void)hipSetDevice(e->device);
   if (e->stream_g) { (void)hipStreamSynchronize(e->stream_g); (void)hipStreamDestroy(e->stream_g); }
   if (e->stream_h2d) { (void)hipStreamSynchronize(e->stream_h2d); (void)hipStreamDestroy(e->stream_h2d); }
+  DTR("g and h2d streams gone");
   for (auto& s : e->slots) {
+    DTR("slot");
     if (s.h_multi) (void)hipHostFree(s.h_multi);
     if (s.d_multi) (void)hipFree(s.d_multi);
     s.mq.clear();
+    DTR("multi freed");
     if (s.own_stream) { (void)hipStreamSynchronize(s.own_stream); (void)hipStreamDestroy(s.own_stream); }
+    DTR("own stream gone");
     if (s.ev_sls) (void)hipEventDestroy(s.ev_sls);
     if (s.ev_in) (void)hipEventDestroy(s.ev_in);
     if (s.T) (void)hipFree(s.T);
@@ -1368,6 +1380,7 @@ int32_t drs_destroy(drs_handle e) {
     for (auto& ev : s.ev) if (ev) (void)hipEventDestroy(ev);
     free_batch(s.scratch);
   }
+  DTR("slots freed");
   for (auto& b : e->batches) free_batch(b);
   for (Mlp* m : {&e->bot, &e->top, &e->fin})
     for (auto& l : m->layers) { l.W = l.b = nullptr; }
@@ -1381,7 +1394,10 @@ int32_t drs_destroy(drs_handle e) {
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
   if (e->d_tab_rows) (void)hipFree(e->d_tab_rows);
   if (e->d_op_tab) (void)hipFree(e->d_op_tab);
+  DTR("device memory freed");
   delete e;
+  if (trc) { fprintf(stderr, "destroy: done\n"); fflush(stderr); }
+#undef DTR
   return DRS_OK;
 }
 

@@ -1041,6 +1041,32 @@ def test_stream4_forms_on_every_model_kind(case):
         eng.close()
 
 
+def test_conversion_worker_pool_created_and_destroyed_without_work():
+    """A small model's per-call inputs never reach the size at which the conversion is spread over the
+    worker pool, so a pool is created (first call) and destroyed ("host_threads", close) without ever
+    running a job -- 400 times in a row.  (A worker that got its first time slice only after the
+    destructor had signalled used to sleep for ever, and the join with it: round 3.)"""
+    meta, z = H.load_fixture("ncf_mini")
+    args = H.args_from(meta["args"], accel_slots=2)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], lT[0])
+    eng = net.engine
+    try:
+        net.stage_batches(None, lS_l, lS_i)
+        n = len(lS_l[0][0])
+        L = int(args.num_indices_per_lookup)
+        ids = np.stack([np.asarray(i, dtype=np.int64) for i in lS_i[0]])[:, :n * L]
+        lens = np.stack([np.asarray(l, dtype=np.int32) for l in lS_l[0]])[:, :n]
+        ref = net.run_staged(0, n)
+        for k in range(400):
+            eng.set_option("host_threads", 1 + k % 7)          # destroys the pool of the call before
+            out = eng.forward_inputs(None, ids, lens, n)       # creates one (no job for it)
+            if k % 50 == 0:
+                assert np.array_equal(out, ref)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("case", ["din_mini", "dien_mini", "ncf_mini"])
 def test_per_call_inputs_of_the_sparse_only_models(case):
     """DIN / DIEN / NCF take no dense input: run_queues' id / length arrays alone, as 2-D arrays or
