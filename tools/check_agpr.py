@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """check_agpr.py <file.s> <kernel name substring>: fails when the compiler-generated part of the
-kernel (everything outside ;;#ASMSTART ... ;;#ASMEND) names an accumulation register.  stream4_kernel (mlp.hip) keeps live data in AGPRs between its asm statements."""
+kernel (everything outside ;;#ASMSTART ... ;;#ASMEND) names an accumulation register, or when the kernel
+uses scratch memory (a spill).  stream4_kernel (mlp.hip) keeps live data in AGPRs between its asm statements."""
 import re
 import sys
 
@@ -33,6 +34,9 @@ def main(path, kern):
               % (lines[st].split(":")[0][-48:], n, get("NumVgprs"), get("NumAgprs"), get("Occupancy"), get("ScratchSize"), len(bad)))
         if bad:
             print("\n".join(bad[:20]))
+            failed = True
+        if get("ScratchSize") > 0:
+            print("kernel spills: ScratchSize %d" % get("ScratchSize"))
             failed = True
     if failed:
         sys.exit(1)
