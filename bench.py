@@ -5,14 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one BLOCK of `--queries_per_step` queries (default 8192; named in `config`):
+A "step" is one BLOCK of `--queries_per_step` queries (default 81 920; named in `config`):
 each query is one pass of the hot path (multi-table SparseLengthsSum gather, bottom MLP,
 feature interaction, top MLP, sigmoid) over one batch of `--batch` samples whose inputs are
 already resident in HBM (the reference engine keeps its pre-generated input sets in process
 memory and a request only names (batch_id, batch_size): inferenceEngine.py:83,200-215).
-`--steps 20 --warmup 5` therefore times 163 840 queries (~1.3 s on one MI355X) after 40 960
-untimed ones: the launch pipeline and the chip's power state are in steady state, and p99 is
-taken over every query of the region.  Queries are submitted through the C ABI
+`--steps 20 --warmup 5` therefore times 1 638 400 queries (~12 s on one MI355X: long enough for an
+outside sampler of GPU activity to see it) after 409 600 untimed ones: the launch pipeline and the
+chip's power state are in steady state, and p99 is taken over every query of the region.  The
+outputs of the region's last launch sets are checked against the CPU oracle afterwards
+(`verified`).  Queries are submitted through the C ABI
 (include/drs.h), `--coalesce` per launch set and `--slots` sets in flight; a query's latency
 runs from the submit of its launch set to the moment its result is observed on the host.
 
@@ -83,7 +85,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--queries_per_step", type=int, default=8192,
+    ap.add_argument("--queries_per_step", type=int, default=81920,
                     help="queries in one step (block); steps*queries_per_step queries are timed")
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
@@ -91,9 +93,10 @@ def parse(argv=None):
     ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--coalesce", type=int, default=0,
                     help="queries per launch set (the engine coalesces requests that are already queued); "
-                         "0 = the engine's own preference for the model: 8, or 16 for the MLP-bound ones")
+                         "0 = the engine's own preference for the model: 12 for gather-bound DLRM, 16 for the MLP-bound "
+                         "models, 8 otherwise (drs_get_option preferred_coalesce)")
     ap.add_argument("--seed", type=int, default=123)
-    ap.add_argument("--cpu_seconds", type=float, default=12.0, help="budget of each cpu_baseline sample")
+    ap.add_argument("--cpu_seconds", type=float, default=8.0, help="budget of each cpu_baseline sample")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_table", default="", help="cpu_baseline: also write the reference's `***` latency table "
                     "(ms per iteration at batch 1 .. 1024, one CPU engine) to this file")
@@ -147,12 +150,16 @@ def make_model(opt, device):
     return args, net, (lX, lS_l, lS_i)
 
 
-def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1):
+def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1, tail=None):
     """Closed loop: exactly n queries, `coalesce` of them per launch set, `slots` launch
     sets in flight.  Every query's latency runs from the submit of its launch set to the
-    moment the set's results are observed on the host.  Returns elapsed seconds."""
+    moment the set's results are observed on the host.  Returns elapsed seconds.
+    tail (a list): the launch sets still in flight when the last query has been submitted -- the
+    last `slots` sets of the region -- are waited for WITH an output buffer and appended as
+    (batch ids, outputs [sum(bs), n_out]): what verify_tail() checks against the oracle."""
     t_submit = [0.0] * slots
     in_slot = [0] * slots
+    ids_in = [None] * slots
     t0 = time.perf_counter()
     i = g = 0
     while i < n:
@@ -163,21 +170,68 @@ def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1):
             if lat is not None:
                 lat.extend([time.perf_counter() - t_submit[s]] * in_slot[s])
         t_submit[s] = time.perf_counter()
+        ids_in[s] = [(start_id + i + k) % nb for k in range(c)]
         if c == 1:
-            eng.forward_async(s, (start_id + i) % nb, bs)
+            eng.forward_async(s, ids_in[s][0], bs)
         else:
-            eng.forward_multi_async(s, [(start_id + i + k) % nb for k in range(c)], [bs] * c)
+            eng.forward_multi_async(s, ids_in[s], [bs] * c)
         in_slot[s] = c
         i += c
         g += 1
     for k in range(slots):
         s = (g + k) % slots
         if in_slot[s]:
-            eng.wait(s)
+            out = eng.wait(s, None if tail is None else bs * in_slot[s])
             if lat is not None:
                 lat.extend([time.perf_counter() - t_submit[s]] * in_slot[s])
+            if tail is not None:
+                tail.append((ids_in[s], out))
             in_slot[s] = 0
     return time.perf_counter() - t0
+
+
+_ORACLE = {}
+
+
+def oracle_twin(opt, net):
+    """The CPU oracle's model object for this workload (same counter-based table fill as
+    drs_fill_table_uniform, same weights), built once: the checker of verify_tail() and the thing
+    cpu_baseline() times.  TEST INFRASTRUCTURE -- never on the measured path."""
+    if "om" not in _ORACLE:
+        from oracle import oracle as orc
+        from tests import helpers as H
+        w = WORKLOADS[opt.workload]
+        cores = host_cores()
+        rows = w["rows"] if isinstance(w["rows"], list) else [w["rows"]] * w["T"]
+        t0 = time.perf_counter()
+        net.emb_w = [orc.fill_table_uniform(rows[t], w["D"], t, -float(np.sqrt(1 / rows[t])), float(np.sqrt(1 / rows[t])),
+                                            opt.seed, nthreads=cores) for t in range(w["T"])]
+        _ORACLE["om"] = H.oracle_model(net)
+        _ORACLE["fill_s"] = time.perf_counter() - t0
+    return _ORACLE["om"], _ORACLE["fill_s"]
+
+
+def verify_tail(opt, net, data, tail, bs):
+    """Outputs of the LAST launch sets of the timed region (as the pipelined engine produced them:
+    default gather, `coalesce` queries per set, `slots` sets in flight) against the oracle's forward
+    on the same inputs, north_star's 1e-4 rel.  Outside the timed window, rank 0 only."""
+    om, _ = oracle_twin(opt, net)
+    w = WORKLOADS[opt.workload]
+    lX, lS_l, lS_i = data
+    cores = host_cores()
+    n, worst, ok = 0, 0.0, True
+    for ids, out in tail:
+        for k, b in enumerate(ids):
+            dense = None if w.get("kind") in NO_DENSE else lX[b]
+            exp = np.asarray(om.forward(dense, lS_i[b], lS_l[b], bs=bs, nthreads=cores), np.float64).reshape(bs, -1)
+            got = np.asarray(out[k * bs:(k + 1) * bs], np.float64).reshape(bs, -1)
+            ok = ok and got.shape == exp.shape and bool(np.all(np.abs(got - exp) <= 1e-4 * np.abs(exp) + 1e-6))
+            worst = max(worst, float((np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)).max()))
+            n += 1
+    return {"verified_queries": n, "launch_sets": len(tail), "max_rel_err": float("%.3g" % worst),
+            "bar": "|got - exp| <= 1e-4 |exp| + 1e-6 (north_star: 1e-4 rel on fp32 MLP outputs)", "ok": ok,
+            "what": "outputs of the last %d launch sets of the timed region vs oracle/drs_oracle.c on the same inputs"
+                    % len(tail)}
 
 
 def host_cores():
@@ -229,17 +283,10 @@ def cpu_baseline(opt, net, data, budget_s):
     (b) torch-CPU `embedding_bag(sum)` + `addmm` (the Caffe2-lineage perfkernel and MKL/oneDNN
         sgemm), torch.set_num_threads(cores), in a subprocess of its own.
     `value` is the faster of the two."""
-    from oracle import oracle as orc
-    from tests import helpers as H
     w = WORKLOADS[opt.workload]
     lX, lS_l, lS_i = data
     cores = host_cores()
-    rows = w["rows"] if isinstance(w["rows"], list) else [w["rows"]] * w["T"]
-    t0 = time.perf_counter()
-    net.emb_w = [orc.fill_table_uniform(rows[t], w["D"], t, -float(np.sqrt(1 / rows[t])), float(np.sqrt(1 / rows[t])),
-                                        opt.seed, nthreads=cores) for t in range(w["T"])]
-    om = H.oracle_model(net)
-    fill_s = time.perf_counter() - t0
+    om, fill_s = oracle_twin(opt, net)
     dense = (lambda b: None) if w.get("kind") in NO_DENSE else (lambda b: lX[b])
     om.forward(dense(0), lS_i[0], lS_l[0], bs=opt.batch, nthreads=cores)   # warm
     n, t0 = 0, time.perf_counter()
@@ -260,6 +307,7 @@ def cpu_baseline(opt, net, data, budget_s):
     except Exception as e:    # a leg of the baseline must never take the benchmark line down
         serving = {"error": repr(e)[:300]}
     del om
+    _ORACLE.clear()
     net.emb_w = None
     torch_leg = None
     try:
@@ -564,6 +612,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = comm = None
+    verify_failed = False
     json_out = sys.stdout
     if world > 1:
         # native libraries (gloo, RCCL) log to fd 1: keep stdout for rank 0's ONE JSON line
@@ -649,11 +698,11 @@ def main():
     # the results: no copy, no sync, no extra launch) stays on inside it, so the roofline figure is
     # taken over the timed region itself; the engine adds up the algorithmic bytes of exactly the
     # launches it timed (a trailing partial launch set counts with its own bytes).
-    lat = []
+    lat, tail = [], []
     eng.reset_kernel_time()
     eng.set_profiling(1)
     barrier()
-    elapsed = run_queries(eng, n_timed, bs, nb, slots, lat, coalesce=co)
+    elapsed = run_queries(eng, n_timed, bs, nb, slots, lat, coalesce=co, tail=tail)
     barrier()
     eng.set_profiling(0)
     sls_ms, sls_n = eng.kernel_time(N.KERNEL_SLS_CLOCK)
@@ -874,9 +923,19 @@ def main():
                         "peak = dense fp32 MFMA (v_mfma_f32_16x16x4_f32) of one MI355X x n_gpus" % world,
             }
         out["gpu_state"] = {"device": local, "before_warmup": state_before, "after_timed_region": state_after}
+        if not opt.timed_only:
+            # the results the timed region itself produced, checked after the fact (VERDICT r3 #1c)
+            try:
+                out["verified"] = verify_tail(opt, net, data, tail, bs)
+            except Exception as e:      # noqa: BLE001  (the line must still come out; "ok" is then absent)
+                out["verified"] = {"verified_queries": 0, "error": repr(e)[:300]}
+            out["verified_queries"] = out["verified"].get("verified_queries", 0)
         if not opt.no_cpu_baseline and not opt.timed_only and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt, net, data, opt.cpu_seconds)
         print(json.dumps(out), file=json_out, flush=True)
+        if out.get("verified", {}).get("ok") is False:
+            print("bench.py: the timed region's outputs differ from the oracle: %s" % json.dumps(out["verified"]), file=sys.stderr)
+            verify_failed = True
 
     if opt.sweep and rank == 0:
         results = []
@@ -903,6 +962,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if verify_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

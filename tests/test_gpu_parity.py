@@ -286,6 +286,33 @@ def test_full_size_rmc1_baseline_shape_matches_oracle():
         for s in range(3):
             assert np.array_equal(outs[s], eng.forward(s % 2, 256 - s))
         assert eng.gather_bytes(0, 256) == 256 * T * (L * D * 4 + L * 4 + 4 + D * 4)
+        # ---- exactly what bench.py times (VERDICT r3 #1a): the DEFAULT gather (sls_flatc_kernel), launch
+        # sets of 12 and 16 queries, pipelined over the gather stream and the MLP stream with 3 sets in
+        # flight -- every query of every set against the oracle: R within the flat-gather tolerance
+        # (same rows, different fp32 summation order), outputs within north_star's 1e-4
+        eng.set_option("sls_exact", 0)
+        assert eng.get_option("shared_stream") == 2 and eng.get_option("preferred_coalesce") == 12
+        ref = {}
+
+        def oracle(bid, bs):
+            if (bid, bs) not in ref:
+                ref[(bid, bs)] = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+            return ref[(bid, bs)]
+        for per_set in (12, 16):
+            sets = [[((s + k) % 2, 256 if (s + k) % 5 else 165) for k in range(per_set)] for s in range(3)]
+            for rnd in range(3):                       # slots are reused while the others are still in flight
+                for s in range(3):
+                    eng.forward_multi_async(s, [b for b, _ in sets[s]], [n for _, n in sets[s]])
+                outs = [eng.wait(s, sum(n for _, n in sets[s])) for s in range(3)]
+            for s in range(3):
+                Rv = eng.fetch_interaction(256 * per_set, slot=s)   # virtual rows: query k at row 256 k
+                o = 0
+                for k, (bid, n) in enumerate(sets[s]):
+                    exp, R_exp = oracle(bid, n)
+                    assert H.close(Rv[256 * k:256 * k + n], R_exp, rtol=1e-5, atol_scale=2e-6), (per_set, s, k)
+                    assert np.array_equal(Rv[256 * k:256 * k + n, :D], R_exp[:, :D])     # bottom MLP: bitwise
+                    assert H.close(outs[s][o:o + n], exp, rtol=H.RTOL_OUT, atol=1e-7), (per_set, s, k)
+                    o += n
     finally:
         net.engine.close()
 
@@ -724,21 +751,26 @@ def test_rmc3_baseline_size_counting_property():
     touch row 0 and the last row of a 10M-row table; and the Caffe2 index ENFORCE must fire
     for row N at that size."""
     T, rows, D, L, B = 12, 10_000_000, 32, 20, 512
-    eng = N.Engine(N.MODEL_DLRM, [rows] * T, D, [64, 32], [D * (T + 1), 16, 1], N.INTERACT_CAT,
-                   sigmoid_top=2, max_batch=B, max_lookups=L, num_staged_batches=1, num_slots=2)
+    # the REAL config-3 graph (bench.py --workload rmc3): bottom 2560-1024-256-32, top 416-512-256-1
+    ln_bot, ln_top = [2560, 1024, 256, 32], [D * (T + 1), 512, 256, 1]
+    eng = N.Engine(N.MODEL_DLRM, [rows] * T, D, ln_bot, ln_top, N.INTERACT_CAT,
+                   sigmoid_top=3, max_batch=B, max_lookups=L, num_staged_batches=1, num_slots=3)
     try:
         for t in range(T):
             eng.fill_table_uniform(t, 1.0, 1.0, 5)
         rng = np.random.RandomState(3)
-        eng.set_fc(N.MLP_BOT, 0, rng.randn(32, 64).astype(np.float32), rng.randn(32).astype(np.float32))
-        eng.set_fc(N.MLP_TOP, 0, rng.randn(16, D * (T + 1)).astype(np.float32) * 0.01, np.zeros(16, np.float32))
-        eng.set_fc(N.MLP_TOP, 1, rng.randn(1, 16).astype(np.float32), np.zeros(1, np.float32))
+        for mlp, ln in ((N.MLP_BOT, ln_bot), (N.MLP_TOP, ln_top)):
+            for i in range(len(ln) - 1):
+                # (pooled columns are all L = 20 here: the first top layer is scaled down so the sigmoid stays inside (0, 1))
+                scale = np.sqrt(2.0 / (ln[i] + ln[i + 1])) * (0.02 if (mlp == N.MLP_TOP and i == 0) else 1.0)
+                eng.set_fc(mlp, i, (rng.randn(ln[i + 1], ln[i]) * scale).astype(np.float32),
+                           (rng.randn(ln[i + 1]) * np.sqrt(1.0 / ln[i + 1]) * 0.1).astype(np.float32))
         idx = [np.sort(rng.randint(0, rows, size=(B, L)), axis=1).astype(np.int64) for _ in range(T)]
         for t in range(T):
             idx[t][0, 0] = 0
             idx[t][B - 1, L - 1] = rows - 1          # the very last row of the table
         lens = [np.full(B, L, dtype=np.int32) for _ in range(T)]
-        dense = rng.rand(B, 64).astype(np.float32)
+        dense = rng.rand(B, ln_bot[0]).astype(np.float32)
         eng.stage_batch(0, dense, [i.reshape(-1) for i in idx], lens)
         outs = {}
         for exact in (1, 0):
@@ -753,12 +785,73 @@ def test_rmc3_baseline_size_counting_property():
         # pooled sums identical -> the whole forward identical between the two gather variants
         for bs in (B, 165, 1):
             assert np.array_equal(outs[(1, bs)], outs[(0, bs)])
+        # the launch sets bench.py --workload rmc3 times: 16 queries of batch 512 (8 192 rows: 32-row
+        # stream4 chains, GEMM launches on the MLP streams), three sets in flight -- every pooled column
+        # still counts L exactly and every query's bits are those of the query served alone
+        assert eng.get_option("preferred_coalesce") == 16 and eng.get_option("mlp_rows32") == 8192
+        sizes = [B, 165, B, 1] * 4
+        for rnd in range(2):
+            for s_ in range(3):
+                eng.forward_multi_async(s_, [0] * 16, sizes)
+            got = [eng.wait(s_, sum(sizes)) for s_ in range(3)]
+        for s_ in range(3):
+            Rv = eng.fetch_interaction(B * 16, slot=s_)
+            o = 0
+            for k, n in enumerate(sizes):
+                assert np.array_equal(Rv[B * k:B * k + n, D:], np.full((n, D * T), float(L), np.float32)), (s_, k)
+                assert np.array_equal(got[s_][o:o + n], outs[(0, n)]), (s_, k)
+                o += n
         assert eng.gather_bytes(0, B) == B * T * (L * D * 4 + L * 4 + 4 + D * 4)
         bad = [i.copy() for i in idx]
         bad[T - 1][7, 3] = rows                       # one past the end
         with pytest.raises(N.DrsError) as ei:
             eng.forward_inputs(dense, [i.reshape(-1) for i in bad], lens, B)
         assert ei.value.code == N.ERR_INDEX_RANGE
+    finally:
+        eng.close()
+
+
+def test_rmc3_baseline_graph_pipelined_sets_match_oracle():
+    """BASELINE config 3's REAL graph as `bench.py --workload rmc3 --batch 512` runs it (VERDICT r3 #1b) --
+    T = 12 tables x 32, L = 20 (two bags per wave in the flat gather), bottom 2560-1024-256-32 (two GEMM
+    launches + a chain), top 416-512-256-1, batch 512, 16 queries per launch set (8 192 rows: the 32-row
+    stream4 chains), three sets in flight over the gather stream and the MLP streams -- on 1 M-row tables,
+    where the oracle can follow: every query of every set against the oracle's forward on the same
+    counter-based table fill (R within the flat-gather tolerance, bottom MLP columns bitwise, outputs
+    1e-4), and the sequential-order gather bitwise."""
+    rows, D, T, L, B = 1_000_000, 32, 12, 20, 512
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, "2560-1024-256-32", "512-256-1", B, nb=2, seed=31)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    eng = net.engine
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
+        net.emb_w = [orc.fill_table_uniform(rows, D, t, lo, hi, args.numpy_rand_seed, nthreads=0) for t in range(T)]
+        om = H.oracle_model(net)
+        assert eng.get_option("preferred_coalesce") == 16 and eng.get_option("mlp_streams") == 3
+        assert eng.get_option("mlp_rows32") == 8192 and eng.get_option("shared_stream") == 2
+        ref = {(bid, bs): om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+               for bid in (0, 1) for bs in (B, 165)}
+        sets = [[((s + k) % 2, B if (s + k) % 3 else 165) for k in range(16)] for s in range(3)]
+        for exact in (0, 1):
+            eng.set_option("sls_exact", exact)
+            for rnd in range(2):
+                for s in range(3):
+                    eng.forward_multi_async(s, [b for b, _ in sets[s]], [n for _, n in sets[s]])
+                outs = [eng.wait(s, sum(n for _, n in sets[s])) for s in range(3)]
+            for s in range(3):
+                Rv = eng.fetch_interaction(B * 16, slot=s)
+                o = 0
+                for k, (bid, n) in enumerate(sets[s]):
+                    exp, R_exp = ref[(bid, n)]
+                    if exact:
+                        assert np.array_equal(Rv[B * k:B * k + n], R_exp), (s, k)
+                        assert H.close(outs[s][o:o + n], exp, rtol=1e-6, atol=1e-7), (s, k)
+                    else:
+                        assert np.array_equal(Rv[B * k:B * k + n, :D], R_exp[:, :D]), (s, k)    # GEMMs + chain: bitwise
+                        assert H.close(Rv[B * k:B * k + n], R_exp, rtol=1e-5, atol_scale=2e-6), (s, k)
+                        assert H.close(outs[s][o:o + n], exp, rtol=H.RTOL_OUT, atol=1e-7), (s, k)
+                    o += n
     finally:
         eng.close()
 

@@ -194,6 +194,10 @@ def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
     assert one["n_gpus"] == 1 and one["latency_ms"]["queries"] == 60 and one["config"]["collective"] is None
     # identical line structure at N = 1 and N = 2
     assert set(one) == set(two) and set(one["roofline"]) == set(two["roofline"])
+    # without --timed_only the line carries the check of the timed region's own outputs against the oracle
+    tiny = [a for a in _TINY if a != "--timed_only"]
+    chk = _bench(["--gpus", "1"] + tiny, cpu, cpu_abi=True)
+    assert chk["verified"]["ok"] is True and chk["verified_queries"] == chk["verified"]["verified_queries"] > 0
 
 
 def test_bench_refuses_more_ranks_than_devices():
@@ -247,6 +251,16 @@ def test_bench_self_spawn_n1_equals_plain_n1_line_shape():
     assert m["flop_per_query"] == 2 * 256 * (128 * 64 + 64 * 64 + 576 * 256 + 256 * 64 + 64) and m["peak"] == 157.3
     assert m["achieved"] == pytest.approx(out["value"] * m["flop_per_query"] / 1e12, rel=1e-2)
 
+
+@pytest.mark.gpu
+def test_bench_line_verifies_the_timed_regions_own_outputs():
+    """VERDICT r3 #1c: what the pipelined engine produced for the LAST launch sets of the timed region
+    (default flat gather, 12 queries per set, 3 sets in flight, MLP on its own stream) is compared with the
+    oracle's forward inside bench.py, at BASELINE configs[1]'s full size."""
+    out = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--queries_per_step", "3000", "--no_cpu_baseline"])
+    v = out["verified"]
+    assert v["ok"] is True and v["launch_sets"] == 3 and out["verified_queries"] == 36
+    assert v["max_rel_err"] <= 1e-4
 
 
 @pytest.mark.gpu
