@@ -111,6 +111,12 @@ def parse(argv=None):
     ap.add_argument("--rows", type=int, default=0, help="override the rows per table (footprint experiments)")
     ap.add_argument("--lookups", type=int, default=0, help="override the lookups per bag")
     ap.add_argument("--tables", type=int, default=0, help="override the number of tables")
+    ap.add_argument("--trace", default="", help="locality-aware index streams instead of uniform rows (the reference's "
+                    "--data_generation synthetic, data_generator/dlrm_data_caffe2.py:34-60): `shipped` = the stack-distance "
+                    "profile the reference ships, `hot` = a reuse-heavy one (both held in tests/golden/traces.npz), or the "
+                    "path of a profile file (two lines: distances, cumulative probabilities; `j` -> table number)")
+    ap.add_argument("--trace_unique", action="store_true", help="--trace: a bag is np.unique of its references (the "
+                    "reference's semantics: ragged bags); default keeps every bag at exactly L lookups")
     ap.add_argument("--torch_cpu_leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--allow_device_sharing", action="store_true",
                     help="ranks beyond the visible device count wrap around instead of failing "
@@ -144,10 +150,39 @@ def make_model(opt, device):
     net = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.MT_Wide_and_Deep,
            "din": M.DIN_Net, "dien": M.DIEN_Net}[kind](args)
     m_den = int(w["bot"].split("-")[0])
-    nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
+    if opt.trace:
+        nb, lX, lS_l, lS_i = trace_inputs(opt, args, m_den, rows, w["L"])
+    else:
+        nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
     net.create(lX[0], lS_l[0], lS_i[0], None)
     net.stage_batches(None if kind in NO_DENSE else lX, lS_l, lS_i)
     return args, net, (lX, lS_l, lS_i)
+
+
+def trace_inputs(opt, args, m_den, rows, L):
+    """--trace: the resident input sets from `--data_generation synthetic` (the reference's LRU-stack
+    trace synthesis from a stack-distance profile, deeprecsys_amd/data_generator/dlrm_data.py): one
+    reference stream per table, cut into the bags of consecutive queries."""
+    import tempfile
+    from deeprecsys_amd.data_generator.dlrm_data import DLRMDataGenerator
+    path, tmp = opt.trace, None
+    if opt.trace in ("shipped", "hot"):
+        from deeprecsys_amd.data_generator.trace_generator import write_dist_to_file
+        z = np.load(os.path.join(ROOT, "tests", "golden", "traces.npz"))
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".sd_cumm", delete=False)
+        tmp.close()
+        write_dist_to_file(tmp.name, z[opt.trace + "/list_sd"].tolist(), z[opt.trace + "/cumm_sd"].tolist())
+        path = tmp.name
+    np.random.seed(opt.seed)
+    try:
+        nb, lX, lS_l, lS_i = DLRMDataGenerator(args).generate_synthetic_input_data(
+            opt.num_batches, opt.batch, False, L, True, m_den, np.asarray(rows), path, False, unique=opt.trace_unique)
+    finally:
+        if tmp is not None:
+            os.unlink(tmp.name)
+    lS_l = [[np.asarray(l, dtype=np.int32) for l in per] for per in lS_l]
+    lS_i = [[np.asarray(i, dtype=np.int64) for i in per] for per in lS_i]
+    return nb, lX, lS_l, lS_i
 
 
 def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1, tail=None):
@@ -852,7 +887,11 @@ def main():
                        "collective": None if world == 1 else
                        ("drs_stats_allreduce (RCCL, one grouped all-reduce of 32 KB)" if comm is not None
                         else (comm_note or "gloo")),
-                       "inputs": "device-resident (pre-staged)"},
+                       "inputs": "device-resident (pre-staged)",
+                       "index_streams": "uniform rows, sorted and distinct within a bag (the reference's random generator)"
+                       if not opt.trace else "--data_generation synthetic: LRU-stack traces from the stack-distance profile `%s`, "
+                       "one reference stream per table, %s" % (opt.trace, "bags = np.unique of L references (ragged)"
+                                                               if opt.trace_unique else "every bag exactly L lookups")},
             "latency_ms": {"p50": round(p50, 4), "p95": round(p95, 4), "p99": round(p99, 4),
                            "queries": int(np.sum(hist)), "sla": SLA_MS, "sla_met": bool(p99 <= SLA_MS)},
             "roofline": {"bound": "hbm", "kernel": "sls gather (multi-table SparseLengthsSum)",

@@ -1,5 +1,6 @@
 """Synthetic inputs: the reference's "random" generator restated
-(data_generator/dlrm_data_caffe2.py:34-60 dispatch, :69-124 inputs, :128-148 targets).
+(data_generator/dlrm_data_caffe2.py:34-60 dispatch, :69-124 inputs, :128-148 targets) and its
+trace-driven "synthetic" branch (:152-222) as it is meant to work.
 
 The engine's inputs are a pure function of numpy's legacy global RNG stream, and
 request packets only carry (batch_id, batch_size), so reproducing the *stream
@@ -33,11 +34,16 @@ class DLRMDataGenerator(DataGenerator):
     def generate_input_data(self):
         a = self.args
         ln_bot = np.array(a.arch_mlp_bot.split("-"), dtype=int)
-        if a.data_generation != "random":
-            # the reference's "synthetic" branch is unreachable (it calls a method as a free
-            # function, dlrm_data_caffe2.py:51) and "dataset" exits; keep both as hard errors
-            sys.exit("ERROR: --data_generation=" + a.data_generation + " is not supported")
         ln_emb = np.array(a.arch_embedding_size.split("-"), dtype=int)
+        if a.data_generation == "dataset":
+            sys.exit("ERROR: Dataset based DLRM instrumentation is currently not supported")
+        if a.data_generation == "synthetic":
+            return self.generate_synthetic_input_data(a.num_batches, a.max_mini_batch_size, a.round_targets,
+                                                      a.num_indices_per_lookup, a.num_indices_per_lookup_fixed,
+                                                      ln_bot[0], ln_emb, a.data_trace_file,
+                                                      a.data_trace_enable_padding)
+        if a.data_generation != "random":
+            sys.exit("ERROR: --data-generation=" + a.data_generation + " is not supported")
         return self.generate_random_input_data(a.num_batches, a.max_mini_batch_size, a.round_targets,
                                                a.num_indices_per_lookup,
                                                a.num_indices_per_lookup_fixed, ln_bot[0], ln_emb)
@@ -66,6 +72,77 @@ class DLRMDataGenerator(DataGenerator):
                             break
                     lengths.append(np.int32(group.size))
                     indices += group.tolist()
+                emb_lengths.append(lengths)
+                emb_indices.append(indices)
+            lS_lengths.append(emb_lengths)
+            lS_indices.append(emb_indices)
+        return (num_batches, lX, lS_lengths, lS_indices)
+
+    def generate_synthetic_input_data(self, num_batches, mini_batch_size, round_targets,
+                                      num_indices_per_lookup, num_indices_per_lookup_fixed, m_den, ln_emb,
+                                      trace_file, enable_padding=False, unique=True):
+        """`--data_generation synthetic`: locality-aware index streams from a stack-distance profile
+        (data_generator/dlrm_data_caffe2.py:34-60 dispatch, :152-222 generator; trace_generator.py:71-97).
+
+        What the reference's branch is MEANT to do, restated -- as shipped it cannot run: it calls the
+        method as a free function (:51, NameError) and unpacks three values from a reader that returns
+        two (:196 vs trace_generator.py:31-43).  Per table i the profile is read from
+        `trace_file.replace("j", str(i))` (:197; a path without "j" serves every table: the profile the
+        reference ships is `data_generator/profile/sd_cumm`), per batch `rand(n, m_den)` dense rows are
+        drawn first (:174), and a bag is `np.unique` of its references -- sorted, duplicates removed,
+        the bag's LENGTH reset to what is left (:207-219); an index outside the table is folded back
+        with `mod` (:210-215).  Variable group sizes draw `random(1)` per bag like :190-193.
+        Deviation (stated): ONE LRU stack per table for the whole run -- the bags of a table are
+        consecutive slices of one reference stream, so reuse crosses bags, queries and batches, which
+        is what exercises L2 / Infinity-Cache in the gather.  The reference line re-creates the stack
+        per bag (a fresh permutation of the table for every bag, no line could ever be re-touched by a
+        later bag).  unique=False keeps every bag at exactly its group size (duplicates and reference
+        order kept): fixed-length bags, what bench.py --trace times.
+        Seeds: the caller seeds numpy (inferenceEngine.py:72); Python's `random` (the line permutation,
+        trace_generator.py:72) is seeded from numpy's stream here so one seed fixes everything."""
+        import os
+        import random
+
+        from . import trace_generator as TG
+        random.seed(int(ra.randint(0, 2 ** 31 - 1)))
+        L = int(num_indices_per_lookup)
+        n = mini_batch_size
+        sizes = [[None] * len(ln_emb) for _ in range(num_batches)]
+        lX = []
+        for j in range(num_batches):
+            lX.append(ra.rand(n, m_den).astype(np.float32))
+            for i, size in enumerate(ln_emb):
+                if num_indices_per_lookup_fixed:
+                    sizes[j][i] = np.full(n, L, dtype=np.int64)
+                else:
+                    sizes[j][i] = np.array([max(1, int(np.round(ra.random(1) * min(size, L))[0])) for _ in range(n)],
+                                           dtype=np.int64)
+        streams = []
+        for i, size in enumerate(ln_emb):
+            path = trace_file.replace("j", str(i))
+            if not os.path.exists(path) and os.path.exists(trace_file):
+                path = trace_file
+            list_sd, cumm_sd = TG.read_dist_from_file(path)
+            total = int(sum(int(sizes[j][i].sum()) for j in range(num_batches)))
+            refs = np.asarray(TG.trace_generate_lru(int(size), list_sd, cumm_sd, total, enable_padding),
+                              dtype=np.uint64).astype(np.int64)
+            if refs.size and (refs.min() < 0 or refs.max() >= size):
+                print("WARNING: distribution is inconsistent with embedding table size (using mod to recover and continue)")
+                refs = np.mod(refs, size)
+            streams.append(refs)
+        pos = [0] * len(ln_emb)
+        lS_lengths, lS_indices = [], []
+        for j in range(num_batches):
+            emb_lengths, emb_indices = [], []
+            for i in range(len(ln_emb)):
+                lengths, indices = [], []
+                for g in sizes[j][i]:
+                    grp = streams[i][pos[i]:pos[i] + int(g)]
+                    pos[i] += int(g)
+                    if unique:
+                        grp = np.unique(grp)
+                    lengths.append(np.int32(grp.size))
+                    indices += grp.tolist()
                 emb_lengths.append(lengths)
                 emb_indices.append(indices)
             lS_lengths.append(emb_lengths)

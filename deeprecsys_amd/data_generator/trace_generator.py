@@ -62,9 +62,9 @@ def generate_stack_distance(cumm_val, cumm_dist, max_i, i, enable_padding=False)
     elif enable_padding:
         fi = cumm_dist[0]
         u = (1.0 - fi) * u + fi
-    for (j, f) in enumerate(cumm_dist):
-        if u <= f:
-            return cumm_val[j]
+    # first j with u <= cumm_dist[j] (the reference scans linearly, :66-68)
+    j = bisect.bisect_left(cumm_dist, float(u[0]))
+    return cumm_val[j] if j < len(cumm_val) else None
 
 
 def trace_generate_lru(table_size, list_sd, cumm_sd, out_trace_len, enable_padding=False):

@@ -6,6 +6,8 @@ variant, concat layout, tril order) and for the k-ordered fp32 MFMA chains again
 the oracle's fmaf chains; 1e-4 relative (BASELINE.json north_star) for fp32 MLP
 outputs against the fp64-accumulated golden values.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -305,14 +307,15 @@ def test_full_size_rmc1_baseline_shape_matches_oracle():
                     eng.forward_multi_async(s, [b for b, _ in sets[s]], [n for _, n in sets[s]])
                 outs = [eng.wait(s, sum(n for _, n in sets[s])) for s in range(3)]
             for s in range(3):
-                Rv = eng.fetch_interaction(256 * per_set, slot=s)   # virtual rows: query k at row 256 k
-                o = 0
+                Rv = eng.fetch_interaction(256 * per_set, slot=s)   # virtual rows: a query starts at the next multiple of 64
+                o = v = 0
                 for k, (bid, n) in enumerate(sets[s]):
                     exp, R_exp = oracle(bid, n)
-                    assert H.close(Rv[256 * k:256 * k + n], R_exp, rtol=1e-5, atol_scale=2e-6), (per_set, s, k)
-                    assert np.array_equal(Rv[256 * k:256 * k + n, :D], R_exp[:, :D])     # bottom MLP: bitwise
+                    assert H.close(Rv[v:v + n], R_exp, rtol=1e-5, atol_scale=2e-6), (per_set, s, k)
+                    assert np.array_equal(Rv[v:v + n, :D], R_exp[:, :D])     # bottom MLP: bitwise
                     assert H.close(outs[s][o:o + n], exp, rtol=H.RTOL_OUT, atol=1e-7), (per_set, s, k)
                     o += n
+                    v += (n + 63) // 64 * 64
     finally:
         net.engine.close()
 
@@ -796,11 +799,12 @@ def test_rmc3_baseline_size_counting_property():
             got = [eng.wait(s_, sum(sizes)) for s_ in range(3)]
         for s_ in range(3):
             Rv = eng.fetch_interaction(B * 16, slot=s_)
-            o = 0
+            o = v = 0
             for k, n in enumerate(sizes):
-                assert np.array_equal(Rv[B * k:B * k + n, D:], np.full((n, D * T), float(L), np.float32)), (s_, k)
+                assert np.array_equal(Rv[v:v + n, D:], np.full((n, D * T), float(L), np.float32)), (s_, k)
                 assert np.array_equal(got[s_][o:o + n], outs[(0, n)]), (s_, k)
                 o += n
+                v += (n + 63) // 64 * 64
         assert eng.gather_bytes(0, B) == B * T * (L * D * 4 + L * 4 + 4 + D * 4)
         bad = [i.copy() for i in idx]
         bad[T - 1][7, 3] = rows                       # one past the end
@@ -841,17 +845,72 @@ def test_rmc3_baseline_graph_pipelined_sets_match_oracle():
                 outs = [eng.wait(s, sum(n for _, n in sets[s])) for s in range(3)]
             for s in range(3):
                 Rv = eng.fetch_interaction(B * 16, slot=s)
-                o = 0
+                o = v = 0
                 for k, (bid, n) in enumerate(sets[s]):
                     exp, R_exp = ref[(bid, n)]
                     if exact:
-                        assert np.array_equal(Rv[B * k:B * k + n], R_exp), (s, k)
+                        assert np.array_equal(Rv[v:v + n], R_exp), (s, k)
                         assert H.close(outs[s][o:o + n], exp, rtol=1e-6, atol=1e-7), (s, k)
                     else:
-                        assert np.array_equal(Rv[B * k:B * k + n, :D], R_exp[:, :D]), (s, k)    # GEMMs + chain: bitwise
-                        assert H.close(Rv[B * k:B * k + n], R_exp, rtol=1e-5, atol_scale=2e-6), (s, k)
+                        assert np.array_equal(Rv[v:v + n, :D], R_exp[:, :D]), (s, k)    # GEMMs + chain: bitwise
+                        assert H.close(Rv[v:v + n], R_exp, rtol=1e-5, atol_scale=2e-6), (s, k)
                         assert H.close(outs[s][o:o + n], exp, rtol=H.RTOL_OUT, atol=1e-7), (s, k)
                     o += n
+                    v += (n + 63) // 64 * 64
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("unique", [True, False])
+def test_gather_on_synthetic_locality_traces_matches_oracle(tmp_path, unique):
+    """`--data_generation synthetic` end to end: index streams synthesised from a stack-distance profile
+    (data_generator/dlrm_data_caffe2.py:34-60,152-222; the reuse-heavy `hot` profile: lines are re-touched
+    within and across bags) staged and gathered -- unique=True: the reference's np.unique bags (ragged:
+    ring-walk kernels); unique=False: every bag exactly L lookups with duplicates (the flat kernel, what
+    `bench.py --trace` times) -- sequential-order gather bitwise, default gather within its tolerance,
+    coalesced sets equal to the queries served alone."""
+    from deeprecsys_amd.data_generator.dlrm_data import DLRMDataGenerator
+    from deeprecsys_amd.data_generator import trace_generator as TG
+    z = np.load(os.path.join(H.GOLDEN, "traces.npz"))
+    path = str(tmp_path / "dist_emb_j.log".replace("j", "hot"))
+    TG.write_dist_to_file(path, z["hot/list_sd"].tolist(), z["hot/cumm_sd"].tolist())
+    rows, D, L, B, nb = [40_000, 60_000, 50_000, 30_000], 64, 80, 96, 2
+    a = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)), arch_mlp_bot="16-32-64",
+                    arch_mlp_top="64-1", arch_interaction_op="cat", num_indices_per_lookup=L, num_batches=nb,
+                    max_mini_batch_size=B, mini_batch_size=B, numpy_rand_seed=4, model_type="dlrm",
+                    data_generation="synthetic", data_trace_file=path, accel_slots=2)
+    np.random.seed(4)
+    _, lX, lS_l, lS_i = DLRMDataGenerator(a).generate_synthetic_input_data(nb, B, False, L, True, 16, np.array(rows), path,
+                                                                           False, unique=unique)
+    lS_l = [[np.asarray(l, np.int32) for l in per] for per in lS_l]
+    lS_i = [[np.asarray(i, np.int64) for i in per] for per in lS_i]
+    net = H.M.DLRM_Net(a)
+    om = H.oracle_model(net)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    eng = net.engine
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        if unique:
+            assert min(int(l.min()) for l in lS_l[0]) < L          # ragged
+        ref = {}
+        for exact in (1, 0):
+            eng.set_option("sls_exact", exact)
+            for bid in range(nb):
+                for bs in (B, 33):
+                    got = net.run_staged(bid, bs)
+                    R = eng.fetch_interaction(bs)
+                    exp, R_exp = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+                    if exact:
+                        assert np.array_equal(R, R_exp), (bid, bs)
+                        assert H.close(got, exp, rtol=1e-6, atol=1e-7)
+                    else:
+                        assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (bid, bs)
+                        assert H.close(got, exp, rtol=H.RTOL_OUT, atol=1e-7)
+                    ref[(exact, bid, bs)] = got
+            jobs = [(0, B), (1, 33), (1, B), (0, 33)]
+            outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+            for (bid, bs), o in zip(jobs, outs):
+                assert np.array_equal(o, ref[(exact, bid, bs)]), (exact, bid, bs)
     finally:
         eng.close()
 

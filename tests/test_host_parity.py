@@ -311,6 +311,58 @@ def test_trace_profile_and_distribution_equal_reference(tmp_path):
     assert bags.dtype == np.int64 and bags.size == 4000 and bags.max() < 5000
 
 
+def _write_profile(tmp_path, name="hot"):
+    from deeprecsys_amd.data_generator import trace_generator as TG
+    _, z = _traces()
+    path = str(tmp_path / ("dist_emb_%s.log" % name))
+    TG.write_dist_to_file(path, z[name + "/list_sd"].tolist(), z[name + "/cumm_sd"].tolist())
+    return path
+
+
+def test_data_generation_synthetic_goes_through_the_trace_generator(tmp_path):
+    """`--data_generation synthetic` (data_generator/dlrm_data_caffe2.py:34-60,152-222): the engine's
+    start-up sequence yields per-table index streams synthesised from the profile file -- a bag is
+    np.unique of its references (sorted, lengths reset to what is left), one seed fixes everything,
+    the profile's reuse shows up ACROSS bags, and indices stay inside their tables; `dataset` and
+    unknown modes exit like the reference."""
+    path = _write_profile(tmp_path, "hot")
+    rows = "3000-5000-4000"
+    a = H.args_from({}, arch_sparse_feature_size=16, arch_embedding_size=rows, arch_mlp_bot="8-16", arch_mlp_top="8-1",
+                    arch_interaction_op="dot", num_indices_per_lookup=20, num_batches=3, max_mini_batch_size=32,
+                    mini_batch_size=32, numpy_rand_seed=9, model_type="dlrm", data_generation="synthetic",
+                    data_trace_file=path)
+    net, lX, lS_l, lS_i, lT = H.materialize(a)
+    net2, lX2, lS_l2, lS_i2, _ = H.materialize(a)
+    assert len(lX) == 3 and lX[0].shape == (32, 8) and lX[0].dtype == np.float32
+    for b in range(3):
+        assert np.array_equal(lX[b], lX2[b])
+        for t, size in enumerate((3000, 5000, 4000)):
+            ln, ix = lS_l[b][t], lS_i[b][t]
+            assert np.array_equal(ln, lS_l2[b][t]) and np.array_equal(ix, lS_i2[b][t])          # one seed fixes everything
+            assert ln.dtype == np.int32 and ln.shape == (32,) and int(ln.sum()) == ix.size
+            assert 1 <= ln.min() and ln.max() <= 20 and ix.min() >= 0 and ix.max() < size
+            o = 0
+            for n in ln:                                                                             # np.unique per bag
+                assert np.all(np.diff(ix[o:o + n]) > 0)
+                o += n
+    assert any(int(l.min()) < 20 for per in lS_l for l in per)                                      # the hot profile repeats lines within a bag
+    # reuse across bags: far fewer distinct rows than references (the uniform generator: ~all distinct)
+    allrefs = np.concatenate([lS_i[b][1] for b in range(3)])
+    assert np.unique(allrefs).size < 0.75 * allrefs.size
+    # the model weights follow the inputs in the same numpy stream, like the random mode
+    assert net.emb_w[0].shape == (3000, 16)
+    # fixed-length bags (what bench.py --trace times): duplicates and reference order kept
+    from deeprecsys_amd.data_generator.dlrm_data import DLRMDataGenerator
+    np.random.seed(9)
+    _, _, fl, fi = DLRMDataGenerator(a).generate_synthetic_input_data(2, 16, False, 20, True, 8, np.array([3000, 5000]), path,
+                                                                      False, unique=False)
+    assert all(int(np.min(l)) == int(np.max(l)) == 20 for per in fl for l in per) and len(fi[0][0]) == 16 * 20
+    for mode in ("dataset", "nonsense"):
+        a.data_generation = mode
+        with pytest.raises(SystemExit):
+            H.materialize(a)
+
+
 def test_measured_mi355x_tables_load_like_the_reference_tables():
     """profiles/accelerator_mi355x/ is a drop-in for the reference's accelerator/ directory:
     GPU_Data reads a results_<model>.txt for EVERY model name it knows (wnd, rm1-3, ncf, mtwnd,

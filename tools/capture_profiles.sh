@@ -117,11 +117,15 @@ run 300 python tools/serve.py --mix --avg_arrival_rate 0.01 --nepochs 512 2>/dev
 #    not created: world == 1), and the self-spawn path
 run 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 1 --steps 5 --warmup 2 --no_cpu_baseline > "$OUT/bench_torchrun_n1.json" 2> "$OUT/bench_torchrun_n1.err"
-# 9. locality-aware traces: the gather on uniform / shipped-profile / reuse-heavy indices
-for p in uniform shipped hot; do
-  run 300 python tools/trace_gather.py --profile $p 2>/dev/null | tail -1 >> "$OUT/traces_gather.jsonl"
-  pmc "$OUT/traces_tcc_summary.txt" "TCC_HIT_sum TCC_MISS_sum" python tools/trace_gather.py --profile $p --steps 1
+# 9. locality-aware traces: the gather on uniform / shipped-profile / reuse-heavy index streams,
+#    through the same line as everything else (bench.py --trace = --data_generation synthetic)
+TR="python bench.py --no_cpu_baseline --steps 3 --warmup 1 --queries_per_step 8192 --num_batches 16"
+run 400 $TR > "$OUT/bench_trace_uniform.json" 2>/dev/null
+for p in shipped hot; do
+  run 600 $TR --trace $p > "$OUT/bench_trace_$p.json" 2>/dev/null
+  pmc "$OUT/traces_tcc_summary.txt" "TCC_HIT_sum TCC_MISS_sum" $TR --timed_only --steps 1 --trace $p
 done
+run 600 $TR --trace hot --trace_unique > "$OUT/bench_trace_hot_unique.json" 2>/dev/null
 # 10. where the host time of a query goes; raw PCIe rate of the box
 run 300 python tools/host_probe.py > "$OUT/host_probe.txt" 2>&1
 run 120 python tools/pcie_probe.py > "$OUT/pcie_probe.txt" 2>&1
