@@ -81,17 +81,19 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
     while finished != args.inference_engines:
         for q in responseQueues:
             if q.qsize():
-                response = q.get()
-                if response is None:
+                item = q.get()
+                if item is None:
                     finished += 1
                     say("Joined ", finished, " inference engines")
                     sys.stdout.flush()
                     continue
-                _latency, running_p95 = agg.add(response)
-                if running_p95 is not None:
-                    say("Running latency: ", running_p95)
-                    sys.stdout.flush()
-                    pidQueue.put(running_p95)
+                # an accelerator engine returns the responses of one launch set in one put (a list)
+                for response in (item if isinstance(item, list) else (item,)):
+                    _latency, running_p95 = agg.add(response)
+                    if running_p95 is not None:
+                        say("Running latency: ", running_p95)
+                        sys.stdout.flush()
+                        pidQueue.put(running_p95)
     say("Finished runing over the inference engines")
 
     log_dir = os.path.dirname(args.log_file)

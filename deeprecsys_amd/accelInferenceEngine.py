@@ -103,7 +103,8 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
 
     inferenceEngineReadyQueue.put(True)
     # --accel_coalesce n: up to n (<= 16) queued requests per launch set; 0: what the engine prefers for the
-    # model (16 for the MLP-bound ones, whose 16-row MLP workgroups then cover all 256 CUs; 8 otherwise)
+    # model (drs_get_option "preferred_coalesce": 12 for gather-bound DLRM, 16 for the MLP-bound models, whose
+    # 16-row MLP workgroups then cover all 256 CUs, 8 otherwise)
     coalesce = 1
     if model is not None:
         want = int(getattr(args, "accel_coalesce", 0))
@@ -132,8 +133,14 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
             fail(requests, e)
         end_time = time.time()
         free[mid].append(slot)
-        for r, o in zip(requests, outs):
-            responseQueue.put(_respond(r, engine_id, start_time, end_time, o.shape[0]))
+        # the responses of a launch set leave in one put (a list) unless --accel_req_batch 1 asks for the
+        # reference's one packet per put; the packets themselves are the reference's (utils/packets.py:32-59)
+        resp = [_respond(r, engine_id, start_time, end_time, o.shape[0]) for r, o in zip(requests, outs)]
+        if batched and len(resp) > 1:
+            responseQueue.put(resp)
+        else:
+            for x in resp:
+                responseQueue.put(x)
 
     def model_of(r):
         mid = int(getattr(r, "model_id", 0) or 0)
@@ -141,18 +148,28 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
             fail([r], ValueError("request for model %d, engine serves %d model(s)" % (mid, n_models)))
         return mid
 
+    batched = int(getattr(args, "accel_req_batch", 1)) > 1
+
+    def take(item):
+        # one put may carry a LIST of requests (loadGenerator, --accel_req_batch): its members are
+        # requests that were already waiting
+        if isinstance(item, list):
+            backlog.extend(item)
+        else:
+            backlog.append(item)
+
     while not shutdown or inflight or backlog:
         # 1. pull: block only when the GPU has nothing to do; otherwise take what is already there
         if not shutdown and len(backlog) < coalesce:
             debugPrint(args, "Accel", "Trying to pull request")
             try:
-                backlog.append(requestQueue.get() if not (inflight or backlog) else requestQueue.get_nowait())
+                take(requestQueue.get() if not (inflight or backlog) else requestQueue.get_nowait())
             except pyqueue.Empty:
                 pass
             # requests that are ALREADY waiting ride along in the same set of launches
             while backlog and backlog[-1] is not None and len(backlog) < coalesce:
                 try:
-                    backlog.append(requestQueue.get_nowait())
+                    take(requestQueue.get_nowait())
                 except pyqueue.Empty:
                     break
             if backlog and backlog[-1] is None:

@@ -5,6 +5,13 @@ signatures; distributions and partitioning pinned by tests/golden/harness.json).
 Extension for this build: `num_accels` accelerator engines, one per
 GPU, all pulling from the single accelRequestQueue; with no CPU engines configured
 every query goes to the accelerators whatever its size.
+
+Requests for the accelerators that are generated back to back (no sleep between them: the
+offered load exceeds what one put per packet can carry, ~40 k/s through a
+multiprocessing.Queue) travel as ONE put of a list of up to `--accel_req_batch`
+ServiceRequests -- the packets themselves are unchanged (utils/packets.py:6-22), an
+engine that finds a list serves its members like requests it found waiting.  The list is
+flushed before every sleep, so at low load every request still leaves at once.
 """
 import math
 import sys
@@ -94,8 +101,20 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
     shares = [share for _a, share in mix_models(args)]
     mix_rng = np.random.RandomState(args.numpy_rand_seed + 7919) if shares else None
 
+    req_batch = max(1, int(getattr(args, "accel_req_batch", 1)))
+    pending = []                                   # accelerator requests not yet put
+
+    def flush():
+        if pending:
+            accelRequestQueue.put(pending[0] if len(pending) == 1 else list(pending))
+            del pending[:]
+
     epoch = exp_epochs = 0
     while tuning_batch_qps or (exp_epochs < args.nepochs):
+        # inter-arrival gaps: one draw per query from the same numpy stream as the reference's
+        # per-query poisson(size=1) (:198-199) -- a block draw yields the same values; only while the
+        # schedulers cannot change the rate under it
+        gaps = None if (tuning_batch_qps or tuning_accel_qps) else np.random.poisson(lam=arrival_rate, size=args.num_batches)
         for batch_id in range(args.num_batches):
             if tuning_batch_qps and pidQueue.qsize() > 0:
                 args, arrival_rate, tuning_batch_qps = query_scheduler.run(pidQueue.get())
@@ -121,7 +140,9 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
                                          model_id=model_id)
                 accel_requests += 1
                 request.arrival_time = time.time()
-                accelRequestQueue.put(request)
+                pending.append(request)
+                if len(pending) >= req_batch:
+                    flush()
             else:
                 pieces = partition_requests(args, request_size)
                 for i, piece in enumerate(pieces):
@@ -131,11 +152,15 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
                     request.arrival_time = time.time()
                     requestQueue.put(request)
                 cpu_requests += 1
-            loadGenSleep(np.random.poisson(lam=arrival_rate, size=1)[0] / 1000.)
+            gap = (np.random.poisson(lam=arrival_rate, size=1)[0] if gaps is None else gaps[batch_id]) / 1000.
+            if gap > 0:
+                flush()                            # nothing waits in the list while this process sleeps
+                loadGenSleep(gap)
         epoch += 1
         if not tuning_batch_qps and not tuning_accel_qps:
             exp_epochs += 1
 
+    flush()
     # one shutdown sentinel per engine (loadGenerator.py:208-214)
     for i in range(n_cpu):
         debugPrint(args, "Load Generator", "sending done signal to " + str(i) + " cpu engine")

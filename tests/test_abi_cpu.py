@@ -122,29 +122,41 @@ def _engine_args(tmp_path, **kw):
     return a
 
 
-def test_accel_engine_request_loop_in_process(cpu_abi, tmp_path):
+@pytest.mark.parametrize("req_batch", [1, 16])
+def test_accel_engine_request_loop_in_process(cpu_abi, tmp_path, req_batch):
     """The accelerator engine's loop (ready token, coalescing of queued requests, several launch
     sets in flight, responses in request order per set, None sentinel) against in-process queues,
     with the real model wrappers on the CPU ABI; outputs sizes and response fields as the
-    reference's engine stamps them (accelInferenceEngine.py:46-83)."""
+    reference's engine stamps them (accelInferenceEngine.py:46-83).  req_batch 1: the reference's
+    protocol, one packet per put in both directions; 16: a put may carry a LIST of requests (single
+    packets still work beside them) and a launch set's responses come back as one list."""
     from deeprecsys_amd.accelInferenceEngine import accelInferenceEngine
-    from deeprecsys_amd.utils.packets import ServiceRequest
-    a = _engine_args(tmp_path, accel_slots=2, accel_coalesce=3)
+    from deeprecsys_amd.utils.packets import ServiceRequest, ServiceResponse
+    a = _engine_args(tmp_path, accel_slots=2, accel_coalesce=3, accel_req_batch=req_batch)
     req, resp, ready = queue.Queue(), queue.Queue(), queue.Queue()
     sizes = [16, 1, 7, 3, 16, 2, 9, 5, 11, 4]
-    for i, bs in enumerate(sizes):
-        req.put(ServiceRequest(batch_id=i % a.num_batches, epoch=0, arrival_time=float(i), batch_size=bs,
-                               sub_id=0, total_sub_batches=1, exp_packet=False))
+    packets = [ServiceRequest(batch_id=i % a.num_batches, epoch=0, arrival_time=float(i), batch_size=bs,
+                              sub_id=0, total_sub_batches=1, exp_packet=False) for i, bs in enumerate(sizes)]
+    if req_batch == 1:
+        for p in packets:
+            req.put(p)
+    else:
+        req.put(packets[:4])
+        req.put(packets[4])
+        req.put(packets[5:])
     req.put(None)
     accelInferenceEngine(a, req, 0, resp, ready)
     assert ready.get_nowait() is True
-    got = []
+    got, puts = [], 0
     while True:
         r = resp.get_nowait()
         if r is None:
             break
-        got.append(r)
+        puts += 1
+        assert isinstance(r, ServiceResponse) or (req_batch > 1 and isinstance(r, list) and 1 < len(r) <= 3)
+        got.extend(r if isinstance(r, list) else [r])
     assert resp.empty()
+    assert puts == len(sizes) if req_batch == 1 else puts < len(sizes)
     assert sorted((r.batch_id, r.batch_size, r.arrival_time) for r in got) == \
         sorted((i % a.num_batches, bs, float(i)) for i, bs in enumerate(sizes))
     assert all(r.out_batch_size == r.batch_size and r.consumer_id == 0 and r.model_id == 0 for r in got)
@@ -168,7 +180,7 @@ def test_accel_engine_serves_a_mixed_model_stream_in_process(cpu_abi, tmp_path):
         r = resp.get_nowait()
         if r is None:
             break
-        got.append(r)
+        got.extend(r if isinstance(r, list) else [r])
     assert sorted((r.model_id, r.batch_size) for r in got) == sorted(plan)
     assert all(r.out_batch_size == r.batch_size for r in got)
 
@@ -218,3 +230,34 @@ def test_product_binding_refuses_anything_but_the_hip_build(monkeypatch):
     finally:
         monkeypatch.undo()
         importlib.reload(N)
+
+
+@pytest.mark.parametrize("case", ["dlrm_rm1_mini", "ncf_mini", "din_mini"])
+def test_stand_alone_model_entry_prints_the_reference_table_lines(cpu_abi, case, capsys, tmp_path):
+    """`python -m deeprecsys_amd.dlrm_s_hip <reference flags>` (models/dlrm_s_caffe2.py:575-661, models/run.sh):
+    generates the inputs, builds the model, runs nepochs x num_batches forwards through run() and prints the
+    six `***` lines in the format accelerator/predict_execution.py:10-29 parses; the last forward's output is
+    the oracle's for the last input set; --enable_profiling adds the per-operator-type table
+    (experiments/operator_breakdown/sweep_p.py:21-28)."""
+    import json
+    import os
+    from deeprecsys_amd import dlrm_s_hip as M, latency_table
+    meta, _ = H.load_fixture(case)
+    cfg = {k: v for k, v in meta["args"].items() if k.startswith("arch_") or k in
+           ("model_type", "model_name", "num_indices_per_lookup", "num_indices_per_lookup_fixed", "user_behavior_tables",
+            "hidden_size", "attention_layers")}
+    path = str(tmp_path / "cfg.json")
+    json.dump(cfg, open(path, "w"))
+    M.main(["--inference_only", "--use_accel", "--config_file", path, "--num_batches", "3", "--nepochs", "2",
+            "--mini_batch_size", "8", "--max_mini_batch_size", "8", "--caffe2_net_type", "async_dag",
+            "--enable_profiling"])
+    out = capsys.readouterr().out
+    f = str(tmp_path / "results.txt")
+    open(f, "w").write(out)
+    rows = latency_table.parse_results(f)
+    assert len(rows) == 1 and len(rows[0]) == 6
+    load, load_it, comp, comp_it, tot, tot_it = rows[0]
+    assert load_it == pytest.approx(load / 6) and comp_it == pytest.approx(comp / 6) and tot_it == pytest.approx(tot / 6)
+    assert tot == pytest.approx(load + comp) and load > 0 and comp > 0
+    assert out.count("Time per operator type:") == 6 and "SparseLengthsSum" in out and " FC" in out
+    assert "Created network" in out and "Running networks" in out

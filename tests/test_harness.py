@@ -67,6 +67,39 @@ def _write_mix_configs(tmp_path):
     return ",".join(files)
 
 
+@pytest.mark.parametrize("rate,req_batch", [(0.0, 16), (0.0, 1), (3.0, 16)])
+def test_load_generator_batches_back_to_back_requests(tmp_path, rate, req_batch):
+    """--accel_req_batch: accelerator requests generated back to back travel as ONE put of a list (the packets
+    are the reference's, utils/packets.py:6-22); the list is flushed before every sleep, so when the
+    inter-arrival gap is non-zero every request leaves at once; 1 = the reference's one packet per put.
+    Sentinels are always their own put (loadGenerator.py:208-214)."""
+    import queue
+    from deeprecsys_amd.loadGenerator import loadGenerator
+    from deeprecsys_amd.utils.packets import ServiceRequest
+    a = _args(tmp_path, num_accels=2, nepochs=3, num_batches=8, avg_arrival_rate=rate, accel_req_batch=req_batch)
+    a.inference_engines = 2
+    np.random.seed(a.numpy_rand_seed)
+    rq, ret, ready, pid, aq = (queue.Queue() for _ in range(5))
+    ready.put(True), ready.put(True)
+    loadGenerator(a, rq, ret, ready, pid, aq)
+    puts = []
+    while not aq.empty():
+        puts.append(aq.get())
+    assert puts[-2:] == [None, None] and rq.empty()
+    body = puts[:-2]
+    flat = [r for p in body for r in (p if isinstance(p, list) else [p])]
+    assert all(isinstance(r, ServiceRequest) for r in flat)
+    assert [(r.epoch, r.batch_id) for r in flat] == [(e, b) for e in range(3) for b in range(8)]      # order kept
+    assert ret.get() == (0, 0, 24)
+    if req_batch == 1:
+        assert len(body) == 24 and not any(isinstance(p, list) for p in body)
+    elif rate == 0.0:
+        assert [len(p) for p in body] == [16, 8]
+    else:
+        # poisson(3 ms) is non-zero ~95 % of the time: (almost) every request is flushed on its own
+        assert len(body) >= 20
+
+
 def test_mixed_model_stream_tags_queries_deterministically(tmp_path):
     """BASELINE config 4's stream: every query is for one of the engine's models, drawn from
     its own seeded stream with the configured shares; the log carries model_id."""
@@ -264,6 +297,33 @@ def test_bench_line_verifies_the_timed_regions_own_outputs():
 
 
 @pytest.mark.gpu
+def test_stand_alone_model_entry_on_the_gpu(tmp_path):
+    """`python -m deeprecsys_amd.dlrm_s_hip` with the reference's flags (models/run.sh:36-57, generate_data.py:20):
+    the six `***` lines parse like the reference's characterisation files and the split is real (the input
+    hand-over of a 256-sample RMC1 query is measurable beside its forward)."""
+    import json
+    import subprocess
+    cfg = dict(arch_mlp_bot="128-64-32", arch_mlp_top="256-64-1", arch_embedding_size="-".join(["400000"] * 8),
+               arch_sparse_feature_size=32, num_indices_per_lookup_fixed=True, num_indices_per_lookup=80,
+               arch_interaction_op="cat", model_type="dlrm", model_name="rm1")
+    path = str(tmp_path / "dlrm_rm1.json")
+    json.dump(cfg, open(path, "w"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "deeprecsys_amd.dlrm_s_hip", "--inference_only", "--use_accel",
+                        "--caffe2_net_type", "async_dag", "--config_file", path, "--nepochs", "20", "--num_batches", "4",
+                        "--mini_batch_size", "256", "--max_mini_batch_size", "256", "--accel_table_init", "device"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    f = str(tmp_path / "results_rm1.txt")
+    open(f, "w").write(r.stdout)
+    rows = latency_table.parse_results(f)
+    assert len(rows) == 1
+    load, load_it, comp, comp_it, tot, tot_it = rows[0]
+    assert tot == pytest.approx(load + comp) and tot_it == pytest.approx(tot / 80)
+    assert 0.005 < comp_it < 5.0 and 0.005 < load_it < 20.0            # ms per iteration
+
+
+@pytest.mark.gpu
 def test_harness_with_a_real_accelerator_engine(tmp_path):
     a = _args(tmp_path, accel_backend="hip", num_accels=1, arch_sparse_feature_size=16,
               arch_embedding_size="2000-3000-1000", arch_mlp_bot="13-32-16", arch_mlp_top="32-1",
@@ -348,6 +408,20 @@ def test_two_real_accel_engines_share_the_queue(tmp_path):
     lines = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
     assert sorted((l["epoch"], l["batch_id"]) for l in lines) == sorted((e, b) for e in range(a.nepochs) for b in range(a.num_batches))
     assert {l["consumer_id"] for l in lines} <= {0, 1}
+    # ... and under a load that saturates the GPU both engines are KEPT BUSY: requests travel
+    # in lists of --accel_req_batch, an engine pulls when it has a free launch-set slot, so neither starves.
+    # RMC1-class queries of ~900 samples: the two engines' gathers share GPU 0, the load generator is faster.
+    b = _args(tmp_path, accel_backend="hip", num_accels=2, arch_sparse_feature_size=64,
+              arch_embedding_size="-".join(["200000"] * 8), arch_mlp_bot="128-64-64", arch_mlp_top="256-64-1",
+              arch_interaction_op="cat", num_indices_per_lookup=80, model_type="dlrm", nepochs=96, num_batches=32,
+              accel_table_init="device", max_mini_batch_size=1024, avg_mini_batch_size=900, var_mini_batch_size=50,
+              batch_size_distribution="normal", avg_arrival_rate=0.001, log_file=str(tmp_path / "two.log"))
+    s = DeepRecSys(b, quiet=True)
+    n = b.nepochs * b.num_batches
+    assert s["accel_requests"] == n and s["responses"] == n
+    lines = [eval(l) for l in open(b.log_file).read().strip().splitlines()]
+    share = sum(1 for l in lines if l["consumer_id"] == 0) / float(n)
+    assert 0.35 <= share <= 0.65, share
 
 
 def test_bench_cpu_baseline_has_the_reference_serving_shape_leg(tmp_path):
