@@ -1722,10 +1722,17 @@ int32_t drs_run_queues_multi_async(drs_handle e, int32_t slot, int32_t n, const 
   const size_t dense_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1);
   const size_t idx_bytes = sizeof(int32_t) * (size_t)e->T * e->cap;
   const size_t off_bytes = sizeof(int32_t) * (size_t)e->T * (e->max_batch + 1);
-  if (!s.h_multi) {
+  if (s.mq.empty()) {
+    // first use: both allocations or neither (a failed second one must not leave a half-built slot behind:
+    // the next call would index device pointers derived from null -- ADVICE r3)
     s.multi_block = (size_t)round_up((int64_t)(dense_bytes + idx_bytes + off_bytes), 256);
-    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&s.h_multi), s.multi_block * DRS_MAX_COALESCE, hipHostMallocDefault));
-    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&s.d_multi), s.multi_block * DRS_MAX_COALESCE));
+    hipError_t r1 = hipHostMalloc(reinterpret_cast<void**>(&s.h_multi), s.multi_block * DRS_MAX_COALESCE, hipHostMallocDefault);
+    hipError_t r2 = r1 == hipSuccess ? hipMalloc(reinterpret_cast<void**>(&s.d_multi), s.multi_block * DRS_MAX_COALESCE) : r1;
+    if (r2 != hipSuccess) {
+      if (r1 == hipSuccess) (void)hipHostFree(s.h_multi);
+      s.h_multi = nullptr; s.d_multi = nullptr; s.multi_block = 0;
+      return fail(e, r2 == hipErrorOutOfMemory ? DRS_ERR_OOM : DRS_ERR_HIP, "per-call input blocks of a launch set: %s", hipGetErrorString(r2));
+    }
     s.mq.assign(DRS_MAX_COALESCE, Batch());
     for (int i = 0; i < DRS_MAX_COALESCE; ++i) {
       char* d = s.d_multi + (size_t)i * s.multi_block;
@@ -1794,15 +1801,20 @@ int32_t drs_run_queues_multi_async(drs_handle e, int32_t slot, int32_t n, const 
     need_off = need_off || !e->sls_uniform || b.uniform_len < 0;
   }
   if (Mv > e->max_rows) return fail(e, DRS_ERR_BAD_ARG, "%lld coalesced rows exceed the slot capacity %lld", (long long)Mv, (long long)e->max_rows);
-  // one copy of the n blocks when they are mostly full (and always when the prefix sums are needed:
-  // they sit at the end of a block); else the used prefix of each
-  if (need_off || 2 * used_sum >= (size_t)n * s.multi_block) {
+  // one copy of the n blocks when they are mostly full; else the used prefix of each block and, where the
+  // kernels will read prefix sums (ragged bags, or "sls_uniform" 0), that block's offsets region as a
+  // second copy -- a set of small ragged queries must not move n full-capacity blocks
+  if (2 * used_sum >= (size_t)n * s.multi_block) {
     const size_t bytes = need_off ? (size_t)n * s.multi_block : (size_t)(n - 1) * s.multi_block + used[n - 1];
     HIP_TRY(e, hipMemcpyAsync(s.d_multi, s.h_multi, bytes, hipMemcpyHostToDevice, e->stream_h2d));
   } else {
-    for (int i = 0; i < n; ++i)
-      HIP_TRY(e, hipMemcpyAsync(s.d_multi + (size_t)i * s.multi_block, s.h_multi + (size_t)i * s.multi_block, used[i],
-                                hipMemcpyHostToDevice, e->stream_h2d));
+    for (int i = 0; i < n; ++i) {
+      const size_t base = (size_t)i * s.multi_block;
+      HIP_TRY(e, hipMemcpyAsync(s.d_multi + base, s.h_multi + base, used[i], hipMemcpyHostToDevice, e->stream_h2d));
+      if (!e->sls_uniform || s.mq[i].uniform_len < 0)
+        HIP_TRY(e, hipMemcpyAsync(s.d_multi + base + dense_bytes + idx_bytes, s.h_multi + base + dense_bytes + idx_bytes,
+                                  off_bytes, hipMemcpyHostToDevice, e->stream_h2d));
+    }
   }
   HIP_TRY(e, hipEventRecord(s.ev_in, e->stream_h2d));
   const hipStream_t ms = job_stream(e, s, Mv), gs = job_gather_stream(e, s, Mv);

@@ -625,7 +625,26 @@ int32_t drs_kernel_bytes(drs_handle e, int32_t, int64_t* bytes) {
 }
 int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   if (!e || !key || !value) return DRS_ERR_BAD_ARG;
-  *value = !strcmp(key, "preferred_coalesce") ? 8 : 0;
+  *value = 0;
+  if (!strcmp(key, "preferred_coalesce")) {
+    // the engine's own rule (csrc/engine.hip drs_create / drs_get_option), so the host code above the ABI
+    // runs with the launch-set sizes the product uses: 16 when the model's MLP launches overlap each
+    // other (MLP FLOP per gathered byte > 20, or a DLRM whose MLP launch outlasts its gather), 12 for
+    // gather-bound DLRM, 8 otherwise
+    double flop = 0;
+    for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
+      for (size_t i = 0; i + 1 < mm->ln.size(); ++i) flop += 2.0 * mm->ln[i] * (mm->ln[i + 1] > 0 ? mm->ln[i + 1] : 64);
+    for (const Mlp& rn : e->rnn) flop += 2.0 * (e->T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
+    const double bytes = (double)e->T * e->max_lookups * e->D * 4.0;
+    int streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
+    if (streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
+      double weights = 0;
+      for (const Mlp* mm : {&e->bot, &e->top})
+        for (size_t i = 0; i + 1 < mm->ln.size(); ++i) weights += (double)mm->ln[i] * mm->ln[i + 1];
+      if (12.0 + weights / 4500.0 > 2048.0 * bytes / 5.5e6) streams = 2;
+    }
+    *value = streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8);
+  }
   return DRS_OK;
 }
 // the collective is RCCL over xGMI: no CPU restatement (the CPU suite combines ranks over gloo)

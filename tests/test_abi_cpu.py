@@ -261,3 +261,19 @@ def test_stand_alone_model_entry_prints_the_reference_table_lines(cpu_abi, case,
     assert tot == pytest.approx(load + comp) and load > 0 and comp > 0
     assert out.count("Time per operator type:") == 6 and "SparseLengthsSum" in out and " FC" in out
     assert "Created network" in out and "Running networks" in out
+
+
+def test_cpu_abi_answers_the_engines_launch_set_preference(cpu_abi):
+    """the CPU restatement used to answer 8 for every model, so the host code ran with other
+    launch-set sizes off-GPU than on it.  It now restates the engine's rule (csrc/engine.hip): 12 for
+    gather-bound DLRM, 16 where MLP launches overlap each other, 8 otherwise."""
+    def pref(kind, rows, D, bot, top, L, **kw):
+        e = N.Engine(kind, rows, D, bot, top, max_batch=16, max_lookups=L, num_staged_batches=1, num_slots=3, **kw)
+        try:
+            return e.get_option("preferred_coalesce")
+        finally:
+            e.close()
+    assert pref(N.MODEL_DLRM, [1000] * 8, 64, [128, 64, 64], [576, 256, 64, 1], 80, sigmoid_top=3) == 12        # RMC1
+    assert pref(N.MODEL_DLRM, [1000] * 12, 32, [2560, 1024, 256, 32], [416, 512, 256, 1], 20, sigmoid_top=3) == 16   # RM3
+    assert pref(N.MODEL_WND, [1000] * 27, 32, [512], [1376, 1024, 512, 256, 1], 1, sigmoid_top=4) == 16
+    assert pref(N.MODEL_DIN, [1000] * 254, 32, [96, 1, 32], [128, 200, 80, 2], 3) == 8
