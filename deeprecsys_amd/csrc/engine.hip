@@ -98,6 +98,9 @@ struct Slot {
   hipStream_t base_stream = nullptr;   // ... as assigned by apply_stream_mode (shared or own)
   hipStream_t own_stream = nullptr;
   hipStream_t gather_stream = nullptr;   // where the gather is launched (== stream unless pipelined)
+  hipStream_t cur = nullptr;             // "mlp_layout" 1: the stream the set's latest MLP launch went on
+  hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // ... events that order a set's launches across the two kinds of stream
+  int n_ev = 0;
   hipEvent_t ev_sls = nullptr;           // pipelined mode: gather done -> the MLP stream may go on
   hipEvent_t ev_in = nullptr;            // pipelined mode: per-call inputs copied -> the gather may start
   Batch zc;                              // per-call inputs read in place from host-mapped pinned memory
@@ -184,6 +187,12 @@ struct drs_engine {
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
   hipStream_t stream_h2d = nullptr; // input copies of drs_run_queues_multi_async (created on first use)
   int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
+  // "mlp_layout" 1 (MLP-bound models, pipelined mode): streams by KERNEL TYPE instead of by launch set -- the
+  // gather and every wide-layer GEMM of every set go on stream_g, strictly one after the other (each fills
+  // the chip by itself: the gather then has the HBM to itself instead of sharing every CU with two
+  // overlapping GEMM launches), the latency-bound chain launches go on the slots' MLP streams beside them;
+  // an event per change of stream orders a set's launches.  0: a set's MLP launches all on its own stream.
+  int mlp_layout = 0;
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
   int zero_copy_inputs = 1;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 by size
   int64_t mlp_wide_kn = 256 * 1024;   // K*N from which a layer gets its own 2-D launch (RM3's 1024x256 included)
@@ -462,6 +471,24 @@ void fill_chain(ChainArgs& c, const Mlp& m, int l0, int cnt, const float* x, int
 
 constexpr size_t kChainLds = 156 * 1024;
 
+// The stream the set's next MLP launch goes on.  "mlp_layout" 0: the set's own MLP stream.  1: wide-layer
+// GEMMs of full launch sets on the gather stream, everything else on the set's MLP stream; when the kind
+// changes inside a set, the new stream waits for an event recorded behind the set's previous launch.
+hipError_t mlp_launch_stream(drs_engine* e, Slot& s, bool wide, int64_t M, hipStream_t* out) {
+  hipStream_t want = s.stream;
+  if (e->mlp_layout == 1 && e->shared_stream == 2 && wide && M > e->mlp_small_rows) want = e->stream_g;
+  if (s.cur && s.cur != want) {
+    hipEvent_t ev = s.ev_k[s.n_ev];
+    s.n_ev = (s.n_ev + 1) & 3;
+    hipError_t r = hipEventRecord(ev, s.cur);
+    if (r == hipSuccess) r = hipStreamWaitEvent(want, ev, 0);
+    if (r != hipSuccess) return r;
+  }
+  s.cur = want;
+  *out = want;
+  return hipSuccess;
+}
+
 // Run all layers of `m` on x -> y.  A huge layer runs as its own 2-D launch; runs of
 // ordinary layers are fused into one LDS-resident chain.  Segment outputs that are not
 // the final one ping-pong between s.H and s.Hb.
@@ -489,13 +516,15 @@ int32_t run_mlp(drs_engine* e, Slot& s, const Mlp& m, const float* x, int64_t ld
     const bool last = l0 + cnt == n_layers;
     float* out = last ? y : (in == s.H ? s.Hb : s.H);
     const int64_t ldo = last ? ldy : e->ldH;
+    hipStream_t st = s.stream;
+    HIP_TRY(e, mlp_launch_stream(e, s, standalone && is_wide(e, m, l0), M, &st));
     if (standalone) {
       HIP_TRY(e, launch_fc(in, ldin, M, m.ln[l0], m.layers[l0].W, m.layers[l0].b, m.ln[l0 + 1],
-                           act_of(m, l0), out, ldo, e->tune, s.stream, last ? done : nullptr,
+                           act_of(m, l0), out, ldo, e->tune, st, last ? done : nullptr,
                            l0 == 0 ? xs : nullptr));
     } else {
       c.y = out; c.ldy = ldo;
-      HIP_TRY(e, launch_chain(c, e->tune, s.stream, last ? done : nullptr, l0 == 0 ? xs : nullptr));
+      HIP_TRY(e, launch_chain(c, e->tune, st, last ? done : nullptr, l0 == 0 ? xs : nullptr));
     }
     in = out; ldin = ldo; l0 += cnt;
   }
@@ -655,6 +684,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   // keep the shared stream: there the extra concurrency only takes CUs from the gather.
   // Safe: a slot is reused only after its previous job was observed complete on the host.
   s.stream = job_stream(e, s, Mv);
+  s.cur = nullptr;               // (the set's first MLP launch needs no event: join() orders it behind the gather)
   const hipStream_t gstream = job_gather_stream(e, s, Mv);
   const bool prof = e->profiling >= 1;
   const bool evts = e->profiling >= 2;
@@ -1247,6 +1277,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // record adds by default costs ~3 us between consecutive gathers (measured: 128 k -> 132 k QPS)
     CREATE_TRY(hipEventCreateWithFlags(&s.ev_sls, hipEventDisableTiming | hipEventDisableSystemFence));
     CREATE_TRY(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming | hipEventDisableSystemFence));
+    for (auto& ev : s.ev_k) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));
     if (alloc_batch(e, s.scratch)) return bail(DRS_ERR_OOM, e->err.c_str());
     s.scratch.n_samples = 0;
     s.h_stage_bytes = sizeof(float) * (size_t)e->max_batch * (e->m_den > 0 ? e->m_den : 1) +
@@ -1361,6 +1392,7 @@ int32_t drs_destroy(drs_handle e) {
     DTR("own stream gone");
     if (s.ev_sls) (void)hipEventDestroy(s.ev_sls);
     if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+    for (auto& ev : s.ev_k) if (ev) (void)hipEventDestroy(ev);
     if (s.T) (void)hipFree(s.T);
     if (s.R) (void)hipFree(s.R);
     if (s.H) (void)hipFree(s.H);
@@ -1839,6 +1871,7 @@ int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R
   if (slot < 0 || slot >= e->n_slots || !h_R || bs < 0 || bs > e->max_rows) return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
   Slot& s = e->slots[slot];
   HIP_TRY(e, hipStreamSynchronize(s.stream));
+  if (e->mlp_layout == 1) HIP_TRY(e, hipStreamSynchronize(e->stream_g));
   const float* src;
   int64_t ld;
   if (e->kind == DRS_MODEL_NCF) { src = s.H2; ld = e->num_int; }
@@ -1972,6 +2005,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     e->mlp_streams = (int)value;
     apply_stream_mode(e);
   }
+  else if (!strcmp(key, "mlp_layout") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_layout = (int)value; }
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
@@ -1985,7 +2019,9 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 4 || value == 8 || value == 16)) e->tune.mlp_stream_waves = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
-  else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214)) e->tune.gemm_tile = (int)value;
+  else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214 || value == 322 || value == 321 || value == 312 || value == 311)) e->tune.gemm_tile = (int)value;
+  else if (!strcmp(key, "mlp_gemm32") && (value == 0 || value == 1)) e->tune.gemm32 = (int)value;
+  else if (!strcmp(key, "mlp_gemm32_blocks") && value >= 1 && value <= 65536) e->tune.gemm32_blocks = (int)value;
   else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
   else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
   else if (!strcmp(key, "mlp_rows32") && value >= 0) e->tune.mlp_rows32 = value;
@@ -2040,9 +2076,9 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams},
+      {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }

@@ -252,6 +252,216 @@ __global__ __launch_bounds__(512, OCC) void gemm_kernel(GArgs a, Done done, XSrc
   signal_done(done, gridDim.x * gridDim.y, smem);
 }
 
+// ---- the same GEMM on v_mfma_f32_32x32x2_f32 (round 4) -------------------------------------------
+// A wave owns WTM x WTN tiles of 32 x 32 (the 2 x 2 form: a 64 x 64 block in four independent
+// accumulators of 16 registers), a workgroup is FOUR waves sitting 2 x 2 (128 x 128 outputs at
+// WTM = WTN = 2), 256 threads, <= 256 registers: two workgroups per CU.  Against the 16x16x4 forms
+// above: an MFMA holds the pipe for 64 cycles instead of 32 (half the issues per FLOP), a lane's
+// operand register of step s is ONE float for 32 output rows (an operand read from LDS feeds
+// 64 x 64 / (64 + 64) = 32 MACs per float instead of 16 x 32 / 48 = 10.7), and the operands of FOUR
+// consecutive steps come from one ds_read_b128.
+//
+// Same arithmetic contract: MFMA step s carries k = 2 s (lanes 0..31) and 2 s + 1 (lanes 32..63),
+// D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)): ONE k-ordered fma chain per output from 0, bias after --
+// the bits of gemm_kernel, fc_kernel and oracle/drs_oracle.c (test_gemm_kernel_every_tile_shape_is_bitwise).
+//
+// LDS image of a 32-deep K chunk, per row 36 floats (32 + 4: the sixteen rows a ds_read_b128 lane
+// group touches land on sixteen different 16-B slots of the 256-B bank row).  Lane (i, h) of a wave
+// needs, for the four steps of the 8-k group t, k = 8 t + 2 j + h (j = 0..3): those four floats are
+// stored NEXT to each other -- element k = 8 t + 2 j + h sits at position 8 t + 4 h + j -- so the lane
+// reads them with one ds_read_b128 at 8 t + 4 h.  The staging thread that holds k = 8 t + 4 u' ..
+// + 3 (a float4 from global memory) writes (x0, x2) to 8 t + 2 u' and (x1, x3) to 8 t + 4 + 2 u':
+// two ds_write_b64, conflict-free (16 consecutive lanes = two rows x eight float4 = 32 banks).
+//
+// Pipeline per chunk c (LDS buffer c & 1), the scheme of gemm_kernel with a ring of two register sets:
+// request chunk c + 2; the four 8-k groups' MFMAs with the ds_write_b64 of chunk c + 1 in their shadow
+// and every group's operands read one group ahead; ONE barrier, placed before the last group so its 16
+// MFMAs (1024 cycles) cover the barrier and the first operand reads of chunk c + 1.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int G3KC = 32, G3LD = 36;
+
+template <int WTM, int WTN>
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc xs) {
+  constexpr int BM = 64 * WTM, BN = 64 * WTN;
+  constexpr int NA = 2 * WTM, NB = 2 * WTN;      // float4 per thread per chunk (rows frow + 32 j)
+  constexpr int NQ = 2 * (NA + NB);              // ds_write_b64 per stashed chunk
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                        // [2][BM][36]
+  float* sB = smem + 2 * BM * G3LD;        // [2][BN][36]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int K = a.K, N = a.N;
+  const int nch = (K + G3KC - 1) / G3KC;
+
+  // staging role: row frow (+32 j), floats 4 u .. 4 u + 3 of the chunk
+  const int frow = tid >> 3, u = tid & 7, fk = 4 * u;
+  const int st = 8 * (u >> 1) + 2 * (u & 1);                    // (x0, x2) here, (x1, x3) at + 4
+  float* const stA = sA + frow * G3LD + st;
+  float* const stB = sB + frow * G3LD + st;
+  // input rows: a 128-row tile may hold two queries' 64-row blocks (first layer: each query's own
+  // dense array, XSrc), so every 64-row half resolves its source on its own
+  const float* xb[WTM];
+  int64_t offA[NA], offB[NB];
+#pragma unroll
+  for (int hm = 0; hm < WTM; ++hm) {
+    int64_t row0, rows;
+    resolve_src(xs, a.x, a.M, m0 + 64 * hm, &xb[hm], &row0, &rows);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      // rows past the end are clamped: they only feed outputs that are never stored
+      const int64_t rr = row0 + frow + 32 * jj;
+      offA[2 * hm + jj] = (rr < rows ? rr : rows - 1) * a.ldx + fk;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) offB[j] = (int64_t)min(n0 + frow + 32 * j, N - 1) * K + fk;
+
+  int f_c = 0;   // next chunk to request (chunks past the end deliver zeros)
+  auto fetch = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+    const int k0 = f_c * G3KC;
+    const bool in = k0 + fk < K;       // K % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const float* p = in ? xb[j >> 1] + offA[j] + k0 : a.zero;
+      asm("" : "+v"(p));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[j]) : "v"(p));
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float* p = in ? a.W + offB[j] + k0 : a.zero;
+      asm("" : "+v"(p));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[j]) : "v"(p));
+    }
+    ++f_c;
+  };
+  auto stash_part = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int q) {
+    if (q < 2 * NA) {
+      const f32x4 v = ra[q >> 1];
+      float* p = stA + (buf * BM + 32 * (q >> 1)) * G3LD + 4 * (q & 1);
+      *reinterpret_cast<float2*>(p) = (q & 1) ? make_float2(v[1], v[3]) : make_float2(v[0], v[2]);
+    } else {
+      const int qq = q - 2 * NA;
+      const f32x4 v = rb[qq >> 1];
+      float* p = stB + (buf * BN + 32 * (qq >> 1)) * G3LD + 4 * (qq & 1);
+      *reinterpret_cast<float2*>(p) = (qq & 1) ? make_float2(v[1], v[3]) : make_float2(v[0], v[2]);
+    }
+  };
+  // wait for one register set: at most the NA + NB loads of the newer request outstanding
+  auto gwait = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+    constexpr int n = NA + NB;
+    if constexpr (NA == 4 && NB == 4)
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(n));
+    else if constexpr (NA == 2 && NB == 4)
+      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(n));
+    else if constexpr (NA == 4 && NB == 2)
+      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]) : "n"(n));
+    else
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]) : "n"(n));
+  };
+
+  f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  fetch(ra0, rb0);
+  fetch(ra1, rb1);
+  gwait(ra0, rb0);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) stash_part(0, ra0, rb0, q);
+  __syncthreads();
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const float* const pa0 = sA + (32 * WTM * wm + i32) * G3LD + 4 * h;
+  const float* const pb0 = sB + (32 * WTN * wn + i32) * G3LD + 4 * h;
+  // operand registers [ping/pong][tile]: the four floats are the lane's operands of the group's four steps
+  f32x4 av[2][WTM], bv[2][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(pa0 + 32 * i * G3LD);
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(pb0 + 32 * j * G3LD);
+
+#define DRS_G3MFMA(SET, RAS, RBS)                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                              \
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                               \
+      _Pragma("unroll") for (int j = 0; j < WTN; ++j)                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[SET][i][s_], bv[SET][j][s_], acc[i][j], 0, 0, 0); \
+    _Pragma("unroll") for (int w_ = 0; w_ < (NQ + 11) / 12; ++w_)                                 \
+      if (wq < NQ) { stash_part(nbuf, RAS, RBS, wq); ++wq; }                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  }
+  // One K chunk: MFMAs on buffer BUF, stash of the NEXT chunk (sets RAS/RBS) into BUF^1, request of
+  // chunk + 2 into the sets this chunk came from (RAF/RBF)
+#define DRS_G3ROUND(BUF, RAF, RBF, RAS, RBS)                                                      \
+  {                                                                                               \
+    fetch(RAF, RBF);                                                                              \
+    const float* pa = pa0 + (BUF) * BM * G3LD;                                                    \
+    const float* pb = pb0 + (BUF) * BN * G3LD;                                                    \
+    gwait(RAS, RBS);                                                                              \
+    const int nbuf = (BUF) ^ 1;                                                                   \
+    int wq = 0;   /* stash writes issued so far (compile-time after unrolling) */                  \
+    _Pragma("unroll") for (int gq = 0; gq < 3; ++gq) {                                            \
+      const int cur = gq & 1, nxt = cur ^ 1;                                                      \
+      _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(pa + 32 * i * G3LD + 8 * (gq + 1)); \
+      _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(pb + 32 * j * G3LD + 8 * (gq + 1)); \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      if (cur == 0) { DRS_G3MFMA(0, RAS, RBS) } else { DRS_G3MFMA(1, RAS, RBS) }                  \
+    }                                                                                             \
+    static_assert(NQ <= 12 * ((NQ + 11) / 12), "all stash writes must precede the barrier");      \
+    __syncthreads();                                                                              \
+    {                                                                                             \
+      const float* pan = pa0 + nbuf * BM * G3LD;                                                  \
+      const float* pbn = pb0 + nbuf * BN * G3LD;                                                  \
+      _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(pan + 32 * i * G3LD); \
+      _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(pbn + 32 * j * G3LD); \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    { DRS_G3MFMA(1, RAS, RBS) }                                                                   \
+  }
+
+  // Always whole PAIRS of rounds: an exit between the two rounds made the compiler copy all 64
+  // accumulator registers at the join (32 v_mov_b64 behind an s_nop 14 on every iteration).  For an
+  // odd chunk count the second round of the last pair runs on a chunk past K, which `fetch` delivers
+  // as zeros: fma(0, 0, c) = c, the chain's bits do not change (c is never -0: the chain starts at +0).
+  for (int c = 0; c < nch; c += 2) {
+    DRS_G3ROUND(0, ra0, rb0, ra1, rb1)
+    DRS_G3ROUND(1, ra1, rb1, ra0, rb0)
+  }
+#undef DRS_G3ROUND
+#undef DRS_G3MFMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing requests
+
+  // epilogue: bias + activation.  C/D of a 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+  // + 4 (lane >> 5): for one register the 32 lanes of a half write 128 contiguous bytes of one row
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) {
+    const int col = n0 + 32 * WTN * wn + 32 * j + i32;
+    if (col < N) {
+      const float bcol = a.b ? a.b[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int64_t row = m0 + 32 * WTM * wm + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (row < a.M) {
+            const float v = act_apply(acc[i][j][q] + bcol, a.act);
+            float* dst = a.y + row * a.ldy + col;
+            if (a.sc1) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = v;
+          }
+        }
+    }
+  }
+  signal_done(done, gridDim.x * gridDim.y, smem);
+}
+
 }  // namespace
 
 // per device (device_init, engine.hip)
@@ -259,6 +469,11 @@ hipError_t gemm_set_attrs() {
   for (const void* k : {reinterpret_cast<const void*>(gemm_kernel<2, 2>), reinterpret_cast<const void*>(gemm_kernel<1, 2>),
                         reinterpret_cast<const void*>(gemm_kernel<2, 1>), reinterpret_cast<const void*>(gemm_kernel<1, 1>),
                         reinterpret_cast<const void*>(gemm_kernel<2, 1, 2, 4>)}) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  for (const void* k : {reinterpret_cast<const void*>(gemm32_kernel<2, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 2>),
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 1>), reinterpret_cast<const void*>(gemm32_kernel<1, 1>)}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -298,6 +513,31 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   else if (blocks(1, 2) >= 256) { tm = 1; tn = 2; }
   else if (blocks(2, 1) >= 256) { tm = 2; tn = 1; }
   else { tm = 1; tn = 1; }
+  // The 32x32x2 forms (gemm32_kernel; "mlp_gemm_tile" 322 | 321 | 312 | 311 forces one, "mlp_gemm32" 1 =
+  // by block count): the largest workgroup tile that still gives every CU two workgroups, else one.
+  {
+    auto b32 = [&](int wm_, int wn_) { return ((M + 64 * wm_ - 1) / (64 * wm_)) * (int64_t)((N + 64 * wn_ - 1) / (64 * wn_)); };
+    int w = 0;
+    if (tune.gemm_tile >= 300) w = tune.gemm_tile - 300;
+    else if (tune.gemm_tile == 0 && tune.gemm32) {
+      const int order[4] = {22, 21, 12, 11};
+      for (int64_t need : {(int64_t)tune.gemm32_blocks, (int64_t)tune.gemm32_blocks / 2})
+        for (int o : order)
+          if (!w && b32(o / 10, o % 10) >= need) w = o;
+      if (!w) w = 11;
+    }
+    if (w) {
+      const int wm_ = w / 10, wn_ = w % 10;
+      const dim3 grid((unsigned)((M + 64 * wm_ - 1) / (64 * wm_)), (unsigned)((N + 64 * wn_ - 1) / (64 * wn_)));
+      const size_t lds = sizeof(float) * 2 * (64 * wm_ + 64 * wn_) * G3LD;
+      if (w == 22) hipLaunchKernelGGL((gemm32_kernel<2, 2>), grid, dim3(256), lds, s, a, d, xs);
+      else if (w == 21) hipLaunchKernelGGL((gemm32_kernel<2, 1>), grid, dim3(256), lds, s, a, d, xs);
+      else if (w == 12) hipLaunchKernelGGL((gemm32_kernel<1, 2>), grid, dim3(256), lds, s, a, d, xs);
+      else hipLaunchKernelGGL((gemm32_kernel<1, 1>), grid, dim3(256), lds, s, a, d, xs);
+      *err = hipGetLastError();
+      return true;
+    }
+  }
   const dim3 grid((unsigned)((M + 32 * tm - 1) / (32 * tm)), (unsigned)((N + 64 * tn - 1) / (64 * tn)));
   const size_t lds = sizeof(float) * 2 * (32 * tm + 64 * tn) * GLD;
 #define DRS_GLAUNCH(TM_, TN_) \

@@ -317,7 +317,12 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                "mlp_gemm_2cu" 1 (default for DLRM and W&D) | 0: take that shape by itself whenever
  *                it gives >= 512 workgroups (W&D +5 %, RM3 +5 %; MT-WnD -5 %: off there)
  *                ("mlp_gemm_min_blocks", default 128: the full 2 x 2 tile is kept while it still gives
- *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference)
+ *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference);
+ *                "mlp_gemm_tile" 322 | 321 | 312 | 311: gemm32_kernel, the same GEMM on
+ *                v_mfma_f32_32x32x2_f32 (four waves, each 2 x 2 | 2 x 1 | 1 x 2 | 1 x 1 tiles of 32 x 32:
+ *                workgroup tiles of 128 x 128 .. 64 x 64, operands by ds_read_b128, two workgroups per CU);
+ *                "mlp_gemm32" 1: take it for every wide layer, the largest workgroup tile that still
+ *                gives "mlp_gemm32_blocks" (default 512) workgroups
  *   "mlp_stream" 2 (default for MLP-bound models) chains run as the weight-tile stream kernel
  *                (tiles of all layers requested six rounds ahead, inputs resident in LDS) when every
  *                K % 4 == 0 and the slabs fit, the tiles read from the layers' PACKED twins (MFMA

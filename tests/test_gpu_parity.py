@@ -196,8 +196,8 @@ def test_fc_matches_oracle_chain(op_engine, M, K, N_, act):
         assert np.array_equal(got, exp)   # MFMA == k-ordered fmaf chain, bit for bit
 
 
-@pytest.mark.parametrize("tile", [22, 12, 21, 11, 214, 0])   # 214: the 2 x 1 shape compiled for two workgroups per CU
-@pytest.mark.parametrize("M,K,N_", [(300, 896, 1024), (65, 68, 130), (2048, 1024, 512), (31, 132, 64), (129, 64, 200)])
+@pytest.mark.parametrize("tile", [22, 12, 21, 11, 214, 322, 321, 312, 311, 0])   # 214: the 2 x 1 shape compiled for two workgroups per CU; 3xy: the v_mfma_f32_32x32x2_f32 forms (x * 64 rows, y * 64 columns per workgroup)
+@pytest.mark.parametrize("M,K,N_", [(300, 896, 1024), (65, 68, 130), (2048, 1024, 512), (31, 132, 64), (129, 64, 200), (257, 1376, 96)])
 def test_gemm_kernel_every_tile_shape_is_bitwise(op_engine, tile, M, K, N_):
     """gemm.hip: each per-wave tile shape (2x2, 1x2, 2x1, 1x1 MFMA tiles; 0 = chosen by block
     count) on shapes with row, column and K tails -- one k-ordered chain per output, bit for bit

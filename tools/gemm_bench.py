@@ -24,15 +24,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--tile", type=int, default=0, help="mlp_gemm_tile (0 auto | 22 | 12 | 21 | 11 | 214)")
+    ap.add_argument("--tile", type=int, default=0, help="mlp_gemm_tile (0 auto | 22 | 12 | 21 | 11 | 214 | 322 | 321 | 312 | 311)")
+    ap.add_argument("--gemm32", type=int, default=0, help="mlp_gemm32 (1: the 32x32x2 kernel, tile by block count)")
+    ap.add_argument("--shapes", default="", help="comma-separated KxN list instead of the models' shapes")
     o = ap.parse_args()
     eng = N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
                    max_batch=4, max_lookups=2, num_staged_batches=1, num_slots=1)
     eng.set_option("mlp_gemm_tile", o.tile)
+    eng.set_option("mlp_gemm32", o.gemm32)
+    shapes = SHAPES if not o.shapes else [("%s" % kn, int(kn.split("x")[0]), int(kn.split("x")[1])) for kn in o.shapes.split(",")]
     dev = torch.device("cuda", 0)
     M = o.rows
     print("%-16s %6s %6s %6s %10s %10s %8s" % ("layer", "M", "K", "N", "us/launch", "TFLOP/s", "of peak"))
-    for name, K, Nn in SHAPES:
+    for name, K, Nn in shapes:
         x = torch.rand(M, K, device=dev)
         W = torch.rand(Nn, K, device=dev) - 0.5
         b = torch.rand(Nn, device=dev)
