@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
         uint32_t rr = r[s][c];
         bad |= in && rr >= rows;
         rr = rr < rows ? rr : 0u;
-        v[s][c] = ld4(in ? W + (uint64_t)(rr * (uint32_t)D) : zcol);
+        v[s][c] = ld4(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
       }
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
         uint32_t rr = p.r[s][c];
         bad |= in && rr >= rows;
         rr = rr < rows ? rr : 0u;
-        v[s][c] = ld4(in ? W + (uint64_t)(rr * (uint32_t)D) : zcol);
+        v[s][c] = ld4(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
       }
     // ... then the next unit's indices and this unit's weights (this lane's pieces, kept across
     // the S samples)
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
           uint32_t rr = p.r[s][c];
           bad |= in && rr >= p.rows;
           rr = rr < p.rows ? rr : 0u;
-          v[uu][s][c] = ld4(in ? p.W + (uint64_t)(rr * (uint32_t)D) : zcol);
+          v[uu][s][c] = ld4(in ? p.W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
         }
     }
     // ... then the indices of the next iteration's units ...

@@ -59,10 +59,7 @@ struct Tune {
   int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
   int sls_xcd = 1;               // ... table-major work order, one contiguous slice per XCD
-  int sls_split = 0;             // ... two waves per bag when a launch has few bags (single query): OFF by
-                                 // default -- it makes a query's fp32 summation order depend on how many
-                                 // queries were coalesced with it (caught by the race hunt), for 0.2 us
-  int sls_depth = 0;             // ... explicit-schedule kernel with this many row loads in flight (0 = compiler's schedule)
+  int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_ring = 2, mlp_stream_waves = 0, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, gemm_min_blocks = 128, mlp_debug = 0;
   int gemm32 = 0;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel), tile by block count

@@ -1198,7 +1198,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   }
   for (int t = 0; t < T; ++t) {
     if (e->rows[t] <= 0) return bail(DRS_ERR_BAD_ARG, "table with no rows");
-    if (e->rows[t] * (int64_t)D >= (1ll << 32)) return bail(DRS_ERR_UNSUPPORTED, "rows*D must be < 2^32 per table");
+    // row offsets travel as 32-bit counts of load-width units (8 or 16 bytes): 32 GiB per table
+    if (e->rows[t] * (int64_t)D >= (1ll << 33)) return bail(DRS_ERR_UNSUPPORTED, "rows*D must be < 2^33 per table");
   }
 
   // prefix sums and bag * length products are int32 on the device
@@ -1903,7 +1904,7 @@ int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const i
   if (!d_W || !d_len || !d_out || (!d_idx && n_idx > 0) || n_bags < 0 || n_idx < 0 || rows <= 0)
     return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
   if (D <= 0 || D > 256 || (D & 3)) return fail(e, DRS_ERR_UNSUPPORTED, "D=%d must be a multiple of 4 in [4,256]", D);
-  if (rows * (int64_t)D >= (1ll << 32) || n_bags >= (1ll << 31) || n_idx >= (1ll << 31))
+  if (rows * (int64_t)D >= (1ll << 33) || n_bags >= (1ll << 31) || n_idx >= (1ll << 31))
     return fail(e, DRS_ERR_UNSUPPORTED, "operand too large");
   if (n_bags == 0) return n_idx == 0 ? DRS_OK : fail(e, DRS_ERR_LENGTHS_SUM, "indices without bags");
   Slot& s = e->slots[0];
@@ -1981,11 +1982,10 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) e->tune.sls_v_d32 = (int)value;
   else if (!strcmp(key, "sls_flat") && value >= 0 && value <= 2) e->tune.sls_flat = (int)value;
   else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
-  else if (!strcmp(key, "sls_split")) e->tune.sls_split = value ? 1 : 0;
   else if (!strcmp(key, "din_fused")) e->din_fused = value ? 1 : 0;
   else if (!strcmp(key, "dien_mfma") && value >= 0 && value <= 2) e->dien_mfma = (int)value;
   else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
-  else if (!strcmp(key, "sls_depth") && (value == 0 || value == 6 || value == 8 || value == 10 || value == 12 || value == 14)) e->tune.sls_depth = (int)value;
+  else if (!strcmp(key, "sls_nt")) e->tune.sls_nt = value ? 1 : 0;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
@@ -2016,7 +2016,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_gemm_2cu") && (value == 0 || value == 1)) e->tune.gemm_2cu = (int)value;
   else if (!strcmp(key, "launch_thread") && (value == 0 || value == 1)) e->launch_thread = (int)value;
   else if (!strcmp(key, "mlp_ring") && value == 2) e->tune.mlp_ring = (int)value;
-  else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 4 || value == 8 || value == 16)) e->tune.mlp_stream_waves = (int)value;
+  else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 4 || value == 8)) e->tune.mlp_stream_waves = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214 || value == 322 || value == 321 || value == 312 || value == 311)) e->tune.gemm_tile = (int)value;
@@ -2074,7 +2074,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"sls_split", t.sls_split}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_depth", t.sls_depth}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},

@@ -43,6 +43,62 @@ struct GArgs {
   int32_t K, N, act, sc1;
 };
 
+// ---- epilogue shared by both kernels ---------------------------------------------------------------
+// The MFMAs are issued with the WEIGHT rows as the A operand and the input rows as B (the product is
+// commutative: same fma chains, same bits), so a lane ends up with FOUR CONSECUTIVE OUTPUT COLUMNS of one
+// output row in four consecutive accumulator registers: bias + activation on a float4 and ONE 16-byte
+// store.  (Round 4: the first form -- inputs as A, one dword store per accumulator register, bias loaded
+// inside the column loop -- had the compiler put an s_waitcnt vmcnt(0) in front of every element, and
+// vmcnt counts stores: 64 serialised write round trips per lane, 25 k - 78 k cycles = 5 % of a
+// 2560 x 1024 x 8192 launch, tools/ubench/gemm_lab.hip.)  Stores go through inline asm so nothing waits
+// on them before signal_done's own drain; SC1 = write-through (outputs the hand-off reads back).
+template <bool SC1>
+__device__ __forceinline__ void gst4(float* p, const f32x4 v) {
+  if (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+template <bool SC1>
+__device__ __forceinline__ void gst1(float* p, const float v) {
+  if (SC1) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+// bias of columns col .. col + 3 (zeros past N / without a bias)
+__device__ __forceinline__ f32x4 bias4(const float* b, int col, int N, bool vec) {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  if (b) {
+    if (vec) { if (col < N) r = *reinterpret_cast<const f32x4*>(b + col); }
+    else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (col + c < N) r[c] = b[col + c];
+    }
+  }
+  return r;
+}
+template <bool SC1>
+__device__ __forceinline__ void epi4(float* yrow, int col, int N, f32x4 v, const f32x4 b, int act) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + b[c], act);
+  if (col < N) gst4<SC1>(yrow + col, v);
+}
+// the same without the alignment / N % 4 == 0 preconditions (drs_fc on arbitrary operands): one copy,
+// activation and store form decided at run time, one dword store per element
+__device__ __noinline__ void epi4_any(float* yrow, int col, int N, f32x4 v, const f32x4 b, int act, int sc1) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (col + c < N) {
+      const float o = act_apply(v[c] + b[c], act);
+      if (sc1) gst1<true>(yrow + col + c, o);
+      else gst1<false>(yrow + col + c, o);
+    }
+}
+// vec: float4 accesses of y and the bias are legal for every column group (N % 4 == 0: a group is inside or outside as a whole)
+__device__ __forceinline__ bool epi_vec_ok(const float* b, const float* y, int64_t ldy, int N) {
+  return !(N & 3) && !(ldy & 3) && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15);
+}
+// MODE: 0 plain stores | 1 write-through | -1 the unaligned form
+#define DRS_EPI_DISPATCH(CALL) \
+  if (!vec) { CALL(-1) } else if (a.sc1) { CALL(1) } else { CALL(0) }
+
 // TM x TN MFMA tiles (16 x 16) per wave; the 8 waves sit 2 x 4, so a workgroup owns
 // 32 TM rows x 64 TN columns.  (2,2) is the full-rate shape; the smaller ones exist so a
 // launch with few rows (one query: 256) or few columns still covers the chip.
@@ -185,7 +241,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_kernel(GArgs a, Done done, XSrc
       _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                             \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][i][s], bv[cur][j][s], acc[i][j], 0, 0, 0); \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][j][s], av[cur][i][s], acc[i][j], 0, 0, 0); \
         if (wq < NQ) { stash_part((BUF) ^ 1, RAS, RBS, wq); ++wq; }                               \
         __builtin_amdgcn_sched_barrier(0);                                                        \
       }                                                                                           \
@@ -204,7 +260,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_kernel(GArgs a, Done done, XSrc
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                 \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][i][s], bv[1][j][s], acc[i][j], 0, 0, 0); \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1][j][s], av[1][i][s], acc[i][j], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                            \
   }
 
@@ -229,25 +285,30 @@ __global__ __launch_bounds__(512, OCC) void gemm_kernel(GArgs a, Done done, XSrc
 #undef DRS_GWAIT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing requests
 
-  // epilogue: bias + activation; lane holds rows 4g+q of each tile, column r
+  // epilogue: bias + activation.  (Weights are the A operand:) lane (r, g) holds, of each tile, output row r
+  // and the four columns 4 g .. 4 g + 3 -- a float4 per tile
+  {
+    const bool vec = epi_vec_ok(a.b, a.y, a.ldy, N);
+    f32x4 b4[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + 16 * TN * wn + 16 * j + r;
-    if (col < N) {
-      const float bcol = a.b ? a.b[col] : 0.f;
+    for (int j = 0; j < TN; ++j) b4[j] = bias4(a.b, n0 + 16 * TN * wn + 16 * j + 4 * g, N, vec);
+    // every bias load has landed before the first store is issued (an empty asm that "reads" the registers
+    // makes the COMPILER wait here, so its scoreboard is clean): the stores below are invisible to its vmcnt
+    // bookkeeping, and a wait it placed later for a bias register would count them as well
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int64_t row = m0 + 16 * TM * wm + 16 * i + 4 * g + q;
-          if (row < a.M) {
-            const float v = act_apply(acc[i][j][q] + bcol, a.act);
-            float* dst = a.y + row * a.ldy + col;
-            if (a.sc1) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *dst = v;
-          }
-        }
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(b4[j]));
+#define DRS_GEPI(MODE_)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                      \
+      const int64_t row = m0 + 16 * TM * wm + 16 * i + r;                                 \
+      if (row < a.M) {                                                                    \
+        float* yrow = a.y + row * a.ldy;                                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                    \
+          { if (MODE_ < 0) epi4_any(yrow, n0 + 16 * TN * wn + 16 * j + 4 * g, N, acc[i][j], b4[j], a.act, a.sc1); \
+          else epi4<MODE_ == 1>(yrow, n0 + 16 * TN * wn + 16 * j + 4 * g, N, acc[i][j], b4[j], a.act); } \
+      }                                                                                   \
     }
+    DRS_EPI_DISPATCH(DRS_GEPI)
+#undef DRS_GEPI
   }
   signal_done(done, gridDim.x * gridDim.y, smem);
 }
@@ -279,6 +340,16 @@ __global__ __launch_bounds__(512, OCC) void gemm_kernel(GArgs a, Done done, XSrc
 // MFMAs (1024 cycles) cover the barrier and the first operand reads of chunk c + 1.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int G3KC = 32, G3LD = 36;
+// tools/ubench/gemm_lab.hip (-DDRS_GEMM_TL): per-workgroup shader-clock / wall-clock stamps of the
+// kernel's phases.  Compiled out of the product build.
+#ifdef DRS_GEMM_TL
+__device__ unsigned long long g_gtl[8 * 8192];
+#define GTL(slot) if (tid == 0) { g_gtl[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = __builtin_readcyclecounter(); }
+#define GTLW(slot) if (tid == 0) { g_gtl[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = wall_clock64(); }
+#else
+#define GTL(slot)
+#define GTLW(slot)
+#endif
 
 template <int WTM, int WTN>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc xs) {
@@ -296,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   const int n0 = blockIdx.y * BN;
   const int K = a.K, N = a.N;
   const int nch = (K + G3KC - 1) / G3KC;
+  GTL(0) GTLW(4)
 
   // staging role: row frow (+32 j), floats 4 u .. 4 u + 3 of the chunk
   const int frow = tid >> 3, u = tid & 7, fk = 4 * u;
@@ -392,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                              \
     _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                               \
       _Pragma("unroll") for (int j = 0; j < WTN; ++j)                                             \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[SET][i][s_], bv[SET][j][s_], acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[SET][j][s_], av[SET][i][s_], acc[i][j], 0, 0, 0); \
     _Pragma("unroll") for (int w_ = 0; w_ < (NQ + 11) / 12; ++w_)                                 \
       if (wq < NQ) { stash_part(nbuf, RAS, RBS, wq); ++wq; }                                      \
     __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -430,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   // accumulator registers at the join (32 v_mov_b64 behind an s_nop 14 on every iteration).  For an
   // odd chunk count the second round of the last pair runs on a chunk past K, which `fetch` delivers
   // as zeros: fma(0, 0, c) = c, the chain's bits do not change (c is never -0: the chain starts at +0).
+  GTL(1)
   for (int c = 0; c < nch; c += 2) {
     DRS_G3ROUND(0, ra0, rb0, ra1, rb1)
     DRS_G3ROUND(1, ra1, rb1, ra0, rb0)
@@ -437,28 +510,38 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
 #undef DRS_G3ROUND
 #undef DRS_G3MFMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing requests
+  GTL(2)
 
-  // epilogue: bias + activation.  C/D of a 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
-  // + 4 (lane >> 5): for one register the 32 lanes of a half write 128 contiguous bytes of one row
+  // epilogue: bias + activation.  (Weights are the A operand:) C/D of a 32 x 32 tile: lane (i32, h) holds output
+  // row i32 and, in registers 4 qq .. 4 qq + 3, the four columns 8 qq + 4 h .. + 3 -- four float4 per tile
+  {
+    const bool vec = epi_vec_ok(a.b, a.y, a.ldy, N);
+    f32x4 b4[WTN][4];
 #pragma unroll
-  for (int j = 0; j < WTN; ++j) {
-    const int col = n0 + 32 * WTN * wn + 32 * j + i32;
-    if (col < N) {
-      const float bcol = a.b ? a.b[col] : 0.f;
+    for (int j = 0; j < WTN; ++j)
 #pragma unroll
-      for (int i = 0; i < WTM; ++i)
+      for (int qq = 0; qq < 4; ++qq) b4[j][qq] = bias4(a.b, n0 + 32 * WTN * wn + 32 * j + 8 * qq + 4 * h, N, vec);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int64_t row = m0 + 32 * WTM * wm + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
-          if (row < a.M) {
-            const float v = act_apply(acc[i][j][q] + bcol, a.act);
-            float* dst = a.y + row * a.ldy + col;
-            if (a.sc1) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *dst = v;
-          }
-        }
+    for (int j = 0; j < WTN; ++j)     // (as in gemm_kernel: bias loads landed before the first asm store)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) asm volatile("" : "+v"(b4[j][qq]));
+#define DRS_G3EPI(MODE_)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) {                                     \
+      const int64_t row = m0 + 32 * WTM * wm + 32 * i + i32;                              \
+      if (row < a.M) {                                                                    \
+        float* yrow = a.y + row * a.ldy;                                                  \
+        _Pragma("unroll") for (int j = 0; j < WTN; ++j)                                   \
+          _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                              \
+            const f32x4 v = {acc[i][j][4 * qq], acc[i][j][4 * qq + 1], acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]}; \
+            if (MODE_ < 0) epi4_any(yrow, n0 + 32 * WTN * wn + 32 * j + 8 * qq + 4 * h, N, v, b4[j][qq], a.act, a.sc1); \
+            else epi4<MODE_ == 1>(yrow, n0 + 32 * WTN * wn + 32 * j + 8 * qq + 4 * h, N, v, b4[j][qq], a.act); \
+          }                                                                               \
+      }                                                                                   \
     }
+    DRS_EPI_DISPATCH(DRS_G3EPI)
+#undef DRS_G3EPI
   }
+  GTL(3) GTLW(5)
   signal_done(done, gridDim.x * gridDim.y, smem);
 }
 

@@ -424,26 +424,33 @@ __device__ __forceinline__ void interact_pairs_mfma(const float* Ts, int t_ld, f
                                                     int D, int itself, float* g_R, int64_t g_ldr, int64_t m0,
                                                     int64_t M, int n_waves, int wave, int lane, POS pos) {
   const int r = lane & 15, g = lane >> 4, off = itself ? 1 : 0;
+  const int nblk = (F + 15) >> 4;       // F > 16 (RM2 in dot mode: 33 features): Z in 16 x 16 blocks, lower triangle of blocks
   for (int row = wave; row < rows; row += n_waves) {
     const float* t = Ts + row * t_ld;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int base = (r < F ? r : 0) * D + g;
-    for (int k0 = 0; k0 < D; k0 += 4) {
-      float v = t[pos(base + k0, row)];
-      v = r < F ? v : 0.f;
-      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(v));   // (s_nop: v was just written by a VALU op the compiler cannot see the consumer of)
-    }
-    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));      // the last step's results
+    for (int bi = 0; bi < nblk; ++bi)
+      for (int bj = 0; bj <= bi; ++bj) {
+        // A operand: features 16 bi + r (output rows), B operand: features 16 bj + r (output columns)
+        const int fa = 16 * bi + r, fb = 16 * bj + r;
+        const int base_a = (fa < F ? fa : 0) * D + g, base_b = (fb < F ? fb : 0) * D + g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < D; k0 += 4) {
+          float va = t[pos(base_a + k0, row)], vb = t[pos(base_b + k0, row)];
+          va = fa < F ? va : 0.f;
+          vb = fb < F ? vb : 0.f;
+          asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(va), "v"(vb));   // (s_nop: the operands were just written by VALU ops the compiler cannot see the consumer of)
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));      // the last step's results
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int fi = 4 * g + i, fj = r;
-      if (fi < F && (fj < fi || (off && fj == fi))) {
-        const int c = D + fi * (fi - 1 + 2 * off) / 2 + fj;
-        const float v = acc[i];
-        Rs[row * r_ld + pos(c, row)] = v;
-        if (g_R && m0 + row < M) g_R[(m0 + row) * g_ldr + c] = v;
+        for (int i = 0; i < 4; ++i) {
+          const int fi = 16 * bi + 4 * g + i, fj = fb;
+          if (fi < F && fj < F && (fj < fi || (off && fj == fi))) {
+            const int c = D + fi * (fi - 1 + 2 * off) / 2 + fj;
+            const float v = acc[i];
+            Rs[row * r_ld + pos(c, row)] = v;
+            if (g_R && m0 + row < M) g_R[(m0 + row) * g_ldr + c] = v;
+          }
+        }
       }
-    }
   }
 }
 
@@ -522,11 +529,7 @@ struct SArgs {
 // no LDS staging of W, no stash, and a workgroup barrier only where one layer's outputs become
 // the next layer's inputs (RMC1: 5 barriers instead of 26) instead of one per 64-k chunk.
 // PK = false: the LDS-staged form described above.  Same fma chains, same bits.
-// NWV = waves per workgroup: 8 (a pass covers 128 output columns), or -- packed form only,
-// "mlp_stream_waves" 16 -- 16 (256 columns per pass, four waves per SIMD, ring of four register
-// sets instead of six to stay inside 128 VGPRs).  The idea was that two waves of a SIMD run their
-// MFMA chains while the other two do the per-round bookkeeping; measured, the launch takes the
-// same time with 8 and 16 waves, so 8 stays the default.
+// NWV = waves per workgroup: 8 (a pass covers 128 output columns).
 static_assert(sizeof(SArgs) + sizeof(Done) + sizeof(XSrc) <= 4096, "kernel arguments: 4 KB");
 // The argument block of the stream kernels is 3.1 KB = 50 cache lines that the host rewrites for every
 // launch: each first touch is a miss of the scalar cache all the way to memory, and the compiler fetches
@@ -556,12 +559,12 @@ __device__ __forceinline__ void kernarg_burst() {
 // queueing for whole CUs -- what gemm_kernel<2, 1, 2, 4> does for the wide layers.
 template <bool PK, int NWV, bool RD3 = false>
 __global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, Done done, XSrc xs) {
-  static_assert(NWV == 8 || (PK && NWV == 16), "16 waves: packed form only");
+  static_assert(NWV == 8, "eight waves per workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   kernarg_burst();
   constexpr int kThreads = 64 * NWV;           // (shadows the file-scope 512)
   constexpr int PASSW = 16 * NWV;              // output columns per pass
-  constexpr int RD = RD3 ? 3 : NWV == 16 ? 4 : 6;   // ring depth (register sets of weight tiles in flight)
+  constexpr int RD = RD3 ? 3 : 6;   // ring depth (register sets of weight tiles in flight)
   static_assert(!RD3 || (PK && NWV == 8), "the 3-deep ring: table-driven packed form only");
   constexpr int LD = 68;                       // staged W rows: 64 k + 4 pad
   const int tid = threadIdx.x;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, 
   // (one per thread); slots [0, n0s) belong to input 0, the rest to input 1, so which input a
   // slot reads is uniform.
   {
-    constexpr int PRE = (NWV == 16 || RD3) ? 4 : 8;   // slots per batch (512 threads: RMC1 needs 6, RM3's 1024-wide chain 8)
+    constexpr int PRE = RD3 ? 4 : 8;   // slots per batch (512 threads: RMC1 needs 6, RM3's 1024-wide chain 8)
     const SInput in0 = a.in[0];
     const SInput in1 = a.in[a.n_inputs > 1 ? 1 : 0];
     const int n0s = (16 * (in0.cols_pad >> 2) + kThreads - 1) / kThreads;
@@ -803,20 +806,12 @@ __global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, 
       if (c < D) {
         v = t[swz(c, row)];
       } else if (c < D + a.P) {
-        if (a.F <= 16) continue;                  // the pairs: on the matrix cores, below
-        // BatchGather order: row i of the (strictly) lower triangle starts at i(i-1)/2 (+ i with itself)
-        const int p = c - D;
-        int i = off ? 0 : 1;
-        while ((i + 1) * (i + off * 2) / 2 <= p) ++i;   // start of row i+1: (i+1)(i+2*off)/2
-        const int j = p - i * (i - 1 + 2 * off) / 2;
-        const int bi = i * D, bj = j * D;
-        for (int k = 0; k < D; ++k) v = fmaf(t[swz(bi + k, row)], t[swz(bj + k, row)], v);
+        continue;                                 // the pairs: on the matrix cores, below
       }
       Rs[row * a.r_ld + swz(c, row)] = v;
       if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
-    if (a.F <= 16)
-      interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+    interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
                           tid >> 6, tid & 63, [](int c, int row) { return swz(c, row); });
     __syncthreads();
   };
@@ -1413,19 +1408,12 @@ __global__ __launch_bounds__(1024 / NT) void stream3_kernel(SArgs a, Done done, 
       if (c < D) {
         v = t[lpos(c)];
       } else if (c < D + a.P) {
-        if (a.F <= 16) continue;                  // the pairs: on the matrix cores, below
-        const int p = c - D;
-        int i = off ? 0 : 1;
-        while ((i + 1) * (i + off * 2) / 2 <= p) ++i;
-        const int j = p - i * (i - 1 + 2 * off) / 2;
-        const int bi = i * D, bj = j * D;
-        for (int k = 0; k < D; ++k) v = fmaf(t[lpos(bi + k)], t[lpos(bj + k)], v);
+        continue;                                 // the pairs: on the matrix cores, below
       }
       Rs[row * a.r_ld + lpos(c)] = v;
       if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
-    if (a.F <= 16)
-      interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+    interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
                           tid >> 6, tid & 63, [](int c, int) { return lpos(c); });
     __syncthreads();
   };
@@ -1882,19 +1870,12 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       if (c < D) {
         v = t[lpos(c)];
       } else if (c < D + a.P) {
-        if (a.F <= 16) continue;                  // the pairs: on the matrix cores, below
-        const int p = c - D;
-        int i = off ? 0 : 1;
-        while ((i + 1) * (i + off * 2) / 2 <= p) ++i;
-        const int j = p - i * (i - 1 + 2 * off) / 2;
-        const int bi = i * D, bj = j * D;
-        for (int k = 0; k < D; ++k) v = fmaf(t[lpos(bi + k)], t[lpos(bj + k)], v);
+        continue;                                 // the pairs: on the matrix cores, below
       }
       Rs[row * a.r_ld + lpos(c)] = v;
       if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
-    if (a.F <= 16)
-      interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16 * R, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+    interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16 * R, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
                           tid >> 6, tid & 63, [](int c, int) { return lpos(c); });
     __syncthreads();
   };
@@ -2253,7 +2234,6 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(stream_kernel<false, 8>);
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8>);
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8, true>);
-  if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 16>);
   if (e == hipSuccess) e = set_max_lds(stream3_kernel<4, 2>);
   if (e == hipSuccess) e = set_max_lds(stream3_kernel<2, 2>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false>);
@@ -2407,8 +2387,6 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     for (int l = 0; l < na; ++l) pk = pk && has_twin(a.W[l]);
     for (int l = 0; l < nb; ++l) pk = pk && has_twin(b->W[l]);
   }
-  // "mlp_stream_waves" 16: sixteen waves, 256-column passes (measured equal to eight on every
-  // model: RMC1's launch 33.7 vs 33.3 us -- kept as an option, not the default)
   // "mlp_stream" 3 (default): stream3_kernel -- two tiles per wave, b128 activation operands; its
   // steps must fit the descriptor table
   // stream3_kernel: 4 waves x up to 4 tiles ("mlp_stream_waves" 4) or 8 waves x up to 2 tiles (default)
@@ -2427,7 +2405,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     const int etl = ((out_pad > N ? out_pad : N) + 15) / 16, tpp = nw3 * tpw3(N, out_pad);
     return ((etl + tpp - 1) / tpp) * ((K + 63) / 64);
   };
-  bool f3 = pk && ((tune.mlp_stream == 3 && tune.mlp_stream_waves != 16) || f4);
+  bool f3 = pk && (tune.mlp_stream == 3 || f4);
   if (f3) {
     int st = 0;
     for (int l = 0; l < na; ++l) {
@@ -2441,9 +2419,9 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     f3 = f3 && st <= DRS_MAX_STREAM_TILES;
   }
   if (sum && !f3 && pad64(b->width[0]) - sum->cols > ((d_out + 127) / 128) * 128) return false;   // zero pad must fall in an existing pass
-  const int nwv = pk && !f3 && tune.mlp_stream_waves == 16 ? 16 : 8;
+  const int nwv = 8;
   const int passw = 16 * nwv;
-  p.packed = f3 ? (f4 ? 5 : nt3 == 4 ? 4 : 3) : pk ? (nwv == 16 ? 2 : 1) : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves | 5: stream4 (6: its 32-row form, set below)
+  p.packed = f3 ? (f4 ? 5 : nt3 == 4 ? 4 : 3) : pk ? 1 : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves | 5: stream4 (6: its 32-row form, set below)
   const int lpad = f3 ? 8 : 4;      // slab rows: 64 m + 8 floats apart in the b128 form, 64 m + 4 else
   // rows per workgroup: 16, or 32 for stream4_kernel's two-halves form ("mlp_rows32": launches of at
   // least that many rows, no summed input, slabs that still fit LDS)
@@ -2669,7 +2647,6 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
       else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5) hipLaunchKernelGGL((stream4_kernel<false, false>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 3) hipLaunchKernelGGL((stream3_kernel<2, 2>), g3, dim3(512), slds, s, sp, d, xs);
-      else if (sp.packed == 2) hipLaunchKernelGGL((stream_kernel<true, 16>), dim3((unsigned)((a.M + 15) / 16)), dim3(1024), slds, s, sp, d, xs);
       else if (sp.packed && tune.mlp_stream_2cu && sp.n_table > 0) hipLaunchKernelGGL((stream_kernel<true, 8, true>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else if (sp.packed) hipLaunchKernelGGL((stream_kernel<true, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else hipLaunchKernelGGL((stream_kernel<false, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);

@@ -90,8 +90,21 @@ __device__ __forceinline__ float2 vsel<2>(bool keep, const float2& v) {
 }
 
 // G lanes per row, V floats per lane, U row loads in flight per lane.
+// table rows are read once per launch (~1 % reuse inside a batch): "sls_nt" reads them with the
+// non-temporal hint (same-session A/B on RMC1, two boxes: +1.5 % queries/s)
+typedef float f4v_nt __attribute__((ext_vector_type(4)));
+typedef float f2v_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_nt(const float4* p) {
+  const f4v_nt t = __builtin_nontemporal_load(reinterpret_cast<const f4v_nt*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float2 ld_nt(const float2* p) {
+  const f2v_nt t = __builtin_nontemporal_load(reinterpret_cast<const f2v_nt*>(p));
+  return make_float2(t.x, t.y);
+}
+
 template <int G, int V, int U, bool EXACT>
-__global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
+__global__ __launch_bounds__(64) void sls_kernel(SlsArgs a, int nt) {
   using vec = typename Vec<V>::type;
   constexpr int NG = 64 / G;                  // lane groups per wave
   constexpr int BAGS = EXACT ? NG : 1;        // bags per wave
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   const float* __restrict__ W = a.tables + a.tab_off[t] + col;
   const uint32_t rows = (uint32_t)a.tab_rows[t];
   const int64_t D = a.D;
-  const uint32_t Du = (uint32_t)a.D;   // rows * D < 2^32 is enforced at table creation
+  const uint32_t Dv = (uint32_t)a.D / V;   // row stride in load-width units: rows * D / V < 2^32 (rows * D < 2^33 is enforced at table creation)
 
   int32_t* my_idx = s_idx[EXACT ? g : 0];
   const int me = EXACT ? gl : lane;           // my slot among the owners
@@ -199,7 +212,8 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
       for (int u = 0; u < U; ++u) {
         bad |= (pos + u * STEP < n) && (r[u] >= rows);
         r[u] = r[u] < rows ? r[u] : 0u;
-        ring[u] = *reinterpret_cast<const vec*>(W + (uint64_t)(r[u] * Du));
+        const vec* rp_ = reinterpret_cast<const vec*>(W) + (uint64_t)(r[u] * Dv);
+        ring[u] = nt ? ld_nt(rp_) : *rp_;
       }
     };
     auto consume = [&](const vec (&ring)[U], int pos) {
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
 // bags (same sample, consecutive tables) per wave.  Requires L * BPW <= NL * (64 / G) and
 // T % BPW == 0 (checked by launch_sls).
 template <int G, int NL, int BPW>
-__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_order) {
+__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_order, int nt) {
   constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
   // Work item w = (table group, sample), numbered TABLE-MAJOR; everything that depends only on
   // the wave (sample, query, tables) is scalar.  XCD-aware order (xcd_order != 0): workgroup id
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
     }
   }
   const int R = BPW * L;
-  const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
+  const uint32_t D4 = (uint32_t)a.D >> 2;          // row stride in 16-byte units: rows * D / 4 < 2^32 (enforced at table creation)
   // table bases and row counts of the wave's BPW tables: scalar loads, issued now and waited
   // for only when the row addresses are formed, i.e. in the shadow of the index loads.  (Left
   // to the compiler they become vector loads -- it cannot prove the arrays are not written by
@@ -370,14 +384,19 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
       rk = kj[u] == z ? (uint32_t)tab_rows_k[z] : rk;
     }
     bad |= g + NG * u < R && ridx[u] >= rk;
-    const uint32_t ro = (ridx[u] < rk ? ridx[u] : 0u) * Du + (uint32_t)col;
-    rp[u] = W + (uint64_t)ro;
+    const uint32_t ro = (ridx[u] < rk ? ridx[u] : 0u) * D4 + ((uint32_t)col >> 2);
+    rp[u] = W + ((uint64_t)ro << 2);
   }
   // ---- phase 3: all row loads, back to back, nothing else in between --------------------------
   __builtin_amdgcn_sched_barrier(0);
   float4 v[NL];
+  if (nt) {
 #pragma unroll
-  for (int u = 0; u < NL; ++u) v[u] = *reinterpret_cast<const float4*>(rp[u]);
+    for (int u = 0; u < NL; ++u) v[u] = ld_nt(reinterpret_cast<const float4*>(rp[u]));
+  } else {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) v[u] = *reinterpret_cast<const float4*>(rp[u]);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- phase 4: per-bag sums in arrival order, then the butterfly over the lane groups --------
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
 // (everything in flight at once) on RMC1's 80 x 256-B bags beside the MLP launch: 0.74 vs 0.72 of
 // peak for 8-query launches, 0.57-0.59 vs 0.51 for a single query; so one-bag-per-wave launches
 // take this one ("sls_flat" 1) and the phased form serves the several-bags-per-wave shapes.
-template <int G, int NL>
+template <int G, int NL, bool NT>
 __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
   constexpr int BPW = 1;
   constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
     }
   }
   const int R = BPW * L;
-  const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
+  const uint32_t D4 = (uint32_t)a.D >> 2;          // row stride in 16-byte units: rows * D / 4 < 2^32 (enforced at table creation)
   const float* Wk[BPW];
   uint32_t rows_k[BPW];
 #pragma unroll
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
     for (int z = 1; z < BPW; ++z) rk = k == z ? rows_k[z] : rk;
     bad |= i < R && r >= rk;
     r = r < rk ? r : 0u;
-    roff[q] = r * Du;
+    roff[q] = r * D4;
   }
 
   // every row load of the wave, back to back
@@ -505,7 +524,12 @@ __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
 #pragma unroll
       for (int z = 1; z < BPW; ++z) W = k == z ? Wk[z] : W;
     }
-    v[u] = *reinterpret_cast<const float4*>(W + (uint64_t)ro);
+    // NT ("sls_nt" 1): the rows are read once (~1 % reuse inside a batch): non-temporal loads
+    if constexpr (NT) {
+      v[u] = ld_nt(reinterpret_cast<const float4*>(W) + (uint64_t)ro);
+    } else {
+      v[u] = reinterpret_cast<const float4*>(W)[(uint64_t)ro];
+    }
   }
 
   float4 acc[BPW];
@@ -542,197 +566,6 @@ __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
   }
 }
 
-// The same kernel with the schedule written down instead of left to the compiler: the row
-// loads go through inline asm (the compiler neither reorders nor counts them), DEPTH of them
-// are requested up front, and from then on each sum of the oldest outstanding row is followed
-// by the request of the next one -- DEPTH loads in flight per lane throughout, whatever a
-// future compiler would make of the plain C++ form.
-template <int G, int NL, int DEPTH>
-__global__ __launch_bounds__(64) void sls_flatx_kernel(SlsArgs a, int L) {
-  constexpr int NG = 64 / G;
-  constexpr int NI = (NL * NG + 63) / 64;
-  constexpr int DP = DEPTH < NL ? DEPTH : NL;
-  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
-  const int lane = threadIdx.x;
-  const int g = lane / G;
-  const int gl = lane - g * G;
-  const int col = min(gl * 4, a.D - 4);
-  const bool col_ok = gl * 4 < a.D;
-  const int64_t bag0 = (int64_t)blockIdx.x;
-  const int smp = (int)(bag0 / a.T);
-  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
-  int b = smp, vrow = a.q.vstart[0] + smp;
-  const int32_t* qidx = a.idx[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i) {
-    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
-    b = in ? smp - a.q.cum[i] : b;
-    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
-    qidx = in ? a.idx[i] : qidx;
-  }
-  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
-#pragma unroll
-    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
-      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
-      b = in ? smp - a.q.cum[i] : b;
-      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
-      qidx = in ? a.idx[i] : qidx;
-    }
-  }
-  const int R = L;
-  const uint32_t Du = (uint32_t)a.D;
-  const float* W0 = a.tables + a.tab_off[t0] + col;
-  const uint32_t rows0 = (uint32_t)a.tab_rows[t0];
-  uint32_t roff[NI];
-  bool bad = false;
-#pragma unroll
-  for (int q = 0; q < NI; ++q) {
-    const int i = lane + 64 * q;
-    const int ii = min(i, R - 1);
-    const int32_t* ip = qidx + (int64_t)t0 * a.idx_stride + (int64_t)b * L + ii;
-    uint32_t r = (uint32_t)*ip;
-    bad |= i < R && r >= rows0;
-    r = r < rows0 ? r : 0u;
-    roff[q] = r * Du;
-  }
-  // every row address first (the index loads above are the compiler's: it waits for them here)
-  const float* rp[NL];
-#pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const int j = g + NG * u;
-    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], j & 63);
-    rp[u] = W0 + (uint64_t)ro;
-  }
-  __builtin_amdgcn_s_waitcnt(0);            // nothing of the compiler's own left in flight
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 v[NL];
-#pragma unroll
-  for (int u = 0; u < DP; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(rp[u]));
-  float4 acc = vzero4();
-  auto add = [&](int u) {
-    const bool keep = g + NG * u < R;
-    acc.x += keep ? v[u][0] : 0.f; acc.y += keep ? v[u][1] : 0.f;
-    acc.z += keep ? v[u][2] : 0.f; acc.w += keep ? v[u][3] : 0.f;
-  };
-#pragma unroll
-  for (int u = DP; u < NL; ++u) {
-    // oldest outstanding row is u - DP: at most DP - 1 newer ones may still be in flight
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[u - DP]) : "n"(DP - 1));
-    add(u - DP);
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(rp[u]));
-  }
-#pragma unroll
-  for (int u = NL - DP; u < NL; ++u) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[u]) : "n"(NL - 1 - u));
-    add(u);
-  }
-#pragma unroll
-  for (int m = G; m < 64; m <<= 1) vadd(acc, vshfl_xor(acc, m));
-  if (bad) atomicOr(a.err, 1);
-  if (col_ok && g == 0) {
-    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)t0 * a.D + col;
-    *reinterpret_cast<float4*>(o) = acc;
-  }
-  if (a.ts) {
-    __builtin_amdgcn_s_waitcnt(0);
-    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
-  }
-}
-
-// (The one-wave kernel above is kept byte for byte as first written: its speed comes from the
-// schedule the compiler happens to give it -- about ten row loads in flight per lane -- and a
-// source-level rewrite that only generalised it to WV waves came out 7 % slower (82 instead of
-// 106 VGPRs, seven loads in flight at the start).  The two-wave form is its own kernel.)
-// WV = 2: the bag is split over the two waves of a 128-thread workgroup (rows [0, NL*NG) and
-// [NL*NG, 2*NL*NG)), partial sums combined through LDS: launches of a single query (2 048 bags on
-// 256 CUs) get twice the waves, each with half the serial work.
-template <int G, int NL, int WV>
-__global__ __launch_bounds__(64 * WV) void sls_flatc2_kernel(SlsArgs a, int L) {
-  constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
-  constexpr int NI = (NL * NG + 63) / 64;          // index registers per lane
-  __shared__ float4 s_part[WV > 1 ? G : 1];
-  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
-
-  const int wv = WV > 1 ? (int)(threadIdx.x >> 6) : 0;
-  const int lane = threadIdx.x & 63;
-  const int g = lane / G;
-  const int gl = lane - g * G;
-  const int col = min(gl * 4, a.D - 4);            // clamp idle lanes onto valid columns
-  const bool col_ok = gl * 4 < a.D;
-  const int base = wv * NL * NG;                   // first row of this wave
-
-  const int64_t bag0 = (int64_t)blockIdx.x;
-  const int smp = (int)(bag0 / a.T);
-  const int t0 = (int)(bag0 - (int64_t)smp * a.T);
-  int b = smp, vrow = a.q.vstart[0] + smp;
-  const int32_t* qidx = a.idx[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i) {
-    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
-    b = in ? smp - a.q.cum[i] : b;
-    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
-    qidx = in ? a.idx[i] : qidx;
-  }
-  if (a.q.n_q > 8) {   // (launch sets of 9 .. 16 queries only: smaller ones never touch the upper half of the argument arrays)
-#pragma unroll
-    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
-      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
-      b = in ? smp - a.q.cum[i] : b;
-      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
-      qidx = in ? a.idx[i] : qidx;
-    }
-  }
-  const int R = L;
-  const uint32_t Du = (uint32_t)a.D;               // rows * D < 2^32 is enforced at table creation
-  const float* W0 = a.tables + a.tab_off[t0] + col;
-  const uint32_t rows0 = (uint32_t)a.tab_rows[t0];
-
-  // ONE coalesced index read per wave: lane i owns rows base + i, base + i + 64, ...; range check
-  // (Caffe2 ENFORCE) and the row's element offset inside its table are computed by the owner
-  uint32_t roff[NI];
-  bool bad = false;
-#pragma unroll
-  for (int q = 0; q < NI; ++q) {
-    const int i = base + lane + 64 * q;
-    const int ii = min(i, R - 1);
-    const int32_t* ip = qidx + (int64_t)t0 * a.idx_stride + (int64_t)b * L + ii;
-    uint32_t r = (uint32_t)*ip;
-    bad |= i < R && r >= rows0;
-    r = r < rows0 ? r : 0u;
-    roff[q] = r * Du;
-  }
-
-  // the wave's row loads and their sum, in the compiler's schedule
-  float4 v[NL];
-#pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const int jl = g + NG * u;                     // row within the wave; (jl >> 6) == (NG * u) >> 6
-    const uint32_t ro = (uint32_t)__shfl((int)roff[(NG * u) >> 6], jl & 63);
-    v[u] = *reinterpret_cast<const float4*>(W0 + (uint64_t)ro);
-  }
-  float4 acc = vzero4();
-#pragma unroll
-  for (int u = 0; u < NL; ++u) vadd(acc, vsel<4>(base + g + NG * u < R, v[u]));
-#pragma unroll
-  for (int m = G; m < 64; m <<= 1) vadd(acc, vshfl_xor(acc, m));
-
-  if (bad) atomicOr(a.err, 1);
-  if (WV > 1) {
-    if (wv == 1 && g == 0) s_part[gl] = acc;
-    __syncthreads();
-    if (wv == 0 && g == 0) vadd(acc, s_part[gl]);
-  }
-  if (col_ok && g == 0 && wv == 0) {
-    float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)t0 * a.D + col;
-    *reinterpret_cast<float4*>(o) = acc;
-  }
-  if (a.ts) {
-    __builtin_amdgcn_s_waitcnt(0);   // include the output store in the span
-    if (WV > 1) __syncthreads();
-    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
-  }
-}
-
 // stop: optional event recorded BY the kernel dispatch itself (its completion signal) -- no
 // separate marker packet between this launch and the next one on the stream
 template <typename K, typename... X>
@@ -746,26 +579,26 @@ void launch_k(K kernel, dim3 grid, hipStream_t s, hipEvent_t stop, const X&... x
 }
 
 template <int G, int V, int U>
-hipError_t launch_variant(const SlsArgs& a, int exact, hipStream_t s, hipEvent_t stop) {
+hipError_t launch_variant(const SlsArgs& a, int exact, int nt, hipStream_t s, hipEvent_t stop) {
   const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
   if (n_bags == 0) return hipSuccess;
   if (exact) {
     constexpr int BAGS = 64 / G;
     const unsigned grid = (unsigned)((n_bags + BAGS - 1) / BAGS);
-    launch_k(sls_kernel<G, V, U, true>, grid, s, stop, a);
+    launch_k(sls_kernel<G, V, U, true>, grid, s, stop, a, nt);
   } else {
-    launch_k(sls_kernel<G, V, U, false>, (unsigned)n_bags, s, stop, a);
+    launch_k(sls_kernel<G, V, U, false>, (unsigned)n_bags, s, stop, a, nt);
   }
   return hipGetLastError();
 }
 
 template <int G, int V>
-hipError_t launch_u(const SlsArgs& a, int exact, int u, hipStream_t s, hipEvent_t stop) {
+hipError_t launch_u(const SlsArgs& a, int exact, int u, int nt, hipStream_t s, hipEvent_t stop) {
   switch (u) {
-    case 4: return launch_variant<G, V, 4>(a, exact, s, stop);
-    case 8: return launch_variant<G, V, 8>(a, exact, s, stop);
-    case 20: return launch_variant<G, V, 20>(a, exact, s, stop);
-    default: return launch_variant<G, V, 16>(a, exact, s, stop);
+    case 4: return launch_variant<G, V, 4>(a, exact, nt, s, stop);
+    case 8: return launch_variant<G, V, 8>(a, exact, nt, s, stop);
+    case 20: return launch_variant<G, V, 20>(a, exact, nt, s, stop);
+    default: return launch_variant<G, V, 16>(a, exact, nt, s, stop);
   }
 }
 
@@ -776,7 +609,7 @@ int lanes_per_row(int D) { return D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 
 // (a wave's bags belong to one sample) and BPW * L rows must fit NL loads per lane.
 struct FlatPlan {
   bool ok = false;
-  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1, coal = 0, split = 0, depth = 0;
+  int G = 0, NL = 0, BPW = 1, L = 0, xcd = 1, coal = 0, nt = 0;
   unsigned grid = 0;
 };
 FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
@@ -804,27 +637,20 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
   if (!nl || (bpw > 1 && nl > 10)) return p;
   p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = tune.sls_xcd ? 1 : 0;
   p.coal = bpw == 1 && tune.sls_flat == 1;      // "sls_flat" 2 forces the phased form
-  p.depth = tune.sls_depth;
+  p.nt = tune.sls_nt;
   const unsigned n_work = (unsigned)a.q.cum[a.q.n_q] * (unsigned)(a.T / bpw);
-  // few bags (a single query: 2 048 on 256 CUs) and at least ten loads per lane: two waves per bag
-  if (p.coal && tune.sls_split && n_work <= 4096 && (nl == 20 || nl == 10)) { p.split = 1; p.NL = nl / 2; }
   p.grid = p.coal ? n_work : (p.xcd ? 8u * ((n_work + 7u) / 8u) : n_work);
   return p;
 }
 
 template <int G, int NL>
 hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
-  if (p.coal && p.split) launch_kb(sls_flatc2_kernel<G, NL, 2>, grid, dim3(128), s, stop, a, p.L);
-  else if (p.coal && p.depth == 6) launch_k(sls_flatx_kernel<G, NL, 6>, grid, s, stop, a, p.L);
-  else if (p.coal && p.depth == 8) launch_k(sls_flatx_kernel<G, NL, 8>, grid, s, stop, a, p.L);
-  else if (p.coal && p.depth == 10) launch_k(sls_flatx_kernel<G, NL, 10>, grid, s, stop, a, p.L);
-  else if (p.coal && p.depth == 12) launch_k(sls_flatx_kernel<G, NL, 12>, grid, s, stop, a, p.L);
-  else if (p.coal && p.depth == 14) launch_k(sls_flatx_kernel<G, NL, 14>, grid, s, stop, a, p.L);
-  else if (p.coal) launch_k(sls_flatc_kernel<G, NL>, grid, s, stop, a, p.L);
-  else if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd);
+  if (p.coal && p.nt) launch_k(sls_flatc_kernel<G, NL, true>, grid, s, stop, a, p.L);
+  else if (p.coal) launch_k(sls_flatc_kernel<G, NL, false>, grid, s, stop, a, p.L);
+  else if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd, p.nt);
   else if constexpr (NL <= 10) {
-    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd);
-    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L, p.xcd);
+    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd, p.nt);
+    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L, p.xcd, p.nt);
   }
   return hipGetLastError();
 }
@@ -876,13 +702,13 @@ hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t
     if (p.ok) return launch_flat(a, p, s, stop);
   }
   const int u = tune.sls_u ? tune.sls_u : 4;
-  if (D == 32 && tune.sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, s, stop);
-  if (D <= 8) return launch_u<2, 4>(a, exact, u, s, stop);
-  if (D <= 16) return launch_u<4, 4>(a, exact, u, s, stop);
-  if (D <= 32) return launch_u<8, 4>(a, exact, u, s, stop);
-  if (D <= 64) return launch_u<16, 4>(a, exact, u, s, stop);
-  if (D <= 128) return launch_u<32, 4>(a, exact, u, s, stop);
-  return launch_u<64, 4>(a, exact, u, s, stop);
+  if (D == 32 && tune.sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, tune.sls_nt, s, stop);
+  if (D <= 8) return launch_u<2, 4>(a, exact, u, tune.sls_nt, s, stop);
+  if (D <= 16) return launch_u<4, 4>(a, exact, u, tune.sls_nt, s, stop);
+  if (D <= 32) return launch_u<8, 4>(a, exact, u, tune.sls_nt, s, stop);
+  if (D <= 64) return launch_u<16, 4>(a, exact, u, tune.sls_nt, s, stop);
+  if (D <= 128) return launch_u<32, 4>(a, exact, u, tune.sls_nt, s, stop);
+  return launch_u<64, 4>(a, exact, u, tune.sls_nt, s, stop);
 }
 
 // ---------------------------------------------------------------------------

@@ -283,9 +283,6 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                as the wave-split variant | 0 ring-walk kernels only
  *   "sls_bpw"    bags per wave of the flat variant: 0 (default: as many of 4 | 2 | 1 as divide the
  *                table count and keep a lane at <= 10 loads) | 1 | 2 | 4
- *   "sls_split"  0 (default) | 1: launches of <= 4096 fixed-length bags (a single query) split each
- *                bag over two waves (0.2 us faster; a query's fp32 summation order then depends on
- *                the size of the launch it was coalesced into)
  *   "din_fused"  1 (default) DRS_MODEL_DIN with sls_exact 0, D in {32, 64} and hidden width in
  *                {1, 2, 4}: ONE launch gathers the bags, applies the attention units and writes the top
  *                MLP's input row (the [rows, T*D] pooled tensor never exists) | 0 gather launch +
@@ -296,8 +293,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                the VALU.  Same bits in all three.
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
- *   "sls_depth"  0 (default: the compiler's schedule of the one-bag-per-wave flat kernel) | 6 | 8 |
- *                10 | 12 | 14: the same kernel with exactly that many row loads in flight per lane
+ *   "sls_nt"     1 (default) | 0: the gather kernels read table rows with non-temporal loads (rows are
+ *                read once per launch; same bits either way)
  *   "sls_xcd"    1 (default) | 0: several-bags-per-wave flat kernel walks its work list table-major,
  *                one contiguous slice per XCD
  *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
@@ -342,8 +339,7 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                tiles (half the waves and LDS traffic beside a gather) | 8: eight waves x up to two |
  *                1 the first kernel with W staged through LDS | 0 always the per-layer chain kernel.
  *                Same bits in every form.
- *                ("mlp_stream_waves" with "mlp_stream" 2: 0 / 8 (default) | 16 waves per workgroup;
- *                "mlp_stream_2cu" 1 (default, except NCF) | 0: "mlp_stream" 2 with a ring of three
+ *                ("mlp_stream_2cu" 1 (default, except NCF) | 0: "mlp_stream" 2 with a ring of three
  *                register sets instead of six, compiled for 128 VGPRs, so that two of its workgroups
  *                share a CU and overlapping launches interleave on the same SIMDs)
  *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into

@@ -678,6 +678,8 @@ def test_coalesced_queries_equal_individual_queries(kind):
     (32, 8, "128-64-32", "256-64-1"),      # reference dlrm_rm1.json widths
     (16, 2, "64-16", "300-4-1"),           # 3 passes, a 4-wide layer, fewer tiles than the prefetch ring
     (4, 1, "4-4", "4-1"),                  # smallest legal widths: 3 tiles in total
+    (16, 20, "32-16", "64-1"),             # 21 features: the dot interaction's pairs in three 16 x 16 blocks (226-wide top input)
+    (8, 32, "16-8", "96-1"),               # 33 features (RM2's count in dot mode): six blocks
 ])
 def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
     rows, L, B = 5000, 3, 100
@@ -700,7 +702,6 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "stream_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1),       # weights from the packed twins, no LDS staging
             "unfused_stream_packed": dict(mlp_stream=2, mlp_fuse=0, shared_stream=1),
             "pipelined_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=2),
-            "packed_16_waves": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_waves=16),
             "packed_ring3_2_per_cu": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),   # 128 VGPRs: two workgroups per CU
             "stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=8),   # 8 waves x 2 tiles, b128 operands
             "stream3_4_waves": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4, mlp_s4_rows=0),   # 4 waves x 4 tiles
