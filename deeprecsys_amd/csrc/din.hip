@@ -17,6 +17,15 @@ namespace drs {
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// a table row piece: read once per launch -- non-temporal when nt ("sls_nt")
+__device__ __forceinline__ float4 ld4row(const float* p, int nt) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  if (nt) {
+    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
 __device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
   acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
   return acc;
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
         uint32_t rr = r[s][c];
         bad |= in && rr >= rows;
         rr = rr < rows ? rr : 0u;
-        v[s][c] = ld4(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
+        v[s][c] = ld4row(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol, a.nt);
       }
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
         uint32_t rr = p.r[s][c];
         bad |= in && rr >= rows;
         rr = rr < rows ? rr : 0u;
-        v[s][c] = ld4(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
+        v[s][c] = ld4row(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol, a.nt);
       }
     // ... then the next unit's indices and this unit's weights (this lane's pieces, kept across
     // the S samples)
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
           uint32_t rr = p.r[s][c];
           bad |= in && rr >= p.rows;
           rr = rr < p.rows ? rr : 0u;
-          v[uu][s][c] = ld4(in ? p.W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
+          v[uu][s][c] = ld4row(in ? p.W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol, a.nt);
         }
     }
     // ... then the indices of the next iteration's units ...
@@ -992,8 +1001,10 @@ int64_t din_fused_grid(const SlsArgs& a, const Tune& tune) {
   return (a.q.cum[a.q.n_q] + f.S - 1) / f.S;
 }
 
-hipError_t launch_din_fused(const SlsArgs& a, int32_t h, const float* packed, float* R, int64_t ldr, const Tune& tune,
+hipError_t launch_din_fused(const SlsArgs& a_in, int32_t h, const float* packed, float* R, int64_t ldr, const Tune& tune,
                             hipStream_t s, hipEvent_t stop) {
+  SlsArgs a = a_in;
+  a.nt = tune.din_nt;
   const int64_t n_smp = a.q.cum[a.q.n_q];
   if (n_smp <= 0) return hipSuccess;
   const int64_t stride = din_unit_stride(a.D, h);

@@ -42,6 +42,7 @@ struct SlsArgs {
   int32_t D;
   int32_t* err;               // device error word: bit0 = index out of range
   uint64_t* ts;               // optional [2 * gridDim.x] start/end wall_clock64() per workgroup
+  int32_t nt;                 // fused DIN launch: table rows by non-temporal loads ("sls_nt"; set by launch_din_fused)
 };
 
 // Per-engine tunables (drs_set_option) and the per-device resources every launch needs.
@@ -60,10 +61,11 @@ struct Tune {
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
   int sls_xcd = 1;               // ... table-major work order, one contiguous slice per XCD
   int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
+  int din_nt = 1;                // fused DIN launch: non-temporal row loads ("din_nt": +2.5 % queries/s, 0.527 -> 0.545 of peak)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_ring = 2, mlp_stream_waves = 0, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, gemm_min_blocks = 128, mlp_debug = 0;
-  int gemm32 = 0;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel), tile by block count
-  int gemm32_blocks = 512;       // ... the largest workgroup tile that gives at least this many workgroups (then half of it)
+  int gemm32 = 1;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel) ...
+  int gemm32_blocks = 512;       // ... when its 128 x 128 workgroups number at least this many (two per CU)
   int64_t mlp_rows32 = 0;        // stream4_kernel: launches of at least this many rows take 32 rows per workgroup (0 = never)
   int64_t mlp_s4_rows = 0;       // "mlp_stream" 3 with four waves: launches of up to this many rows take stream4_kernel instead
 };

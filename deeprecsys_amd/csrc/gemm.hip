@@ -22,6 +22,8 @@
 //   one barrier, placed three quarters into the chunk (see DRS_GROUND).
 #include <string.h>
 
+#include <type_traits>
+
 #include "drs_internal.h"
 #include "mlp_dev.h"
 
@@ -346,12 +348,20 @@ constexpr int G3KC = 32, G3LD = 36;
 __device__ unsigned long long g_gtl[8 * 8192];
 #define GTL(slot) if (tid == 0) { g_gtl[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = __builtin_readcyclecounter(); }
 #define GTLW(slot) if (tid == 0) { g_gtl[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = wall_clock64(); }
+#define GTLID(slot) if (tid == 0) { unsigned xcc_, hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc_), "=s"(hw_)); \
+    g_gtl[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = ((unsigned long long)hw_ << 32) | xcc_; }
 #else
+#define GTLID(slot)
 #define GTL(slot)
 #define GTLW(slot)
 #endif
 
-template <int WTM, int WTN>
+// SPREAD (default): the request of chunk c + 2 goes out one load per MFMA step of chunk c's first two groups
+// instead of as one block of ~95 instructions between two rounds (tools/ubench/gemm_lab.hip, 2560 x 1024:
+// 8 192 rows 377 -> 367 us, 4 096 rows -- one workgroup per CU, nobody to fill the gap -- 198 -> 185 us)
+// (DBG, tools/ubench/gemm_lab.hip only: timing experiments that drop a part of the loop -- 2 no LDS stash, 4 no
+// barrier, 8 no global requests; the results are then not the GEMM's)
+template <int WTM, int WTN, int SPREAD = 1, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc xs) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr int NA = 2 * WTM, NB = 2 * WTN;      // float4 per thread per chunk (rows frow + 32 j)
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   const int n0 = blockIdx.y * BN;
   const int K = a.K, N = a.N;
   const int nch = (K + G3KC - 1) / G3KC;
-  GTL(0) GTLW(4)
+  GTL(0) GTLW(4) GTLID(6)
 
   // staging role: row frow (+32 j), floats 4 u .. 4 u + 3 of the chunk
   const int frow = tid >> 3, u = tid & 7, fk = 4 * u;
@@ -410,6 +420,20 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     }
     ++f_c;
   };
+  auto fetch_one = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], int q) {   // load q of the request `fetch` issues as a whole
+    const int k0 = f_c * G3KC;
+    const bool in = k0 + fk < K;
+    if (q < NA) {
+      const float* p = in ? xb[q >> 1] + offA[q] + k0 : a.zero;
+      asm("" : "+v"(p));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[q]) : "v"(p));
+    } else {
+      const float* p = in ? a.W + offB[q - NA] + k0 : a.zero;
+      asm("" : "+v"(p));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[q - NA]) : "v"(p));
+    }
+    if (q == NA + NB - 1) ++f_c;
+  };
   auto stash_part = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int q) {
     if (q < 2 * NA) {
       const f32x4 v = ra[q >> 1];
@@ -423,8 +447,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     }
   };
   // wait for one register set: at most the NA + NB loads of the newer request outstanding
-  auto gwait = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
-    constexpr int n = NA + NB;
+  auto gwait = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], auto newer) {
+    constexpr int n = decltype(newer)::value;   // loads of the newer request that may stay outstanding
     if constexpr (NA == 4 && NB == 4)
       asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]) : "n"(n));
     else if constexpr (NA == 2 && NB == 4)
@@ -436,9 +460,11 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   };
 
   f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  using AllNewer = std::integral_constant<int, NA + NB>;
+  using NoneNewer = std::integral_constant<int, 0>;
   fetch(ra0, rb0);
   fetch(ra1, rb1);
-  gwait(ra0, rb0);
+  gwait(ra0, rb0, AllNewer{});
 #pragma unroll
   for (int q = 0; q < NQ; ++q) stash_part(0, ra0, rb0, q);
   __syncthreads();
@@ -460,34 +486,38 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
 #pragma unroll
   for (int j = 0; j < WTN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(pb0 + 32 * j * G3LD);
 
-#define DRS_G3MFMA(SET, RAS, RBS)                                                                 \
+  // (Dealing the shadow work out one item per MFMA with a sched_barrier after each was measured too: the same
+  // at two workgroups per CU, 6 % SLOWER at one -- the scheduler's own placement inside a step stays.)
+#define DRS_G3MFMA(SET, RAS, RBS, RAF, RBF)                                                       \
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                              \
     _Pragma("unroll") for (int i = 0; i < WTM; ++i)                                               \
       _Pragma("unroll") for (int j = 0; j < WTN; ++j)                                             \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[SET][j][s_], av[SET][i][s_], acc[i][j], 0, 0, 0); \
     _Pragma("unroll") for (int w_ = 0; w_ < (NQ + 11) / 12; ++w_)                                 \
-      if (wq < NQ) { stash_part(nbuf, RAS, RBS, wq); ++wq; }                                      \
+      if (wq < NQ) { if (!(DBG & 2)) stash_part(nbuf, RAS, RBS, wq); ++wq; }                      \
+    if (SPREAD && fq < NA + NB) { if (!(DBG & 8)) fetch_one(RAF, RBF, fq); ++fq; }                \
     __builtin_amdgcn_sched_barrier(0);                                                            \
   }
   // One K chunk: MFMAs on buffer BUF, stash of the NEXT chunk (sets RAS/RBS) into BUF^1, request of
   // chunk + 2 into the sets this chunk came from (RAF/RBF)
 #define DRS_G3ROUND(BUF, RAF, RBF, RAS, RBS)                                                      \
   {                                                                                               \
-    fetch(RAF, RBF);                                                                              \
+    if (!SPREAD) fetch(RAF, RBF);                                                                 \
     const float* pa = pa0 + (BUF) * BM * G3LD;                                                    \
     const float* pb = pb0 + (BUF) * BN * G3LD;                                                    \
-    gwait(RAS, RBS);                                                                              \
+    if (DBG & 8) {} else if (SPREAD) gwait(RAS, RBS, NoneNewer{}); else gwait(RAS, RBS, AllNewer{}); \
     const int nbuf = (BUF) ^ 1;                                                                   \
     int wq = 0;   /* stash writes issued so far (compile-time after unrolling) */                  \
+    int fq = 0;   /* SPREAD: loads of the next request issued so far */                            \
     _Pragma("unroll") for (int gq = 0; gq < 3; ++gq) {                                            \
       const int cur = gq & 1, nxt = cur ^ 1;                                                      \
       _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(pa + 32 * i * G3LD + 8 * (gq + 1)); \
       _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(pb + 32 * j * G3LD + 8 * (gq + 1)); \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      if (cur == 0) { DRS_G3MFMA(0, RAS, RBS) } else { DRS_G3MFMA(1, RAS, RBS) }                  \
+      if (cur == 0) { DRS_G3MFMA(0, RAS, RBS, RAF, RBF) } else { DRS_G3MFMA(1, RAS, RBS, RAF, RBF) }                  \
     }                                                                                             \
     static_assert(NQ <= 12 * ((NQ + 11) / 12), "all stash writes must precede the barrier");      \
-    __syncthreads();                                                                              \
+    if (!(DBG & 4)) __syncthreads();                                                              \
     {                                                                                             \
       const float* pan = pa0 + nbuf * BM * G3LD;                                                  \
       const float* pbn = pb0 + nbuf * BN * G3LD;                                                  \
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
       _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(pbn + 32 * j * G3LD); \
     }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    { DRS_G3MFMA(1, RAS, RBS) }                                                                   \
+    { DRS_G3MFMA(1, RAS, RBS, RAF, RBF) }                                                                \
   }
 
   // Always whole PAIRS of rounds: an exit between the two rounds made the compiler copy all 64
@@ -597,18 +627,16 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   else if (blocks(2, 1) >= 256) { tm = 2; tn = 1; }
   else { tm = 1; tn = 1; }
   // The 32x32x2 forms (gemm32_kernel; "mlp_gemm_tile" 322 | 321 | 312 | 311 forces one, "mlp_gemm32" 1 =
-  // by block count): the largest workgroup tile that still gives every CU two workgroups, else one.
+  // by block count)
   {
     auto b32 = [&](int wm_, int wn_) { return ((M + 64 * wm_ - 1) / (64 * wm_)) * (int64_t)((N + 64 * wn_ - 1) / (64 * wn_)); };
     int w = 0;
     if (tune.gemm_tile >= 300) w = tune.gemm_tile - 300;
-    else if (tune.gemm_tile == 0 && tune.gemm32) {
-      const int order[4] = {22, 21, 12, 11};
-      for (int64_t need : {(int64_t)tune.gemm32_blocks, (int64_t)tune.gemm32_blocks / 2})
-        for (int o : order)
-          if (!w && b32(o / 10, o % 10) >= need) w = o;
-      if (!w) w = 11;
-    }
+    // by block count: the 128 x 128 form when it gives every CU its two workgroups (RM3 config 3's
+    // 2560 x 1024 layer at 8 192 rows: 512 of them, 372 us against 391 us for the 16x16x4 kernel, the model
+    // +4.5 % queries/s); smaller launches (W&D's 4 096 rows, the 1024 x 256 layer) stay with gemm_kernel, whose
+    // 64 x 64 workgroups cover the chip where 128 x 128 ones would leave CUs idle (measured: W&D -5 % otherwise)
+    else if (tune.gemm_tile == 0 && tune.gemm32 && b32(2, 2) >= tune.gemm32_blocks) w = 22;
     if (w) {
       const int wm_ = w / 10, wn_ = w % 10;
       const dim3 grid((unsigned)((M + 64 * wm_ - 1) / (64 * wm_)), (unsigned)((N + 64 * wn_ - 1) / (64 * wn_)));

@@ -702,13 +702,16 @@ hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t
     if (p.ok) return launch_flat(a, p, s, stop);
   }
   const int u = tune.sls_u ? tune.sls_u : 4;
-  if (D == 32 && tune.sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, tune.sls_nt, s, stop);
-  if (D <= 8) return launch_u<2, 4>(a, exact, u, tune.sls_nt, s, stop);
-  if (D <= 16) return launch_u<4, 4>(a, exact, u, tune.sls_nt, s, stop);
-  if (D <= 32) return launch_u<8, 4>(a, exact, u, tune.sls_nt, s, stop);
-  if (D <= 64) return launch_u<16, 4>(a, exact, u, tune.sls_nt, s, stop);
-  if (D <= 128) return launch_u<32, 4>(a, exact, u, tune.sls_nt, s, stop);
-  return launch_u<64, 4>(a, exact, u, tune.sls_nt, s, stop);
+  // the non-temporal hint is for bags of many rows out of big tables; the one-lookup models (W&D, NCF, MT-WnD:
+  // the sequential form) keep their rows cacheable -- NCF's tables live in the Infinity Cache (measured: -3 % with it)
+  const int nt = exact ? 0 : tune.sls_nt;
+  if (D == 32 && tune.sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, nt, s, stop);
+  if (D <= 8) return launch_u<2, 4>(a, exact, u, nt, s, stop);
+  if (D <= 16) return launch_u<4, 4>(a, exact, u, nt, s, stop);
+  if (D <= 32) return launch_u<8, 4>(a, exact, u, nt, s, stop);
+  if (D <= 64) return launch_u<16, 4>(a, exact, u, nt, s, stop);
+  if (D <= 128) return launch_u<32, 4>(a, exact, u, nt, s, stop);
+  return launch_u<64, 4>(a, exact, u, nt, s, stop);
 }
 
 // ---------------------------------------------------------------------------

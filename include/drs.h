@@ -293,8 +293,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                the VALU.  Same bits in all three.
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
- *   "sls_nt"     1 (default) | 0: the gather kernels read table rows with non-temporal loads (rows are
- *                read once per launch; same bits either way)
+ *   "sls_nt"     1 (default) | 0: the many-rows-per-bag gather kernels read table rows with non-temporal
+ *                loads (rows are read once per launch; same bits either way; the one-lookup models' gather
+ *                keeps plain loads: their tables are cache-resident).  "din_nt" 1 (default) | 0: the same for
+ *                the fused DIN launch
  *   "sls_xcd"    1 (default) | 0: several-bags-per-wave flat kernel walks its work list table-major,
  *                one contiguous slice per XCD
  *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
@@ -318,8 +320,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                "mlp_gemm_tile" 322 | 321 | 312 | 311: gemm32_kernel, the same GEMM on
  *                v_mfma_f32_32x32x2_f32 (four waves, each 2 x 2 | 2 x 1 | 1 x 2 | 1 x 1 tiles of 32 x 32:
  *                workgroup tiles of 128 x 128 .. 64 x 64, operands by ds_read_b128, two workgroups per CU);
- *                "mlp_gemm32" 1: take it for every wide layer, the largest workgroup tile that still
- *                gives "mlp_gemm32_blocks" (default 512) workgroups
+ *                "mlp_gemm32" 1 (default) | 0: wide layers whose 128 x 128 tiles number at least
+ *                "mlp_gemm32_blocks" (default 512: two workgroups per CU) take the 2 x 2 form (RM3 config 3's
+ *                2560 x 1024 layer at 8 192 rows), smaller launches keep gemm_kernel
  *   "mlp_stream" 2 (default for MLP-bound models) chains run as the weight-tile stream kernel
  *                (tiles of all layers requested six rounds ahead, inputs resident in LDS) when every
  *                K % 4 == 0 and the slabs fit, the tiles read from the layers' PACKED twins (MFMA

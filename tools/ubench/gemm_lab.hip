@@ -6,7 +6,9 @@
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DDRS_GEMM_TL -I deeprecsys_amd/csrc \
 //       tools/ubench/gemm_lab.hip -o tools/ubench/gemm_lab
-//   tools/ubench/gemm_lab [M K N]
+//   tools/ubench/gemm_lab [M K N [variants]]     variants: how many of the forms below to run (default 2: the
+//   kernel with block / spread requests; 3 adds the aliased-input run; 4-6 the knock-out timings -- their
+//   results are not the GEMM's; 7-8 read LDS never written and have faulted: do not run them)
 #include "../../deeprecsys_amd/csrc/gemm.hip"
 
 #include <algorithm>
@@ -46,7 +48,10 @@ static float time_launch(F launch, int iters) {
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 2560, N = argc > 3 ? atoi(argv[3]) : 1024;
+  const int n_variants = argc > 4 ? atoi(argv[4]) : 2;
   CK(gemm_set_attrs());
+  for (const void* k : {(const void*)gemm32_kernel<2, 2, 0>, (const void*)gemm32_kernel<2, 2, 1, 2>, (const void*)gemm32_kernel<2, 2, 1, 4>, (const void*)gemm32_kernel<2, 2, 1, 8>, (const void*)gemm32_kernel<2, 2, 1, 6>, (const void*)gemm32_kernel<2, 2, 1, 14>})
+    CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   std::vector<float> hx((size_t)M * K), hW((size_t)N * K), hb(N);
   unsigned s = 12345;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); };
@@ -83,14 +88,28 @@ int main(int argc, char** argv) {
     printf("%-28s M=%d K=%d N=%d  %.2f us  %.1f TFLOP/s  (%.3f of 157.3)\n", name, M, K, N, us, fl / us / 1e6, fl / us / 1e6 / 157.3);
   };
 
-  {
+  for (int variant = 0; variant < n_variants && variant < 8; ++variant) {
+    a.ldx = variant == 2 ? 0 : K;   // variant 2: every input row aliases row 0 (the X half of the traffic always hits in cache; results are NOT the GEMM's)
     const dim3 grid((M + 127) / 128, (N + 127) / 128);
     const size_t lds = sizeof(float) * 2 * (128 + 128) * G3LD;
-    auto launch = [&]() { hipLaunchKernelGGL((gemm32_kernel<2, 2>), grid, dim3(256), lds, 0, a, d, xs); };
+    static const char* names[8] = {"gemm32_kernel<2,2,0>", "gemm32_kernel<2,2,SPREAD>", "gemm32<2,2,SPREAD> ldx=0", "SPREAD, no stash", "SPREAD, no barrier",
+                                   "SPREAD, no requests", "SPREAD, no stash/barrier", "SPREAD, none of the three"};
+    const char* nm = names[variant];
+    auto launch = [&]() {
+      switch (variant) {
+        case 0: hipLaunchKernelGGL((gemm32_kernel<2, 2, 0>), grid, dim3(256), lds, 0, a, d, xs); break;
+        case 3: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 2>), grid, dim3(256), lds, 0, a, d, xs); break;
+        case 4: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 4>), grid, dim3(256), lds, 0, a, d, xs); break;
+        case 5: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 8>), grid, dim3(256), lds, 0, a, d, xs); break;
+        case 6: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 6>), grid, dim3(256), lds, 0, a, d, xs); break;
+        case 7: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 14>), grid, dim3(256), lds, 0, a, d, xs); break;
+        default: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1>), grid, dim3(256), lds, 0, a, d, xs); break;
+      }
+    };
     CK(hipMemset(y, 0, (size_t)M * N * 4));
     const float us = time_launch(launch, 20);
-    report("gemm32_kernel<2,2>", us);
-    check("gemm32_kernel<2,2>");
+    report(nm, us);
+    check(nm);
 #ifdef DRS_GEMM_TL
     launch();
     CK(hipDeviceSynchronize());
@@ -121,10 +140,31 @@ int main(int argc, char** argv) {
     stat("start after first", startw, "us");
     stat("end after first start", endw, "us");
     stat("shader clock", clk, "GHz");
+    {   // K loop by XCD, and by position of the workgroup's tile
+      double sx[8] = {0}, nx[8] = {0};
+      std::vector<double> by_y(grid.y, 0.0), by_xo(8, 0.0);
+      for (int i = 0; i < nwg; ++i) {
+        const unsigned xcc = (unsigned)(t[8 * i + 6] & 0xf);
+        sx[xcc & 7] += loop[i]; nx[xcc & 7] += 1;
+        by_y[i / grid.x] += loop[i] / grid.x;
+        by_xo[(i % grid.x) * 8 / grid.x] += loop[i] / (nwg / 8.0);
+      }
+      printf("  K loop avg by XCD (workgroups):");
+      for (int k = 0; k < 8; ++k) printf(" %d: %.0f (%.0f)", k, nx[k] ? sx[k] / nx[k] : 0.0, nx[k]);
+      printf("\n  K loop avg by blockIdx.y:");
+      for (unsigned k = 0; k < grid.y; ++k) printf(" %.0f", by_y[k]);
+      printf("\n  K loop avg by eighth of blockIdx.x:");
+      for (int k = 0; k < 8; ++k) printf(" %.0f", by_xo[k]);
+      // pairs sharing a CU: same (xcc, se, cu) bits of HW_ID
+      printf("\n  first 16 workgroups: (id xcc hw_id loop)");
+      for (int i = 0; i < 16 && i < nwg; ++i) printf(" (%d %u %08x %.0f)", i, (unsigned)(t[8 * i + 6] & 0xf), (unsigned)(t[8 * i + 6] >> 32), loop[i]);
+      printf("\n");
+    }
     const double ideal = (double)((K + 31) / 32) * 64 * 64 * 2;   // two waves per SIMD x 64 MFMAs x 64 cycles per chunk
     printf("  K loop ideal at two workgroups per CU: %.0f cycles (MFMA pipe time of both waves of a SIMD)\n", ideal);
 #endif
   }
+  a.ldx = K;
   {
     const dim3 grid((M + 63) / 64, (N + 63) / 64);
     const size_t lds = sizeof(float) * 2 * (64 + 64) * GLD;
