@@ -1350,7 +1350,9 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // launch set 52.8 k instead of 50.1 k queries/s; beside a full set's gather it costs the gather
     // 1.5-4 % more than stream3_kernel does (same-session A/B on two boxes), so it takes the small
     // launch sets only ("mlp_s4_rows").
-    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; e->tune.mlp_s4_rows = 1024; }
+    // Round 4: full sets (>= 2 048 rows) as stream4_kernel with 32 rows per workgroup where the slabs fit LDS
+    // (RMC1: 139 KB) -- 96 workgroups per 12-query set instead of 192: +1.6 % queries/s (mlp.hip stream_plan)
+    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; e->tune.mlp_s4_rows = 1024; e->tune.mlp_rows32 = 2048; }
     // W&D and DIEN: their stream launches (512-256-1 tail; top MLP) as stream4_kernel compiled for two
     // workgroups per CU: 95.1 k -> 96.2 k and 168 k -> 172 k queries/s (MT-WnD -4 %, NCF -9 %, DIN, RM3: +-0)
     if (e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;

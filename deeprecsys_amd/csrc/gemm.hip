@@ -434,6 +434,36 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     }
     if (q == NA + NB - 1) ++f_c;
   };
+  // SPREAD == 2 (the launcher takes it when K % 64 == 0 and every row offset fits 32 bits): the loop's
+  // requests in the scalar-base form -- global_load_dwordx4 v, v_off32, s[base] -- with the lane's byte offset
+  // of its row CONSTANT and the chunk's k0 carried by the SGPR base: no vector arithmetic per load at all
+  // (the vector form above spends two 64-bit adds, two selects and a nop on each of a round's eight loads).
+  // Requests past the last chunk re-read it (K % 64 == 0: every chunk whose MFMAs run exists).
+  uint32_t voA[NA], voB[NB];
+  const float* sbA[WTM];
+  const float* sbB = a.W;
+  if constexpr (SPREAD == 2) {
+#pragma unroll
+    for (int j2 = 0; j2 < NA; ++j2) voA[j2] = (uint32_t)(offA[j2] * 4);
+#pragma unroll
+    for (int j2 = 0; j2 < NB; ++j2) voB[j2] = (uint32_t)(offB[j2] * 4);
+  }
+  auto uni = [](const float* p) {   // a workgroup-uniform pointer, held in SGPRs
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  };
+  auto set_bases = [&]() {
+    const int kk = (f_c < nch ? f_c : nch - 1) * G3KC;
+#pragma unroll
+    for (int hm = 0; hm < WTM; ++hm) sbA[hm] = uni(xb[hm]) + kk;
+    sbB = uni(a.W) + kk;
+  };
+  auto fetch_one_s = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], int q) {
+    if (q < NA) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[q]) : "v"(voA[q]), "s"(sbA[q >> 1]));
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[q - NA]) : "v"(voB[q - NA]), "s"(sbB));
+    if (q == NA + NB - 1) { ++f_c; set_bases(); }
+  };
   auto stash_part = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int q) {
     if (q < 2 * NA) {
       const f32x4 v = ra[q >> 1];
@@ -464,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   using NoneNewer = std::integral_constant<int, 0>;
   fetch(ra0, rb0);
   fetch(ra1, rb1);
+  if constexpr (SPREAD == 2) set_bases();
   gwait(ra0, rb0, AllNewer{});
 #pragma unroll
   for (int q = 0; q < NQ; ++q) stash_part(0, ra0, rb0, q);
@@ -495,7 +526,10 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[SET][j][s_], av[SET][i][s_], acc[i][j], 0, 0, 0); \
     _Pragma("unroll") for (int w_ = 0; w_ < (NQ + 11) / 12; ++w_)                                 \
       if (wq < NQ) { if (!(DBG & 2)) stash_part(nbuf, RAS, RBS, wq); ++wq; }                      \
-    if (SPREAD && fq < NA + NB) { if (!(DBG & 8)) fetch_one(RAF, RBF, fq); ++fq; }                \
+    if (SPREAD && fq < NA + NB) {                                                                 \
+      if (DBG & 8) {} else if (SPREAD == 2) fetch_one_s(RAF, RBF, fq); else fetch_one(RAF, RBF, fq); \
+      ++fq;                                                                                       \
+    }                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                            \
   }
   // One K chunk: MFMAs on buffer BUF, stash of the NEXT chunk (sets RAS/RBS) into BUF^1, request of
@@ -586,7 +620,8 @@ hipError_t gemm_set_attrs() {
     if (e != hipSuccess) return e;
   }
   for (const void* k : {reinterpret_cast<const void*>(gemm32_kernel<2, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 2>),
-                        reinterpret_cast<const void*>(gemm32_kernel<2, 1>), reinterpret_cast<const void*>(gemm32_kernel<1, 1>)}) {
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 1>), reinterpret_cast<const void*>(gemm32_kernel<1, 1>),
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 2, 2>)}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -641,7 +676,10 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
       const int wm_ = w / 10, wn_ = w % 10;
       const dim3 grid((unsigned)((M + 64 * wm_ - 1) / (64 * wm_)), (unsigned)((N + 64 * wn_ - 1) / (64 * wn_)));
       const size_t lds = sizeof(float) * 2 * (64 * wm_ + 64 * wn_) * G3LD;
-      if (w == 22) hipLaunchKernelGGL((gemm32_kernel<2, 2>), grid, dim3(256), lds, s, a, d, xs);
+      // scalar-base requests when every chunk is whole and the row offsets fit 32 bits (gemm32_kernel, SPREAD == 2)
+      const bool sbase = !(K & 63) && (uint64_t)M * (uint64_t)ldx * 4u < (1ull << 32) && (uint64_t)N * (uint64_t)K * 4u < (1ull << 32);
+      if (w == 22 && sbase) hipLaunchKernelGGL((gemm32_kernel<2, 2, 2>), grid, dim3(256), lds, s, a, d, xs);
+      else if (w == 22) hipLaunchKernelGGL((gemm32_kernel<2, 2>), grid, dim3(256), lds, s, a, d, xs);
       else if (w == 21) hipLaunchKernelGGL((gemm32_kernel<2, 1>), grid, dim3(256), lds, s, a, d, xs);
       else if (w == 12) hipLaunchKernelGGL((gemm32_kernel<1, 2>), grid, dim3(256), lds, s, a, d, xs);
       else hipLaunchKernelGGL((gemm32_kernel<1, 1>), grid, dim3(256), lds, s, a, d, xs);

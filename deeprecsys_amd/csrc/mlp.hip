@@ -2330,6 +2330,15 @@ static inline int pad64(int n) { return (n + 63) & ~63; }
 static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune, const XSrc& xs,
                         bool publish, SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr,
                         const SumArgs* sum = nullptr) {
+  // Gather-bound DLRM ("mlp_stream" 3 on four waves) with "mlp_rows32": launches of at least that many rows
+  // take stream4_kernel's 32-row form when its slabs fit -- half as many workgroups sit beside the next
+  // set's gather (RMC1, 12-query sets, same session, three runs each: stream3 130.7-132.1 k queries/s,
+  // stream4 with 16 rows 129.0-129.5 k, with 32 rows 133.3-133.4 k) -- and stream3_kernel otherwise.
+  if (tune.mlp_stream == 3 && tune.mlp_stream_waves == 4 && tune.mlp_rows32 > 0 && a.M >= tune.mlp_rows32 && !sum) {
+    Tune t4 = tune;
+    t4.mlp_stream = 4;
+    if (stream_plan(a, b, t4, xs, publish, out, lds_bytes, dot, sum) && out->packed == 6) return true;
+  }
   SArgs& p = *out;
   memset(&p, 0, sizeof p);
   const int na = a.n_layers, nb = b ? b->n_layers : 0;

@@ -60,8 +60,17 @@ def summarize(responses_list, final_response_latencies):
     meas = [r for r in responses_list if (not r["exp_packet"]) and r["sub_id"] == 0]
     out = {"responses": len(responses_list), "measured_queries": len(meas), "qps": None,
            "p95_ms": None, "p99_ms": None}
-    if len(meas) >= 2 and meas[-1]["inference_end_time"] > meas[0]["inference_end_time"]:
-        out["qps"] = len(meas) / (meas[-1]["inference_end_time"] - meas[0]["inference_end_time"])
+    # The reference divides by (last - first) inference_end_time of the response LIST
+    # (DeepRecSys.py:168-173) -- kept.  Responses travel in per-engine batches here, so the list is only
+    # ordered per engine and its last entry can be older than its first (the reference would print a negative
+    # rate): then the earliest and the latest end time themselves bound the window.
+    if len(meas) >= 2:
+        dt = meas[-1]["inference_end_time"] - meas[0]["inference_end_time"]
+        if dt <= 0:
+            t = [r["inference_end_time"] for r in meas]
+            dt = max(t) - min(t)
+        if dt > 0:
+            out["qps"] = len(meas) / dt
     if len(final_response_latencies):
         out["p95_ms"] = float(np.percentile(final_response_latencies, 95) * 1000.)
         out["p99_ms"] = float(np.percentile(final_response_latencies, 99) * 1000.)

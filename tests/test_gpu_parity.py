@@ -1290,6 +1290,50 @@ def test_create_rejects_what_the_int32_offsets_cannot_hold():
     assert e.value.code == N.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("D,L", [(128, 20), (128, 3), (256, 5)])
+def test_table_beyond_2_pow_32_floats(D, L):
+    """Row offsets travel as 32-bit counts of 16-byte units (round 4): a table of rows*D in [2^32, 2^33)
+    floats (17 GB here) gathers the right rows -- bags made of the LAST rows of the table (whose float offsets
+    do not fit 32 bits), the first ones and random ones, pooled sums against the fill function the oracle
+    shares with the device-side table init (orc_fill_value), in the sequential form (bitwise: the oracle's
+    summation order) and the default one (flat kernel for D = 128, ring walk for D = 256)."""
+    rows = (1 << 32) // D + 4096
+    assert (1 << 32) <= rows * D < (1 << 33)
+    B = 8
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, 1, L, "16-%d" % D, "8-1", B, nb=1, seed=5)
+    idx = lS_i[0][0].reshape(B, L)
+    idx[0] = np.arange(rows - L, rows)                 # the table's last rows
+    idx[1] = np.arange(L)                              # its first
+    idx[2] = np.sort(np.concatenate([[0], np.arange(rows - L + 1, rows)]))[:L] if L > 1 else idx[2]
+    idx[3] = (1 << 32) // D + np.arange(L) - L // 2    # around the old limit
+    lS_i[0][0] = idx.reshape(-1)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
+        seed = args.numpy_rand_seed
+        L_ = orc.lib()
+        def row(r):
+            return np.array([L_.orc_fill_value(seed, 0, int(r) * D + c, lo, hi) for c in range(D)], dtype=np.float32)
+        exp = np.zeros((B, D), dtype=np.float32)
+        for b in range(B):
+            acc = np.zeros(D, dtype=np.float32)
+            for r in idx[b]:
+                acc = (acc + row(r)).astype(np.float32)      # sequential fp32 sum, the perfkernel's order
+            exp[b] = acc
+        for exact in (1, 0):
+            net.engine.set_option("sls_exact", exact)
+            net.run_staged(0, B)
+            R = net.engine.fetch_interaction(B)
+            pooled = R[:, D:2 * D]                           # cat: [dense_out | table 0]
+            if exact:
+                assert np.array_equal(pooled, exp)
+            else:
+                assert H.close(pooled, exp, rtol=1e-5, atol_scale=2e-6)
+    finally:
+        net.engine.close()
+
+
 def test_options_are_per_handle_and_engines_coexist():
     """Two engines in one process (the mixed-model accelerator engine does this) keep their own
     tunables: setting an option on one must not leak into the other,

@@ -6,8 +6,8 @@
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DDRS_GEMM_TL -I deeprecsys_amd/csrc \
 //       tools/ubench/gemm_lab.hip -o tools/ubench/gemm_lab
-//   tools/ubench/gemm_lab [M K N [variants]]     variants: how many of the forms below to run (default 2: the
-//   kernel with block / spread requests; 3 adds the aliased-input run; 4-6 the knock-out timings -- their
+//   tools/ubench/gemm_lab [M K N [variants]]     variants: how many of the forms below to run (default 3: the
+//   kernel with block / spread / scalar-base requests; 4-6 the knock-out timings -- their
 //   results are not the GEMM's; 7-8 read LDS never written and have faulted: do not run them)
 #include "../../deeprecsys_amd/csrc/gemm.hip"
 
@@ -48,7 +48,7 @@ static float time_launch(F launch, int iters) {
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 2560, N = argc > 3 ? atoi(argv[3]) : 1024;
-  const int n_variants = argc > 4 ? atoi(argv[4]) : 2;
+  const int n_variants = argc > 4 ? atoi(argv[4]) : 3;
   CK(gemm_set_attrs());
   for (const void* k : {(const void*)gemm32_kernel<2, 2, 0>, (const void*)gemm32_kernel<2, 2, 1, 2>, (const void*)gemm32_kernel<2, 2, 1, 4>, (const void*)gemm32_kernel<2, 2, 1, 8>, (const void*)gemm32_kernel<2, 2, 1, 6>, (const void*)gemm32_kernel<2, 2, 1, 14>})
     CK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -89,15 +89,16 @@ int main(int argc, char** argv) {
   };
 
   for (int variant = 0; variant < n_variants && variant < 8; ++variant) {
-    a.ldx = variant == 2 ? 0 : K;   // variant 2: every input row aliases row 0 (the X half of the traffic always hits in cache; results are NOT the GEMM's)
+    a.ldx = K;
     const dim3 grid((M + 127) / 128, (N + 127) / 128);
     const size_t lds = sizeof(float) * 2 * (128 + 128) * G3LD;
-    static const char* names[8] = {"gemm32_kernel<2,2,0>", "gemm32_kernel<2,2,SPREAD>", "gemm32<2,2,SPREAD> ldx=0", "SPREAD, no stash", "SPREAD, no barrier",
+    static const char* names[8] = {"gemm32_kernel<2,2,0>", "gemm32_kernel<2,2,SPREAD>", "gemm32<2,2,2> scalar-base requests", "SPREAD, no stash", "SPREAD, no barrier",
                                    "SPREAD, no requests", "SPREAD, no stash/barrier", "SPREAD, none of the three"};
     const char* nm = names[variant];
     auto launch = [&]() {
       switch (variant) {
         case 0: hipLaunchKernelGGL((gemm32_kernel<2, 2, 0>), grid, dim3(256), lds, 0, a, d, xs); break;
+        case 2: hipLaunchKernelGGL((gemm32_kernel<2, 2, 2>), grid, dim3(256), lds, 0, a, d, xs); break;
         case 3: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 2>), grid, dim3(256), lds, 0, a, d, xs); break;
         case 4: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 4>), grid, dim3(256), lds, 0, a, d, xs); break;
         case 5: hipLaunchKernelGGL((gemm32_kernel<2, 2, 1, 8>), grid, dim3(256), lds, 0, a, d, xs); break;
