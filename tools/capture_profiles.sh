@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun session -> everything under profiles/ (run from the repo root ON THE GPU BOX):
-#   gpurun --timeout 2400 -- 'bash tools/capture_profiles.sh r02'
+#   gpurun --timeout 3000 -- 'bash tools/capture_profiles.sh r04'
 # writes gpurun_out/<tag>/..., which tools/publish_profiles.py copies into profiles/.
 set -u
 TAG=${1:-r02}
@@ -64,9 +64,20 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
 done
 pmc "$OUT/wnd_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
     python bench.py --workload wnd --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --set shared_stream=1
-# the wide-layer GEMM alone (tools/gemm_bench.py): durations + MFMA-busy
+# the wide-layer GEMM alone (tools/gemm_bench.py): durations + MFMA-busy; at 2 048 rows (every shape) and, for
+# RM3 config 3's real launch, 8 192 rows (gemm32_kernel's 128 x 128 form) against gemm_kernel on the same box
 trace gemm python tools/gemm_bench.py --iters 50
 pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --iters 20
+trace gemm_8192 python tools/gemm_bench.py --rows 8192 --iters 30 --shapes 2560x1024,1024x256
+trace gemm_8192_gemm_kernel python tools/gemm_bench.py --rows 8192 --iters 30 --shapes 2560x1024,1024x256 --gemm32 0
+pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --rows 8192 --iters 10 --shapes 2560x1024
+pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --rows 8192 --iters 10 --shapes 2560x1024 --gemm32 0
+# per-workgroup phase stamps, shader clock and bit check of the same launch (tools/ubench/gemm_lab.hip, built by `make lab`)
+[ -x tools/ubench/gemm_lab ] && run 200 tools/ubench/gemm_lab 8192 2560 1024 > "$OUT/gemm_lab.txt" 2>&1
+[ -x tools/ubench/gemm_lab ] && run 200 tools/ubench/gemm_lab 4096 2560 1024 >> "$OUT/gemm_lab.txt" 2>&1
+# RM3: streams by launch set (default) against streams by kernel type ("mlp_layout" 1): both gather fractions, both rates
+run 600 $R3 --set mlp_layout=1 > "$OUT/rmc3_bench_layout1.json" 2>/dev/null
+run 600 $R3 --set mlp_gemm32=0 > "$OUT/rmc3_bench_gemm32_0.json" 2>/dev/null
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
@@ -75,6 +86,10 @@ run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=2 > "$OUT/bench_mlp_stream2.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=4 > "$OUT/bench_mlp_stream4.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 8 > "$OUT/bench_coalesce8.json" 2>/dev/null
+# round 4: what the non-temporal row loads and the 32-row MLP form are worth on this box (same line, one option off)
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set sls_nt=0 > "$OUT/bench_sls_nt0.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_rows32=0 > "$OUT/bench_mlp_rows32_0.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 > "$OUT/bench_again.json" 2>/dev/null
 # the MLP launch ALONE (one stream, 8-query sets = 128 workgroups) in its three forms: durations from
 # rocprofv3, MFMA counters, and the in-kernel timeline of stream4_kernel (needs libdrs_hip_tl.so: make timeline)
 MA="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --coalesce 8 --set shared_stream=1 --set mlp_s4_rows=0"

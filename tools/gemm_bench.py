@@ -25,13 +25,14 @@ def main():
     ap.add_argument("--rows", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--tile", type=int, default=0, help="mlp_gemm_tile (0 auto | 22 | 12 | 21 | 11 | 214 | 322 | 321 | 312 | 311)")
-    ap.add_argument("--gemm32", type=int, default=0, help="mlp_gemm32 (1: the 32x32x2 kernel, tile by block count)")
+    ap.add_argument("--gemm32", type=int, default=-1, help="mlp_gemm32 (-1: the engine's default | 0 gemm_kernel only | 1 gemm32_kernel where its 128 x 128 tiles number >= mlp_gemm32_blocks)")
     ap.add_argument("--shapes", default="", help="comma-separated KxN list instead of the models' shapes")
     o = ap.parse_args()
     eng = N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,
                    max_batch=4, max_lookups=2, num_staged_batches=1, num_slots=1)
     eng.set_option("mlp_gemm_tile", o.tile)
-    eng.set_option("mlp_gemm32", o.gemm32)
+    if o.gemm32 >= 0:
+        eng.set_option("mlp_gemm32", o.gemm32)
     shapes = SHAPES if not o.shapes else [("%s" % kn, int(kn.split("x")[0]), int(kn.split("x")[1])) for kn in o.shapes.split(",")]
     dev = torch.device("cuda", 0)
     M = o.rows
