@@ -724,7 +724,8 @@ def main():
         # N ranks share the host's cores (and each rank's drs_wait polls): the per-call-input workers of a
         # rank are capped at its share of the cgroup quota, and the extra legs run on rank 0 only, after
         # the job's statistics have been combined (8 ranks x 8 spinning threads on 16 CPUs)
-        eng.set_option("host_threads", max(0, min(7, host_cores() // world - 1)))
+        host_threads = max(0, min(7, host_cores() // world - 1))
+        eng.set_option("host_threads", host_threads)
     state_before = gpu_state(local) if rank == 0 else None
     # warmup
     run_queries(eng, n_warm, bs, nb, slots, coalesce=co)
@@ -887,6 +888,8 @@ def main():
                        "collective": None if world == 1 else
                        ("drs_stats_allreduce (RCCL, one grouped all-reduce of 32 KB)" if comm is not None
                         else (comm_note or "gloo")),
+                       "host": {"cores": host_cores(), "ranks": world,
+                                "conversion_workers_per_rank": eng.get_option("host_threads")},
                        "inputs": "device-resident (pre-staged)",
                        "index_streams": "uniform rows, sorted and distinct within a bag (the reference's random generator)"
                        if not opt.trace else "--data_generation synthetic: LRU-stack traces from the stack-distance profile `%s`, "

@@ -334,7 +334,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                and accumulators in AGPRs under fixed names, the next segment's first chunk
  *                requested while the last one runs ("mlp_rows32" n: its launches of >= n rows take 32 rows per
  *                workgroup -- two halves sharing the weight operands; default 8192 for MLP-bound DLRM,
- *                else 0 = never; "mlp_s4_rows" n: with "mlp_stream" 3 on four waves, launches of up to n
+ *                2048 for gather-bound DLRM (whose full sets then take stream4_kernel in that form when its
+ *                slabs fit LDS -- RMC1: 139 KB -- instead of stream3_kernel: half the workgroups beside the next
+ *                set's gather), else 0 = never; "mlp_s4_rows" n: with "mlp_stream" 3 on four waves, launches of up to n
  *                rows take stream4_kernel; default 1024 for gather-bound DLRM) | 3 stream3_kernel: the same packed
  *                twins, activation operands as four ds_read_b128 per 64-k chunk, accumulators in fixed
  *                AGPRs, weight loads spread through the MFMA stream (EXEC-masked for tiles a wave does
@@ -358,7 +360,11 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                  MLP of set i and gathers never overlap each other
  *                  ("mlp_streams" n: alternate the MLP side over n streams; default 1 for
  *                  gather-bound models, one per slot (up to 4) for MLP-bound ones, decided in
- *                  drs_create from MLP FLOP per gathered byte)
+ *                  drs_create from MLP FLOP per gathered byte;
+ *                  "mlp_layout" 0 (default) the MLP side's streams are dealt by launch set | 1 by
+ *                  kernel type: wide-layer GEMM launches go on the GATHER's stream, serialised with it,
+ *                  chains on the MLP streams, an event per kernel -- RM3 config 3: the gather runs at
+ *                  0.63 instead of 0.26 of the HBM peak, the model 3-10 % slower, so it is not the default)
  *                1 one stream: sets strictly back to back, each kernel has the chip to itself
  *                0 one stream per slot: whole sets overlap freely
  *   "zero_copy_inputs" how drs_forward_inputs' converted inputs (one packed, pinned block per slot:

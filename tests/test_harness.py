@@ -233,6 +233,22 @@ def test_bench_rank_entry_world_size_2_end_to_end_on_cpu():
     assert chk["verified"]["ok"] is True and chk["verified_queries"] == chk["verified"]["verified_queries"] > 0
 
 
+def test_bench_rank_entry_world_size_8_shares_the_host():
+    """The driver's largest launch: 8 ranks on one node.  Above the CPU restatement of the ABI (gloo), the line
+    is the whole job's -- 8 x the per-rank queries -- and every rank's per-call conversion workers are capped at
+    its share of the cores this process may use (8 ranks x (poll thread + workers) on a
+    16-CPU cgroup), which the line records."""
+    import bench
+    cpu = {"OMP_NUM_THREADS": "1"}
+    eight = _bench(["--gpus", "8", "--collective", "gloo", "--allow_device_sharing"] + _TINY, cpu, timeout=900, cpu_abi=True)
+    assert eight["n_gpus"] == 8 and eight["latency_ms"]["queries"] == 8 * 60
+    assert eight["value"] == pytest.approx(8 * 60 / eight["config"]["timed_seconds"], rel=0.15)
+    h = eight["config"]["host"]
+    assert h["ranks"] == 8 and h["cores"] == bench.host_cores()
+    assert h["conversion_workers_per_rank"] == max(0, min(7, bench.host_cores() // 8 - 1))
+    assert (h["conversion_workers_per_rank"] + 1) * 8 <= max(8, h["cores"])     # workers + caller fit the budget
+
+
 def test_bench_refuses_more_ranks_than_devices():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import subprocess
