@@ -159,7 +159,7 @@ __device__ __forceinline__ Owner owner_of(const SlsArgs& a, int smp) {
 // S x C row loads per lane are in flight (C = rows per bag covered per round: 3 when no bag of the
 // launch is longer, else 4); loads past a bag's end read the zero page instead of branching.
 // Bytes per sample: T bags of rows + indices in, 4 D floats out.
-template <int G, int S, int H, int C, int NW, int UUO = 0>
+template <int G, int S, int H, int C, int NW>
 __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const float* __restrict__ packed,
                                                             int64_t stride, const float* __restrict__ zero,
                                                             float* __restrict__ R, int64_t ldr) {
@@ -168,7 +168,9 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
   // of its units at once (S x UU x C row loads per lane either way), so a small launch -- one
   // query: S = 1 -- needs a quarter of the dependent round trips.  The units are still applied and
   // summed in ascending order: the bits do not depend on S.
-  constexpr int UU = UUO ? UUO : (S >= 4 ? 1 : 4 / S);   // UUO ("din_uu"): S = 4 with two units in flight (24 row loads per lane)
+  // (Round 4: S = 4 with TWO units in flight -- 24 row loads per lane, 256 VGPRs -- through the generic loop
+  // below: 78 us instead of 48 for the 2 048-sample launch; not kept.)
+  constexpr int UU = S >= 4 ? 1 : 4 / S;
   static_assert(S <= NW, "wave s finishes sample s");
   __shared__ float4 s_z[S][NW][G];
   if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
   }
 }
 
-struct FusedShape { int S, C, UU; };
+struct FusedShape { int S, C; };
 // Waves per workgroup.  FIXED for every launch size: it decides which units a lane group sums, i.e.
 // the association of the fp32 Sum over the units -- a query's bits must not depend on how many
 // queries were coalesced with it.  Measured on the din.json shape (254 tables, 3 lookups, D 32),
@@ -509,18 +511,15 @@ struct FusedShape { int S, C, UU; };
 // 4 x 1 63 us; one query (256 samples): 4 x 1 16 us, 8 x 1 12 us.
 constexpr int kWaves = 4;
 
-template <int G, int S, int H, int C, int NW, int UUO = 0>
+template <int G, int S, int H, int C, int NW>
 void launch_fused_k(const SlsArgs& a, const float* packed, int64_t stride, const float* zero, float* R, int64_t ldr,
                     unsigned grid, hipStream_t s, hipEvent_t stop) {
-  if (stop) hipExtLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW, UUO>), dim3(grid), dim3(64 * NW), 0, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
-  else hipLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW, UUO>), dim3(grid), dim3(64 * NW), 0, s, a, packed, stride, zero, R, ldr);
+  if (stop) hipExtLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW>), dim3(grid), dim3(64 * NW), 0, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
+  else hipLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW>), dim3(grid), dim3(64 * NW), 0, s, a, packed, stride, zero, R, ldr);
 }
 template <int G, int S, int H>
 void launch_fused_c(const FusedShape& f, const SlsArgs& a, const float* packed, int64_t stride, const float* zero,
                     float* R, int64_t ldr, unsigned grid, hipStream_t s, hipEvent_t stop) {
-  if constexpr (S == 4 && H == 1) {
-    if (f.C == 3 && f.UU == 2) { launch_fused_k<G, S, H, 3, kWaves, 2>(a, packed, stride, zero, R, ldr, grid, s, stop); return; }
-  }
   if (f.C == 3) launch_fused_k<G, S, H, 3, kWaves>(a, packed, stride, zero, R, ldr, grid, s, stop);
   else launch_fused_k<G, S, H, 4, kWaves>(a, packed, stride, zero, R, ldr, grid, s, stop);
 }
@@ -546,7 +545,6 @@ FusedShape fused_shape(const SlsArgs& a, const Tune& tune) {
   const int64_t n_smp = a.q.cum[a.q.n_q];
   f.S = tune.din_s > 0 ? tune.din_s : (n_smp >= 1024 ? 4 : n_smp >= 512 ? 2 : 1);
   f.C = 3;
-  f.UU = tune.din_uu;
   for (int i = 0; i < a.q.n_q; ++i)
     if (a.uniform_len[i] < 0 || a.uniform_len[i] > 3) f.C = 4;
   return f;
