@@ -982,10 +982,9 @@ def main():
     if opt.sweep and rank == 0:
         results = []
         for exact, flat in ((1, 0), (0, 0), (0, 1)):
-            for u in ((4,) if flat else (4, 8, 16)):
+            for u in (4,):
                 eng.set_option("sls_exact", exact)
                 eng.set_option("sls_flat", flat)
-                eng.set_option("sls_u", u)
                 run_queries(eng, 400, bs, nb, slots, coalesce=co)
                 el = run_queries(eng, 4000, bs, nb, slots, coalesce=co)
                 eng.reset_kernel_time()

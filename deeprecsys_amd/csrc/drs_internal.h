@@ -55,15 +55,12 @@ struct Tune {
   uint64_t w_arena_floats = 0;
   uint64_t w_packed_lo = 0, w_packed_hi = 0;   // float range of the arena whose layers carry a packed twin
   uint32_t w_zero_off = 0;          // ... whose first 64 floats are zeros (float offset of them)
-  int sls_u = 0;                 // row loads per register ring and lane (0 = default 4)
-  int sls_v_d32 = 4;             // lane width for D == 32 (4 | 2)
   int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
-  int sls_xcd = 1;               // ... table-major work order, one contiguous slice per XCD
   int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
   int din_nt = 1;                // fused DIN launch: non-temporal row loads ("din_nt": +2.5 % queries/s, 0.527 -> 0.545 of peak)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
-  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_ring = 2, mlp_stream_waves = 0, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, gemm_min_blocks = 128, mlp_debug = 0;
+  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_stream_waves = 0, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, mlp_debug = 0;
   int gemm32 = 1;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel) ...
   int gemm32_blocks = 512;       // ... when its 128 x 128 workgroups number at least this many (two per CU)
   int64_t mlp_rows32 = 0;        // stream4_kernel: launches of at least this many rows take 32 rows per workgroup (0 = never)

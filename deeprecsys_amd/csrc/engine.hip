@@ -1980,10 +1980,7 @@ int32_t drs_interact_dot(drs_handle e, const float* d_T, int64_t B, int32_t F, i
 int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   if (!e || !key) return DRS_ERR_BAD_ARG;
   if (!strcmp(key, "sls_exact")) e->sls_exact = value ? 1 : 0;
-  else if (!strcmp(key, "sls_u") && (value == 0 || value == 4 || value == 8 || value == 16 || value == 20)) e->tune.sls_u = (int)value;
-  else if (!strcmp(key, "sls_v_d32") && (value == 4 || value == 2)) e->tune.sls_v_d32 = (int)value;
   else if (!strcmp(key, "sls_flat") && value >= 0 && value <= 2) e->tune.sls_flat = (int)value;
-  else if (!strcmp(key, "sls_xcd")) e->tune.sls_xcd = value ? 1 : 0;
   else if (!strcmp(key, "din_fused")) e->din_fused = value ? 1 : 0;
   else if (!strcmp(key, "dien_mfma") && value >= 0 && value <= 2) e->dien_mfma = (int)value;
   else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
@@ -2018,10 +2015,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_stream_2cu") && (value == 0 || value == 1)) e->tune.mlp_stream_2cu = (int)value;
   else if (!strcmp(key, "mlp_gemm_2cu") && (value == 0 || value == 1)) e->tune.gemm_2cu = (int)value;
   else if (!strcmp(key, "launch_thread") && (value == 0 || value == 1)) e->launch_thread = (int)value;
-  else if (!strcmp(key, "mlp_ring") && value == 2) e->tune.mlp_ring = (int)value;
   else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 4 || value == 8)) e->tune.mlp_stream_waves = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_gemm_min_blocks") && value >= 1 && value <= 4096) e->tune.gemm_min_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214 || value == 322 || value == 321 || value == 312 || value == 311)) e->tune.gemm_tile = (int)value;
   else if (!strcmp(key, "mlp_gemm32") && (value == 0 || value == 1)) e->tune.gemm32 = (int)value;
   else if (!strcmp(key, "mlp_gemm32_blocks") && value >= 1 && value <= 65536) e->tune.gemm32_blocks = (int)value;
@@ -2076,11 +2071,11 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   if (!e || !key || !value) return DRS_ERR_BAD_ARG;
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
-      {"sls_exact", e->sls_exact}, {"sls_u", t.sls_u}, {"sls_v_d32", t.sls_v_d32}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"sls_xcd", t.sls_xcd}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
+      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, {"mlp_gemm_min_blocks", t.gemm_min_blocks},
-      {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_ring", t.mlp_ring}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
+      {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)

@@ -657,7 +657,7 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   // (2,2) already when it covers half the chip: in the pipelined engine other launches (the next
   // set's gather, the other MLP streams' GEMMs and chains) fill the remaining CUs, and a 2 x 2
   // wave tile does twice the MFMAs per operand read (measured: RM3 +4 %, W&D +2 % queries/s)
-  else if (blocks(2, 2) >= tune.gemm_min_blocks) { tm = 2; tn = 2; }
+  else if (blocks(2, 2) >= 128) { tm = 2; tn = 2; }
   else if (blocks(1, 2) >= 256) { tm = 1; tn = 2; }
   else if (blocks(2, 1) >= 256) { tm = 2; tn = 1; }
   else { tm = 1; tn = 1; }

@@ -592,14 +592,12 @@ hipError_t launch_variant(const SlsArgs& a, int exact, int nt, hipStream_t s, hi
   return hipGetLastError();
 }
 
+// U (row loads per register ring and lane) is 4: two rings, so 4..8 loads in flight per lane, the waves per
+// CU provide the rest of the memory-level parallelism.  (8, 16 and 20 were options until round 4 -- measured
+// equal or slower on every shape -- as was a 16-lane x 8-byte form for D == 32.)
 template <int G, int V>
-hipError_t launch_u(const SlsArgs& a, int exact, int u, int nt, hipStream_t s, hipEvent_t stop) {
-  switch (u) {
-    case 4: return launch_variant<G, V, 4>(a, exact, nt, s, stop);
-    case 8: return launch_variant<G, V, 8>(a, exact, nt, s, stop);
-    case 20: return launch_variant<G, V, 20>(a, exact, nt, s, stop);
-    default: return launch_variant<G, V, 16>(a, exact, nt, s, stop);
-  }
+hipError_t launch_u(const SlsArgs& a, int exact, int nt, hipStream_t s, hipEvent_t stop) {
+  return launch_variant<G, V, 4>(a, exact, nt, s, stop);
 }
 
 int lanes_per_row(int D) { return D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64; }
@@ -635,7 +633,7 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
   const int need = (bpw * L + NG - 1) / NG;
   const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : 0;
   if (!nl || (bpw > 1 && nl > 10)) return p;
-  p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = tune.sls_xcd ? 1 : 0;
+  p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = 1;
   p.coal = bpw == 1 && tune.sls_flat == 1;      // "sls_flat" 2 forces the phased form
   p.nt = tune.sls_nt;
   const unsigned n_work = (unsigned)a.q.cum[a.q.n_q] * (unsigned)(a.T / bpw);
@@ -675,11 +673,8 @@ hipError_t launch_flat(const SlsArgs& a, const FlatPlan& p, hipStream_t s, hipEv
 
 }  // namespace
 
-// Tunables (drs_set_option, kept per engine in Tune): "sls_u" row loads per register ring and
-// lane of the ring-walk kernel (0 = measured best for 8-query launches: 4 for both variants --
-// two rings, so 4..8 in flight per lane; the waves per CU provide the rest of the memory-level
-// parallelism), "sls_v_d32" the lane width used for D == 32 (8 lanes x 16 B or 16 lanes x 8 B),
-// "sls_flat" / "sls_bpw" the flat variant and its bags per wave (0 = auto).
+// Tunables (drs_set_option, kept per engine in Tune): "sls_flat" / "sls_bpw" the flat variant and its bags
+// per wave (0 = auto), "sls_nt" non-temporal row loads.
 bool sls_flat_applicable(const SlsArgs& a, const Tune& tune) { return flat_plan(a, tune).ok; }
 
 int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
@@ -689,7 +684,6 @@ int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
     return p.ok ? (int64_t)p.grid : n_bags;
   }
   int G = lanes_per_row(a.D);
-  if (a.D == 32 && tune.sls_v_d32 == 2) G = 16;
   const int bags = 64 / G;
   return (n_bags + bags - 1) / bags;
 }
@@ -701,17 +695,15 @@ hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t
     const FlatPlan p = flat_plan(a, tune);
     if (p.ok) return launch_flat(a, p, s, stop);
   }
-  const int u = tune.sls_u ? tune.sls_u : 4;
   // the non-temporal hint is for bags of many rows out of big tables; the one-lookup models (W&D, NCF, MT-WnD:
   // the sequential form) keep their rows cacheable -- NCF's tables live in the Infinity Cache (measured: -3 % with it)
   const int nt = exact ? 0 : tune.sls_nt;
-  if (D == 32 && tune.sls_v_d32 == 2) return launch_u<16, 2>(a, exact, u, nt, s, stop);
-  if (D <= 8) return launch_u<2, 4>(a, exact, u, nt, s, stop);
-  if (D <= 16) return launch_u<4, 4>(a, exact, u, nt, s, stop);
-  if (D <= 32) return launch_u<8, 4>(a, exact, u, nt, s, stop);
-  if (D <= 64) return launch_u<16, 4>(a, exact, u, nt, s, stop);
-  if (D <= 128) return launch_u<32, 4>(a, exact, u, nt, s, stop);
-  return launch_u<64, 4>(a, exact, u, nt, s, stop);
+  if (D <= 8) return launch_u<2, 4>(a, exact, nt, s, stop);
+  if (D <= 16) return launch_u<4, 4>(a, exact, nt, s, stop);
+  if (D <= 32) return launch_u<8, 4>(a, exact, nt, s, stop);
+  if (D <= 64) return launch_u<16, 4>(a, exact, nt, s, stop);
+  if (D <= 128) return launch_u<32, 4>(a, exact, nt, s, stop);
+  return launch_u<64, 4>(a, exact, nt, s, stop);
 }
 
 // ---------------------------------------------------------------------------

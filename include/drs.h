@@ -297,10 +297,6 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                loads (rows are read once per launch; same bits either way; the one-lookup models' gather
  *                keeps plain loads: their tables are cache-resident).  "din_nt" 1 (default) | 0: the same for
  *                the fused DIN launch
- *   "sls_xcd"    1 (default) | 0: several-bags-per-wave flat kernel walks its work list table-major,
- *                one contiguous slice per XCD
- *   "sls_u"      row loads per register ring and lane: 0 (default: 4) | 4 | 8 | 16 | 20
- *   "sls_v_d32"  lane width for D == 32: 4 (8 lanes x 16 B) | 2 (16 lanes x 8 B)
  *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
  *                read (bag b starts at b*L) | 0 always read the staged prefix sums
  *   "mlp_split"  1 (default) a layer with K*N >= "mlp_wide_kn" weights (RM3's 2560x1024)
@@ -315,8 +311,7 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                workgroups per CU (ring of two chunks, <= 128 VGPRs, 70 KB of LDS);
  *                "mlp_gemm_2cu" 1 (default for DLRM and W&D) | 0: take that shape by itself whenever
  *                it gives >= 512 workgroups (W&D +5 %, RM3 +5 %; MT-WnD -5 %: off there)
- *                ("mlp_gemm_min_blocks", default 128: the full 2 x 2 tile is kept while it still gives
- *                that many workgroups; 129 / 257 measured on W&D, MT-WnD, RM3: no difference);
+ *                (the full 2 x 2 tile is kept while it still gives 128 workgroups);
  *                "mlp_gemm_tile" 322 | 321 | 312 | 311: gemm32_kernel, the same GEMM on
  *                v_mfma_f32_32x32x2_f32 (four waves, each 2 x 2 | 2 x 1 | 1 x 2 | 1 x 1 tiles of 32 x 32:
  *                workgroup tiles of 128 x 128 .. 64 x 64, operands by ds_read_b128, two workgroups per CU);

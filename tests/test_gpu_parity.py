@@ -124,27 +124,16 @@ def test_sls_exact_is_bitwise_and_split_is_close(op_engine, D, L):
     exp = orc.sls(W, idx, lengths)
     dW, di, dl = (torch.from_numpy(a).cuda() for a in (W, idx, lengths))
     out = torch.full((bags, D), float("nan"), device="cuda")
-    for u in (0, 4, 8, 16, 20):
-        op_engine.set_option("sls_u", u)
-        out.fill_(float("nan"))
-        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
-        op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
-                      out.data_ptr(), exact_order=True)
-        assert np.array_equal(out.cpu().numpy(), exp), (D, L, u)
-        out.fill_(float("nan"))
-        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
-        op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
-                      out.data_ptr(), exact_order=False)
-        assert H.close(out.cpu().numpy(), exp, rtol=1e-5, atol_scale=1e-6), (D, L, u)
-    op_engine.set_option("sls_u", 0)
-    if D == 32:
-        op_engine.set_option("sls_v_d32", 2)
-        out.fill_(float("nan"))
-        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
-        op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
-                      out.data_ptr(), exact_order=True)
-        op_engine.set_option("sls_v_d32", 4)
-        assert np.array_equal(out.cpu().numpy(), exp)
+    out.fill_(float("nan"))
+    torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
+    op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
+                  out.data_ptr(), exact_order=True)
+    assert np.array_equal(out.cpu().numpy(), exp), (D, L)
+    out.fill_(float("nan"))
+    torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
+    op_engine.sls(dW.data_ptr(), rows, D, di.data_ptr(), dl.data_ptr(), bags, idx.size,
+                  out.data_ptr(), exact_order=False)
+    assert H.close(out.cpu().numpy(), exp, rtol=1e-5, atol_scale=1e-6), (D, L)
 
 
 def test_sls_enforces_like_caffe2(op_engine):
@@ -1355,11 +1344,11 @@ def test_options_are_per_handle_and_engines_coexist():
         return e
     a, b = make(64, 8, 20), make(32, 4, 20)
     try:
-        defaults = {k: a.get_option(k) for k in ("sls_exact", "sls_flat", "sls_bpw", "sls_u", "mlp_stream",
+        defaults = {k: a.get_option(k) for k in ("sls_exact", "sls_flat", "sls_bpw", "sls_nt", "mlp_stream",
                                                  "mlp_gemm", "mlp_gemm_tile", "mlp_kc", "mlp_preload")}
         assert defaults == {k: b.get_option(k) for k in defaults}
         ref_a, ref_b = a.forward(0, 64), b.forward(0, 64)
-        changed = {"sls_exact": 1, "sls_flat": 0, "sls_bpw": 2, "sls_u": 8, "mlp_stream": 0, "mlp_gemm": 0,
+        changed = {"sls_exact": 1, "sls_flat": 0, "sls_bpw": 2, "sls_nt": 0, "mlp_stream": 0, "mlp_gemm": 0,
                    "mlp_gemm_tile": 11, "mlp_kc": 64, "mlp_preload": 1}
         for k, v in changed.items():
             a.set_option(k, v)
