@@ -434,35 +434,44 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     }
     if (q == NA + NB - 1) ++f_c;
   };
-  // SPREAD == 2 (the launcher takes it when K % 64 == 0 and every row offset fits 32 bits): the loop's
-  // requests in the scalar-base form -- global_load_dwordx4 v, v_off32, s[base] -- with the lane's byte offset
-  // of its row CONSTANT and the chunk's k0 carried by the SGPR base: no vector arithmetic per load at all
-  // (the vector form above spends two 64-bit adds, two selects and a nop on each of a round's eight loads).
-  // Requests past the last chunk re-read it (K % 64 == 0: every chunk whose MFMAs run exists).
+  // SPREAD == 2 (the launcher takes it when K % 32 == 0 and every row offset fits 32 bits): the loop's
+  // requests as BUFFER loads -- buffer_load_dwordx4 v, v_off32, s[rsrc:rsrc+3], s_k0 offen -- with the lane's
+  // byte offset of its row CONSTANT, the chunk's k0 in the scalar offset and the matrix base in the resource
+  // descriptor: no vector arithmetic per load at all (the flat form above spends two 64-bit adds, two selects
+  // and a nop on each of a round's eight loads).  Requests for chunks past K -- the pad chunk of an odd chunk
+  // count, whose MFMAs do run, and the ring's two trailing requests -- go through a descriptor with
+  // num_records = 0: every lane is out of range, the hardware returns zeros and touches no memory.
+  typedef int rsrc_t __attribute__((ext_vector_type(4)));
   uint32_t voA[NA], voB[NB];
-  const float* sbA[WTM];
-  const float* sbB = a.W;
+  rsrc_t rsA[WTM], rsB;
+  uint32_t s_k0 = 0;              // byte offset of the next request's chunk inside a row
+  uint32_t s_nrec = 0xfffff000u;  // ... and the descriptors' num_records for it (0 past K)
+  auto mk_rsrc = [](const float* p) {   // raw buffer (stride 0) over a workgroup-uniform base; words held in SGPRs
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    rsrc_t r = {(int)lo, (int)(hi & 0xffffu), (int)0xfffff000u, 0x00020000};
+    return r;
+  };
+  auto set_chunk = [&]() {
+    s_k0 = (uint32_t)f_c * (G3KC * 4u);
+    s_nrec = f_c < nch ? 0xfffff000u : 0u;
+  };
   if constexpr (SPREAD == 2) {
 #pragma unroll
     for (int j2 = 0; j2 < NA; ++j2) voA[j2] = (uint32_t)(offA[j2] * 4);
 #pragma unroll
     for (int j2 = 0; j2 < NB; ++j2) voB[j2] = (uint32_t)(offB[j2] * 4);
-  }
-  auto uni = [](const float* p) {   // a workgroup-uniform pointer, held in SGPRs
-    const uint64_t v = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
-  };
-  auto set_bases = [&]() {
-    const int kk = (f_c < nch ? f_c : nch - 1) * G3KC;
 #pragma unroll
-    for (int hm = 0; hm < WTM; ++hm) sbA[hm] = uni(xb[hm]) + kk;
-    sbB = uni(a.W) + kk;
-  };
+    for (int hm = 0; hm < WTM; ++hm)
+      rsA[hm] = mk_rsrc(xb[hm]);
+    rsB = mk_rsrc(a.W);
+  }
   auto fetch_one_s = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], int q) {
-    if (q < NA) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[q]) : "v"(voA[q]), "s"(sbA[q >> 1]));
-    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[q - NA]) : "v"(voB[q - NA]), "s"(sbB));
-    if (q == NA + NB - 1) { ++f_c; set_bases(); }
+    rsrc_t r = q < NA ? rsA[q >> 1] : rsB;
+    r[2] = (int)s_nrec;
+    if (q < NA) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[q]) : "v"(voA[q]), "s"(r), "s"(s_k0));
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[q - NA]) : "v"(voB[q - NA]), "s"(r), "s"(s_k0));
+    if (q == NA + NB - 1) { ++f_c; set_chunk(); }
   };
   auto stash_part = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int q) {
     if (q < 2 * NA) {
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   using NoneNewer = std::integral_constant<int, 0>;
   fetch(ra0, rb0);
   fetch(ra1, rb1);
-  if constexpr (SPREAD == 2) set_bases();
+  if constexpr (SPREAD == 2) set_chunk();
   gwait(ra0, rb0, AllNewer{});
 #pragma unroll
   for (int q = 0; q < NQ; ++q) stash_part(0, ra0, rb0, q);
@@ -621,7 +630,8 @@ hipError_t gemm_set_attrs() {
   }
   for (const void* k : {reinterpret_cast<const void*>(gemm32_kernel<2, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 2>),
                         reinterpret_cast<const void*>(gemm32_kernel<2, 1>), reinterpret_cast<const void*>(gemm32_kernel<1, 1>),
-                        reinterpret_cast<const void*>(gemm32_kernel<2, 2, 2>)}) {
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 2, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 2, 2>),
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 1, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 1, 2>)}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -672,17 +682,21 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
     // +4.5 % queries/s); smaller launches (W&D's 4 096 rows, the 1024 x 256 layer) stay with gemm_kernel, whose
     // 64 x 64 workgroups cover the chip where 128 x 128 ones would leave CUs idle (measured: W&D -5 % otherwise)
     else if (tune.gemm_tile == 0 && tune.gemm32 && b32(2, 2) >= tune.gemm32_blocks) w = 22;
+    // ... and MT-WnD and MLP-bound DLRM take the 64 x 128 form for them instead ("mlp_gemm32_small" 12, set per
+    // model by drs_create)
+    else if (tune.gemm_tile == 0 && tune.gemm32 && tune.gemm32_small) w = tune.gemm32_small;
     if (w) {
       const int wm_ = w / 10, wn_ = w % 10;
       const dim3 grid((unsigned)((M + 64 * wm_ - 1) / (64 * wm_)), (unsigned)((N + 64 * wn_ - 1) / (64 * wn_)));
       const size_t lds = sizeof(float) * 2 * (64 * wm_ + 64 * wn_) * G3LD;
-      // scalar-base requests when every chunk is whole and the row offsets fit 32 bits (gemm32_kernel, SPREAD == 2)
-      const bool sbase = !(K & 63) && (uint64_t)M * (uint64_t)ldx * 4u < (1ull << 32) && (uint64_t)N * (uint64_t)K * 4u < (1ull << 32);
-      if (w == 22 && sbase) hipLaunchKernelGGL((gemm32_kernel<2, 2, 2>), grid, dim3(256), lds, s, a, d, xs);
-      else if (w == 22) hipLaunchKernelGGL((gemm32_kernel<2, 2>), grid, dim3(256), lds, s, a, d, xs);
-      else if (w == 21) hipLaunchKernelGGL((gemm32_kernel<2, 1>), grid, dim3(256), lds, s, a, d, xs);
-      else if (w == 12) hipLaunchKernelGGL((gemm32_kernel<1, 2>), grid, dim3(256), lds, s, a, d, xs);
-      else hipLaunchKernelGGL((gemm32_kernel<1, 1>), grid, dim3(256), lds, s, a, d, xs);
+      // scalar-base requests when K is whole 32-k chunks and the row offsets fit 32 bits (gemm32_kernel, SPREAD == 2)
+      // (offsets + a row's bytes stay below the descriptors' num_records of 0xfffff000)
+      const bool sbase = !(K & 31) && ((uint64_t)M * (uint64_t)ldx + (uint64_t)K) * 4u < 0xfffff000ull && ((uint64_t)N + 1) * (uint64_t)K * 4u < 0xfffff000ull;
+#define DRS_G3LAUNCH(WM_, WN_)                                                                              \
+      if (sbase) hipLaunchKernelGGL((gemm32_kernel<WM_, WN_, 2>), grid, dim3(256), lds, s, a, d, xs);          \
+      else hipLaunchKernelGGL((gemm32_kernel<WM_, WN_>), grid, dim3(256), lds, s, a, d, xs);
+      if (w == 22) { DRS_G3LAUNCH(2, 2) } else if (w == 21) { DRS_G3LAUNCH(2, 1) } else if (w == 12) { DRS_G3LAUNCH(1, 2) } else { DRS_G3LAUNCH(1, 1) }
+#undef DRS_G3LAUNCH
       *err = hipGetLastError();
       return true;
     }
