@@ -96,6 +96,10 @@ MA="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --querie
 trace mlp_alone_stream4 $MA --set mlp_stream=4 --set mlp_stream_2cu=0
 trace mlp_alone_stream3 $MA --set mlp_stream=3 --set mlp_stream_waves=4
 trace mlp_alone_stream2 $MA --set mlp_stream=2 --set mlp_stream_2cu=0
+# (2 048 rows take stream4_kernel's 32-row form by default since round 4: the two lines above both ran it; the
+#  16-row forms alone, for the record)
+trace mlp_alone_stream4_16rows $MA --set mlp_stream=4 --set mlp_stream_2cu=0 --set mlp_rows32=0
+trace mlp_alone_stream3_16rows $MA --set mlp_stream=3 --set mlp_stream_waves=4 --set mlp_rows32=0
 pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $MA --set mlp_stream=4
 pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" $MA --set mlp_stream=4
 [ -f deeprecsys_amd/libdrs_hip_tl.so ] && TL_ROWS=40 run 200 python tools/mlp_timeline.py --coalesce 8 --set mlp_stream=4 --set shared_stream=1 > "$OUT/mlp_timeline_stream4.txt" 2>&1
