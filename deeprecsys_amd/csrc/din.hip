@@ -17,14 +17,17 @@ namespace drs {
 namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-// a table row piece: read once per launch -- non-temporal when nt ("sls_nt")
-__device__ __forceinline__ float4 ld4row(const float* p, int nt) {
+// a table row piece: read once per launch -- non-temporal when NT ("din_nt"; a compile-time property: a
+// run-time select between the two loads can be merged into one plain load, sls.hip)
+template <bool NT>
+__device__ __forceinline__ float4 ld4row(const float* p) {
   typedef float f4v __attribute__((ext_vector_type(4)));
-  if (nt) {
+  if constexpr (NT) {
     const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
     return make_float4(t.x, t.y, t.z, t.w);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
   }
-  return *reinterpret_cast<const float4*>(p);
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
   acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
@@ -159,7 +162,7 @@ __device__ __forceinline__ Owner owner_of(const SlsArgs& a, int smp) {
 // S x C row loads per lane are in flight (C = rows per bag covered per round: 3 when no bag of the
 // launch is longer, else 4); loads past a bag's end read the zero page instead of branching.
 // Bytes per sample: T bags of rows + indices in, 4 D floats out.
-template <int G, int S, int H, int C, int NW>
+template <int G, int S, int H, int C, int NW, bool NT>
 __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const float* __restrict__ packed,
                                                             int64_t stride, const float* __restrict__ zero,
                                                             float* __restrict__ R, int64_t ldr) {
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
         uint32_t rr = r[s][c];
         bad |= in && rr >= rows;
         rr = rr < rows ? rr : 0u;
-        v[s][c] = ld4row(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol, a.nt);
+        v[s][c] = ld4row<NT>(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
       }
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
         uint32_t rr = p.r[s][c];
         bad |= in && rr >= rows;
         rr = rr < rows ? rr : 0u;
-        v[s][c] = ld4row(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol, a.nt);
+        v[s][c] = ld4row<NT>(in ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
       }
     // ... then the next unit's indices and this unit's weights (this lane's pieces, kept across
     // the S samples)
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
           uint32_t rr = p.r[s][c];
           bad |= in && rr >= p.rows;
           rr = rr < p.rows ? rr : 0u;
-          v[uu][s][c] = ld4row(in ? p.W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol, a.nt);
+          v[uu][s][c] = ld4row<NT>(in ? p.W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
         }
     }
     // ... then the indices of the next iteration's units ...
@@ -514,8 +517,13 @@ constexpr int kWaves = 4;
 template <int G, int S, int H, int C, int NW>
 void launch_fused_k(const SlsArgs& a, const float* packed, int64_t stride, const float* zero, float* R, int64_t ldr,
                     unsigned grid, hipStream_t s, hipEvent_t stop) {
-  if (stop) hipExtLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW>), dim3(grid), dim3(64 * NW), 0, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
-  else hipLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW>), dim3(grid), dim3(64 * NW), 0, s, a, packed, stride, zero, R, ldr);
+  if (a.nt) {
+    if (stop) hipExtLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW, true>), dim3(grid), dim3(64 * NW), 0, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
+    else hipLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW, true>), dim3(grid), dim3(64 * NW), 0, s, a, packed, stride, zero, R, ldr);
+  } else {
+    if (stop) hipExtLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW, false>), dim3(grid), dim3(64 * NW), 0, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
+    else hipLaunchKernelGGL((din_fused_kernel<G, S, H, C, NW, false>), dim3(grid), dim3(64 * NW), 0, s, a, packed, stride, zero, R, ldr);
+  }
 }
 template <int G, int S, int H>
 void launch_fused_c(const FusedShape& f, const SlsArgs& a, const float* packed, int64_t stride, const float* zero,
@@ -797,6 +805,11 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
   // n % U of sample n / U, n = t * bs + b (the reference's Reshape, models/dien.py:316-320).
   // Fetched NB steps ahead into a register ring: a step lasts ~1 us, a load from the gather's
   // buffer (L2 / MALL / HBM) about as long -- one step of distance left the MFMAs waiting for it.
+  // (Round 4, read off the ISA: across the loop's back edge the compiler's counter model forgets the ring and
+  // every step waits vmcnt(7)..(0) -- for the set requested ONE step earlier: the effective lead is one step,
+  // not four.  An inline-asm ring with an explicit vmcnt(24) was tried: the compiler copies ring registers whose
+  // loads are still in flight (at the joins of the per-role branches and for operand placement), the recurrent
+  // state came out wrong; it needs the fixed-register convention of stream4_kernel and was not finished.)
   constexpr int NB = 4;
   float xr[NB][D / 4];
   auto fetch_x = [&](int t, float (&xb)[D / 4]) {

@@ -103,8 +103,10 @@ __device__ __forceinline__ float2 ld_nt(const float2* p) {
   return make_float2(t.x, t.y);
 }
 
-template <int G, int V, int U, bool EXACT>
-__global__ __launch_bounds__(64) void sls_kernel(SlsArgs a, int nt) {
+// NT: the hint must be a COMPILE-TIME property of the load: a run-time `nt ? ld_nt(p) : *p` is if-converted
+// into one plain load (the hint is metadata the merge drops): measured in the ISA, 0 of 5 / 2 of 14 loads kept it.
+template <int G, int V, int U, bool EXACT, bool NT = false>
+__global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
   using vec = typename Vec<V>::type;
   constexpr int NG = 64 / G;                  // lane groups per wave
   constexpr int BAGS = EXACT ? NG : 1;        // bags per wave
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a, int nt) {
         bad |= (pos + u * STEP < n) && (r[u] >= rows);
         r[u] = r[u] < rows ? r[u] : 0u;
         const vec* rp_ = reinterpret_cast<const vec*>(W) + (uint64_t)(r[u] * Dv);
-        ring[u] = nt ? ld_nt(rp_) : *rp_;
+        if constexpr (NT) ring[u] = ld_nt(rp_); else ring[u] = *rp_;
       }
     };
     auto consume = [&](const vec (&ring)[U], int pos) {
@@ -277,8 +279,8 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a, int nt) {
 // FLAT variant: fixed-length bags, G lanes per row (16 B per lane), NL loads per lane, BPW
 // bags (same sample, consecutive tables) per wave.  Requires L * BPW <= NL * (64 / G) and
 // T % BPW == 0 (checked by launch_sls).
-template <int G, int NL, int BPW>
-__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_order, int nt) {
+template <int G, int NL, int BPW, bool NT = false>
+__global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_order) {
   constexpr int NG = 64 / G;                       // lane groups = rows per load instruction
   // Work item w = (table group, sample), numbered TABLE-MAJOR; everything that depends only on
   // the wave (sample, query, tables) is scalar.  XCD-aware order (xcd_order != 0): workgroup id
@@ -390,12 +392,10 @@ __global__ __launch_bounds__(64) void sls_flat_kernel(SlsArgs a, int L, int xcd_
   // ---- phase 3: all row loads, back to back, nothing else in between --------------------------
   __builtin_amdgcn_sched_barrier(0);
   float4 v[NL];
-  if (nt) {
 #pragma unroll
-    for (int u = 0; u < NL; ++u) v[u] = ld_nt(reinterpret_cast<const float4*>(rp[u]));
-  } else {
-#pragma unroll
-    for (int u = 0; u < NL; ++u) v[u] = *reinterpret_cast<const float4*>(rp[u]);
+  for (int u = 0; u < NL; ++u) {
+    if constexpr (NT) v[u] = ld_nt(reinterpret_cast<const float4*>(rp[u]));
+    else v[u] = *reinterpret_cast<const float4*>(rp[u]);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -585,9 +585,11 @@ hipError_t launch_variant(const SlsArgs& a, int exact, int nt, hipStream_t s, hi
   if (exact) {
     constexpr int BAGS = 64 / G;
     const unsigned grid = (unsigned)((n_bags + BAGS - 1) / BAGS);
-    launch_k(sls_kernel<G, V, U, true>, grid, s, stop, a, nt);
+    launch_k(sls_kernel<G, V, U, true>, grid, s, stop, a);
+  } else if (nt) {
+    launch_k(sls_kernel<G, V, U, false, true>, (unsigned)n_bags, s, stop, a);
   } else {
-    launch_k(sls_kernel<G, V, U, false>, (unsigned)n_bags, s, stop, a, nt);
+    launch_k(sls_kernel<G, V, U, false>, (unsigned)n_bags, s, stop, a);
   }
   return hipGetLastError();
 }
@@ -631,7 +633,8 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
       if (a.T % c == 0 && c * L <= 5 * NG) { bpw = c; break; }
   }
   const int need = (bpw * L + NG - 1) / NG;
-  const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : 0;
+  // 30 loads per lane (RM2: L = 120, D = 64) only in the one-bag-per-wave form and only with "sls_flat30"
+  const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : (need <= 30 && tune.sls_flat30 && bpw == 1 && tune.sls_flat == 1) ? 30 : 0;
   if (!nl || (bpw > 1 && nl > 10)) return p;
   p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = 1;
   p.coal = bpw == 1 && tune.sls_flat == 1;      // "sls_flat" 2 forces the phased form
@@ -645,10 +648,18 @@ template <int G, int NL>
 hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
   if (p.coal && p.nt) launch_k(sls_flatc_kernel<G, NL, true>, grid, s, stop, a, p.L);
   else if (p.coal) launch_k(sls_flatc_kernel<G, NL, false>, grid, s, stop, a, p.L);
-  else if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd, p.nt);
+  else if constexpr (NL > 20) { return hipErrorInvalidValue; }
+  else if (p.nt) {
+    if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1, true>, grid, s, stop, a, p.L, p.xcd);
+    else if constexpr (NL <= 10) {
+      if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2, true>, grid, s, stop, a, p.L, p.xcd);
+      else launch_k(sls_flat_kernel<G, NL, 4, true>, grid, s, stop, a, p.L, p.xcd);
+    }
+  }
+  else if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1>, grid, s, stop, a, p.L, p.xcd);
   else if constexpr (NL <= 10) {
-    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd, p.nt);
-    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L, p.xcd, p.nt);
+    if (p.BPW == 2) launch_k(sls_flat_kernel<G, NL, 2>, grid, s, stop, a, p.L, p.xcd);
+    else launch_k(sls_flat_kernel<G, NL, 4>, grid, s, stop, a, p.L, p.xcd);
   }
   return hipGetLastError();
 }
@@ -657,6 +668,7 @@ hipError_t launch_flat_g(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStre
   switch (p.NL) {
     case 5: return launch_flat_b<G, 5>(a, p, grid, s, stop);
     case 10: return launch_flat_b<G, 10>(a, p, grid, s, stop);
+    case 30: return launch_flat_b<G, 30>(a, p, grid, s, stop);
     default: return launch_flat_b<G, 20>(a, p, grid, s, stop);
   }
 }

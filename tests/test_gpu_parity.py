@@ -908,7 +908,7 @@ def test_gather_on_synthetic_locality_traces_matches_oracle(tmp_path, unique):
 # ------------------------------------------------------------------------------------
 # flat gather variant (fixed-length bags: what every shipped reference config generates)
 @pytest.mark.parametrize("D,T,L", [(64, 8, 80), (32, 8, 80), (32, 12, 20), (32, 10, 20), (64, 4, 20), (128, 4, 7),
-                                   (64, 6, 2), (32, 4, 33), (48, 4, 20), (64, 3, 41)])
+                                   (64, 6, 2), (32, 4, 33), (48, 4, 20), (64, 3, 41), (64, 4, 120), (32, 4, 200)])
 def test_flat_gather_variants_match_oracle(D, T, L):
     """Every shape of the flat variant (1 / 2 / 4 bags per wave, 5 / 10 / 20 loads per lane, row
     widths 128 / 256 / 512 B, lengths that leave a ragged last load) against the oracle's
@@ -936,6 +936,7 @@ def test_flat_gather_variants_match_oracle(D, T, L):
             return np.concatenate([orc.sls(tables[t], idx[b][t][:bs].reshape(-1), np.full(bs, L, np.int32))
                                    for t in range(T)], axis=1)
         bpws = [w for w in (0, 1, 2, 4) if w == 0 or T % w == 0]
+        eng.set_option("sls_flat30", 1)     # (the 30-loads-per-lane form of the one-bag-per-wave kernel: RM2's 120 x 256-B bags)
         for bpw in bpws:
             eng.set_option("sls_bpw", bpw)
             for bs in (B, 1, 65):
