@@ -57,7 +57,6 @@ struct Tune {
   uint32_t w_zero_off = 0;          // ... whose first 64 floats are zeros (float offset of them)
   int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
-  int sls_flat30 = 0;            // ... one-bag-per-wave flat kernel also for bags of up to 30 loads per lane (RM2)
   int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
   int din_nt = 1;                // fused DIN launch: non-temporal row loads ("din_nt": +2.5 % queries/s, 0.527 -> 0.545 of peak)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)

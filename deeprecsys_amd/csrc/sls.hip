@@ -633,8 +633,9 @@ FlatPlan flat_plan(const SlsArgs& a, const Tune& tune) {
       if (a.T % c == 0 && c * L <= 5 * NG) { bpw = c; break; }
   }
   const int need = (bpw * L + NG - 1) / NG;
-  // 30 loads per lane (RM2: L = 120, D = 64) only in the one-bag-per-wave form and only with "sls_flat30"
-  const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : (need <= 30 && tune.sls_flat30 && bpw == 1 && tune.sls_flat == 1) ? 30 : 0;
+  // (30 loads per lane -- RM2: L = 120, D = 64 -- in the one-bag-per-wave form was measured in round 4: 497.6 us per
+  // launch against the ring walk's 497.4 us; not kept)
+  const int nl = need <= 5 ? 5 : need <= 10 ? 10 : need <= 20 ? 20 : 0;
   if (!nl || (bpw > 1 && nl > 10)) return p;
   p.ok = true; p.G = G; p.NL = nl; p.BPW = bpw; p.L = L; p.xcd = 1;
   p.coal = bpw == 1 && tune.sls_flat == 1;      // "sls_flat" 2 forces the phased form
@@ -648,7 +649,6 @@ template <int G, int NL>
 hipError_t launch_flat_b(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStream_t s, hipEvent_t stop) {
   if (p.coal && p.nt) launch_k(sls_flatc_kernel<G, NL, true>, grid, s, stop, a, p.L);
   else if (p.coal) launch_k(sls_flatc_kernel<G, NL, false>, grid, s, stop, a, p.L);
-  else if constexpr (NL > 20) { return hipErrorInvalidValue; }
   else if (p.nt) {
     if (p.BPW == 1) launch_k(sls_flat_kernel<G, NL, 1, true>, grid, s, stop, a, p.L, p.xcd);
     else if constexpr (NL <= 10) {
@@ -668,7 +668,6 @@ hipError_t launch_flat_g(const SlsArgs& a, const FlatPlan& p, dim3 grid, hipStre
   switch (p.NL) {
     case 5: return launch_flat_b<G, 5>(a, p, grid, s, stop);
     case 10: return launch_flat_b<G, 10>(a, p, grid, s, stop);
-    case 30: return launch_flat_b<G, 30>(a, p, grid, s, stop);
     default: return launch_flat_b<G, 20>(a, p, grid, s, stop);
   }
 }

@@ -936,7 +936,6 @@ def test_flat_gather_variants_match_oracle(D, T, L):
             return np.concatenate([orc.sls(tables[t], idx[b][t][:bs].reshape(-1), np.full(bs, L, np.int32))
                                    for t in range(T)], axis=1)
         bpws = [w for w in (0, 1, 2, 4) if w == 0 or T % w == 0]
-        eng.set_option("sls_flat30", 1)     # (the 30-loads-per-lane form of the one-bag-per-wave kernel: RM2's 120 x 256-B bags)
         for bpw in bpws:
             eng.set_option("sls_bpw", bpw)
             for bs in (B, 1, 65):
