@@ -809,7 +809,9 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
   // every step waits vmcnt(7)..(0) -- for the set requested ONE step earlier: the effective lead is one step,
   // not four.  An inline-asm ring with an explicit vmcnt(24) was tried: the compiler copies ring registers whose
   // loads are still in flight (at the joins of the per-role branches and for operand placement), the recurrent
-  // state came out wrong; it needs the fixed-register convention of stream4_kernel and was not finished.)
+  // state came out wrong.  A second form with the ring in fixed accumulation registers (loads and the input
+  // product's MFMAs through inline asm) ran no faster -- 165 k against 172 k queries/s -- before it was even
+  // right: the wait is not what bounds the step, the two waves of a SIMD already cover it for each other.)
   constexpr int NB = 4;
   float xr[NB][D / 4];
   auto fetch_x = [&](int t, float (&xb)[D / 4]) {
