@@ -386,7 +386,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   }
   for (int t = 0; t < T; ++t) {
     if (e->rows[t] <= 0) return bail(DRS_ERR_BAD_ARG, "table with no rows");
-    if (e->rows[t] * (int64_t)D >= (1ll << 32)) return bail(DRS_ERR_UNSUPPORTED, "rows*D must be < 2^32 per table");
+    if (e->rows[t] * (int64_t)D >= (1ll << 33)) return bail(DRS_ERR_UNSUPPORTED, "rows*D must be < 2^33 per table");   // (the HIP engine's limit: engine.hip)
   }
   auto init_mlp = [](Mlp& m) {
     const size_t n = m.ln.size() > 0 ? m.ln.size() - 1 : 0;
