@@ -25,6 +25,7 @@ Failure policy: any error is printed, the None sentinel is still sent so the
 orchestrator's join loop (DeepRecSys.py:89) cannot hang, and the process exits 1.
 """
 import queue as pyqueue
+import os
 import sys
 import time
 
@@ -125,13 +126,20 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
         responseQueue.put(None)
         sys.exit(1)
 
+    stats = {"pull": 0.0, "submit": 0.0, "collect": 0.0, "respond": 0.0, "sets": 0, "queries": 0} \
+        if os.environ.get("DRS_ENGINE_STATS") else None
+
     def finish_oldest():
         mid, slot, requests, start_time = inflight.pop(0)
+        t_c = time.perf_counter() if stats else 0.0
         try:
             outs = models[mid].net.collect_staged_multi([r.batch_size for r in requests], slot)
         except Exception as e:
             fail(requests, e)
         end_time = time.time()
+        if stats:
+            stats["collect"] += time.perf_counter() - t_c
+            t_c = time.perf_counter()
         free[mid].append(slot)
         # the responses of a launch set leave in one put (a list) unless --accel_req_batch 1 asks for the
         # reference's one packet per put; the packets themselves are the reference's (utils/packets.py:32-59)
@@ -141,6 +149,10 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
         else:
             for x in resp:
                 responseQueue.put(x)
+        if stats:
+            stats["respond"] += time.perf_counter() - t_c
+            stats["sets"] += 1
+            stats["queries"] += len(resp)
 
     def model_of(r):
         mid = int(getattr(r, "model_id", 0) or 0)
@@ -160,6 +172,7 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
 
     while not shutdown or inflight or backlog:
         # 1. pull: block only when the GPU has nothing to do; otherwise take what is already there
+        t_p = time.perf_counter() if stats else 0.0
         if not shutdown and len(backlog) < coalesce:
             debugPrint(args, "Accel", "Trying to pull request")
             try:
@@ -175,6 +188,9 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
             if backlog and backlog[-1] is None:
                 shutdown = True
                 backlog.pop()
+        if stats:
+            stats["pull"] += time.perf_counter() - t_p
+            t_p = time.perf_counter()
         # 2. submit: the oldest waiting request picks the model; same-model requests behind it join
         submitted = False
         if backlog:
@@ -203,9 +219,14 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
                     fail(requests, e)
                 inflight.append((mid, slot, requests, start_time))
                 submitted = True
+        if stats:
+            stats["submit"] += time.perf_counter() - t_p
         # 3. nothing new could be started: retire the oldest set in flight
         if not submitted and inflight:
             finish_oldest()
+    if stats:
+        print("[Accel %s] DRS_ENGINE_STATS %s" % (engine_id, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}))
+        sys.stdout.flush()
     debugPrint(args, "Accel", "Sending final done signal")
     responseQueue.put(None)
     if model is not None:

@@ -14,6 +14,7 @@ engine that finds a list serves its members like requests it found waiting.  The
 flushed before every sleep, so at low load every request still leaves at once.
 """
 import math
+import os
 import sys
 import time
 
@@ -104,10 +105,17 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
     req_batch = max(1, int(getattr(args, "accel_req_batch", 1)))
     pending = []                                   # accelerator requests not yet put
 
+    gstats = {"put": 0.0, "sleep": 0.0, "puts": 0} if os.environ.get("DRS_ENGINE_STATS") else None
+    t_gen0 = time.perf_counter()
+
     def flush():
         if pending:
+            t_f = time.perf_counter() if gstats else 0.0
             accelRequestQueue.put(pending[0] if len(pending) == 1 else list(pending))
             del pending[:]
+            if gstats:
+                gstats["put"] += time.perf_counter() - t_f
+                gstats["puts"] += 1
 
     epoch = exp_epochs = 0
     while tuning_batch_qps or (exp_epochs < args.nepochs):
@@ -161,6 +169,10 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
             exp_epochs += 1
 
     flush()
+    if gstats:
+        print("[LoadGen] DRS_ENGINE_STATS %s" % dict(gstats, total=round(time.perf_counter() - t_gen0, 4),
+                                                     accel_requests=accel_requests))
+        sys.stdout.flush()
     # one shutdown sentinel per engine (loadGenerator.py:208-214)
     for i in range(n_cpu):
         debugPrint(args, "Load Generator", "sending done signal to " + str(i) + " cpu engine")

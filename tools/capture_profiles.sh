@@ -131,6 +131,10 @@ for m in rm1 rm2 rm3 wnd ncf mtwnd din dien; do
 done
 # 7. the queue harness end to end: one accel engine, RMC1 and the W&D + NCF mixed stream
 run 300 python tools/serve.py --avg_arrival_rate 0.01 --nepochs 512 2>/dev/null | tail -1 > "$OUT/serve_rmc1.json"
+# (at 0.01 ms the load generator's integer-millisecond Poisson gaps -- 1 % of the queries wait 1 ms -- offer ~70-100 k
+#  queries/s; at 0.001 ms the engine process is what saturates)
+run 300 python tools/serve.py --avg_arrival_rate 0.001 --nepochs 512 2>/dev/null | tail -1 > "$OUT/serve_rmc1_rate0001.json"
+run 300 python tools/serve.py --mix --avg_arrival_rate 0.001 --nepochs 512 2>/dev/null | tail -1 > "$OUT/serve_mix_wnd_ncf_rate0001.json"
 run 300 python tools/serve.py --mix --avg_arrival_rate 0.01 --nepochs 512 2>/dev/null | tail -1 > "$OUT/serve_mix_wnd_ncf.json"
 # 8. the driver's multi-GPU launch line, on the one GPU of this box (RCCL communicator of size 1 is
 #    not created: world == 1), and the self-spawn path
