@@ -62,6 +62,7 @@ struct Tune {
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_stream_waves = 0, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, mlp_debug = 0;
   int gemm32 = 1;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel) ...
+  int gemm32_small_blocks = 0;   // ... when that shape gives at least this many workgroups
   int gemm32_small = 0;          // ... and smaller launches this gemm32 shape (0 = gemm_kernel | 22 | 21 | 12 | 11)
   int gemm32_blocks = 512;       // ... when its 128 x 128 workgroups number at least this many (two per CU)
   int64_t mlp_rows32 = 0;        // stream4_kernel: launches of at least this many rows take 32 rows per workgroup (0 = never)

@@ -1363,11 +1363,15 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     if (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1) { e->tune.mlp_stream = 4; e->tune.mlp_rows32 = 8192; }
     // wide layers as two 64 x 64 GEMM workgroups per CU (gemm.hip) where that measured faster
     e->tune.gemm_2cu = e->kind == DRS_MODEL_DLRM || e->kind == DRS_MODEL_WND;
-    // MT-WnD and MLP-bound DLRM: the wide layers that do not reach 512 tiles of 128 x 128 (MT-WnD's 1888 x 1024 and
-    // 1024 x 512 at 4 096 rows; RM3's 1024 x 256; the reference JSON's 2560 x 1024 at 4 096 rows) as gemm32_kernel's
-    // 64 x 128 workgroups instead of gemm_kernel (same session: MT-WnD 69.5 k -> 72.8 k queries/s, RM3 reference JSON
-    // 66.7 k -> 68.8 k, RM3 config 3 35.3 k -> 35.9 k; W&D 96.6 k -> 95.5 k: not there)
-    if (e->kind == DRS_MODEL_MTWND || (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1)) e->tune.gemm32_small = 12;
+    // Wide layers that do not reach 512 tiles of 128 x 128 take gemm32_kernel's 64 x 128 workgroups instead of
+    // gemm_kernel when those number at least "mlp_gemm32_small_blocks" (same session, two runs each; k queries/s):
+    //   MT-WnD (1888 x 1024 and 1024 x 512 at 4 096 rows: 512 and 256 tiles)   off 69.2 | >= 0: 71.8 | >= 512: 66.4
+    //   RM3 reference JSON (2560 x 1024, 1024 x 256 at 4 096 rows: 512, 128)   off 66.5 | >= 0: 68.1 | >= 512: 72.2
+    //   RM3 config 3 (1024 x 256 at 8 192 rows: 256 tiles)                     off 34.8 | >= 0: 35.2 | >= 512: 34.7
+    //   W&D (1376 x 1024 and 1024 x 512 at 4 096 rows: 512, 256)               off 96.0 | >= 0: 94.7 | >= 512: 97.0
+    // i.e. 256 for MT-WnD and MLP-bound DLRM (a 128-tile launch leaves half the chip idle), 512 for W&D.
+    if (e->kind == DRS_MODEL_MTWND || (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1)) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 256; }
+    if (e->kind == DRS_MODEL_WND) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 512; }
     // ... and the packed stream kernel in its 128-VGPR form, two workgroups per CU, for every model whose
     // MLP launches overlap each other (measured with 16-query sets: DIEN +8 %, W&D +5 %, MT-WnD +4 %, DIN +3 %,
     // RM3 +2 %; NCF -2 %: its launch is bound by its own 512 KB of outputs crossing PCIe)
@@ -2025,6 +2029,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214 || value == 322 || value == 321 || value == 312 || value == 311)) e->tune.gemm_tile = (int)value;
   else if (!strcmp(key, "mlp_gemm32") && (value == 0 || value == 1)) e->tune.gemm32 = (int)value;
   else if (!strcmp(key, "mlp_gemm32_small") && (value == 0 || value == 22 || value == 21 || value == 12 || value == 11)) e->tune.gemm32_small = (int)value;
+  else if (!strcmp(key, "mlp_gemm32_small_blocks") && value >= 0 && value <= 65536) e->tune.gemm32_small_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm32_blocks") && value >= 1 && value <= 65536) e->tune.gemm32_blocks = (int)value;
   else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
   else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
@@ -2080,7 +2085,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};

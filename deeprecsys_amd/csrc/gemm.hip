@@ -684,7 +684,8 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
     else if (tune.gemm_tile == 0 && tune.gemm32 && b32(2, 2) >= tune.gemm32_blocks) w = 22;
     // ... and MT-WnD and MLP-bound DLRM take the 64 x 128 form for them instead ("mlp_gemm32_small" 12, set per
     // model by drs_create)
-    else if (tune.gemm_tile == 0 && tune.gemm32 && tune.gemm32_small) w = tune.gemm32_small;
+    else if (tune.gemm_tile == 0 && tune.gemm32 && tune.gemm32_small &&
+             b32(tune.gemm32_small / 10, tune.gemm32_small % 10) >= tune.gemm32_small_blocks) w = tune.gemm32_small;
     if (w) {
       const int wm_ = w / 10, wn_ = w % 10;
       const dim3 grid((unsigned)((M + 64 * wm_ - 1) / (64 * wm_)), (unsigned)((N + 64 * wn_ - 1) / (64 * wn_)));

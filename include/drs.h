@@ -318,7 +318,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                "mlp_gemm32" 1 (default) | 0: wide layers whose 128 x 128 tiles number at least
  *                "mlp_gemm32_blocks" (default 512: two workgroups per CU) take the 2 x 2 form (RM3 config 3's
  *                2560 x 1024 layer at 8 192 rows), smaller launches keep gemm_kernel unless
- *                "mlp_gemm32_small" names a gemm32 shape for them (22 | 21 | 12 | 11; default 12 for MT-WnD and MLP-bound DLRM, else 0)
+ *                "mlp_gemm32_small" names a gemm32 shape for them (22 | 21 | 12 | 11) that gives at least
+ *                "mlp_gemm32_small_blocks" workgroups (defaults: 12 with 256 for MT-WnD and MLP-bound DLRM, 12 with 512 for
+ *                W&D, else 0)
  *   "mlp_stream" 2 (default for MLP-bound models) chains run as the weight-tile stream kernel
  *                (tiles of all layers requested six rounds ahead, inputs resident in LDS) when every
  *                K % 4 == 0 and the slabs fit, the tiles read from the layers' PACKED twins (MFMA
