@@ -916,7 +916,13 @@ def main():
                          # the launch structure keeps HBM, gaps and MLP phases included
                          "sustained_over_timed_region": {
                              "GBps": round(sls_bytes / elapsed / 1e9, 1),
-                             "frac": round(sls_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+                             "frac": round(sls_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                             # wall time per gather launch minus the launch itself: what separates
+                             # consecutive gathers on their stream when no profiler sits in the queue
+                             # (rocprofv3's kernel trace shows 4.8 us: its own packets)
+                             "launch_period_us": None if not sls_n else round(elapsed / sls_n * 1e6, 3),
+                             "gap_between_launches_us": None if not sls_n else round(
+                                 elapsed / sls_n * 1e6 - sls_ms / sls_n * 1e3, 3)},
                          "gather_alone": None if not alone_n else {
                              "what": "the same launch sets on ONE stream: the gather has the chip to itself",
                              "avg_launch_us": round(alone_ms / alone_n * 1e3, 3), "launches": alone_n,
