@@ -90,7 +90,8 @@ def parse(argv=None):
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
-    ap.add_argument("--slots", type=int, default=3)
+    ap.add_argument("--slots", type=int, default=0,
+                    help="launch sets in flight; 0 = what the engine asks for (drs_get_option preferred_slots: 3, NCF 6)")
     ap.add_argument("--coalesce", type=int, default=0,
                     help="queries per launch set (the engine coalesces requests that are already queued); "
                          "0 = the engine's own preference for the model: 12 for gather-bound DLRM, 16 for the MLP-bound "
@@ -703,7 +704,8 @@ def main():
             comm = None
             comm_note = "gloo (RCCL communicator did not come up: %s)" % (err or "on another rank")
             print("bench.py rank %d: %s" % (rank, comm_note), file=sys.stderr)
-    bs, nb, slots = opt.batch, opt.num_batches, opt.slots
+    bs, nb = opt.batch, opt.num_batches
+    slots = opt.slots if opt.slots > 0 else min(eng.num_slots, max(1, int(eng.get_option("preferred_slots"))))
     co = opt.coalesce if opt.coalesce > 0 else max(1, int(eng.get_option("preferred_coalesce")))
     qps_ = max(1, opt.queries_per_step)
     n_timed, n_warm = opt.steps * qps_, opt.warmup * qps_

@@ -2123,7 +2123,10 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
-      {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
+      {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},
+      // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
+      // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
+      {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};
   for (auto& kv : tab)

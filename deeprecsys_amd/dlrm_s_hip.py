@@ -73,6 +73,12 @@ class _HipNet(object):
         return [_init_table(int(n), m) for n in ln_emb]
 
     # -- device -------------------------------------------------------------------
+    def _num_slots(self):
+        """--accel_slots n launch sets in flight; 0 (default): what the engine asks for (drs_get_option
+        "preferred_slots": 3 -- gather | MLP | enqueue --, 6 for NCF, whose sets are one short latency-bound launch)."""
+        req = int(getattr(self.args, "accel_slots", 0) or 0)
+        return req if req > 0 else (6 if self.kind == N.MODEL_NCF else 3)
+
     def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top, ln_task=None, num_tasks=0):
         a = self.args
         n_stage = max(int(getattr(a, "num_batches", 0)), 1)
@@ -82,8 +88,11 @@ class _HipNet(object):
                        sigmoid_top=sigmoid_top, max_batch=max_batch,
                        max_lookups=max(int(a.num_indices_per_lookup), 1),
                        num_staged_batches=n_stage,
-                       num_slots=max(int(getattr(a, "accel_slots", 3)), 1), device=self._device,
+                       num_slots=self._num_slots(), device=self._device,
                        ln_task=ln_task, num_tasks=num_tasks)
+        if int(getattr(a, "accel_slots", 0) or 0) <= 0 and eng.get_option("preferred_slots") != eng.num_slots:
+            raise RuntimeError("accel_slots 0: created %d slots, the engine prefers %d" % (
+                eng.num_slots, eng.get_option("preferred_slots")))
         # A/B aid for runs through the queue harness: DRS_ENGINE_OPTS="key=value,key=value"
         import os
         for kv in filter(None, os.environ.get("DRS_ENGINE_OPTS", "").split(",")):

@@ -267,12 +267,15 @@ def test_cpu_abi_answers_the_engines_launch_set_preference(cpu_abi):
     """the CPU restatement used to answer 8 for every model, so the host code ran with other
     launch-set sizes off-GPU than on it.  It now restates the engine's rule (csrc/engine.hip): 12 for
     gather-bound DLRM, 16 where MLP launches overlap each other, 8 otherwise."""
-    def pref(kind, rows, D, bot, top, L, **kw):
+    def pref(kind, rows, D, bot, top, L, key="preferred_coalesce", **kw):
         e = N.Engine(kind, rows, D, bot, top, max_batch=16, max_lookups=L, num_staged_batches=1, num_slots=3, **kw)
         try:
-            return e.get_option("preferred_coalesce")
+            return e.get_option(key)
         finally:
             e.close()
+    # ... and launch sets in flight: 3, NCF 6
+    assert pref(N.MODEL_DLRM, [1000] * 8, 64, [128, 64, 64], [576, 256, 64, 1], 80, key="preferred_slots", sigmoid_top=3) == 3
+    assert pref(N.MODEL_NCF, [1000, 1000, 200, 200], 64, [512], [128, 256, 128, 64, 64], 1, key="preferred_slots") == 6
     assert pref(N.MODEL_DLRM, [1000] * 8, 64, [128, 64, 64], [576, 256, 64, 1], 80, sigmoid_top=3) == 12        # RMC1
     assert pref(N.MODEL_DLRM, [1000] * 12, 32, [2560, 1024, 256, 32], [416, 512, 256, 1], 20, sigmoid_top=3) == 16   # RM3
     assert pref(N.MODEL_WND, [1000] * 27, 32, [512], [1376, 1024, 512, 256, 1], 1, sigmoid_top=4) == 16
