@@ -56,8 +56,10 @@ struct GArgs {
 // on them before signal_done's own drain; SC1 = write-through (outputs the hand-off reads back).
 template <bool SC1>
 __device__ __forceinline__ void gst4(float* p, const f32x4 v) {
-  if (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  // (s_nop 1: the two wait states gfx940+ wants before a VALU may overwrite the data registers of a store of
+  // more than 64 bits -- the compiler's hazard recogniser does not look inside the statement)
+  if (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 template <bool SC1>
 __device__ __forceinline__ void gst1(float* p, const float v) {

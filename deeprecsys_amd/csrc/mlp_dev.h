@@ -105,7 +105,10 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
   // last workgroup of the launch: everything the query produced is visible to it.  Stream the
   // outputs, the device error word and the gather's clock span to host-mapped pinned memory in
   // ONE batch of write-through system-scope stores, wait once for them, then publish the flag.
-  // (16 bytes per lane and 4 loads in flight: NCF hands 512 KB per launch set over this way.)
+  // (16 bytes per lane and 4 loads in flight: NCF hands 1 MB per 16-query launch set over this way.  Round 4 tried
+  // 12 loads in flight, and the last arriver of each of 16 runs of workgroups copying its run's rows so that 16 CUs
+  // write to the host at once: neither moved NCF -- 404-424 k queries/s with three sets in flight either way, 558 k
+  // with the copy left out: the 27-31 GB/s of 64-byte PCIe writes are the bound, not who issues them.)
   // Round trips on this path: [loads of outputs | error word | span partials, all in flight
   // together] -> [host stores, one PCIe acknowledgement wait] -> flag.  The first version loaded
   // the error word and stored it only after the outputs had been acknowledged: two more
@@ -141,7 +144,11 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
         for (int j = 0; j < 4; ++j) {
           const unsigned i = i0 + threadIdx.x + j * blockDim.x;
           float* q = d.host_out + 4 * (size_t)i;
-          if (i < n4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v[j]) : "memory");   // system scope, write-through
+          // system scope, write-through.  (s_nop 1: gfx940+ wants TWO wait states between a store of more than 64 bits
+          // and a VALU write of its data registers, and the compiler's hazard recogniser does not look inside the
+          // statement.  A 12-deep version of this loop had its batch registers reused one instruction after the
+          // store: sporadic wrong first words of a float4 on the host -- round 4, found by the MT-WnD parity test.)
+          if (i < n4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v[j]) : "memory");
         }
       }
       done4 = n4 << 2;
