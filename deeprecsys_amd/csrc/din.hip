@@ -10,8 +10,10 @@
 // row gather, so the default launch FUSES gather, units and Concat: the [rows, T * D] pooled
 // tensor (32 KB per sample, a third of the gathered bytes) is never written or re-read.
 #include <hip/hip_ext.h>
+#include <string.h>
 
 #include "drs_internal.h"
+#include "mlp_dev.h"
 
 namespace drs {
 namespace {
@@ -736,7 +738,8 @@ struct DienW { const float* w[8]; };   // {i2h_w, i2h_b, gates_t_w, gates_t_b} x
 template <int D, int H, int SPLIT>
 __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma_kernel(const float* __restrict__ T, int64_t ldt,
                                                                                      QTable q, int Tn, DienW W,
-                                                                                     float* __restrict__ R, int64_t ldr) {
+                                                                                     float* __restrict__ R, int64_t ldr,
+                                                                                     DienTop top, Done done) {
   static_assert(D % 4 == 0 && H % 16 == 0 && H <= 64, "16 hidden units per wave");
   // SPLIT = 1: 2 x H / 16 waves; the first H / 16 run layer 1 (of step t + 1), the others layer 2
   // (of step t) -- the two layers of an iteration are independent, so the per-step critical path of
@@ -746,6 +749,7 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
   // measured as well: 130 us on half as many CUs instead of 76 us, no gain in queries/s.)
   constexpr int NW = H / 16, NT = 64 * (SPLIT ? 2 : 1) * NW;
   __shared__ float s0[2][H][16], s1[2][H][16];
+  extern __shared__ __attribute__((aligned(16))) float dien_top_lds[];   // fused top MLP: 2 x [kmax][16] (none otherwise)
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW, role = (threadIdx.x >> 6) / NW;
   const bool do1 = !SPLIT || role == 0, do2 = !SPLIT || role == 1;   // (wave-uniform)
   const int r = lane & 15, g = lane >> 4;
@@ -926,25 +930,106 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
       }
     }
     const int tab = c < D ? 0 : c < 2 * D ? Tn - 2 : Tn - 1;
-    R[(int64_t)(vi + bi) * ldr + H + c] = T[(int64_t)(vi + bi) * ldt + (int64_t)tab * D + c % D];
+    const float ev = T[(int64_t)(vi + bi) * ldt + (int64_t)tab * D + c % D];
+    R[(int64_t)(vi + bi) * ldr + H + c] = ev;
+    if (top.n > 0) dien_top_lds[(H + c) * 16 + i / (3 * D)] = ev;
   }
+  if (top.n <= 0) return;                              // (uniform: a kernel argument)
+
+  // ---- the top MLP of the workgroup's 16 samples, in the same launch (round 4) ----------------------------
+  // Every CU holds two workgroups of this model at a time (the recurrence: 2 x 120 registers per SIMD; the
+  // stream kernel that ran the top MLP: 256), so a set cost each CU t_rnn + t_top of workgroup time at two
+  // in flight -- and the top launch, 19 us alone, took 60-110 us beside recurrences.  Here its three small
+  // layers (160-200-80-2: 0.1 MFLOP per sample) follow the last step as MFMA chains of the same form:
+  // A = 16 rows of W [N, K] (lane (r, g): W[16 t + r][4 s + g], every 64-k chunk of them requested up front),
+  // B = the layer's input [k][sample] in LDS, D[m = unit 4 g + qd][n = sample r]; k ascending from a zero
+  // accumulator (through the zero-padded end of the last 64-k chunk, like theirs), bias, activation: the bits of
+  // the stream kernels' chains (mlp.hip).  Tiles of 16 units go
+  // round the workgroup's waves; the last layer stores to the output buffer and the workgroup signs off the
+  // launch set itself (signal_done).
+  {
+    constexpr int NWV = NT / 64;
+    const int wv = threadIdx.x >> 6;
+    float* in = dien_top_lds;
+    float* nxt = dien_top_lds + top.kmax * 16;           // (kmax: a multiple of 64)
+    const int lastb = (U - 1) & 1;
+    for (int i = threadIdx.x; i < H * 16; i += NT) in[i] = (&s1[lastb][0][0])[i];
+    // k beyond a layer's K up to the next multiple of 64 meets zero weights in the twin: the inputs there must
+    // be finite -- zeros
+    for (int i = (H + 3 * D) * 16 + threadIdx.x; i < ((top.K[0] + 63) & ~63) * 16; i += NT) in[i] = 0.f;
+    __syncthreads();
+    for (int l = 0; l < top.n; ++l) {
+      const int K = top.K[l], N = top.N[l], nch = (K + 63) >> 6;
+      const bool fin = l + 1 == top.n;
+      if (!fin)
+        for (int i = N * 16 + threadIdx.x; i < ((N + 63) & ~63) * 16; i += NT) nxt[i] = 0.f;
+      for (int t = wv; 16 * t < N; t += NWV) {
+        // A operands from the layer's PACKED twin (mlp.hip pack_stream_kernel: per 128 units and 64 k a block of
+        // 8192 floats, 1024 per 16 units, float4 q of lane (r, g) = W[unit r][64 c + 16 q + 4 j + g], j = 0..3 --
+        // element j is the operand of MFMA step 16 c + 4 q + j): one coalesced 1-KB request per four steps.
+        // (The first version read W [N, K] itself, a dword per lane and step: 16 cache lines per request, and
+        // the launch took 100 us alone against 69 + 22 for the two it replaced.)
+        const float* wp = top.Wp[l] + ((size_t)(t >> 3) * nch * 8192 + (t & 7) * 1024 + lane * 4);
+        f32x4_ wq[4][4];
+        float bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nch) {                                  // (uniform)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) wq[c][qq] = *reinterpret_cast<const f32x4_*>(wp + c * 8192 + qq * 256);
+          }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bv[qd] = top.b[l][min(16 * t + 4 * g + qd, N - 1)];
+        f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);               // (all of the tile's requests before its first MFMA)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nch) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c][qq][j], in[(64 * c + 16 * qq + 4 * j + g) * 16 + r], acc, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);         // (keeps the LDS operands next to their MFMAs)
+            }
+          }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int unit = 16 * t + 4 * g + qd;
+          if (unit < N) {
+            const float v = act_apply(acc[qd] + bv[qd], top.act[l]);
+            if (!fin) nxt[unit * 16 + r] = v;
+            else if (live) {
+              float* dst = top.out + (int64_t)(v0 + b) * top.ldo + unit;
+              if (top.sc1) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else *dst = v;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      float* sw = in; in = nxt; nxt = sw;
+    }
+  }
+  signal_done(done, gridDim.x, dien_top_lds);
 }
 
 template <int D>
 bool launch_dien_mfma_h(const float* T, int64_t ldt, const QTable& q, int Tn, int H, const DienW& W, float* R,
-                        int64_t ldr, unsigned grid, int split, hipStream_t s) {
+                        int64_t ldr, unsigned grid, int split, hipStream_t s, const DienTop& top, const Done& done) {
+  const size_t lds = top.n > 0 ? sizeof(float) * 2 * 16 * (size_t)top.kmax : 0;
   if (split) {
     switch (H) {
-      case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 1>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-      case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 1>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-      case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 1>), dim3(grid), dim3(512), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+      case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 1>), dim3(grid), dim3(128), lds, s, T, ldt, q, Tn, W, R, ldr, top, done); return true;
+      case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 1>), dim3(grid), dim3(256), lds, s, T, ldt, q, Tn, W, R, ldr, top, done); return true;
+      case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 1>), dim3(grid), dim3(512), lds, s, T, ldt, q, Tn, W, R, ldr, top, done); return true;
       default: return false;
     }
   }
   switch (H) {
-    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 0>), dim3(grid), dim3(64), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 0>), dim3(grid), dim3(128), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
-    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 0>), dim3(grid), dim3(256), 0, s, T, ldt, q, Tn, W, R, ldr); return true;
+    case 16: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 16, 0>), dim3(grid), dim3(64), lds, s, T, ldt, q, Tn, W, R, ldr, top, done); return true;
+    case 32: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 32, 0>), dim3(grid), dim3(128), lds, s, T, ldt, q, Tn, W, R, ldr, top, done); return true;
+    case 64: hipLaunchKernelGGL((dien_rnn_mfma_kernel<D, 64, 0>), dim3(grid), dim3(256), lds, s, T, ldt, q, Tn, W, R, ldr, top, done); return true;
     default: return false;
   }
 }
@@ -972,19 +1057,42 @@ hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int
   return hipGetLastError();
 }
 
+// The top MLP rides in the recurrence's launch when its layers fit the in-kernel form: at most 4 of them, every
+// input width a multiple of 4 (whole MFMA steps) and <= 256 (a tile's A operands live in 64 registers), the two
+// activation buffers inside the default 64 KB of LDS next to the state buffers.
+bool dien_top_fusable(int32_t n_layers, const int32_t* widths, int32_t H) {
+  if (n_layers < 1 || n_layers > 4 || H % 16 != 0) return false;
+  for (int l = 0; l < n_layers; ++l)
+    if (widths[l] <= 0 || widths[l] > 256 || (widths[l] & 3) || widths[l + 1] <= 0) return false;
+  return sizeof(float) * (2 * 16 * (size_t)dien_top_kmax(n_layers, widths) + 4 * 16 * (size_t)H) <= 60 * 1024;
+}
+// rows of one LDS activation buffer: the widest layer input, up to the end of its last 64-k chunk
+int32_t dien_top_kmax(int32_t n_layers, const int32_t* widths) {
+  int kmax = 0;
+  for (int l = 0; l < n_layers; ++l) kmax = widths[l] > kmax ? widths[l] : kmax;
+  return (kmax + 63) & ~63;
+}
+
 hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t Tn, int32_t D, int32_t H,
                            const float* packed, const float* const* w, int mfma, float* R, int64_t ldr,
-                           hipStream_t s) {
+                           hipStream_t s, const DienTop* top, const Done* done) {
   const int64_t n = q.cum[q.n_q];
   if (n <= 0) return hipSuccess;
   bool ok = false;
+  if (top && top->n > 0 && !(mfma && H % 16 == 0)) return hipErrorInvalidValue;   // (the engine asks dien_top_fusable first)
   if (mfma && H % 16 == 0) {
     DienW W;
     for (int i = 0; i < 8; ++i) W.w[i] = w[i];
+    DienTop tp;
+    memset(&tp, 0, sizeof tp);
+    if (top) tp = *top;
+    Done dn;
+    memset(&dn, 0, sizeof dn);
+    if (done && tp.n > 0) dn = *done;
     const unsigned g16 = (unsigned)((n + 15) / 16);
-    if (D == 16) ok = launch_dien_mfma_h<16>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s);
-    else if (D == 32) ok = launch_dien_mfma_h<32>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s);
-    else if (D == 64) ok = launch_dien_mfma_h<64>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s);
+    if (D == 16) ok = launch_dien_mfma_h<16>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s, tp, dn);
+    else if (D == 32) ok = launch_dien_mfma_h<32>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s, tp, dn);
+    else if (D == 64) ok = launch_dien_mfma_h<64>(T, ldt, q, Tn, H, W, R, ldr, g16, mfma == 2, s, tp, dn);
     return ok ? hipGetLastError() : hipErrorInvalidValue;
   }
   const unsigned grid = (unsigned)((n + 3) / 4);

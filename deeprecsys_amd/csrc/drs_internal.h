@@ -210,9 +210,22 @@ int64_t dien_packed_floats(int32_t D, int32_t H);
 hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int32_t H, hipStream_t stream);
 // (mfma: the 16-samples-per-workgroup matrix-core form when H % 16 == 0, reading the row-major
 // weights w[8] (host array of device pointers); else one wave per sample on `packed`; same bits)
+// top (optional, matrix-core form only): the model's top MLP over R's rows in the same launch -- n <= 4 layers,
+// every K a multiple of 4 and <= 256 (dien_top_fusable) -- written to out [rows, ldo]; `done`
+// then makes the launch sign off the launch set (mlp_dev.h signal_done).  Same bits as the stream kernels' chains.
+struct DienTop {
+  int32_t n, kmax, sc1, pad_;      // layers (0: none) | rows of an LDS activation buffer (dien_top_kmax) | write-through output stores
+  const float* Wp[4];              // the layers' PACKED twins (mlp.hip pack_stream_kernel; W + roundup64(K N) in the arena)
+  const float* b[4];
+  int32_t K[4], N[4], act[4];
+  float* out;
+  int64_t ldo;
+};
+bool dien_top_fusable(int32_t n_layers, const int32_t* widths /* n_layers + 1 */, int32_t H);
+int32_t dien_top_kmax(int32_t n_layers, const int32_t* widths);
 hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t Tn, int32_t D, int32_t H,
                            const float* packed, const float* const* w, int mfma, float* R, int64_t ldr,
-                           hipStream_t stream);
+                           hipStream_t stream, const DienTop* top = nullptr, const Done* done = nullptr);
 
 // Weights of one FC layer (W [N, K] row-major) in the stream kernel's MFMA-operand order (mlp.hip):
 // per 128-column pass and 64-k chunk, per wave (16 columns), four float4 per lane.

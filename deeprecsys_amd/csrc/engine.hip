@@ -167,6 +167,7 @@ struct drs_engine {
   const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2) ...
   float* d_att_packed = nullptr; // ... and the units' weights packed for the DIN kernels (din.hip)
   bool att_dirty = true;         // a unit's weights changed since the last pack
+  int dien_fuse_top = 1;         // DIEN: the top MLP inside the recurrence's launch when it fits (din.hip dien_top_fusable)
   int dien_mfma = 2;             // DIEN recurrence on the matrix cores, 16 samples per workgroup: 2 = one wave set per layer | 1 = every wave both layers | 0 one wave per sample (VALU)
   int din_fused = 1;             // gather + attention units + Concat in one launch (default mode)
   std::vector<Mlp> rnn;          // DIEN: the two BasicRNN layers, each {i2h, gates_t}; packed into d_att_packed
@@ -805,9 +806,25 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       rw[4 * l + 0] = e->rnn[l].layers[0].W; rw[4 * l + 1] = e->rnn[l].layers[0].b;
       rw[4 * l + 2] = e->rnn[l].layers[1].W; rw[4 * l + 3] = e->rnn[l].layers[1].b;
     }
-    HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, e->rnn[0].ln[1], e->d_att_packed, rw, e->dien_mfma, s.R,
-                               e->ldR, s.stream));
-    if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
+    // the top MLP in the recurrence's own launch when it fits ("dien_fuse_top", default on): one workgroup per 16
+    // samples instead of two, one launch less per set
+    const int Hh = e->rnn[0].ln[1];
+    DienTop tp;
+    memset(&tp, 0, sizeof tp);
+    const int nt = (int)e->top.layers.size();
+    if (e->dien_fuse_top && e->dien_mfma && Hh % 16 == 0 && nt >= 1 && nt <= 4 && e->top.layers[0].packed &&
+        dien_top_fusable(nt, e->top.ln.data(), Hh) && e->top.ln[0] == Hh + 3 * e->D) {
+      tp.n = nt; tp.sc1 = dp ? 1 : 0; tp.out = out; tp.ldo = e->n_out;
+      for (int l = 0; l < nt; ++l) {
+        const Layer& L = e->top.layers[l];
+        tp.Wp[l] = L.W + ((size_t)L.m * L.n + 63) / 64 * 64; tp.b[l] = L.b;
+        tp.K[l] = e->top.ln[l]; tp.N[l] = e->top.ln[l + 1]; tp.act[l] = act_of(e->top, l);
+      }
+      tp.kmax = dien_top_kmax(nt, e->top.ln.data());
+    }
+    HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, Hh, e->d_att_packed, rw, e->dien_mfma, s.R,
+                               e->ldR, s.stream, tp.n ? &tp : nullptr, dp));
+    if (!tp.n && (rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
   } else if (e->kind == DRS_MODEL_DIN) {
     // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
     HIP_TRY(e, join());
@@ -2029,6 +2046,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_flat") && value >= 0 && value <= 2) e->tune.sls_flat = (int)value;
   else if (!strcmp(key, "din_fused")) e->din_fused = value ? 1 : 0;
   else if (!strcmp(key, "dien_mfma") && value >= 0 && value <= 2) e->dien_mfma = (int)value;
+  else if (!strcmp(key, "dien_fuse_top") && (value == 0 || value == 1)) e->dien_fuse_top = (int)value;
   else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
   else if (!strcmp(key, "sls_nt")) e->tune.sls_nt = value ? 1 : 0;
   else if (!strcmp(key, "din_nt")) e->tune.din_nt = value ? 1 : 0;
@@ -2120,7 +2138,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},

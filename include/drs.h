@@ -291,6 +291,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                matrix cores, 16 samples per workgroup, one set of waves per layer (layer 2 a step behind
  *                layer 1) | 1 every wave runs both layers of its 16 hidden units | 0 one wave per sample on
  *                the VALU.  Same bits in all three.
+ *   "dien_fuse_top" 1 (default) | 0: DRS_MODEL_DIEN, matrix-core recurrence: the top MLP of a workgroup's 16
+ *                samples runs in the recurrence's own launch when it fits (<= 4 layers, every input width a
+ *                multiple of 4 and <= 256), which then signs off the launch set; 0: a stream-kernel launch
+ *                of its own behind it.  Same bits.
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
  *   "sls_nt"     1 (default) | 0: the many-rows-per-bag gather kernels read table rows with non-temporal

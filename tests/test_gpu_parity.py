@@ -613,13 +613,16 @@ def test_dien_recurrent_layers_match_oracle(D, Hs, U, init):
                 assert H.close(got, exp, rtol=max(rtol, H.RTOL_OUT), atol=atol), (b, bs, np.abs(got - exp).max())
                 ref[(b, bs)] = got
         jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1)]
-        for mfma in (1, 2, 0):
+        assert eng.get_option("dien_fuse_top") == 1
+        for mfma, fuse in ((1, 1), (2, 0), (2, 1), (1, 0), (0, 1)):
             # the matrix-core form (16 samples per workgroup; hidden sizes that are multiples of 16)
-            # and the one-wave-per-sample form run the same fma chains: the same bits
+            # and the one-wave-per-sample form run the same fma chains: the same bits -- with the top MLP
+            # inside the recurrence's launch (its default when it fits) or in a launch of its own behind it
             eng.set_option("dien_mfma", mfma)
+            eng.set_option("dien_fuse_top", fuse)
             outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
             for (b, bs), o in zip(jobs, outs):
-                assert np.array_equal(o, ref[(b, bs)]), (mfma, b, bs)
+                assert np.array_equal(o, ref[(b, bs)]), (mfma, fuse, b, bs)
     finally:
         eng.close()
 
