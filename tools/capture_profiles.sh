@@ -125,6 +125,9 @@ run 400 python bench.py --workload din --steps 5 --warmup 2 --queries_per_step 4
 run 400 python bench.py --workload dien --steps 5 --warmup 2 --queries_per_step 4096 --cpu_seconds 6 > "$OUT/bench_dien_cpu.json" 2>/dev/null
 run 300 python bench.py --workload din --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048 --set din_fused=0 > "$OUT/bench_din_two_launch.json" 2>/dev/null
 run 300 python bench.py --workload dien --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 2048 --set dien_mfma=0 > "$OUT/bench_dien_valu.json" 2>/dev/null
+# (round 4: the top MLP in a launch of its own behind the recurrence, as before; NCF with three launch sets in flight)
+run 300 python bench.py --workload dien --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 --set dien_fuse_top=0 > "$OUT/bench_dien_two_launch.json" 2>/dev/null
+run 300 python bench.py --workload ncf --slots 3 --no_cpu_baseline --timed_only --steps 3 --warmup 1 --queries_per_step 4096 > "$OUT/bench_ncf_slots3.json" 2>/dev/null
 # 6. reference-format characterisation tables (accelerator/predict_execution.py "***" files)
 for m in rm1 rm2 rm3 wnd ncf mtwnd din dien; do
   run 300 python tools/characterize.py --model $m --out "$OUT/accelerator_mi355x/" > "$OUT/characterize_$m.txt" 2>&1
