@@ -196,6 +196,11 @@ struct drs_engine {
   // an event per change of stream orders a set's launches.  0: a set's MLP launches all on its own stream.
   int mlp_layout = 0;
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
+  // launch sets whose outputs are at least this many bytes (0: never) leave by a copy-engine transfer queued behind the
+  // last kernel + a stream-ordered flag write, instead of the last workgroup's in-kernel copy: MT-WnD's 2 MB per
+  // 16-query set (72.7 k -> 75.2 k queries/s, what leaving the copy out altogether gives); NCF's 1 MB sets lose with it
+  // (two more HIP calls per 30-us set: 472 k -> 398 k at six sets in flight), hence the threshold
+  int64_t out_dma = 1536 * 1024;
   int zero_copy_inputs = 1;         // drs_forward_inputs: 0 per-array copies | 1 read in place over PCIe | 2 one DMA copy | 3 by size
   int64_t mlp_wide_kn = 256 * 1024;   // K*N from which a layer gets its own 2-D launch (RM3's 1024x256 included)
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
@@ -794,6 +799,10 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   float* out = s.d_out;          // kernels store to the device buffer; see Done::host_out
   done.dev_out = s.d_out; done.host_out = reinterpret_cast<float*>(s.dm_out + kOutOffset);
   done.out_words = (uint32_t)(Mv * e->n_out);
+  // "out_dma": the outputs leave through a copy-engine transfer queued behind the last kernel, and the flag through
+  // a stream-ordered 32-bit write behind that -- the last workgroup then hands over the error word only
+  const bool out_dma = e->zero_copy && e->out_dma && (int64_t)done.out_words * 4 >= e->out_dma;
+  if (out_dma) { done.out_words = 0; done.host_flag = nullptr; }
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   xs.q = q;
@@ -898,6 +907,11 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     HIP_TRY(e, hipMemcpyAsync(s.h_out + kOutOffset, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
                               hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(e, hipMemcpyAsync(s.h_out + 1, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  }
+  if (out_dma) {
+    HIP_TRY(e, hipMemcpyAsync(s.h_out + kOutOffset, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
+                              hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(e, hipStreamWriteValue32(s.stream, s.dm_out, s.seq, 0));
   }
   s.polled = e->zero_copy != 0;
   return DRS_OK;
@@ -2090,6 +2104,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
   else if (!strcmp(key, "mlp_rows32") && value >= 0) e->tune.mlp_rows32 = value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
+  else if (!strcmp(key, "out_dma") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->out_dma = value; }
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
   return DRS_OK;
@@ -2146,7 +2161,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
-      {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"device", e->device}};
+      {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);

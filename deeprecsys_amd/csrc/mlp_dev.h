@@ -186,7 +186,7 @@ __device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, voi
   // L2 write-back fence (G16 R1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0 && d.host_flag)              // (null: the flag follows a DMA copy of the outputs, engine "out_dma")
     __hip_atomic_store(d.host_flag, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -393,6 +393,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
  *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
  *                MLP launches of consecutive small sets overlap each other
+ *   "out_dma"    bytes (default 1 572 864; 0 = never): with "zero_copy" 1, launch sets with at least this many bytes of
+ *                outputs hand them over by a copy-engine transfer queued behind the last kernel and a
+ *                stream-ordered write of the completion flag behind that (MT-WnD's 2 MB per 16-query set);
+ *                smaller sets by the last workgroup's own system-scope stores
  *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
  *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
  * unknown key -> DRS_ERR_BAD_ARG.  Options belong to the handle: two engines in one process

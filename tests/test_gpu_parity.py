@@ -399,13 +399,20 @@ def test_full_size_reference_shapes_match_oracle(name):
         for (bid, bs), o in zip(jobs16, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, "16 coalesced", bid, bs)
         # other launch structures of the same arithmetic: bit-identical
-        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_gemm_2cu", "mlp_fuse", "shared_stream")}
+        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_gemm_2cu", "mlp_fuse", "shared_stream", "out_dma")}
         for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=3, mlp_stream_waves=8),
                      dict(mlp_stream=3, mlp_stream_waves=4), dict(mlp_gemm=0), dict(mlp_gemm_2cu=0), dict(mlp_gemm_2cu=1),
-                     dict(mlp_fuse=0), dict(shared_stream=1)):
+                     dict(mlp_fuse=0), dict(shared_stream=1), dict(out_dma=1)):
             for key, val in opts.items():
                 eng.set_option(key, val)
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, opts)
+            if "out_dma" in opts:
+                # outputs by copy engine + stream-ordered flag write (what sets with megabytes of outputs take):
+                # 16 coalesced queries, several sets in flight on the slots
+                for rep in range(3):
+                    outs = net.run_staged_multi([b for b, _ in jobs16], [n for _, n in jobs16])
+                    for (bid, bs), o in zip(jobs16, outs):
+                        assert np.array_equal(o, ref[(bid, bs)]), (name, "out_dma", rep, bid, bs)
             for key in opts:
                 eng.set_option(key, defaults[key])
         # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
