@@ -90,6 +90,9 @@ def parse(argv=None):
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
+    ap.add_argument("--table_placements", type=int, default=4,
+                    help="places in HBM tried for the table arena before the warm-up (the engine's own launch sets time "
+                         "each, the fastest stays: DLRM_Net.tune_table_placement); 1 = wherever hipMalloc put it")
     ap.add_argument("--slots", type=int, default=0,
                     help="launch sets in flight; 0 = what the engine asks for (drs_get_option preferred_slots: 3, NCF 6)")
     ap.add_argument("--coalesce", type=int, default=0,
@@ -157,6 +160,7 @@ def make_model(opt, device):
         nb, lX, lS_l, lS_i = generate_fast_input_data(opt.num_batches, opt.batch, m_den, rows, w["L"], opt.seed)
     net.create(lX[0], lS_l[0], lS_i[0], None)
     net.stage_batches(None if kind in NO_DENSE else lX, lS_l, lS_i)
+    net.table_placement = net.tune_table_placement(opt.table_placements) if getattr(opt, "table_placements", 1) > 1 else None
     return args, net, (lX, lS_l, lS_i)
 
 
@@ -893,6 +897,8 @@ def main():
                        "host": {"cores": host_cores(), "ranks": world,
                                 "conversion_workers_per_rank": eng.get_option("host_threads")},
                        "inputs": "device-resident (pre-staged)",
+                       # before the warm-up: the table arena tried in a few places of HBM, the fastest kept (rank 0's)
+                       "table_placement": getattr(net, "table_placement", None),
                        "index_streams": "uniform rows, sorted and distinct within a bag (the reference's random generator)"
                        if not opt.trace else "--data_generation synthetic: LRU-stack traces from the stack-distance profile `%s`, "
                        "one reference stream per table, %s" % (opt.trace, "bags = np.unique of L references (ragged)"

@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <memory>
@@ -158,6 +159,9 @@ struct drs_engine {
   std::vector<int64_t> rows;
   std::vector<int64_t> tab_off;  // element offsets
   float* tables = nullptr;
+  // "table_placement": further copies of the arena in other places of HBM; `tables` is the one in use (see drs_set_option)
+  std::vector<float*> arenas;
+  size_t tables_bytes = 0;
   int64_t* d_tab_off = nullptr;
   int64_t* d_tab_rows = nullptr;
   std::vector<bool> table_set;
@@ -1294,6 +1298,8 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   e->tune.device = device_id;
   CREATE_TRY(device_init(device_id, &e->tune.zero));
   CREATE_TRY(hipMalloc(&e->tables, sizeof(float) * (size_t)off));
+  e->tables_bytes = sizeof(float) * (size_t)off;
+  e->arenas.assign(1, e->tables);
   CREATE_TRY(hipMalloc(&e->d_tab_off, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_tab_rows, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_op_tab, sizeof(int64_t) * 2));
@@ -1502,6 +1508,8 @@ int32_t drs_destroy(drs_handle e) {
   if (e->d_att) (void)hipFree(e->d_att);
   if (e->d_att_packed) (void)hipFree(e->d_att_packed);
   if (e->w_arena) (void)hipFree(e->w_arena);
+  for (float* a : e->arenas)
+    if (a && a != e->tables) (void)hipFree(a);
   if (e->tables) (void)hipFree(e->tables);
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
   if (e->d_tab_rows) (void)hipFree(e->d_tab_rows);
@@ -1513,11 +1521,21 @@ int32_t drs_destroy(drs_handle e) {
   return DRS_OK;
 }
 
+// new table contents make the other placement candidates stale: only the arena in use survives
+static void drop_other_placements(drs_engine* e) {
+  if (e->arenas.size() <= 1) return;
+  for (float*& a : e->arenas)
+    if (a != e->tables) { (void)hipFree(a); a = nullptr; }
+  e->arenas.assign(1, e->tables);
+}
+
 int32_t drs_set_table(drs_handle e, int32_t t, const float* h_W, int64_t rows) {
   int32_t rc = check_handle(e);
   if (rc) return rc;
   if (t < 0 || t >= e->T || !h_W) return fail(e, DRS_ERR_BAD_ARG, "bad table id / null data");
   if (rows != e->rows[t]) return fail(e, DRS_ERR_BAD_ARG, "table %d has %lld rows, got %lld", t, (long long)e->rows[t], (long long)rows);
+  if ((rc = drs_sync(e))) return rc;
+  drop_other_placements(e);
   HIP_TRY(e, hipMemcpy(e->tables + e->tab_off[t], h_W, sizeof(float) * (size_t)rows * e->D, hipMemcpyHostToDevice));
   e->table_set[t] = true;
   return DRS_OK;
@@ -1527,6 +1545,7 @@ int32_t drs_fill_table_uniform(drs_handle e, int32_t t, float lo, float hi, uint
   int32_t rc = check_handle(e);
   if (rc) return rc;
   if (t < 0 || t >= e->T) return fail(e, DRS_ERR_BAD_ARG, "bad table id");
+  if (e->arenas.size() > 1) { if ((rc = drs_sync(e))) return rc; drop_other_placements(e); }
   HIP_TRY(e, launch_fill_uniform(e->tables + e->tab_off[t], e->rows[t] * e->D, t, lo, hi, seed, e->slots[0].stream));
   HIP_TRY(e, hipStreamSynchronize(e->slots[0].stream));
   e->table_set[t] = true;
@@ -2104,6 +2123,39 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
   else if (!strcmp(key, "mlp_rows32") && value >= 0) e->tune.mlp_rows32 = value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
+  else if (!strcmp(key, "table_placement")) {
+    // Where a multi-gigabyte allocation lands in HBM moves the gather by up to 6 % and stays for the allocation's
+    // lifetime: the feeder may try a few places with the model's own launch sets and keep the best.
+    //   -1: copy the tables into one more allocation and use that one (the earlier ones stay allocated, or the allocator
+    //       hands the same pages out again) | k >= 0: use candidate k | -2: free every candidate but the one in use.
+    // Refused (DRS_ERR_OOM, nothing changes) when one more copy would not leave 3/4 of the device's memory free.
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    if (value == -1) {
+      size_t free_b = 0, total_b = 0;
+      if (e->arenas.size() >= 8 || hipMemGetInfo(&free_b, &total_b) != hipSuccess || e->tables_bytes > free_b / 4)
+        return fail(e, DRS_ERR_OOM, "table_placement: no room for one more copy of the tables (%zu bytes)", e->tables_bytes);
+      float* fresh = nullptr;
+      if (hipMalloc(&fresh, e->tables_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(e, DRS_ERR_OOM, "table_placement: hipMalloc"); }
+      // (a device-to-device hipMemcpy may return before the copy is done, and the engine's streams do not wait for the
+      // null stream: without the synchronize the next gather read a half-copied arena)
+      if (hipMemcpy(fresh, e->tables, e->tables_bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+          hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(e, DRS_ERR_HIP, "table_placement: copy");
+      }
+      e->arenas.push_back(fresh);
+      e->tables = fresh;
+    } else if (value >= 0 && (size_t)value < e->arenas.size()) {
+      e->tables = e->arenas[(size_t)value];
+    } else if (value == -2) {
+      for (float*& a : e->arenas)
+        if (a != e->tables) { (void)hipFree(a); a = nullptr; }
+      e->arenas.assign(1, e->tables);
+    } else {
+      return fail(e, DRS_ERR_BAD_ARG, "table_placement %lld (candidates: %zu)", (long long)value, e->arenas.size());
+    }
+  }
   else if (!strcmp(key, "out_dma") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->out_dma = value; }
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
@@ -2161,7 +2213,9 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
-      {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device}};
+      {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
+      {"table_placement", (int64_t)(std::find(e->arenas.begin(), e->arenas.end(), e->tables) - e->arenas.begin())},
+      {"table_placements", (int64_t)e->arenas.size()}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);

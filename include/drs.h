@@ -393,6 +393,14 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
  *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
  *                MLP launches of consecutive small sets overlap each other
+ *   "table_placement" where the table arena lives.  A multi-gigabyte allocation's place in HBM moves the gather by
+ *                up to 6 % and stays for the allocation's lifetime; a feeder that has staged its input sets can
+ *                try a few: -1 = copy the tables into one more allocation and use that one (the earlier ones stay
+ *                allocated; DRS_ERR_OOM, nothing changed, when one more copy would take more than a quarter of the
+ *                free memory or 8 exist) | k >= 0 = use candidate k | -2 = free every candidate but the one in use.
+ *                Reading it gives the index in use, "table_placements" (read only) the number of candidates.
+ *                drs_set_table / drs_fill_table_uniform drop the candidates not in use (they would be stale).
+ *                Results never depend on it.  (DLRM_Net.tune_table_placement times each with the model's own sets.)
  *   "out_dma"    bytes (default 1 572 864; 0 = never): with "zero_copy" 1, launch sets with at least this many bytes of
  *                outputs hand them over by a copy-engine transfer queued behind the last kernel and a
  *                stream-ordered write of the completion flag behind that (MT-WnD's 2 MB per 16-query set);

@@ -415,6 +415,23 @@ def test_full_size_reference_shapes_match_oracle(name):
                         assert np.array_equal(o, ref[(bid, bs)]), (name, "out_dma", rep, bid, bs)
             for key in opts:
                 eng.set_option(key, defaults[key])
+        # the tables in another place of HBM ("table_placement": one more copy, switch between them, free the others)
+        if name in ("ncf", "rm2", "wnd"):
+            assert eng.get_option("table_placements") == 1 and eng.get_option("table_placement") == 0
+            eng.set_option("table_placement", -1)
+            assert eng.get_option("table_placements") == 2 and eng.get_option("table_placement") == 1
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "second placement")
+            eng.set_option("table_placement", 0)
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "first placement again")
+            eng.set_option("table_placement", 1)
+            eng.set_option("table_placement", -2)
+            assert eng.get_option("table_placements") == 1 and eng.get_option("table_placement") == 0
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after freeing the others")
+            with pytest.raises(Exception):
+                eng.set_option("table_placement", 3)
+            tuned = net.tune_table_placement(3, sets=16) if hasattr(net, "_n_staged") else None
+            assert tuned is None or (len(tuned["gather_alone_us"]) >= 2 and eng.get_option("table_placements") == 1)
+            assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after tuning")
         # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
         eng.set_option("sls_exact", 0)
         got = net.run_staged(0, B)
