@@ -207,6 +207,12 @@ class _HipNet(object):
         nb = int(getattr(self, "_n_staged", 0))
         if nb < 1 or candidates < 2:
             return None
+        # only where it was measured to pay: gather-bound DLRM (one MLP stream: RMC1 +1.2 %, RM2 +8.6 %).  The shapes
+        # whose set period is MLP work have nothing to gain (their gather is a tenth of a set, and RM1 reference JSON /
+        # DIN showed no spread between places), and MT-WnD LOSES 11 % when this runs before sets that hand their
+        # outputs over by DMA ("out_dma"; 74.8 k -> 66.5 k queries/s, not with the in-kernel copy: unexplained)
+        if self.kind != N.MODEL_DLRM or int(eng.get_option("mlp_streams")) != 1:
+            return None
         co = max(1, min(int(eng.get_option("preferred_coalesce")), 16))
         bs = int(eng.max_batch)
         prev = eng.get_option("shared_stream")

@@ -429,8 +429,9 @@ def test_full_size_reference_shapes_match_oracle(name):
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after freeing the others")
             with pytest.raises(Exception):
                 eng.set_option("table_placement", 3)
-            tuned = net.tune_table_placement(3, sets=16) if hasattr(net, "_n_staged") else None
-            assert tuned is None or (len(tuned["gather_alone_us"]) >= 2 and eng.get_option("table_placements") == 1)
+            tuned = net.tune_table_placement(3, sets=16)      # (gather-bound DLRM only: rm2 here)
+            assert (tuned is None) == (name != "rm2"), (name, tuned)
+            assert tuned is None or (len(tuned["gather_alone_us"]) == 3 and eng.get_option("table_placements") == 1)
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after tuning")
         # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
         eng.set_option("sls_exact", 0)
