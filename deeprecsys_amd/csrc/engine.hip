@@ -2215,7 +2215,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
       {"table_placement", (int64_t)(std::find(e->arenas.begin(), e->arenas.end(), e->tables) - e->arenas.begin())},
-      {"table_placements", (int64_t)e->arenas.size()}};
+      {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);

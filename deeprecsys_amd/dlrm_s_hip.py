@@ -196,13 +196,17 @@ class _HipNet(object):
             self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
         self._n_staged = len(lS_l)
 
-    def tune_table_placement(self, candidates=4, sets=128):
+    def tune_table_placement(self, candidates=4, sets=128, free_losers=None):
         """Where a multi-gigabyte hipMalloc lands in HBM moves the gather by up to 6 % and stays for the
         allocation's lifetime.  With the input sets staged, this runs the model's own launch
         sets (the engine's preferred size, full batches, one stream: the gather alone) on up to `candidates`
         copies of the table arena -- drs_set_option "table_placement" -- and keeps the copy whose gather is
-        fastest; the others are freed.  Returns {"gather_alone_us": [...], "kept": k}, or None when the engine
-        has nothing to time (no staged sets) or no room for a second copy.  ~30 ms per candidate."""
+        fastest.  The others are freed only when together they exceed 16 GB (free_losers None; True / False force
+        it): after multi-gigabyte hipFrees the runtime's copy-engine transfers -- and by a per cent or two the
+        gather itself -- are slower for the rest of the process (RMC1 +1.2 % with the losers freed,
+        +3.5 % with them left to the engine's destruction), and 6 GB of a 288 GB part are small change.  Returns
+        {"gather_alone_us": [...], "kept": k, "losers": "freed" | "held"}, or None when the engine has nothing to
+        time (no staged sets) or no room for a second copy.  ~30 ms per candidate."""
         eng = self.engine
         nb = int(getattr(self, "_n_staged", 0))
         if nb < 1 or candidates < 2:
@@ -246,11 +250,15 @@ class _HipNet(object):
                 times.append(gather_us())
             kept = int(np.argmin(times))
             eng.set_option("table_placement", kept)
-            return {"gather_alone_us": [round(t, 2) for t in times], "kept": kept} if len(times) > 1 else None
+            if free_losers is None:
+                free_losers = (len(times) - 1) * int(eng.get_option("table_bytes")) > (16 << 30)
+            return ({"gather_alone_us": [round(t, 2) for t in times], "kept": kept,
+                     "losers": "freed" if free_losers else "held"} if len(times) > 1 else None)
         except N.DrsError:
             return None                                 # (staged sets smaller than a full batch, ...: serve from where it is)
         finally:
-            eng.set_option("table_placement", -2)
+            if free_losers or free_losers is None:
+                eng.set_option("table_placement", -2)
 
     def run_staged(self, batch_id, batch_size):
         self._out = self.engine.forward(int(batch_id), int(batch_size))

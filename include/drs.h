@@ -398,7 +398,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                try a few: -1 = copy the tables into one more allocation and use that one (the earlier ones stay
  *                allocated; DRS_ERR_OOM, nothing changed, when one more copy would take more than a quarter of the
  *                free memory or 8 exist) | k >= 0 = use candidate k | -2 = free every candidate but the one in use.
- *                Reading it gives the index in use, "table_placements" (read only) the number of candidates.
+ *                Reading it gives the index in use, "table_placements" (read only) the number of candidates,
+ *                "table_bytes" (read only) the size of one.  Freeing gigabytes has a price of its own: the runtime's
+ *                copy-engine transfers (and, by a per cent or two, the gather) are slower for the rest of the process
+ *                after it, so a feeder may prefer to leave small losers allocated until drs_destroy.
  *                drs_set_table / drs_fill_table_uniform drop the candidates not in use (they would be stale).
  *                Results never depend on it.  (DLRM_Net.tune_table_placement times each with the model's own sets.)
  *   "out_dma"    bytes (default 1 572 864; 0 = never): with "zero_copy" 1, launch sets with at least this many bytes of
