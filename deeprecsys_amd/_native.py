@@ -71,6 +71,7 @@ SYMBOLS = [
     ("drs_kernel_bytes", C.c_int32, [C.c_void_p, C.c_int32, _i64p]),
     ("drs_debug_gather_stamps", C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _i64p]),
     ("drs_gather_bytes", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i64p]),
+    ("drs_last_dispatch", C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]),
     ("drs_comm_unique_id", C.c_int32, [C.POINTER(C.c_uint8)]),
     ("drs_comm_create", C.c_int32, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ("drs_comm_destroy", C.c_int32, [C.c_void_p]),
@@ -406,6 +407,13 @@ class Engine(object):
         self._check(lib().drs_debug_gather_stamps(self._h, slot, buf.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                   2 * cap, C.byref(n)), "drs_debug_gather_stamps")
         return buf[:2 * n.value].reshape(-1, 2)
+
+    def last_dispatch(self, slot=0):
+        """Which kernels served the launch set last enqueued on `slot`: list of "name<form>[...]" tokens."""
+        buf = C.create_string_buffer(1024)
+        self._check(lib().drs_last_dispatch(self._h, slot, buf, 1024), "drs_last_dispatch")
+        import re
+        return re.findall(r"[\w]+(?:<[^>]*>)?(?:\[[^\]]*\])?", buf.value.decode())
 
     def gather_bytes(self, batch_id, bs):
         b = C.c_int64(0)

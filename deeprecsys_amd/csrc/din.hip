@@ -1135,6 +1135,7 @@ hipError_t launch_din_fused(const SlsArgs& a_in, int32_t h, const float* packed,
   const int64_t stride = din_unit_stride(a.D, h);
   const FusedShape f = fused_shape(a, tune);
   const unsigned grid = (unsigned)din_fused_grid(a, tune);
+  log_launch(tune.log, "din_fused_kernel<%d,S%d,h%d,C%d%s>[%u wg]", a.D == 32 ? 8 : 16, f.S, h, f.C, a.nt ? ",nt" : "", grid);
   if (a.D == 32) launch_fused_s<8>(f, a, h, packed, stride, tune.zero, R, ldr, grid, s, stop);
   else launch_fused_s<16>(f, a, h, packed, stride, tune.zero, R, ldr, grid, s, stop);
   return hipGetLastError();

@@ -45,6 +45,15 @@ struct SlsArgs {
   int32_t nt;                 // fused DIN launch: table rows by non-temporal loads ("sls_nt"; set by launch_din_fused)
 };
 
+// What the launch functions chose for the launch set being enqueued ("which kernel serves which shape"):
+// each launch appends "name<template args>[grid x block] " to the log of the slot (drs_last_dispatch).
+// Host-side bookkeeping only; nothing on the device reads it.
+struct DispatchLog {
+  char text[768];
+  int len;
+};
+void log_launch(DispatchLog* log, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
 // Per-engine tunables (drs_set_option) and the per-device resources every launch needs.
 // Nothing here is process-global: two engines in one process (the mixed-model accelerator
 // engine; engines on different GPUs) keep their own copy.
@@ -67,6 +76,7 @@ struct Tune {
   int gemm32_blocks = 512;       // ... when its 128 x 128 workgroups number at least this many (two per CU)
   int64_t mlp_rows32 = 0;        // stream4_kernel: launches of at least this many rows take 32 rows per workgroup (0 = never)
   int64_t mlp_s4_rows = 0;       // "mlp_stream" 3 with four waves: launches of up to this many rows take stream4_kernel instead
+  DispatchLog* log = nullptr;    // where the launch functions note what they chose (the slot being enqueued; may be null)
 };
 // Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs
 // it (HIP function attributes are per device) and the device's zero page.

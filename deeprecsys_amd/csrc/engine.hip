@@ -60,6 +60,19 @@ hipError_t device_init(int device, const float** zero_page) {
   *zero_page = zero[device];
   return hipSuccess;
 }
+
+// "name<...>[grid] " appended to the slot's dispatch log (drs_last_dispatch); a full log drops what does not fit
+void log_launch(DispatchLog* log, const char* fmt, ...) {
+  if (!log) return;
+  const int room = (int)sizeof(log->text) - log->len;
+  if (room <= 2) return;
+  if (log->len > 0) { log->text[log->len++] = ' '; log->text[log->len] = 0; }
+  va_list ap;
+  va_start(ap, fmt);
+  const int n = vsnprintf(log->text + log->len, (size_t)(sizeof(log->text) - log->len), fmt, ap);
+  va_end(ap);
+  if (n > 0) log->len = log->len + n < (int)sizeof(log->text) ? log->len + n : (int)sizeof(log->text) - 1;
+}
 }  // namespace drs
 
 namespace {
@@ -147,6 +160,20 @@ struct Slot {
   std::vector<Batch> mq;     // block i viewed as a batch (device pointers into d_multi)
   int32_t launch_rc = 0;     // status of the launches the launcher thread made for the job in flight
   std::string launch_err;
+  DispatchLog dlog = {{0}, 0};   // what the launch functions chose for the set last enqueued here (drs_last_dispatch)
+};
+
+// One copy of the table arena.  kind 0: a plain hipMalloc.  kind 1: built with the virtual-memory API --
+// a reserved address range of chosen alignment, physical memory created in chunks of a chosen size
+// (0: one handle for the whole arena) and mapped into it ("table_alloc" and friends, DESIGN.md 3.5:
+// what a table is, models/dlrm_s_caffe2.py:297-299, does not say where it lives).
+struct Arena {
+  float* p = nullptr;
+  int kind = 0;
+  size_t va_bytes = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+  void* va_base = nullptr;        // kind 1: the reserved address range [va_base, va_base + va_reserved) that holds
+  size_t va_reserved = 0;         // [p, p + va_bytes) -- larger than the arena when p had to be aligned by hand
 };
 
 }  // namespace
@@ -160,8 +187,13 @@ struct drs_engine {
   std::vector<int64_t> tab_off;  // element offsets
   float* tables = nullptr;
   // "table_placement": further copies of the arena in other places of HBM; `tables` is the one in use (see drs_set_option)
-  std::vector<float*> arenas;
+  std::vector<Arena> arenas;
   size_t tables_bytes = 0;
+  // how the NEXT arena is built (drs_create's first one, "table_placement" -1 candidates)
+  int table_alloc = 0;              // 0 hipMalloc | 1 virtual-memory API
+  int64_t vmm_chunk = 0;            // bytes of physical memory per handle (0: one handle); rounded up to the granularity
+  int64_t vmm_align = 0;            // alignment of the reserved address range (0: the allocation granularity)
+  int vmm_shuffle = 0;              // lab: map the chunks in a permuted order (neighbouring addresses, distant memory)
   int64_t* d_tab_off = nullptr;
   int64_t* d_tab_rows = nullptr;
   std::vector<bool> table_set;
@@ -269,6 +301,92 @@ void free_batch(Batch& b) {
   if (b.idx) (void)hipFree(b.idx);
   if (b.off) (void)hipFree(b.off);
   b = Batch();
+}
+
+// ---- table arenas ---------------------------------------------------------------------------------
+void arena_free(Arena& a) {
+  if (!a.p) { a = Arena(); return; }
+  if (a.kind == 0) {
+    (void)hipFree(a.p);
+  } else {
+    (void)hipMemUnmap(a.p, a.va_bytes);
+    for (auto& h : a.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(a.va_base, a.va_reserved);
+  }
+  a = Arena();
+}
+
+// `bytes` of device memory for the tables, built as e->table_alloc / vmm_* say.  On failure nothing stays
+// allocated and *out is empty.
+hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
+  *out = Arena();
+  if (e->table_alloc == 0) {
+    void* p = nullptr;
+    hipError_t r = hipMalloc(&p, bytes);
+    if (r != hipSuccess) return r;
+    out->p = static_cast<float*>(p);
+    out->va_bytes = bytes;
+    return hipSuccess;
+  }
+  hipMemAllocationProp prop;
+  memset(&prop, 0, sizeof prop);
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = e->device;
+  size_t gran = 0;
+  hipError_t r = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+  if (r != hipSuccess) return r;
+  if (gran == 0) gran = (size_t)2 << 20;
+  const size_t chunk = e->vmm_chunk > 0 ? (size_t)round_up(e->vmm_chunk, (int64_t)gran) : 0;
+  const size_t total = (size_t)round_up((int64_t)bytes, (int64_t)(chunk ? chunk : gran));
+  const size_t align = e->vmm_align > 0 ? (size_t)round_up(e->vmm_align, (int64_t)gran) : 0;
+  // hipMemAddressReserve does not honour its alignment argument beyond the granularity (measured: "1 GiB aligned"
+  // came back 2 MiB aligned): reserve `align` bytes more and align inside the range by hand
+  void* base = nullptr;
+  const size_t reserved = total + align;
+  r = hipMemAddressReserve(&base, reserved, 0, nullptr, 0);
+  if (r != hipSuccess) return r;
+  void* va = align ? reinterpret_cast<void*>(((uintptr_t)base + align - 1) / align * align) : base;
+  Arena a;
+  a.p = static_cast<float*>(va);
+  a.kind = 1;
+  a.va_bytes = total;
+  a.va_base = base;
+  a.va_reserved = reserved;
+  const size_t n = chunk ? total / chunk : 1, csz = chunk ? chunk : total;
+  // chunk i of physical memory goes to place perm(i) of the range ("table_vmm_shuffle": a fixed odd-multiplier walk)
+  size_t mapped = 0;
+  for (size_t i = 0; i < n && r == hipSuccess; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    r = hipMemCreate(&h, csz, &prop, 0);
+    if (r != hipSuccess) break;
+    a.handles.push_back(h);
+    size_t place = i;
+    if (e->vmm_shuffle && n > 2) {
+      size_t mul = (n / 2) | 1;                       // odd and coprime with a power-of-two n; else fall back to a reversal
+      place = (n & (n - 1)) == 0 ? (i * mul + n / 3) % n : n - 1 - i;
+    }
+    r = hipMemMap(static_cast<char*>(va) + place * csz, csz, 0, h, 0);
+    if (r == hipSuccess) ++mapped;
+  }
+  if (r == hipSuccess) {
+    hipMemAccessDesc desc;
+    memset(&desc, 0, sizeof desc);
+    desc.location = prop.location;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    r = hipMemSetAccess(va, total, &desc, 1);
+  }
+  if (r != hipSuccess) {
+    // unmap what was mapped (chunk by chunk: a partially mapped range cannot be unmapped in one call)
+    if (mapped == n) (void)hipMemUnmap(va, total);
+    else if (!e->vmm_shuffle) for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(static_cast<char*>(va) + i * csz, csz);
+    for (auto& h : a.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(base, reserved);
+    (void)hipGetLastError();
+    return r;
+  }
+  *out = a;
+  return hipSuccess;
 }
 
 // ---- host-side worker pool for the per-call input pass ----------------------------------------
@@ -536,6 +654,14 @@ hipError_t mlp_launch_stream(drs_engine* e, Slot& s, bool wide, int64_t M, hipSt
   return hipSuccess;
 }
 
+// "mlp_layout" 1: a launch or copy that goes straight on s.stream (interaction, row copies, DIN attention, the
+// output copy and flag write, the timing event) must sit behind the set's latest MLP launch, which may have gone
+// on the gather's stream (a wide layer): bring the set back to s.stream first.  A no-op otherwise.
+hipError_t rejoin_stream(drs_engine* e, Slot& s) {
+  hipStream_t st;
+  return mlp_launch_stream(e, s, false, 0, &st);
+}
+
 // Run all layers of `m` on x -> y.  A huge layer runs as its own 2-D launch; runs of
 // ordinary layers are fused into one LDS-resident chain.  Segment outputs that are not
 // the final one ping-pong between s.H and s.Hb.
@@ -732,6 +858,10 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   // Safe: a slot is reused only after its previous job was observed complete on the host.
   s.stream = job_stream(e, s, Mv);
   s.cur = nullptr;               // (the set's first MLP launch needs no event: join() orders it behind the gather)
+  s.dlog.len = 0; s.dlog.text[0] = 0;
+  e->tune.log = &s.dlog;         // the launch functions note what they choose for this set (drs_last_dispatch)
+  log_launch(&s.dlog, "set[%d queries, %d rows, gather on %s, mlp on %s]", q.n_q, (int)Mv,
+             job_gather_stream(e, s, Mv) == e->stream_g ? "stream_g" : "own", s.stream == s.own_stream ? "own" : "shared");
   const hipStream_t gstream = job_gather_stream(e, s, Mv);
   const bool prof = e->profiling >= 1;
   const bool evts = e->profiling >= 2;
@@ -835,12 +965,15 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       }
       tp.kmax = dien_top_kmax(nt, e->top.ln.data());
     }
+    log_launch(&s.dlog, "%s<%d,%d%s>[%d wg]", e->dien_mfma && Hh % 16 == 0 ? "dien_rnn_mfma_kernel" : "dien_rnn_kernel", e->D, Hh,
+               tp.n ? ",top" : "", e->dien_mfma && Hh % 16 == 0 ? (c + 15) / 16 : (c + 3) / 4);
     HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, Hh, e->d_att_packed, rw, e->dien_mfma, s.R,
                                e->ldR, s.stream, tp.n ? &tp : nullptr, dp));
     if (!tp.n && (rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
   } else if (e->kind == DRS_MODEL_DIN) {
     // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
     HIP_TRY(e, join());
+    if (!din_fused) log_launch(&s.dlog, "din_attention_kernel[%lld wg]", (long long)((Mv + 3) / 4));
     if (!din_fused)
       HIP_TRY(e, launch_din_attention(s.T, e->ldT, Mv, e->T, e->D, e->att[0].ln[1], e->d_att_packed, s.R, e->ldR, s.stream));
     if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
@@ -866,6 +999,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       }
     }
     if (!fused) {
+      log_launch(&s.dlog, "add_rows_kernel");
       HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, Mv, D, s.stream));
       if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
       if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
@@ -880,6 +1014,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     if (fused) {
       // nothing else to launch
     } else if (e->bot.layers.empty()) {
+      log_launch(&s.dlog, "copy_rows_multi_kernel");
       HIP_TRY(e, launch_copy_rows_multi(xs, e->m_den, s.T, e->ldT, s.stream));
     } else {
       if ((rc = run_mlp(e, s, e->bot, nullptr, e->m_den, Mv, s.T, e->ldT, nullptr, &xs))) return rc;
@@ -888,6 +1023,8 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     const float* top_in = s.T;
     int64_t ld_top = e->ldT;
     if (!fused && e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
+      HIP_TRY(e, rejoin_stream(e, s));
+      log_launch(&s.dlog, "interact_dot_kernel[%lld wg]", (long long)((Mv + 3) / 4));
       HIP_TRY(e, launch_interact_dot(s.T, e->ldT, Mv, e->T + 1, e->D, e->itself, s.R, e->ldR, s.stream));
       top_in = s.R;
       ld_top = e->ldR;
@@ -903,6 +1040,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
           return rc;
     } else if (!fused && (rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
   }
+  HIP_TRY(e, rejoin_stream(e, s));     // ("mlp_layout" 1: the tail below is ordered behind a last launch on the gather's stream)
   if (evts) {
     HIP_TRY(e, hipEventRecord(s.ev[2], s.stream));
     s.ev_pending = true;
@@ -913,6 +1051,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     HIP_TRY(e, hipMemcpyAsync(s.h_out + 1, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   }
   if (out_dma) {
+    log_launch(&s.dlog, "out_dma[%lld B]", (long long)(sizeof(float) * (size_t)Mv * e->n_out));
     HIP_TRY(e, hipMemcpyAsync(s.h_out + kOutOffset, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
                               hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(e, hipStreamWriteValue32(s.stream, s.dm_out, s.seq, 0));
@@ -1297,9 +1436,13 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
 #define CREATE_TRY(call) if (!hip_ok(call)) return bail(last_rr == hipErrorOutOfMemory ? DRS_ERR_OOM : DRS_ERR_HIP, (std::string(#call ": ") + e->err).c_str())
   e->tune.device = device_id;
   CREATE_TRY(device_init(device_id, &e->tune.zero));
-  CREATE_TRY(hipMalloc(&e->tables, sizeof(float) * (size_t)off));
   e->tables_bytes = sizeof(float) * (size_t)off;
-  e->arenas.assign(1, e->tables);
+  {
+    Arena first;
+    CREATE_TRY(arena_alloc(e, e->tables_bytes, &first));
+    e->tables = first.p;
+    e->arenas.assign(1, first);
+  }
   CREATE_TRY(hipMalloc(&e->d_tab_off, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_tab_rows, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_op_tab, sizeof(int64_t) * 2));
@@ -1508,9 +1651,8 @@ int32_t drs_destroy(drs_handle e) {
   if (e->d_att) (void)hipFree(e->d_att);
   if (e->d_att_packed) (void)hipFree(e->d_att_packed);
   if (e->w_arena) (void)hipFree(e->w_arena);
-  for (float* a : e->arenas)
-    if (a && a != e->tables) (void)hipFree(a);
-  if (e->tables) (void)hipFree(e->tables);
+  for (Arena& a : e->arenas) arena_free(a);
+  e->tables = nullptr;
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
   if (e->d_tab_rows) (void)hipFree(e->d_tab_rows);
   if (e->d_op_tab) (void)hipFree(e->d_op_tab);
@@ -1524,9 +1666,9 @@ int32_t drs_destroy(drs_handle e) {
 // new table contents make the other placement candidates stale: only the arena in use survives
 static void drop_other_placements(drs_engine* e) {
   if (e->arenas.size() <= 1) return;
-  for (float*& a : e->arenas)
-    if (a != e->tables) { (void)hipFree(a); a = nullptr; }
-  e->arenas.assign(1, e->tables);
+  std::vector<Arena> keep;
+  for (Arena& a : e->arenas) { if (a.p == e->tables) keep.push_back(a); else arena_free(a); }
+  e->arenas = keep;
 }
 
 int32_t drs_set_table(drs_handle e, int32_t t, const float* h_W, int64_t rows) {
@@ -2131,31 +2273,83 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     // Refused (DRS_ERR_OOM, nothing changes) when one more copy would not leave 3/4 of the device's memory free.
     int32_t rc = drs_sync(e);
     if (rc) return rc;
-    if (value == -1) {
+    if (value == -1 || value == -3) {
+      // (-3, a lab's request: one more copy as long as it fits beside 4 GB of headroom -- tools/placement_lab.py scans
+      // the whole of HBM with it)
       size_t free_b = 0, total_b = 0;
-      if (e->arenas.size() >= 8 || hipMemGetInfo(&free_b, &total_b) != hipSuccess || e->tables_bytes > free_b / 4)
+      if (e->arenas.size() >= 256 || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+          (value == -1 ? e->tables_bytes > free_b / 4 : e->tables_bytes + ((size_t)4 << 30) > free_b))
         return fail(e, DRS_ERR_OOM, "table_placement: no room for one more copy of the tables (%zu bytes)", e->tables_bytes);
-      float* fresh = nullptr;
-      if (hipMalloc(&fresh, e->tables_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(e, DRS_ERR_OOM, "table_placement: hipMalloc"); }
+      Arena fresh;
+      hipError_t ar = arena_alloc(e, e->tables_bytes, &fresh);
+      if (ar != hipSuccess) { (void)hipGetLastError(); return fail(e, DRS_ERR_OOM, "table_placement: arena allocation: %s", hipGetErrorString(ar)); }
       // (a device-to-device hipMemcpy may return before the copy is done, and the engine's streams do not wait for the
       // null stream: without the synchronize the next gather read a half-copied arena)
-      if (hipMemcpy(fresh, e->tables, e->tables_bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+      if (hipMemcpy(fresh.p, e->tables, e->tables_bytes, hipMemcpyDeviceToDevice) != hipSuccess ||
           hipStreamSynchronize(nullptr) != hipSuccess) {
-        (void)hipFree(fresh);
+        arena_free(fresh);
         return fail(e, DRS_ERR_HIP, "table_placement: copy");
       }
       e->arenas.push_back(fresh);
-      e->tables = fresh;
+      e->tables = fresh.p;
     } else if (value >= 0 && (size_t)value < e->arenas.size()) {
-      e->tables = e->arenas[(size_t)value];
+      e->tables = e->arenas[(size_t)value].p;
     } else if (value == -2) {
-      for (float*& a : e->arenas)
-        if (a != e->tables) { (void)hipFree(a); a = nullptr; }
-      e->arenas.assign(1, e->tables);
+      drop_other_placements(e);
     } else {
       return fail(e, DRS_ERR_BAD_ARG, "table_placement %lld (candidates: %zu)", (long long)value, e->arenas.size());
     }
   }
+  else if (!strcmp(key, "table_vmm_swap") || !strcmp(key, "table_vmm_remap")) {
+    // lab (tools/placement_lab.py): is the gather's speed on an arena a property of its MEMORY or of its MAPPING?
+    //   "table_vmm_swap"  (i << 16) | j: the physical handles of arenas i and j change places (both built with "table_alloc" 1
+    //                     and the same chunking; both hold the same tables, so results do not change)
+    //   "table_vmm_remap" i: arena i's handles are unmapped and mapped again at a freshly reserved address range
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    hipMemAccessDesc desc;
+    memset(&desc, 0, sizeof desc);
+    desc.location.type = hipMemLocationTypeDevice;
+    desc.location.id = e->device;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    auto map_all = [&](Arena& a) -> hipError_t {
+      const size_t csz = a.va_bytes / a.handles.size();
+      for (size_t k = 0; k < a.handles.size(); ++k) {
+        hipError_t r = hipMemMap(reinterpret_cast<char*>(a.p) + k * csz, csz, 0, a.handles[k], 0);
+        if (r != hipSuccess) return r;
+      }
+      return hipMemSetAccess(a.p, a.va_bytes, &desc, 1);
+    };
+    if (!strcmp(key, "table_vmm_swap")) {
+      const size_t i = (size_t)(value >> 16), j = (size_t)(value & 0xffff);
+      if (i >= e->arenas.size() || j >= e->arenas.size() || i == j) return fail(e, DRS_ERR_BAD_ARG, "table_vmm_swap: no such arenas");
+      Arena &a = e->arenas[i], &b = e->arenas[j];
+      if (a.kind != 1 || b.kind != 1 || a.va_bytes != b.va_bytes || a.handles.size() != b.handles.size())
+        return fail(e, DRS_ERR_BAD_ARG, "table_vmm_swap: both arenas must come from the virtual-memory API with the same chunking");
+      HIP_TRY(e, hipMemUnmap(a.p, a.va_bytes));
+      HIP_TRY(e, hipMemUnmap(b.p, b.va_bytes));
+      std::swap(a.handles, b.handles);
+      HIP_TRY(e, map_all(a));
+      HIP_TRY(e, map_all(b));
+    } else {
+      const size_t i = (size_t)value;
+      if (i >= e->arenas.size() || e->arenas[i].kind != 1) return fail(e, DRS_ERR_BAD_ARG, "table_vmm_remap: not an arena of the virtual-memory API");
+      Arena& a = e->arenas[i];
+      void* va = nullptr;
+      HIP_TRY(e, hipMemAddressReserve(&va, a.va_bytes, 0, nullptr, 0));
+      HIP_TRY(e, hipMemUnmap(a.p, a.va_bytes));
+      HIP_TRY(e, hipMemAddressFree(a.va_base, a.va_reserved));
+      const bool in_use = e->tables == a.p;
+      a.p = static_cast<float*>(va);
+      a.va_base = va; a.va_reserved = a.va_bytes;
+      HIP_TRY(e, map_all(a));
+      if (in_use) e->tables = a.p;
+    }
+  }
+  else if (!strcmp(key, "table_alloc") && (value == 0 || value == 1)) e->table_alloc = (int)value;
+  else if (!strcmp(key, "table_vmm_chunk") && value >= 0) e->vmm_chunk = value;
+  else if (!strcmp(key, "table_vmm_align") && value >= 0) e->vmm_align = value;
+  else if (!strcmp(key, "table_vmm_shuffle") && (value == 0 || value == 1)) e->vmm_shuffle = (int)value;
   else if (!strcmp(key, "out_dma") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->out_dma = value; }
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
@@ -2214,11 +2408,24 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
       {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
-      {"table_placement", (int64_t)(std::find(e->arenas.begin(), e->arenas.end(), e->tables) - e->arenas.begin())},
-      {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes}};
+      {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
+      {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},
+      {"table_alloc", e->table_alloc}, {"table_vmm_chunk", e->vmm_chunk}, {"table_vmm_align", e->vmm_align}, {"table_vmm_shuffle", e->vmm_shuffle},
+      {"table_address", (int64_t)(uintptr_t)e->tables}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);
+}
+
+int32_t drs_last_dispatch(drs_handle e, int32_t slot, char* buf, int64_t cap) {
+  if (!e || !buf || cap < 1) return DRS_ERR_BAD_ARG;
+  if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  if (e->launcher) e->launcher->drain();
+  const Slot& s = e->slots[slot];
+  const int64_t n = s.dlog.len < cap - 1 ? s.dlog.len : cap - 1;
+  memcpy(buf, s.dlog.text, (size_t)n);
+  buf[n] = 0;
+  return DRS_OK;
 }
 
 int32_t drs_gather_bytes(drs_handle e, int32_t batch_id, int32_t bs, int64_t* bytes) {

@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     for (int jj = 0; jj < 2; ++jj) {
       // rows past the end are clamped: they only feed outputs that are never stored
       const int64_t rr = row0 + frow + 32 * jj;
-      offA[2 * hm + jj] = (rr < rows ? rr : rows - 1) * a.ldx + fk;
+      // (an empty source -- rows == 0, which the engine's query table never holds -- reads its row 0 slot: never row -1)
+      offA[2 * hm + jj] = (rr < rows ? rr : (rows > 0 ? rows - 1 : 0)) * a.ldx + fk;
     }
   }
 #pragma unroll
@@ -695,6 +696,7 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
       // scalar-base requests when K is whole 32-k chunks and the row offsets fit 32 bits (gemm32_kernel, SPREAD == 2)
       // (offsets + a row's bytes stay below the descriptors' num_records of 0xfffff000)
       const bool sbase = !(K & 31) && ((uint64_t)M * (uint64_t)ldx + (uint64_t)K) * 4u < 0xfffff000ull && ((uint64_t)N + 1) * (uint64_t)K * 4u < 0xfffff000ull;
+      log_launch(tune.log, "gemm32_kernel<%d,%d%s>[%u x %u wg, %dx%d]", wm_, wn_, sbase ? ",sbase" : "", grid.x, grid.y, K, N);
 #define DRS_G3LAUNCH(WM_, WN_)                                                                              \
       if (sbase) hipLaunchKernelGGL((gemm32_kernel<WM_, WN_, 2>), grid, dim3(256), lds, s, a, d, xs);          \
       else hipLaunchKernelGGL((gemm32_kernel<WM_, WN_>), grid, dim3(256), lds, s, a, d, xs);
@@ -706,6 +708,7 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
   }
   const dim3 grid((unsigned)((M + 32 * tm - 1) / (32 * tm)), (unsigned)((N + 64 * tn - 1) / (64 * tn)));
   const size_t lds = sizeof(float) * 2 * (32 * tm + 64 * tn) * GLD;
+  log_launch(tune.log, "gemm_kernel<%d,%d%s>[%u x %u wg, %dx%d]", tm, tn, two_per_cu ? ",2cu" : "", grid.x, grid.y, K, N);
 #define DRS_GLAUNCH(TM_, TN_) \
   if (tm == TM_ && tn == TN_) hipLaunchKernelGGL((gemm_kernel<TM_, TN_>), grid, dim3(kGThreads), lds, s, a, d, xs);
   if (two_per_cu) hipLaunchKernelGGL((gemm_kernel<2, 1, 2, 4>), grid, dim3(kGThreads), lds, s, a, d, xs);

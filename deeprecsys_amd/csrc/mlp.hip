@@ -2268,6 +2268,7 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
   dim3 grid((unsigned)((M + 15) / 16), (unsigned)((N + PN - 1) / PN));
   bool vec = aligned16(x) && aligned16(W) && (ldx & 3) == 0 && (K & 3) == 0;
   for (int i = 0; i < xs.q.n_q; ++i) vec = vec && aligned16(xs.x[i]);
+  log_launch(tune.log, "fc_kernel<%s,%d>[%u x %u wg, %dx%d]", vec ? "vec" : "scalar", kc, grid.x, grid.y, K, N);
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
     if (vec)                                                                                      \
@@ -2650,6 +2651,14 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
       slds += 8192;
 #endif
       const dim3 g3((unsigned)((a.M + 15) / 16));
+      {
+        // which form serves this launch (drs_last_dispatch; DESIGN.md dispatch table)
+        const char* form = sp.packed == 6 ? "stream4_kernel<rows32>" : sp.packed == 4 ? "stream3_kernel<4waves>" :
+            sp.packed == 5 ? (sp.in[1].col2 >= 0 ? "stream4_kernel<sum>" : (tune.mlp_stream == 4 && tune.mlp_stream_2cu) ? "stream4_kernel<2cu>" : "stream4_kernel") :
+            sp.packed == 3 ? "stream3_kernel<8waves>" : sp.packed ? ((tune.mlp_stream_2cu && sp.n_table > 0) ? "stream_kernel<packed,2cu>" : "stream_kernel<packed>") : "stream_kernel<lds>";
+        log_launch(tune.log, "%s[%u wg, %d layers%s, %zu B lds]", form, sp.packed == 6 ? (unsigned)((a.M + 31) / 32) : g3.x,
+                   sp.n_layers, dot ? ", dot" : "", slds);
+      }
       if (sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2>), dim3((unsigned)((a.M + 31) / 32)), dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 4) hipLaunchKernelGGL((stream3_kernel<4, 2>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs);
@@ -2681,6 +2690,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
   if (b) second = *b;
   const dim3 grid((unsigned)((a.M + 15) / 16));
   const int sld = chain_slab_ld2(a, b);
+  log_launch(tune.log, "chain_kernel<%s,%d>[%u wg, %d layers]", vec ? "vec" : "scalar", kc, grid.x, a.n_layers + (b ? b->n_layers : 0));
 #define LAUNCH(KC_)                                                                               \
   if (kc == KC_) {                                                                                \
     if (vec)                                                                                      \

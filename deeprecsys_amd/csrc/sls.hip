@@ -704,8 +704,14 @@ hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t
   if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
   if (!exact) {
     const FlatPlan p = flat_plan(a, tune);
-    if (p.ok) return launch_flat(a, p, s, stop);
+    if (p.ok) {
+      log_launch(tune.log, "%s<%d,%d%s%s>[%u wg, L=%d]", p.coal ? "sls_flatc_kernel" : "sls_flat_kernel", p.G, p.NL,
+                 p.coal ? "" : (p.BPW == 4 ? ",bpw4" : p.BPW == 2 ? ",bpw2" : ",bpw1"), p.nt ? ",nt" : "", p.grid, p.L);
+      return launch_flat(a, p, s, stop);
+    }
   }
+  log_launch(tune.log, "sls_kernel<%d,%s>[%lld wg]", lanes_per_row(D), exact ? "sequential" : (tune.sls_nt ? "split,nt" : "split"),
+             (long long)sls_grid_blocks(a, exact, tune));
   // the non-temporal hint is for bags of many rows out of big tables; the one-lookup models (W&D, NCF, MT-WnD:
   // the sequential form) keep their rows cacheable -- NCF's tables live in the Infinity Cache (measured: -3 % with it)
   const int nt = exact ? 0 : tune.sls_nt;

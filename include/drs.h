@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DRS_ABI_VERSION 4
+#define DRS_ABI_VERSION 5
 
 typedef struct drs_engine* drs_handle;
 
@@ -397,13 +397,18 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                up to 6 % and stays for the allocation's lifetime; a feeder that has staged its input sets can
  *                try a few: -1 = copy the tables into one more allocation and use that one (the earlier ones stay
  *                allocated; DRS_ERR_OOM, nothing changed, when one more copy would take more than a quarter of the
- *                free memory or 8 exist) | k >= 0 = use candidate k | -2 = free every candidate but the one in use.
+ *                free memory or 256 exist) | k >= 0 = use candidate k | -2 = free every candidate but the one in use.
  *                Reading it gives the index in use, "table_placements" (read only) the number of candidates,
  *                "table_bytes" (read only) the size of one.  Freeing gigabytes has a price of its own: the runtime's
  *                copy-engine transfers (and, by a per cent or two, the gather) are slower for the rest of the process
  *                after it, so a feeder may prefer to leave small losers allocated until drs_destroy.
  *                drs_set_table / drs_fill_table_uniform drop the candidates not in use (they would be stale).
  *                Results never depend on it.  (DLRM_Net.tune_table_placement times each with the model's own sets.)
+ *   "table_alloc" how the NEXT arena is built (a "table_placement" -1 candidate): 0 hipMalloc | 1 the virtual-memory
+ *                API -- an address range reserved with alignment "table_vmm_align" bytes (0: the allocation granularity),
+ *                physical memory created in handles of "table_vmm_chunk" bytes (0: one handle for the whole arena)
+ *                and mapped into it; "table_vmm_shuffle" 1 maps the chunks in a permuted order (an experiment:
+ *                neighbouring addresses on distant memory).  "table_address" (read only): the arena's address.
  *   "out_dma"    bytes (default 1 572 864; 0 = never): with "zero_copy" 1, launch sets with at least this many bytes of
  *                outputs hand them over by a copy-engine transfer queued behind the last kernel and a
  *                stream-ordered write of the completion flag behind that (MT-WnD's 2 MB per 16-query set);
@@ -438,6 +443,14 @@ int32_t drs_kernel_bytes(drs_handle h, int32_t kernel /*DRS_KERNEL_SLS | _SLS_CL
  * launch on `slot`; out holds 2*n_blocks words.  Tuning aid (tools/gather_timeline.py) */
 int32_t drs_debug_gather_stamps(drs_handle h, int32_t slot, uint64_t* out, int64_t cap,
                                 int64_t* n_blocks);
+/* Which kernels served the launch set last enqueued on `slot`, as text: one token per launch in launch
+ * order, "name<form>[workgroups, ...]", after a "set[...]" token with the set's size and streams -- e.g.
+ * "set[12 queries, 3072 rows, gather on stream_g, mlp on shared] sls_flatc_kernel<16,20,nt>[24576 wg, L=80]
+ * stream4_kernel<rows32>[96 wg, 5 layers, 142400 B lds]".  The reference has one operator list per model
+ * (models/dlrm_s_caffe2.py:223-389); here the launch form depends on the set's row count, and this is how a
+ * caller (tests, tools/dispatch_table.py -> DESIGN.md's dispatch table) sees which one ran.  buf receives at
+ * most cap - 1 characters and a terminating 0.                                                        */
+int32_t drs_last_dispatch(drs_handle h, int32_t slot, char* buf, int64_t cap);
 /* algorithmic bytes of the gather for a query of `bs` samples of `batch_id`:
  * sum over bags of len*D*4 + len*4 + 4 + D*4  (SURVEY.md 8d / BASELINE.md 2)   */
 int32_t drs_gather_bytes(drs_handle h, int32_t batch_id, int32_t bs, int64_t* bytes);

@@ -663,6 +663,11 @@ int32_t drs_debug_gather_stamps(drs_handle e, int32_t, uint64_t*, int64_t, int64
   *n_blocks = 0;
   return DRS_OK;
 }
+int32_t drs_last_dispatch(drs_handle e, int32_t, char* buf, int64_t cap) {   // (no launches on the CPU: an empty list)
+  if (!e || !buf || cap < 1) return DRS_ERR_BAD_ARG;
+  buf[0] = 0;
+  return DRS_OK;
+}
 int32_t drs_gather_bytes(drs_handle e, int32_t batch_id, int32_t bs, int64_t* bytes) {
   int32_t rc = check_handle(e);
   if (rc) return rc;

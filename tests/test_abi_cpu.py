@@ -20,7 +20,7 @@ def test_cpu_abi_restates_every_entry_point_of_the_header(cpu_abi):
     assert declared == bound, declared ^ bound          # the binding covers the whole header ...
     for name in declared:
         assert hasattr(cpu_abi, name), name              # ... and so does the CPU restatement
-    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 4 and cpu_abi.drs_backend() == b"cpu:oracle"
+    assert N.device_count() == 1 and cpu_abi.drs_abi_version() == 5 and cpu_abi.drs_backend() == b"cpu:oracle"
 
 
 @pytest.mark.parametrize("case", H.MODEL_CASES)
@@ -200,7 +200,7 @@ def test_hip_library_loads_and_exports_every_symbol_of_the_header():
     assert len(declared) >= 28
     for name in declared:
         assert hasattr(L, name), "libdrs_hip.so does not export %s" % name
-    assert N.lib().drs_abi_version() == 4 and N.lib().drs_backend() == b"hip:gfx950"
+    assert N.lib().drs_abi_version() == 5 and N.lib().drs_backend() == b"hip:gfx950"
     if N.device_count() == 0:
         with pytest.raises(N.DrsError) as ei:
             N.Engine(N.MODEL_DLRM, [16, 16], 8, [4, 8], [24, 4, 1], N.INTERACT_CAT, sigmoid_top=2,

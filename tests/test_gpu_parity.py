@@ -449,6 +449,118 @@ def test_full_size_reference_shapes_match_oracle(name):
         eng.close()
 
 
+# ------------------------------------------------------------------------------------
+# The engine as the reference's run scripts build it: max_mini_batch_size 1024
+# (run_DeepRecSys.sh:32-36, experiments/scheduling/run_Scheduler.sh:38-44), queries = prefixes of
+# 1024-sample batches (inferenceEngine.py:200-206).  A slot then holds 16 x 1024 virtual rows and
+# launch sets pick their kernel forms by row count at sizes the batch-256 tests never reach.
+RUN_SCRIPT_SHAPES = {
+    "rmc1": dict(kind="dlrm", rows=[1_000_000] * 8, D=64, L=80, bot="128-64-64", top="256-64-1"),     # BASELINE config 2's tables
+    "rm2": FULL_SIZE["rm2"],       # run_DeepRecSys.sh's own model (dlrm_rm2.json)
+    "wnd": FULL_SIZE["wnd"],
+}
+# first token of a launch set's dispatch: the gather kernel the shape takes by default / with sls_exact
+GATHER_FORM = {"rmc1": ("sls_flatc_kernel<16,20,nt>", "sls_kernel<16,sequential>"),
+               "rm2": ("sls_kernel<16,split,nt>", "sls_kernel<16,sequential>"),
+               "wnd": ("sls_kernel<8,sequential>", "sls_kernel<8,sequential>")}
+
+
+@pytest.mark.parametrize("name", sorted(RUN_SCRIPT_SHAPES))
+def test_engine_built_as_the_run_scripts_build_it(name):
+    """max_batch 1024, two staged 1024-sample batches: single queries of 257 .. 1024 samples (sequential gather:
+    R bitwise, outputs 1e-6; default gather: its tolerance, outputs north_star's 1e-4), then pipelined launch sets
+    of 12 and 16 mixed-size queries drawn like the run scripts draw them -- normal(165, 16) and
+    lognormal(5.1, 0.2), clamped to [1, 1024] -- three sets in flight, EVERY query against the oracle.  The
+    kernel forms each row count selected are read back (drs_last_dispatch) and written to
+    gpurun_out/dispatch_1024_<name>.json."""
+    import json
+    from deeprecsys_amd.data_generator.dlrm_data import generate_fast_input_data
+    from deeprecsys_amd.loadGenerator import model_batch_size_distribution
+    w = RUN_SCRIPT_SHAPES[name]
+    B, seed, nb = 1024, 31, 2
+    rows, D, L, T = w["rows"], w["D"], w["L"], len(w["rows"])
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_bot=w["bot"], arch_mlp_top=w["top"], arch_interaction_op="cat",
+                       num_indices_per_lookup=L, num_batches=nb, max_mini_batch_size=B, mini_batch_size=B,
+                       numpy_rand_seed=seed, accel_table_init="device", model_type=w["kind"], accel_slots=3)
+    np.random.seed(seed)
+    net = H.NET_CLS[w["kind"]](args)
+    m_den = int(w["bot"].split("-")[0])
+    _, lX, lS_l, lS_i = generate_fast_input_data(nb, B, m_den, rows, L, seed)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    eng = net.engine
+    forms = {}
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        net.emb_w = [orc.fill_table_uniform(rows[t], D, t, -float(np.sqrt(1 / rows[t])), float(np.sqrt(1 / rows[t])),
+                                            seed, nthreads=0) for t in range(T)]
+        om = H.oracle_model(net)
+        ref = {}
+
+        def oracle(bid, bs):
+            if (bid, bs) not in ref:
+                ref[(bid, bs)] = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+            return ref[(bid, bs)]
+        singles = (257, 320, 512, 1000, 1024)
+        eng.set_option("sls_exact", 1)
+        for bs in singles:
+            bid = bs % 2
+            got = net.run_staged(bid, bs)
+            R = eng.fetch_interaction(bs)
+            exp, R_exp = oracle(bid, bs)
+            assert np.array_equal(R, R_exp), (name, "sequential gather", bs)
+            assert H.close(got, exp, rtol=1e-6, atol=1e-7), (name, bs, np.abs(got - exp).max())
+            forms["single %d, sls_exact" % bs] = eng.last_dispatch()
+            assert forms["single %d, sls_exact" % bs][1] == "%s[%d wg]" % (GATHER_FORM[name][1], -(-bs * T // (64 // (16 if D == 64 else 8)))), forms
+        eng.set_option("sls_exact", 0)
+        for bs in singles:
+            bid = (bs + 1) % 2
+            got = net.run_staged(bid, bs)
+            R = eng.fetch_interaction(bs)
+            exp, R_exp = oracle(bid, bs)
+            assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (name, "default gather", bs)
+            assert H.close(got, exp, rtol=H.RTOL_OUT, atol=1e-7), (name, bs, np.abs(got - exp).max())
+            forms["single %d" % bs] = eng.last_dispatch()
+            assert forms["single %d" % bs][1].startswith(GATHER_FORM[name][0]), forms
+        assert eng.get_option("shared_stream") == 2
+        for dist, avg, var in (("normal", 165, 16), ("lognormal", 5.1, 0.2)):
+            da = H.args_from({}, batch_size_distribution=dist, avg_mini_batch_size=avg, var_mini_batch_size=var,
+                             max_mini_batch_size=B, num_batches=3 * 16)
+            np.random.seed(123)                                   # utils/utils.py:110, loadGenerator.py:20-43
+            sizes = [int(x) for x in model_batch_size_distribution(da)]
+            # the tails the clamps exist for: one query at each end of [1, 1024] in every draw
+            sizes[5], sizes[21] = 1, B
+            for per_set in (12, 16):
+                sets = [[((s + k) % 2, sizes[s * 16 + k]) for k in range(per_set)] for s in range(3)]
+                for rnd in range(3):                              # slots are reused while the others are still in flight
+                    for s in range(3):
+                        eng.forward_multi_async(s, [b for b, _ in sets[s]], [n for _, n in sets[s]])
+                    outs = [eng.wait(s, sum(n for _, n in sets[s])) for s in range(3)]
+                for s in range(3):
+                    vrows = sum((n + 63) // 64 * 64 for _, n in sets[s])
+                    Rv = eng.fetch_interaction(vrows, slot=s)
+                    forms["%s, %d queries, %d rows" % (dist, per_set, vrows)] = eng.last_dispatch(s)
+                    o = v = 0
+                    for k, (bid, n) in enumerate(sets[s]):
+                        exp, R_exp = oracle(bid, n)
+                        assert H.close(Rv[v:v + n], R_exp, rtol=1e-5, atol_scale=2e-6), (name, dist, per_set, s, k, n)
+                        assert H.close(outs[s][o:o + n], exp, rtol=H.RTOL_OUT, atol=1e-7), (name, dist, per_set, s, k, n)
+                        o += n
+                        v += (n + 63) // 64 * 64
+        # a set of 16 full 1024-sample queries: the slot's whole capacity (16 384 virtual rows)
+        full = [(k % 2, B) for k in range(16)]
+        outs = net.run_staged_multi([b for b, _ in full], [n for _, n in full])
+        forms["16 x 1024"] = eng.last_dispatch(0)
+        for (bid, n), o in zip(full, outs):
+            assert H.close(o, oracle(bid, n)[0], rtol=H.RTOL_OUT, atol=1e-7), (name, "16 x 1024", bid)
+    finally:
+        eng.close()
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                               "dispatch_1024_%s.json" % name), "w") as f:
+            json.dump(forms, f, indent=1)
+
+
 def test_split_variant_within_tolerance_full_size():
     rows, D, T, L, B = 200_000, 32, 8, 80, 128
     args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, "128-64-32", "256-64-1", B, nb=1)
