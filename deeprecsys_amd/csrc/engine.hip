@@ -167,13 +167,17 @@ struct Slot {
 // a reserved address range of chosen alignment, physical memory created in chunks of a chosen size
 // (0: one handle for the whole arena) and mapped into it ("table_alloc" and friends, DESIGN.md 3.5:
 // what a table is, models/dlrm_s_caffe2.py:297-299, does not say where it lives).
+struct VaRange { void* base = nullptr; size_t reserved = 0; float* p = nullptr; };   // a reserved address range and the (aligned) arena address inside it
 struct Arena {
   float* p = nullptr;
   int kind = 0;
   size_t va_bytes = 0;
-  std::vector<hipMemGenericAllocationHandle_t> handles;
-  void* va_base = nullptr;        // kind 1: the reserved address range [va_base, va_base + va_reserved) that holds
-  size_t va_reserved = 0;         // [p, p + va_bytes) -- larger than the arena when p had to be aligned by hand
+  std::vector<hipMemGenericAllocationHandle_t> handles;   // kind 1: the physical memory, in chunks ...
+  std::vector<size_t> place;                              // ... handle i sits at chunk position place[i] of the range
+  std::vector<hipMemGenericAllocationHandle_t> pads;      // "table_va_perturb": 4 KiB allocations made between address candidates
+  std::vector<VaRange> vas;                               // address ranges reserved for it ("table_va_next"); [va_cur] is mapped
+  int va_cur = 0;
+  size_t align = 0;
 };
 
 }  // namespace
@@ -188,11 +192,25 @@ struct drs_engine {
   float* tables = nullptr;
   // "table_placement": further copies of the arena in other places of HBM; `tables` is the one in use (see drs_set_option)
   std::vector<Arena> arenas;
+  std::vector<hipMemGenericAllocationHandle_t> spacers;   // "table_spacer": device memory taken (never mapped) between placement candidates
   size_t tables_bytes = 0;
   // how the NEXT arena is built (drs_create's first one, "table_placement" -1 candidates)
   int table_alloc = 0;              // 0 hipMalloc | 1 virtual-memory API
-  int64_t vmm_chunk = 0;            // bytes of physical memory per handle (0: one handle); rounded up to the granularity
+  int64_t vmm_chunk = -1;           // bytes of physical memory per handle (0: one handle | -1: 1 GiB handles from 1 GiB on, else one); rounded up to whole 2 MiB pages
   int64_t vmm_align = 0;            // alignment of the reserved address range (0: the allocation granularity)
+  // arena_alloc_selected: scratch of the gather probe and what the last selection saw
+  int32_t* probe_idx = nullptr;
+  float* probe_out = nullptr;
+  int64_t* probe_tab = nullptr;
+  int32_t* probe_err = nullptr;
+  int64_t probe_rows = 0;
+  int32_t probe_bags = 0, probe_L = 0;
+  int64_t sel_want_pool = 0;        // "table_select_pool": chunks the next selection allocates (0: 2 n + 8)
+  int64_t sel_pool = 0, sel_kept = 0, sel_best_ns = 0, sel_worst_ns = 0, sel_kept_worst_ns = 0, sel_ms = 0;
+  int64_t probe_gather_ns = 0;      // result of the last "table_probe_gather"
+  int64_t probe_mbs = 0;            // result of the last "table_probe"
+  int probe_windows = 0, probe_sorted = 0;
+  int64_t probe_ps = 0;             // result of the last "table_probe_latency": picoseconds per dependent load
   int vmm_shuffle = 0;              // lab: map the chunks in a permuted order (neighbouring addresses, distant memory)
   int64_t* d_tab_off = nullptr;
   int64_t* d_tab_rows = nullptr;
@@ -304,6 +322,43 @@ void free_batch(Batch& b) {
 }
 
 // ---- table arenas ---------------------------------------------------------------------------------
+hipError_t va_reserve(size_t total, size_t align, VaRange* out) {
+  // hipMemAddressReserve does not honour its alignment argument beyond the granularity (measured: "1 GiB aligned"
+  // came back 2 MiB aligned): reserve `align` bytes more and align inside the range by hand
+  void* base = nullptr;
+  const size_t reserved = total + align;
+  hipError_t r = hipMemAddressReserve(&base, reserved, 0, nullptr, 0);
+  if (r != hipSuccess) return r;
+  out->base = base;
+  out->reserved = reserved;
+  out->p = static_cast<float*>(align ? reinterpret_cast<void*>(((uintptr_t)base + align - 1) / align * align) : base);
+  return hipSuccess;
+}
+
+// the arena's physical handles at address `at` (handle i at place[i]); on failure nothing stays mapped there
+hipError_t arena_map(const Arena& a, float* at, int device) {
+  const size_t n = a.handles.size(), csz = a.va_bytes / n;
+  hipError_t r = hipSuccess;
+  std::vector<size_t> done;
+  for (size_t i = 0; i < n && r == hipSuccess; ++i) {
+    r = hipMemMap(reinterpret_cast<char*>(at) + a.place[i] * csz, csz, 0, a.handles[i], 0);
+    if (r == hipSuccess) done.push_back(a.place[i]);
+  }
+  if (r == hipSuccess) {
+    hipMemAccessDesc desc;
+    memset(&desc, 0, sizeof desc);
+    desc.location.type = hipMemLocationTypeDevice;
+    desc.location.id = device;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    r = hipMemSetAccess(at, a.va_bytes, &desc, 1);
+  }
+  if (r != hipSuccess) {
+    for (size_t pl : done) (void)hipMemUnmap(reinterpret_cast<char*>(at) + pl * csz, csz);
+    (void)hipGetLastError();
+  }
+  return r;
+}
+
 void arena_free(Arena& a) {
   if (!a.p) { a = Arena(); return; }
   if (a.kind == 0) {
@@ -311,18 +366,175 @@ void arena_free(Arena& a) {
   } else {
     (void)hipMemUnmap(a.p, a.va_bytes);
     for (auto& h : a.handles) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(a.va_base, a.va_reserved);
+    for (auto& h : a.pads) (void)hipMemRelease(h);
+    for (auto& v : a.vas) (void)hipMemAddressFree(v.base, v.reserved);
   }
   a = Arena();
+}
+
+// The model's OWN gather kernel on a one-table problem laid over [base, base + bytes): `bags` bags of L sorted,
+// distinct rows each (one row per L-th of the range, what np.unique leaves of a bag's draws,
+// data_generator/dlrm_data_caffe2.py:105-110), the launch the engine would make for them.  *us = average
+// duration of a launch.  Why the real kernel: synthetic row-read probes that saturate the memory system read every
+// gigabyte of HBM equally fast; the gather kernels, with a handful of loads in flight per lane, do not
+// (profiles/r05_placement/).
+hipError_t probe_gather(drs_engine* e, const float* base, size_t bytes, double* us) {
+  *us = 0;
+  const int D = e->D;
+  const int64_t rows = (int64_t)(bytes / ((size_t)D * 4));
+  const int L = e->max_lookups > 256 ? 256 : e->max_lookups;
+  const int bags = 16384;
+  if (rows < L || rows >= (1ll << 31)) return hipErrorInvalidValue;
+  hipError_t r = hipSuccess;
+  if (!e->probe_idx || e->probe_rows != rows || e->probe_L != L) {
+    if (e->probe_idx) { (void)hipFree(e->probe_idx); e->probe_idx = nullptr; }
+    std::vector<int32_t> idx((size_t)bags * L);
+    uint32_t z = 0x2545F491u;
+    for (int b = 0; b < bags; ++b)
+      for (int j = 0; j < L; ++j) {
+        z ^= z << 13; z ^= z >> 17; z ^= z << 5;
+        const int64_t lo = rows * j / L, hi = rows * (j + 1) / L;
+        idx[(size_t)b * L + j] = (int32_t)(lo + (int64_t)(z % (uint32_t)(hi > lo ? hi - lo : 1)));
+      }
+    if ((r = hipMalloc(&e->probe_idx, sizeof(int32_t) * idx.size())) != hipSuccess) return r;
+    if ((r = hipMemcpy(e->probe_idx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice)) != hipSuccess) return r;
+    if (!e->probe_out && (r = hipMalloc(&e->probe_out, sizeof(float) * (size_t)bags * D)) != hipSuccess) return r;
+    if (!e->probe_tab && (r = hipMalloc(&e->probe_tab, sizeof(int64_t) * 2)) != hipSuccess) return r;
+    if (!e->probe_err && (r = hipMalloc(&e->probe_err, sizeof(int32_t))) != hipSuccess) return r;
+    const int64_t tab[2] = {0, rows};
+    if ((r = hipMemcpy(e->probe_tab, tab, sizeof tab, hipMemcpyHostToDevice)) != hipSuccess) return r;
+    if ((r = hipMemset(e->probe_err, 0, sizeof(int32_t))) != hipSuccess) return r;
+    e->probe_rows = rows; e->probe_L = L; e->probe_bags = bags;
+  }
+  SlsArgs a;
+  memset(&a, 0, sizeof a);
+  a.tables = base; a.tab_off = e->probe_tab; a.tab_rows = e->probe_tab + 1;
+  a.q.n_q = 1; a.q.vstart[1] = bags; a.q.cum[1] = bags; a.q.bs[0] = bags;
+  a.idx[0] = e->probe_idx; a.off[0] = nullptr; a.uniform_len[0] = L;
+  a.idx_stride = (int64_t)bags * L; a.off_stride = bags + 1;
+  a.out = e->probe_out; a.ld_out = D; a.col0 = 0; a.T = 1; a.D = D; a.err = e->probe_err; a.ts = nullptr;
+  Tune t = e->tune;
+  t.log = nullptr;
+  const int exact = L <= e->sls_short_bag && !sls_flat_applicable(a, t);
+  hipEvent_t e0, e1;
+  if ((r = hipEventCreate(&e0)) != hipSuccess) return r;
+  if ((r = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return r; }
+  const int warm = 2, reps = 6;
+  for (int i = 0; i < warm + reps && r == hipSuccess; ++i) {
+    if (i == warm) r = hipEventRecord(e0, nullptr);
+    if (r == hipSuccess) r = launch_sls(a, exact, t, nullptr);
+  }
+  if (r == hipSuccess) r = hipEventRecord(e1, nullptr);
+  if (r == hipSuccess) r = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (r == hipSuccess) r = hipEventElapsedTime(&ms, e0, e1);
+  if (r == hipSuccess) *us = (double)ms * 1e3 / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return r;
+}
+
+// "table_alloc" 3: the arena out of the fastest gigabytes of a pool.  ceil(bytes / 1 GiB) = n chunks are needed;
+// up to 2 n + 8 one-GiB handles are created (never more than half of the free memory), each is timed with
+// probe_gather, the n fastest are mapped back to back as the arena and the rest is released at once: one copy of
+// the tables, nothing held.  Costs ~1 ms per pool chunk at engine start.
+hipError_t arena_alloc_selected(drs_engine* e, size_t bytes, Arena* out) {
+  *out = Arena();
+  const size_t chunk = (size_t)1 << 30;
+  const size_t n = (bytes + chunk - 1) / chunk;
+  const auto t_begin = std::chrono::steady_clock::now();
+  hipMemAllocationProp prop;
+  memset(&prop, 0, sizeof prop);
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = e->device;
+  size_t free_b = 0, total_b = 0;
+  hipError_t r = hipMemGetInfo(&free_b, &total_b);
+  if (r != hipSuccess) return r;
+  size_t m = 2 * n + 8;
+  if (e->sel_want_pool > 0) m = (size_t)e->sel_want_pool;
+  if (m > 192) m = 192;
+  while (m > n && m * chunk > free_b / 2) --m;
+  if (m < n) m = n;
+  std::vector<hipMemGenericAllocationHandle_t> pool;
+  for (size_t i = 0; i < m; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+    pool.push_back(h);
+  }
+  auto release_all = [&]() { for (auto& h : pool) (void)hipMemRelease(h); };
+  if (pool.size() < n) { release_all(); return hipErrorOutOfMemory; }
+  m = pool.size();
+  std::vector<double> us(m, 0.0);
+  if (m > n) {
+    Arena all;
+    all.kind = 1; all.va_bytes = m * chunk; all.handles = pool;
+    for (size_t i = 0; i < m; ++i) all.place.push_back(i);
+    VaRange v;
+    r = va_reserve(all.va_bytes, 0, &v);
+    if (r == hipSuccess) {
+      r = arena_map(all, v.p, e->device);
+      if (r == hipSuccess) {
+        // two rounds, the faster reading of each chunk counts (a single reading can catch a clock ramp)
+        for (int round = 0; round < 2 && r == hipSuccess; ++round)
+          for (size_t i = 0; i < m && r == hipSuccess; ++i) {
+            double t = 0;
+            r = probe_gather(e, reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.p) + i * chunk), chunk, &t);
+            if (r == hipSuccess && (round == 0 || t < us[i])) us[i] = t;
+          }
+        (void)hipMemUnmap(v.p, all.va_bytes);
+      }
+      (void)hipMemAddressFree(v.base, v.reserved);
+    }
+    if (r != hipSuccess) { release_all(); (void)hipGetLastError(); return r; }
+  }
+  std::vector<size_t> order(m);
+  for (size_t i = 0; i < m; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return us[x] < us[y]; });
+  std::vector<size_t> keep(order.begin(), order.begin() + (long)n);
+  std::sort(keep.begin(), keep.end());
+  Arena a;
+  a.kind = 1;
+  a.va_bytes = n * chunk;
+  a.align = e->vmm_align > 0 ? (size_t)e->vmm_align : 0;
+  std::vector<bool> kept(m, false);
+  for (size_t k : keep) { a.handles.push_back(pool[k]); a.place.push_back(a.place.size()); kept[k] = true; }
+  for (size_t i = 0; i < m; ++i) if (!kept[i]) (void)hipMemRelease(pool[i]);
+  VaRange v;
+  r = va_reserve(a.va_bytes, a.align, &v);
+  if (r == hipSuccess) {
+    r = arena_map(a, v.p, e->device);
+    if (r != hipSuccess) (void)hipMemAddressFree(v.base, v.reserved);
+  }
+  if (r != hipSuccess) { for (auto& h : a.handles) (void)hipMemRelease(h); (void)hipGetLastError(); return r; }
+  a.vas.push_back(v);
+  a.p = v.p;
+  e->sel_pool = (int64_t)m; e->sel_kept = (int64_t)n;
+  e->sel_best_ns = (int64_t)(us[order[0]] * 1e3); e->sel_worst_ns = (int64_t)(us[order[m - 1]] * 1e3);
+  e->sel_kept_worst_ns = (int64_t)(us[order[n - 1]] * 1e3);
+  e->sel_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_begin).count();
+  *out = a;
+  return hipSuccess;
 }
 
 // `bytes` of device memory for the tables, built as e->table_alloc / vmm_* say.  On failure nothing stays
 // allocated and *out is empty.
 hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
   *out = Arena();
-  if (e->table_alloc == 0) {
+  if (e->table_alloc == 3) {
+    if (arena_alloc_selected(e, bytes, out) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();           // (no room for a pool, no virtual-memory API ...: a plain allocation)
+  }
+  if (e->table_alloc == 0 || e->table_alloc == 2 || e->table_alloc == 3) {
+    // 2: physically contiguous device memory, best effort (hipDeviceMallocContiguous: the driver assembles the
+    // allocation from neighbouring free blocks instead of taking whatever blocks head its free lists -- DESIGN.md 3.5)
     void* p = nullptr;
-    hipError_t r = hipMalloc(&p, bytes);
+    hipError_t r = hipErrorOutOfMemory;
+    if (e->table_alloc == 2) {
+      r = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous);
+      if (r != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    }
+    if (r != hipSuccess) r = hipMalloc(&p, bytes);
     if (r != hipSuccess) return r;
     out->p = static_cast<float*>(p);
     out->va_bytes = bytes;
@@ -336,57 +548,72 @@ hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
   size_t gran = 0;
   hipError_t r = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
   if (r != hipSuccess) return r;
-  if (gran == 0) gran = (size_t)2 << 20;
-  const size_t chunk = e->vmm_chunk > 0 ? (size_t)round_up(e->vmm_chunk, (int64_t)gran) : 0;
+  if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;      // (the runtime reports 4 KiB; whole 2 MiB pages keep every mapping a huge page)
+  // "table_vmm_chunk" -1 (the default): 1 GiB handles for arenas of at least 1 GiB, one handle for smaller ones
+  const int64_t want = e->vmm_chunk < 0 ? (bytes >= ((size_t)1 << 30) ? (int64_t)1 << 30 : 0) : e->vmm_chunk;
+  const size_t chunk = want > 0 ? (size_t)round_up(want, (int64_t)gran) : 0;
   const size_t total = (size_t)round_up((int64_t)bytes, (int64_t)(chunk ? chunk : gran));
-  const size_t align = e->vmm_align > 0 ? (size_t)round_up(e->vmm_align, (int64_t)gran) : 0;
-  // hipMemAddressReserve does not honour its alignment argument beyond the granularity (measured: "1 GiB aligned"
-  // came back 2 MiB aligned): reserve `align` bytes more and align inside the range by hand
-  void* base = nullptr;
-  const size_t reserved = total + align;
-  r = hipMemAddressReserve(&base, reserved, 0, nullptr, 0);
-  if (r != hipSuccess) return r;
-  void* va = align ? reinterpret_cast<void*>(((uintptr_t)base + align - 1) / align * align) : base;
   Arena a;
-  a.p = static_cast<float*>(va);
   a.kind = 1;
   a.va_bytes = total;
-  a.va_base = base;
-  a.va_reserved = reserved;
+  a.align = e->vmm_align > 0 ? (size_t)round_up(e->vmm_align, (int64_t)gran) : 0;
   const size_t n = chunk ? total / chunk : 1, csz = chunk ? chunk : total;
-  // chunk i of physical memory goes to place perm(i) of the range ("table_vmm_shuffle": a fixed odd-multiplier walk)
-  size_t mapped = 0;
-  for (size_t i = 0; i < n && r == hipSuccess; ++i) {
+  for (size_t i = 0; i < n; ++i) {
     hipMemGenericAllocationHandle_t h;
     r = hipMemCreate(&h, csz, &prop, 0);
     if (r != hipSuccess) break;
     a.handles.push_back(h);
-    size_t place = i;
-    if (e->vmm_shuffle && n > 2) {
-      size_t mul = (n / 2) | 1;                       // odd and coprime with a power-of-two n; else fall back to a reversal
-      place = (n & (n - 1)) == 0 ? (i * mul + n / 3) % n : n - 1 - i;
-    }
-    r = hipMemMap(static_cast<char*>(va) + place * csz, csz, 0, h, 0);
-    if (r == hipSuccess) ++mapped;
+    // chunk i of physical memory goes to place perm(i) of the range ("table_vmm_shuffle", a lab option: a fixed odd-multiplier walk)
+    size_t pl = i;
+    if (e->vmm_shuffle && n > 2) pl = (n & (n - 1)) == 0 ? (i * ((n / 2) | 1) + n / 3) % n : n - 1 - i;
+    a.place.push_back(pl);
   }
+  VaRange v;
+  if (r == hipSuccess) r = va_reserve(total, a.align, &v);
   if (r == hipSuccess) {
-    hipMemAccessDesc desc;
-    memset(&desc, 0, sizeof desc);
-    desc.location = prop.location;
-    desc.flags = hipMemAccessFlagsProtReadWrite;
-    r = hipMemSetAccess(va, total, &desc, 1);
+    r = arena_map(a, v.p, e->device);
+    if (r != hipSuccess) (void)hipMemAddressFree(v.base, v.reserved);
   }
   if (r != hipSuccess) {
-    // unmap what was mapped (chunk by chunk: a partially mapped range cannot be unmapped in one call)
-    if (mapped == n) (void)hipMemUnmap(va, total);
-    else if (!e->vmm_shuffle) for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(static_cast<char*>(va) + i * csz, csz);
     for (auto& h : a.handles) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(base, reserved);
     (void)hipGetLastError();
     return r;
   }
+  a.vas.push_back(v);
+  a.va_cur = 0;
+  a.p = v.p;
   *out = a;
   return hipSuccess;
+}
+
+// The arena in use moves to another address range: "table_va_next" reserves one more range and maps the arena's
+// memory there (the ranges tried so far stay reserved -- address space only, no memory), "table_va_select" k goes
+// back to candidate k and gives the other ranges up.  Why an ADDRESS matters: DESIGN.md 3.5 (the gather's speed on
+// an arena follows the arena's virtual address, i.e. the page-table blocks behind it, not its memory).
+int32_t arena_move(drs_engine* e, Arena& a, int64_t to /* -1: a fresh range */) {
+  if (a.kind != 1) return fail(e, DRS_ERR_STATE, "the table arena was not built with the virtual-memory API (\"table_alloc\" 1)");
+  if (to >= (int64_t)a.vas.size()) return fail(e, DRS_ERR_BAD_ARG, "address candidate %lld of %zu", (long long)to, a.vas.size());
+  if (to < 0) {
+    if (a.vas.size() >= 64) return fail(e, DRS_ERR_BAD_ARG, "64 address candidates are the limit");
+    VaRange v;
+    hipError_t r = va_reserve(a.va_bytes, a.align, &v);
+    if (r != hipSuccess) { (void)hipGetLastError(); return fail(e, DRS_ERR_OOM, "hipMemAddressReserve: %s", hipGetErrorString(r)); }
+    a.vas.push_back(v);
+    to = (int64_t)a.vas.size() - 1;
+  }
+  if (to == a.va_cur) return DRS_OK;
+  HIP_TRY(e, hipMemUnmap(a.p, a.va_bytes));
+  hipError_t r = arena_map(a, a.vas[(size_t)to].p, e->device);
+  if (r != hipSuccess) {
+    // back to where it was: the engine must not be left without its tables
+    hipError_t r2 = arena_map(a, a.p, e->device);
+    return fail(e, DRS_ERR_HIP, "mapping the tables at another address: %s%s", hipGetErrorString(r), r2 == hipSuccess ? "" : " (and the old mapping could not be restored)");
+  }
+  const bool in_use = e->tables == a.p;
+  a.va_cur = (int)to;
+  a.p = a.vas[(size_t)to].p;
+  if (in_use) e->tables = a.p;
+  return DRS_OK;
 }
 
 // ---- host-side worker pool for the per-call input pass ----------------------------------------
@@ -1437,12 +1664,6 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   e->tune.device = device_id;
   CREATE_TRY(device_init(device_id, &e->tune.zero));
   e->tables_bytes = sizeof(float) * (size_t)off;
-  {
-    Arena first;
-    CREATE_TRY(arena_alloc(e, e->tables_bytes, &first));
-    e->tables = first.p;
-    e->arenas.assign(1, first);
-  }
   CREATE_TRY(hipMalloc(&e->d_tab_off, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_tab_rows, sizeof(int64_t) * T));
   CREATE_TRY(hipMalloc(&e->d_op_tab, sizeof(int64_t) * 2));
@@ -1595,6 +1816,20 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF;
   }
   apply_stream_mode(e);
+  {
+    // The table arena, last (its builder may run the gather kernels as a probe): one hipMalloc.  With
+    // DRS_TABLE_SELECT=1 in the environment, gather-bound DLRM with gigabytes of tables gets "table_alloc" 3
+    // (arena_alloc_selected: the fastest gigabytes of a pool by a one-table run of the model's gather kernel) -- an
+    // experiment that did NOT work: that probe reads every gigabyte equally fast (profiles/r05_placement/README.md);
+    // what does see the property is the model's own launch sets (DLRM_Net.tune_table_placement).
+    const char* env = getenv("DRS_TABLE_SELECT");
+    const bool want = env ? atoi(env) != 0 : false;
+    if (want && e->kind == DRS_MODEL_DLRM && e->mlp_streams <= 2 && e->max_lookups >= 8 && e->tables_bytes >= ((size_t)1 << 30)) e->table_alloc = 3;
+    Arena first;
+    CREATE_TRY(arena_alloc(e, e->tables_bytes, &first));
+    e->tables = first.p;
+    e->arenas.assign(1, first);
+  }
 #undef CREATE_TRY
   *out = e;
   return DRS_OK;
@@ -1652,7 +1887,12 @@ int32_t drs_destroy(drs_handle e) {
   if (e->d_att_packed) (void)hipFree(e->d_att_packed);
   if (e->w_arena) (void)hipFree(e->w_arena);
   for (Arena& a : e->arenas) arena_free(a);
+  for (auto& h : e->spacers) (void)hipMemRelease(h);
   e->tables = nullptr;
+  if (e->probe_idx) (void)hipFree(e->probe_idx);
+  if (e->probe_out) (void)hipFree(e->probe_out);
+  if (e->probe_tab) (void)hipFree(e->probe_tab);
+  if (e->probe_err) (void)hipFree(e->probe_err);
   if (e->d_tab_off) (void)hipFree(e->d_tab_off);
   if (e->d_tab_rows) (void)hipFree(e->d_tab_rows);
   if (e->d_op_tab) (void)hipFree(e->d_op_tab);
@@ -1664,11 +1904,17 @@ int32_t drs_destroy(drs_handle e) {
 }
 
 // new table contents make the other placement candidates stale: only the arena in use survives
+static void drop_spacers(drs_engine* e);
 static void drop_other_placements(drs_engine* e) {
+  drop_spacers(e);
   if (e->arenas.size() <= 1) return;
   std::vector<Arena> keep;
   for (Arena& a : e->arenas) { if (a.p == e->tables) keep.push_back(a); else arena_free(a); }
   e->arenas = keep;
+}
+static void drop_spacers(drs_engine* e) {
+  for (auto& h : e->spacers) (void)hipMemRelease(h);
+  e->spacers.clear();
 }
 
 int32_t drs_set_table(drs_handle e, int32_t t, const float* h_W, int64_t rows) {
@@ -2300,54 +2546,123 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
       return fail(e, DRS_ERR_BAD_ARG, "table_placement %lld (candidates: %zu)", (long long)value, e->arenas.size());
     }
   }
-  else if (!strcmp(key, "table_vmm_swap") || !strcmp(key, "table_vmm_remap")) {
-    // lab (tools/placement_lab.py): is the gather's speed on an arena a property of its MEMORY or of its MAPPING?
-    //   "table_vmm_swap"  (i << 16) | j: the physical handles of arenas i and j change places (both built with "table_alloc" 1
-    //                     and the same chunking; both hold the same tables, so results do not change)
-    //   "table_vmm_remap" i: arena i's handles are unmapped and mapped again at a freshly reserved address range
+  else if (!strcmp(key, "table_va_next") || !strcmp(key, "table_va_select") || !strcmp(key, "table_va_goto")) {
     int32_t rc = drs_sync(e);
     if (rc) return rc;
-    hipMemAccessDesc desc;
-    memset(&desc, 0, sizeof desc);
-    desc.location.type = hipMemLocationTypeDevice;
-    desc.location.id = e->device;
-    desc.flags = hipMemAccessFlagsProtReadWrite;
-    auto map_all = [&](Arena& a) -> hipError_t {
-      const size_t csz = a.va_bytes / a.handles.size();
-      for (size_t k = 0; k < a.handles.size(); ++k) {
-        hipError_t r = hipMemMap(reinterpret_cast<char*>(a.p) + k * csz, csz, 0, a.handles[k], 0);
-        if (r != hipSuccess) return r;
+    auto it = std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; });
+    if (it == e->arenas.end()) return fail(e, DRS_ERR_STATE, "no table arena in use");
+    if (!strcmp(key, "table_va_next")) {
+      // value k > 0: k allocations of 4 KiB first -- they take the device-memory pages the driver would otherwise
+      // hand to the page-table blocks of the new range, i.e. the range's page tables land somewhere else
+      if (value > 0 && it->kind == 1) {
+        hipMemAllocationProp prop;
+        memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = e->device;
+        for (int64_t k = 0; k < value && it->pads.size() < 65536; ++k) {
+          hipMemGenericAllocationHandle_t h;
+          if (hipMemCreate(&h, 4096, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+          it->pads.push_back(h);
+        }
       }
-      return hipMemSetAccess(a.p, a.va_bytes, &desc, 1);
-    };
-    if (!strcmp(key, "table_vmm_swap")) {
-      const size_t i = (size_t)(value >> 16), j = (size_t)(value & 0xffff);
-      if (i >= e->arenas.size() || j >= e->arenas.size() || i == j) return fail(e, DRS_ERR_BAD_ARG, "table_vmm_swap: no such arenas");
-      Arena &a = e->arenas[i], &b = e->arenas[j];
-      if (a.kind != 1 || b.kind != 1 || a.va_bytes != b.va_bytes || a.handles.size() != b.handles.size())
-        return fail(e, DRS_ERR_BAD_ARG, "table_vmm_swap: both arenas must come from the virtual-memory API with the same chunking");
-      HIP_TRY(e, hipMemUnmap(a.p, a.va_bytes));
-      HIP_TRY(e, hipMemUnmap(b.p, b.va_bytes));
-      std::swap(a.handles, b.handles);
-      HIP_TRY(e, map_all(a));
-      HIP_TRY(e, map_all(b));
-    } else {
-      const size_t i = (size_t)value;
-      if (i >= e->arenas.size() || e->arenas[i].kind != 1) return fail(e, DRS_ERR_BAD_ARG, "table_vmm_remap: not an arena of the virtual-memory API");
-      Arena& a = e->arenas[i];
-      void* va = nullptr;
-      HIP_TRY(e, hipMemAddressReserve(&va, a.va_bytes, 0, nullptr, 0));
-      HIP_TRY(e, hipMemUnmap(a.p, a.va_bytes));
-      HIP_TRY(e, hipMemAddressFree(a.va_base, a.va_reserved));
-      const bool in_use = e->tables == a.p;
-      a.p = static_cast<float*>(va);
-      a.va_base = va; a.va_reserved = a.va_bytes;
-      HIP_TRY(e, map_all(a));
-      if (in_use) e->tables = a.p;
+      return arena_move(e, *it, -1);
+    }
+    if (value < 0) return fail(e, DRS_ERR_BAD_ARG, "%s %lld", key, (long long)value);
+    if ((rc = arena_move(e, *it, value))) return rc;
+    if (!strcmp(key, "table_va_goto")) return DRS_OK;      // (every candidate stays reserved)
+    // the ranges not in use are given back (address space only)
+    for (size_t k = 0; k < it->vas.size(); ++k)
+      if ((int)k != it->va_cur) (void)hipMemAddressFree(it->vas[k].base, it->vas[k].reserved);
+    const VaRange keep = it->vas[(size_t)it->va_cur];
+    it->vas.assign(1, keep);
+    it->va_cur = 0;
+  }
+  else if (!strcmp(key, "table_probe_windows") && value >= 0 && value <= 4096) e->probe_windows = (int)value;
+  else if (!strcmp(key, "table_probe_sorted") && (value == 0 || value == 1)) e->probe_sorted = (int)value;
+  else if (!strcmp(key, "table_probe_gather")) {
+    // lab: the selection's probe (the model's own gather kernel on a one-table problem) over arena `value` as a whole;
+    // result "table_probe_gather_ns"
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    if (value < 0 || (size_t)value >= e->arenas.size()) return fail(e, DRS_ERR_BAD_ARG, "table_probe_gather %lld", (long long)value);
+    const Arena& a = e->arenas[(size_t)value];
+    double us = 0, us2 = 0;
+    HIP_TRY(e, probe_gather(e, a.p, std::min(a.va_bytes, e->tables_bytes), &us));
+    HIP_TRY(e, probe_gather(e, a.p, std::min(a.va_bytes, e->tables_bytes), &us2));
+    e->probe_gather_ns = (int64_t)(std::min(us, us2) * 1e3);
+  }
+  else if (!strcmp(key, "table_probe_latency")) {
+    // lab: dependent-load latency over arena `value` as ONE chunk; result "table_probe_ns" (picoseconds per load)
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    if (value < 0 || (size_t)value >= e->arenas.size()) return fail(e, DRS_ERR_BAD_ARG, "table_probe_latency %lld", (long long)value);
+    const Arena& a = e->arenas[(size_t)value];
+    Slot& s0 = e->slots[0];
+    const int steps = 4096;
+    uint64_t ticks = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      HIP_TRY(e, probe_latency(a.p, std::min(a.va_bytes, e->tables_bytes), 1, steps, s0.d_ts, s0.own_stream));
+      HIP_TRY(e, hipStreamSynchronize(s0.own_stream));
+      HIP_TRY(e, hipMemcpy(&ticks, s0.d_ts, sizeof ticks, hipMemcpyDeviceToHost));
+    }
+    e->probe_ps = (int64_t)((double)ticks / e->wall_clock_khz * 1e9 / steps);     // ticks / kHz = ms; -> ps per load
+  }
+  else if (!strcmp(key, "table_probe")) {
+    // lab: the row-read probe over arena `value` as a whole, or (value = -(k + 1)) over 1 GiB chunk k of the arena in
+    // use; the result is read with drs_get_option "table_probe_mbs" (MB/s of row bytes)
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    const char* base = nullptr;
+    size_t bytes = 0;
+    if (value >= 0 && (size_t)value < e->arenas.size()) { base = reinterpret_cast<const char*>(e->arenas[(size_t)value].p); bytes = e->arenas[(size_t)value].va_bytes; }
+    else if (value < 0 && (size_t)(-(value + 1)) * ((size_t)1 << 30) < e->tables_bytes) {
+      const size_t off = (size_t)(-(value + 1)) << 30;
+      base = reinterpret_cast<const char*>(e->tables) + off;
+      bytes = std::min((size_t)1 << 30, e->tables_bytes - off);
+    } else return fail(e, DRS_ERR_BAD_ARG, "table_probe %lld", (long long)value);
+    double gbs = 0;
+    HIP_TRY(e, probe_rows(base, bytes, 24576, 64, e->slots[0].d_out, e->slots[0].own_stream, &gbs, e->probe_windows, e->probe_sorted));   // warm-up pass
+    HIP_TRY(e, probe_rows(base, bytes, 24576, 24, e->slots[0].d_out, e->slots[0].own_stream, &gbs, e->probe_windows, e->probe_sorted));
+    e->probe_mbs = (int64_t)(gbs * 1e3);
+  }
+  else if (!strcmp(key, "table_vmm_swap")) {
+    // lab (tools/placement_lab.py): is the gather's speed on an arena a property of its MEMORY or of its ADDRESS?
+    // (i << 16) | j: the physical handles of arenas i and j change places (both built with "table_alloc" 1 and the same
+    // chunking; both hold the same tables, so results do not change)
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    const size_t i = (size_t)(value >> 16), j = (size_t)(value & 0xffff);
+    if (value < 0 || i >= e->arenas.size() || j >= e->arenas.size() || i == j) return fail(e, DRS_ERR_BAD_ARG, "table_vmm_swap: no such arenas");
+    Arena &a = e->arenas[i], &b = e->arenas[j];
+    if (a.kind != 1 || b.kind != 1 || a.va_bytes != b.va_bytes || a.handles.size() != b.handles.size())
+      return fail(e, DRS_ERR_BAD_ARG, "table_vmm_swap: both arenas must come from the virtual-memory API with the same chunking");
+    HIP_TRY(e, hipMemUnmap(a.p, a.va_bytes));
+    HIP_TRY(e, hipMemUnmap(b.p, b.va_bytes));
+    std::swap(a.handles, b.handles);
+    std::swap(a.place, b.place);
+    HIP_TRY(e, arena_map(a, a.p, e->device));
+    HIP_TRY(e, arena_map(b, b.p, e->device));
+  }
+  else if (!strcmp(key, "table_alloc") && value >= 0 && value <= 3) e->table_alloc = (int)value;
+  else if (!strcmp(key, "table_spacer") && value >= 0) {
+    // `value` bytes of device memory are taken in 1 GiB pieces and never mapped: the next placement candidate comes from
+    // further on in HBM.  "table_placement" -2 gives them back (as does drs_destroy).
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = e->device;
+    size_t free_b = 0, total_b = 0;
+    for (int64_t got = 0; got < value; got += (int64_t)1 << 30) {
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < ((size_t)8 << 30)) break;
+      hipMemGenericAllocationHandle_t h;
+      if (hipMemCreate(&h, (size_t)1 << 30, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+      e->spacers.push_back(h);
     }
   }
-  else if (!strcmp(key, "table_alloc") && (value == 0 || value == 1)) e->table_alloc = (int)value;
-  else if (!strcmp(key, "table_vmm_chunk") && value >= 0) e->vmm_chunk = value;
+  else if (!strcmp(key, "table_select_pool") && value >= 0 && value <= 192) e->sel_want_pool = value;
+  else if (!strcmp(key, "table_vmm_chunk") && value >= -1) e->vmm_chunk = value;
   else if (!strcmp(key, "table_vmm_align") && value >= 0) e->vmm_align = value;
   else if (!strcmp(key, "table_vmm_shuffle") && (value == 0 || value == 1)) e->vmm_shuffle = (int)value;
   else if (!strcmp(key, "out_dma") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->out_dma = value; }
@@ -2411,7 +2726,12 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
       {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},
       {"table_alloc", e->table_alloc}, {"table_vmm_chunk", e->vmm_chunk}, {"table_vmm_align", e->vmm_align}, {"table_vmm_shuffle", e->vmm_shuffle},
-      {"table_address", (int64_t)(uintptr_t)e->tables}};
+      {"table_address", (int64_t)(uintptr_t)e->tables}, {"table_select_pool", e->sel_pool}, {"table_select_kept", e->sel_kept},
+      {"table_select_best_ns", e->sel_best_ns}, {"table_select_worst_ns", e->sel_worst_ns}, {"table_select_kept_worst_ns", e->sel_kept_worst_ns},
+      {"table_select_ms", e->sel_ms}, {"table_probe_mbs", e->probe_mbs}, {"table_probe_gather_ns", e->probe_gather_ns}, {"table_probe_ps", e->probe_ps},
+      {"table_kind", [&]() -> int64_t { for (const Arena& a : e->arenas) if (a.p == e->tables) return a.kind; return 0; }()},
+      {"table_va_candidates", [&]() -> int64_t { for (const Arena& a : e->arenas) if (a.p == e->tables) return (int64_t)a.vas.size(); return 0; }()},
+      {"table_va", [&]() -> int64_t { for (const Arena& a : e->arenas) if (a.p == e->tables) return a.va_cur; return 0; }()}};
   for (auto& kv : tab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);

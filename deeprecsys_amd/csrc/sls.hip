@@ -739,6 +739,102 @@ __global__ void fill_uniform_kernel(float* W, int64_t n, int32_t t, float lo, fl
   }
 }
 
+// ---------------------------------------------------------------------------
+// Row-read probe of a range of device memory: the access shape of the many-rows-per-bag gather (a wave =
+// 80 random 256-byte rows, 4 per load instruction, all 20 loads of a lane in flight, non-temporal) without
+// index arrays or outputs.  What it is for: DESIGN.md 3.5 -- the same gather runs up to 9 % faster on some
+// gigabytes of HBM than on others, and the arena builder keeps the gigabytes this probe reads fastest.
+__global__ __launch_bounds__(64) void probe_rows_kernel(const float4* __restrict__ base, uint32_t rows, uint32_t seed,
+                                                        float4* __restrict__ sink, uint32_t windows, uint32_t stride_rows, int sorted) {
+  // windows == 0: the wave's 80 rows anywhere in [0, rows).  windows > 0: wave w reads inside window w % windows
+  // (window k = rows [k * stride_rows, k * stride_rows + rows)), like a bag of one table; sorted: ascending, one row per
+  // eightieth of the window (what np.unique leaves of a bag's indices)
+  const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+  const uint64_t w0 = windows ? (uint64_t)(blockIdx.x % windows) * stride_rows : 0;
+  uint32_t r[20];
+#pragma unroll
+  for (int u = 0; u < 20; ++u) {
+    uint32_t z = (blockIdx.x * 80u + (uint32_t)(4 * u + g)) * 0x9E3779B1u + seed;
+    z = (z ^ (z >> 16)) * 0x85EBCA6Bu;
+    z = (z ^ (z >> 13)) * 0xC2B2AE35u;
+    z ^= z >> 16;
+    if (sorted) {
+      const uint32_t lo = (uint32_t)(((uint64_t)(4 * u + g) * rows) / 80), hi = (uint32_t)(((uint64_t)(4 * u + g + 1) * rows) / 80);
+      r[u] = lo + (uint32_t)(((uint64_t)z * (hi > lo ? hi - lo : 1)) >> 32);
+    } else {
+      r[u] = (uint32_t)(((uint64_t)z * rows) >> 32);
+    }
+  }
+  float4 v[20];
+#pragma unroll
+  for (int u = 0; u < 20; ++u) v[u] = ld_nt(base + (w0 + r[u]) * 16 + gl);
+  float4 acc = vzero4();
+#pragma unroll
+  for (int u = 0; u < 20; ++u) vadd(acc, v[u]);
+  if (acc.x == 1.2345e-30f) sink[lane] = acc;      // (keeps the loads alive; never true for table data)
+}
+
+// time `reps` launches of `waves` waves over [base, base + bytes); GB/s of row bytes in *gbs
+hipError_t probe_rows(const void* base, size_t bytes, int waves, int reps, float* sink, hipStream_t s, double* gbs,
+                      int windows, int sorted) {
+  *gbs = 0;
+  uint64_t rows = bytes / 256, stride = 0;
+  if (windows > 0) { stride = rows / (uint64_t)windows; rows = stride; }
+  if (rows < 80 || rows > 0xffffffffull) return hipErrorInvalidValue;
+  hipEvent_t e0, e1;
+  hipError_t r = hipEventCreate(&e0);
+  if (r != hipSuccess) return r;
+  r = hipEventCreate(&e1);
+  if (r != hipSuccess) { (void)hipEventDestroy(e0); return r; }
+  hipLaunchKernelGGL(probe_rows_kernel, dim3((unsigned)waves), dim3(64), 0, s, static_cast<const float4*>(base), (uint32_t)rows, 1u,
+                     reinterpret_cast<float4*>(sink), (uint32_t)windows, (uint32_t)stride, sorted);
+  r = hipEventRecord(e0, s);
+  for (int i = 0; i < reps && r == hipSuccess; ++i) {
+    hipLaunchKernelGGL(probe_rows_kernel, dim3((unsigned)waves), dim3(64), 0, s, static_cast<const float4*>(base), (uint32_t)rows,
+                       0x51ED27u * (uint32_t)(i + 2), reinterpret_cast<float4*>(sink), (uint32_t)windows, (uint32_t)stride, sorted);
+    r = hipGetLastError();
+  }
+  if (r == hipSuccess) r = hipEventRecord(e1, s);
+  if (r == hipSuccess) r = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (r == hipSuccess) r = hipEventElapsedTime(&ms, e0, e1);
+  if (r == hipSuccess && ms > 0.f) *gbs = (double)waves * 80.0 * 256.0 * reps / (ms * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return r;
+}
+
+// Latency probe: workgroup k walks `steps` DEPENDENT 16-byte loads through random 256-byte rows of chunk k
+// ([base + k * chunk_bytes, + chunk_bytes)); out[k] = device-clock ticks (100 MHz) for the walk.  One lane per
+// chunk, all chunks at once: the walks do not disturb each other, and a launch is steps x ~1 us long.
+__global__ __launch_bounds__(64) void probe_latency_kernel(const float4* __restrict__ base, uint64_t chunk_rows, uint32_t rows,
+                                                           int steps, uint32_t seed, uint64_t* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const float4* b = base + (uint64_t)blockIdx.x * chunk_rows * 16;
+  uint32_t z = seed + blockIdx.x * 0x9E3779B1u;
+  float sink = 0.f;
+  const uint64_t t0 = wall_clock64();
+  for (int i = 0; i < steps; ++i) {
+    z = (z ^ (z >> 16)) * 0x85EBCA6Bu;
+    z = (z ^ (z >> 13)) * 0xC2B2AE35u;
+    z ^= z >> 16;
+    const uint32_t r = (uint32_t)(((uint64_t)z * rows) >> 32);
+    const float4 v = ld_nt(b + (uint64_t)r * 16 + (z & 15));
+    z += __float_as_uint(v.x) | 1u;                  // the next address depends on the loaded value
+    sink += v.y;
+  }
+  const uint64_t t1 = wall_clock64();
+  out[blockIdx.x] = t1 - t0 + (sink == 1.2345e-30f ? 1 : 0);
+}
+
+hipError_t probe_latency(const void* base, size_t chunk_bytes, int n_chunks, int steps, uint64_t* d_ticks, hipStream_t s) {
+  const uint64_t rows = chunk_bytes / 256;
+  if (rows < 1 || rows > 0xffffffffull || n_chunks < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(probe_latency_kernel, dim3((unsigned)n_chunks), dim3(64), 0, s, static_cast<const float4*>(base), rows,
+                     (uint32_t)rows, steps, 12345u, d_ticks);
+  return hipGetLastError();
+}
+
 hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
                                hipStream_t s) {
   if (n <= 0) return hipSuccess;

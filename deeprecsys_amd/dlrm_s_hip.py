@@ -196,30 +196,31 @@ class _HipNet(object):
             self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
         self._n_staged = len(lS_l)
 
-    def tune_table_placement(self, candidates=4, sets=128, free_losers=None):
-        """Where a multi-gigabyte hipMalloc lands in HBM moves the gather by up to 6 % and stays for the
-        allocation's lifetime.  With the input sets staged, this runs the model's own launch
-        sets (the engine's preferred size, full batches, one stream: the gather alone) on up to `candidates`
-        copies of the table arena -- drs_set_option "table_placement" -- and keeps the copy whose gather is
-        fastest.  The others are freed only when together they exceed 16 GB (free_losers None; True / False force
-        it): after multi-gigabyte hipFrees the runtime's copy-engine transfers -- and by a per cent or two the
-        gather itself -- are slower for the rest of the process (RMC1 +1.2 % with the losers freed,
-        +3.5 % with them left to the engine's destruction), and 6 GB of a 288 GB part are small change.  Returns
-        {"gather_alone_us": [...], "kept": k, "losers": "freed" | "held"}, or None when the engine has nothing to
-        time (no staged sets) or no room for a second copy.  ~30 ms per candidate."""
+    def tune_table_placement(self, candidates=6, sets=128, spacer_gb=None, policies=(1, 0)):
+        """Where the tables live in HBM, and with which cache policy their rows are read, moves the many-rows-per-bag
+        gather by up to 9 % -- a property of the PHYSICAL memory (it follows the memory through address changes;
+        gigabytes-wide regions of HBM are "fast" or "slow", and they are different regions for non-temporal and for
+        plain loads) that no synthetic probe sees, only the model's own launch sets (DESIGN.md 3.5,
+        profiles/r05_placement/README.md).  With the input sets staged, this times full launch sets of the engine's
+        preferred size (one stream: the gather alone) on the arena drs_create made, under each load policy ("sls_nt"
+        1 / 0), then on up to `candidates` - 1 further arenas taken from further on in HBM (virtual-memory API,
+        1 GiB handles; `spacer_gb` of untouched memory between two candidates, default = the arena's size), and
+        keeps the fastest (arena, policy).  It stops as soon as one arena's best reading is 5 % under another's (the
+        fast level is reached).  Every other arena and the spacers are released before it returns: one copy of the
+        tables, nothing held.  Returns {"gather_alone_us": [[nt, plain], ...], "kept": k, "sls_nt": p, ...} or
+        None when the engine has nothing to time.  ~70 ms per candidate."""
         eng = self.engine
         nb = int(getattr(self, "_n_staged", 0))
-        if nb < 1 or candidates < 2:
+        if nb < 1 or candidates < 1:
             return None
-        # only where it was measured to pay: gather-bound DLRM (one MLP stream: RMC1 +1.2 %, RM2 +8.6 %).  The shapes
-        # whose set period is MLP work have nothing to gain (their gather is a tenth of a set, and RM1 reference JSON /
-        # DIN showed no spread between places), and MT-WnD LOSES 11 % when this runs before sets that hand their
-        # outputs over by DMA ("out_dma"; 74.8 k -> 66.5 k queries/s, not with the in-kernel copy: unexplained)
+        # only where it was measured to pay: gather-bound DLRM (one MLP stream).  The MLP-bound shapes have nothing to
+        # gain (their gather is a tenth of a set), the one-lookup models' tables are cache resident.
         if self.kind != N.MODEL_DLRM or int(eng.get_option("mlp_streams")) != 1:
             return None
         co = max(1, min(int(eng.get_option("preferred_coalesce")), 16))
         bs = int(eng.max_batch)
         prev = eng.get_option("shared_stream")
+        nt0 = int(eng.get_option("sls_nt"))
 
         def gather_us():
             eng.set_option("shared_stream", 1)
@@ -238,27 +239,49 @@ class _HipNet(object):
                 eng.set_option("shared_stream", prev)
             return ms / n * 1e3 if n else None
 
+        def both():
+            out = []
+            for p in policies:
+                eng.set_option("sls_nt", p)
+                out.append(gather_us())
+            return out
+
+        times, best = [], None          # best = (us, arena index, policy)
         try:
-            times = [gather_us()]
-            if times[0] is None:
+            t = both()
+            if t[0] is None:
                 return None
+            times.append(t)
+            size_gb = max(1, -(-int(eng.get_option("table_bytes")) // (1 << 30)))
+            gap = size_gb if spacer_gb is None else int(spacer_gb)
+            eng.set_option("table_alloc", 1)
+            eng.set_option("table_vmm_chunk", -1)
             for _ in range(1, candidates):
+                per_arena = [min(tt) for tt in times]
+                if min(per_arena) <= 0.95 * max(per_arena):
+                    break                               # an arena a whole level (5-9 %) under the slowest one: the fast level has been seen
                 try:
+                    if gap > 0:
+                        eng.set_option("table_spacer", gap << 30)
                     eng.set_option("table_placement", -1)
                 except N.DrsError:
                     break                               # no room for one more copy: the ones so far compete
-                times.append(gather_us())
-            kept = int(np.argmin(times))
-            eng.set_option("table_placement", kept)
-            if free_losers is None:
-                free_losers = (len(times) - 1) * int(eng.get_option("table_bytes")) > (16 << 30)
-            return ({"gather_alone_us": [round(t, 2) for t in times], "kept": kept,
-                     "losers": "freed" if free_losers else "held"} if len(times) > 1 else None)
+                times.append(both())
+            flat = [(u, k, policies[i]) for k, tt in enumerate(times) for i, u in enumerate(tt)]
+            best = min(flat)
+            return {"gather_alone_us": [[round(u, 2) for u in tt] for tt in times], "policies": ["nt" if p else "plain" for p in policies],
+                    "kept": best[1], "sls_nt": best[2], "candidates": len(times), "losers": "freed"}
         except N.DrsError:
             return None                                 # (staged sets smaller than a full batch, ...: serve from where it is)
         finally:
-            if free_losers or free_losers is None:
+            try:
+                eng.set_option("table_alloc", 0)
+                eng.set_option("sls_nt", best[2] if best else nt0)
+                if best:
+                    eng.set_option("table_placement", best[1])
                 eng.set_option("table_placement", -2)
+            except N.DrsError:
+                pass
 
     def run_staged(self, batch_id, batch_size):
         self._out = self.engine.forward(int(batch_id), int(batch_size))

@@ -431,11 +431,10 @@ def test_full_size_reference_shapes_match_oracle(name):
                 eng.set_option("table_placement", 3)
             tuned = net.tune_table_placement(3, sets=16)      # (gather-bound DLRM only: rm2 here)
             assert (tuned is None) == (name != "rm2"), (name, tuned)
-            if tuned is not None:      # three candidates of 4 GB: the losers stay allocated (freeing gigabytes costs the rest of the process)
-                assert len(tuned["gather_alone_us"]) == 3 and tuned["losers"] == "held" and eng.get_option("table_placements") == 3
-                assert eng.get_option("table_placement") == tuned["kept"]
-                eng.set_option("table_placement", -2)
-                assert eng.get_option("table_placements") == 1
+            if tuned is not None:      # up to three arenas x two load policies timed, the best kept, every other arena released
+                assert 1 <= len(tuned["gather_alone_us"]) <= 3 and all(len(t) == 2 for t in tuned["gather_alone_us"])
+                assert tuned["losers"] == "freed" and eng.get_option("table_placements") == 1 and eng.get_option("table_placement") == 0
+                assert eng.get_option("sls_nt") == tuned["sls_nt"] and eng.get_option("table_alloc") == 0
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after tuning")
         # default gather (flat / wave-split / lane-group-per-bag by shape): the pooling tolerance
         eng.set_option("sls_exact", 0)

@@ -101,6 +101,13 @@ def main():
                     "separated by ';', are taken in turn")
     ap.add_argument("--swap", action="store_true", help="--scan: then swap the physical memory of the fastest and the slowest "
                     "virtual-memory-API arena, and map each again at a fresh address")
+    ap.add_argument("--variants", default="", help="--scan: engine options (k=v,k=v) under which every arena is timed once more")
+    ap.add_argument("--follow", type=int, default=0, help="--scan: then move the fastest and the slowest virtual-memory-API "
+                    "arena through this many fresh address ranges each")
+    ap.add_argument("--va_search", type=int, default=0, help="instead: one arena of the virtual-memory API mapped at this many "
+                    "address ranges in turn, each timed twice")
+    ap.add_argument("--va_align", type=int, default=0)
+    ap.add_argument("--va_perturb", type=int, default=0, help="--va_search: 4 KiB device allocations made before each new range")
     ap.add_argument("--rows", type=int, default=0, help="override the rows per table (a smaller arena: a finer scan)")
     o = ap.parse_args()
     opt = B.parse(["--workload", o.workload, "--batch", str(o.batch), "--table_placements", "1"])
@@ -112,6 +119,8 @@ def main():
     nb, bs = opt.num_batches, o.batch
     co = int(eng.get_option("preferred_coalesce"))
     res = {"workload": o.workload, "batch": bs, "coalesce": co, "table_bytes": eng.get_option("table_bytes"),
+           "arena_of_drs_create": {k: eng.get_option(k) for k in ("table_kind", "table_select_pool", "table_select_kept", "table_select_best_ns",
+                                                                  "table_select_worst_ns", "table_select_kept_worst_ns", "table_select_ms")},
            "gpu": B.gpu_state(0), "h2d_gbs_before": h2d_gbs(), "candidates": []}
     picks = [int(x) for x in o.recipes.split(",")] if o.recipes else list(range(len(RECIPES)))
 
@@ -123,6 +132,34 @@ def main():
             d["piped_qps"] = round(piped_qps(eng, nb, bs, co, 3, o.queries))
         return d
 
+    if o.va_search:
+        # ONE arena (virtual-memory API, no copies), mapped at a series of address ranges: the same memory, the same
+        # tables -- only the address (and the page-table blocks behind it) changes
+        eng.set_option("table_alloc", 1)
+        eng.set_option("table_vmm_chunk", -1)
+        eng.set_option("table_vmm_align", o.va_align)
+        eng.set_option("table_placement", -3)
+        k = eng.get_option("table_placement")
+        eng.set_option("table_placement", k)
+        eng.set_option("table_placement", -2)          # the hipMalloc arena of drs_create goes
+        cand = [dict(measure("first", 0), va=0, address=hex(eng.get_option("table_address")))]
+        for i in range(1, o.va_search):
+            eng.set_option("table_va_next", o.va_perturb)
+            cand.append(dict(measure("first", 0), va=i, address=hex(eng.get_option("table_address"))))
+        for c in reversed(cand):
+            eng.set_option("table_va_goto", c["va"])
+            c["again"] = measure("again", 0)["gather_alone_us"]
+        best = int(np.argmin([c["gather_alone_us"] for c in cand]))
+        eng.set_option("table_va_select", best)
+        res["va_search"] = cand
+        res["va_us"] = [c["gather_alone_us"] for c in cand]
+        res["va_us_again"] = [c["again"] for c in cand]
+        res["kept"] = dict(measure("kept, the other ranges given back", 0), va=best, address=hex(eng.get_option("table_address")),
+                           placements=eng.get_option("table_placements"))
+        res["h2d_gbs_after"] = h2d_gbs()
+        print(json.dumps(res, indent=1))
+        eng.close()
+        return
     if o.scan:
         cycle = [tuple(int(x) for x in c.split(",")) for c in o.scan_alloc.split(";")]
         scan = [dict(measure("first", 0), k=0, address=hex(eng.get_option("table_address")), alloc=(0, 0))]
@@ -137,8 +174,43 @@ def main():
                 break
             k = eng.get_option("table_placement")
             scan.append(dict(measure("first", k), k=k, address=hex(eng.get_option("table_address")), alloc=cycle[i % len(cycle)]))
+        for c in scan:
+            eng.set_option("table_probe_gather", c["k"])
+            c["probe_gather_us"] = eng.get_option("table_probe_gather_ns") / 1e3
+        T = len(net.ln_emb) if hasattr(net, "ln_emb") else eng.T
+        for c in scan:
+            for name, win, srt in (("probe_gbs", 0, 0), ("probe_win_gbs", T, 0), ("probe_win_sorted_gbs", T, 1)):
+                eng.set_option("table_probe_windows", win)
+                eng.set_option("table_probe_sorted", srt)
+                eng.set_option("table_probe", c["k"])
+                c[name] = eng.get_option("table_probe_mbs") / 1e3
         for c in scan[::max(1, len(scan) // 8)]:
             c["again"] = measure("again", c["k"])["gather_alone_us"]
+        res["probe_gbs"] = [c["probe_gbs"] for c in scan]
+        # the same arenas under the other gather kernels / work orders (does the level belong to the memory or to how
+        # one kernel walks it?)
+        for key, val in (kv.split("=") for kv in o.variants.split(",") if kv):
+            prev = eng.get_option(key)
+            eng.set_option(key, int(val))
+            for c in scan:
+                eng.set_option("table_placement", c["k"])
+                c["%s=%s" % (key, val)] = round(gather_alone_us(eng, nb, bs, co, o.sets)[0], 2)
+            eng.set_option(key, prev)
+            res["%s=%s" % (key, val)] = [c["%s=%s" % (key, val)] for c in scan]
+        if o.follow:
+            # memory or address, second take: the fastest and the slowest virtual-memory-API arena each move through
+            # fresh address ranges (the same memory every time)
+            vm = [c for c in scan if c["alloc"][0] == 1]
+            if len(vm) >= 2:
+                fast, slow = min(vm, key=lambda c: c["gather_alone_us"]), max(vm, key=lambda c: c["gather_alone_us"])
+                res["follow"] = {}
+                for name, c in (("fast", fast), ("slow", slow)):
+                    eng.set_option("table_placement", c["k"])
+                    runs = [c["gather_alone_us"]]
+                    for _ in range(o.follow):
+                        eng.set_option("table_va_next", 0)
+                        runs.append(measure("moved", c["k"])["gather_alone_us"])
+                    res["follow"][name] = {"k": c["k"], "us_at_successive_addresses": runs}
         res["scan"] = scan
         res["scan_us"] = [c["gather_alone_us"] for c in scan]
         if o.swap:
