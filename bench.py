@@ -678,7 +678,12 @@ def main():
                                                  # statistics themselves under --collective gloo)
     from deeprecsys_amd import _native as N
     from deeprecsys_amd import stats
+    from deeprecsys_amd.utils import affinity
 
+    # this rank onto the cores of its GPU's NUMA node (an even share of them when several ranks' GPUs hang off one
+    # node; an even deal of the allowed cores where sysfs knows no node) -- BEFORE the engine allocates pinned
+    # memory and starts its conversion workers
+    host_bind = affinity.bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     device = local
     if opt.allow_device_sharing:
         device = local % max(N.device_count(), 1)
@@ -903,7 +908,7 @@ def main():
                        "collective": None if world == 1 else
                        ("drs_stats_allreduce (RCCL, one grouped all-reduce of 32 KB)" if comm is not None
                         else (comm_note or "gloo")),
-                       "host": {"cores": host_cores(), "ranks": world,
+                       "host": {"cores": host_cores(), "ranks": world, "rank0_binding": host_bind,
                                 "conversion_workers_per_rank": eng.get_option("host_threads")},
                        "inputs": "device-resident (pre-staged)",
                        # before the warm-up: the table arena tried in a few places of HBM, the fastest kept (rank 0's)

@@ -53,20 +53,38 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
     ctx = multiprocessing.get_context(getattr(args, "mp_start_method", "spawn"))
     Process, Queue = ctx.Process, ctx.Queue
     requestQueue = Queue(maxsize=1024)
-    accelRequestQueue = Queue(maxsize=32 * max(n_accel, 1))
+    # --load_generators k: k generator processes, each with its own accelerator queue; accelerator engine e listens
+    # to queue e % k (k = 1: the reference's one generator and one shared accelRequestQueue)
+    n_gen = max(1, int(getattr(args, "load_generators", 1)))
+    if n_gen > 1:
+        if n_cpu > 0 or args.tune_batch_qps or args.tune_accel_qps:
+            sys.exit("ERROR: --load_generators > 1 serves accelerator engines at a fixed arrival rate "
+                     "(no CPU engines, no scheduler sweep)")
+        n_gen = min(n_gen, n_accel)
+    accelRequestQueues = [Queue(maxsize=32 * max(-(-n_accel // n_gen), 1)) for _ in range(n_gen)]
+    accelRequestQueue = accelRequestQueues[0]
     pidQueue = Queue()
     inferenceEngineReadyQueue = Queue()
     loadGeneratorReturnQueue = Queue()
     responseQueues = [Queue() for _ in range(args.inference_engines)]
 
-    load_gen = Process(target=loadGenerator,
-                       args=(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineReadyQueue,
-                             pidQueue, accelRequestQueue))
+    load_gens = []
+    gen_ready = [inferenceEngineReadyQueue] if n_gen == 1 else [Queue() for _ in range(n_gen)]
+    for g in range(n_gen):
+        ga = args
+        if n_gen > 1:
+            import copy
+            ga = copy.copy(args)
+            ga._gen_shard = (g, n_gen)
+        load_gens.append(Process(target=loadGenerator,
+                                 args=(ga, requestQueue, loadGeneratorReturnQueue, gen_ready[g],
+                                       pidQueue, accelRequestQueues[g])))
+    load_gen = load_gens[0]
     engines = []
     for i in range(args.inference_engines):
         if i >= n_cpu:
             p = Process(target=accelInferenceEngine,
-                        args=(args, accelRequestQueue, i, responseQueues[i], inferenceEngineReadyQueue))
+                        args=(args, accelRequestQueues[(i - n_cpu) % n_gen], i, responseQueues[i], inferenceEngineReadyQueue))
         else:
             p = Process(target=cpu_engine,
                         args=(args, requestQueue, i, responseQueues[i], inferenceEngineReadyQueue))
@@ -74,7 +92,19 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
         engines.append(p)
     for p in engines:
         p.start()
-    load_gen.start()
+    for lg in load_gens:
+        lg.start()
+    if n_gen > 1:
+        # every engine announces itself once (the reference's protocol): relay the tokens to each generator
+        import threading
+
+        def relay():
+            for _ in range(args.inference_engines):
+                inferenceEngineReadyQueue.get()
+            for q in gen_ready:
+                for _ in range(args.inference_engines):
+                    q.put(True)
+        threading.Thread(target=relay, daemon=True).start()
 
     agg = ResponseAggregator(args.req_granularity, with_model=bool(mix_models(args)))
     finished = 0
@@ -103,8 +133,12 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
         for r in agg.responses_list:
             f.write(str(r) + "\n")
 
-    load_gen.join()
-    cpu_sub_requests, cpu_requests, accel_requests = loadGeneratorReturnQueue.get()
+    cpu_sub_requests = cpu_requests = accel_requests = 0
+    for lg in load_gens:
+        a_, b_, c_ = loadGeneratorReturnQueue.get()
+        cpu_sub_requests, cpu_requests, accel_requests = cpu_sub_requests + a_, cpu_requests + b_, accel_requests + c_
+    for lg in load_gens:
+        lg.join()
     agg_requests = cpu_sub_requests + accel_requests
     say("Exiting DeepRecSys after printing ", len(agg.responses_list), "/", agg_requests)
     say("CPU sub requests ", cpu_sub_requests, "/", agg_requests)

@@ -56,6 +56,13 @@ def _build_hip_model(args, engine_id):
     from . import _native
     ndev = max(_native.device_count(), 1)
     args._drs_device = (int(getattr(args, "accel_device_offset", 0)) + int((engine_id or 0) - first)) % ndev
+    # this engine process onto the cores next to its GPU (utils/affinity.py) before anything is pinned or any worker
+    # thread starts; engines that share a GPU share its cores
+    from .utils import affinity
+    n_acc = max(1, int(getattr(args, "num_accels", 1)))
+    if not getattr(args, "_drs_bound", False) and n_acc <= ndev:
+        args._drs_binding = affinity.bind_rank(args._drs_device, min(n_acc + int(getattr(args, "accel_device_offset", 0)), ndev))
+        args._drs_bound = True
     if args.model_type not in M.WRAPPERS:
         raise SystemExit("Model type %r has no accelerator path (%s)" % (args.model_type, " | ".join(sorted(M.WRAPPERS))))
     datagen = DLRMDataGenerator(args)

@@ -76,10 +76,20 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
     for _ in range(args.inference_engines):        # block until every engine built its model
         inferenceEngineReadyQueue.get()
 
+    if getattr(args, "_gen_shard", (0, 1))[1] > 1:
+        np.random.seed(args.numpy_rand_seed)       # k generators must draw the SAME query sizes (the reference's one generator draws from an unseeded stream)
     model_arrival_times(args)                      # consumed for RNG-stream parity (unused, as in the reference)
     batch_size_distributions = model_batch_size_distribution(args)
     n_accel = accel_engine_count(args)
     n_cpu = args.inference_engines - n_accel
+    # --load_generators k (this build, SURVEY.md 8e at N = 8): generator g of k serves the query slots with
+    # batch_id % k == g of every epoch to ITS queue (the accelerator engines e with e % k == g listen there), at
+    # 1/k of the arrival rate each -- the same queries, the same aggregate rate, k Python loops instead of one.
+    # Query sizes come from the same seeded draw in every generator; the gaps from a per-generator stream.
+    shard, n_shards = getattr(args, "_gen_shard", (0, 1))
+    if n_shards > 1:
+        n_accel = len([e for e in range(n_accel) if e % n_shards == shard])   # the sentinels this generator owes
+        np.random.seed(args.numpy_rand_seed + 104729 * (shard + 1))
 
     cpu_sub_requests = cpu_requests = accel_requests = 0
     tune_batch, tune_accel = args.tune_batch_qps, args.tune_accel_qps
@@ -102,7 +112,14 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
     shares = [share for _a, share in mix_models(args)]
     mix_rng = np.random.RandomState(args.numpy_rand_seed + 7919) if shares else None
 
+    # requests per put: the reference's one packet per put whenever CPU engines are configured (a list would let small
+    # CPU-routed queries overtake accelerator requests still waiting in it); at most 8 when several accelerator engines
+    # pull from this queue (a whole list lands on ONE engine: 16 would be two launch sets there while its peers idle)
     req_batch = max(1, int(getattr(args, "accel_req_batch", 1)))
+    if n_cpu > 0:
+        req_batch = 1
+    elif n_accel > 1:
+        req_batch = min(req_batch, 8)
     pending = []                                   # accelerator requests not yet put
 
     gstats = {"put": 0.0, "sleep": 0.0, "puts": 0} if os.environ.get("DRS_ENGINE_STATS") else None
@@ -122,7 +139,7 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
         # inter-arrival gaps: one draw per query from the same numpy stream as the reference's
         # per-query poisson(size=1) (:198-199) -- a block draw yields the same values; only while the
         # schedulers cannot change the rate under it
-        gaps = None if (tuning_batch_qps or tuning_accel_qps) else np.random.poisson(lam=arrival_rate, size=args.num_batches)
+        gaps = None if (tuning_batch_qps or tuning_accel_qps) else np.random.poisson(lam=arrival_rate * n_shards, size=args.num_batches)
         for batch_id in range(args.num_batches):
             if tuning_batch_qps and pidQueue.qsize() > 0:
                 args, arrival_rate, tuning_batch_qps = query_scheduler.run(pidQueue.get())
@@ -139,6 +156,8 @@ def loadGenerator(args, requestQueue, loadGeneratorReturnQueue, inferenceEngineR
 
             request_size = int(batch_size_distributions[batch_id])
             model_id = int(mix_rng.choice(len(shares), p=shares)) if shares else 0
+            if batch_id % n_shards != shard:
+                continue                                       # another generator's query slot
             exploring = bool(tuning_batch_qps or tuning_accel_qps)
             to_accel = n_accel > 0 and (n_cpu == 0 or request_size >= args.accel_request_size_thres)
             if to_accel:

@@ -65,6 +65,7 @@ REFERENCE_FLAGS = [
 # additions of this build (several accelerator engines, one per GPU)
 EXTRA_FLAGS = [
     ("num_accels", _I, 1),            # accelerator engine processes (one per GPU)
+    ("load_generators", _I, 1),       # load generator processes (k > 1: generator g feeds the accelerator engines e % k == g)
     ("accel_backend", _S, "hip"),     # "hip": real forward on the GPU | "sim": latency table
     ("accel_device_offset", _I, 0),   # first GPU ordinal used by the accel engines
     ("accel_table_init", _S, "numpy"),  # "numpy": reference RNG stream | "device": counter-based fill

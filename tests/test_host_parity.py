@@ -375,3 +375,74 @@ def test_measured_mi355x_tables_load_like_the_reference_tables():
         assert t.shape == (6,) and np.all(t > 0), m
         mid = float(latency_table.predict_time(m, 32, gd))
         assert min(t[2], t[3]) <= mid <= max(t[2], t[3]), m     # 16 < 32 < 64
+
+
+# ------------------------------------------------------------------------------------
+# N = 8 host readiness (VERDICT r4 #6a): every rank / accelerator engine process is bound to the cores of
+# its GPU's NUMA node before it pins memory or starts workers (deeprecsys_amd/utils/affinity.py)
+def test_rank_core_masks_for_1_2_4_8_ranks():
+    from deeprecsys_amd.utils import affinity as A
+    assert A.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert A.format_cpulist({0, 1, 2, 3, 8, 10, 11}) == "0-3,8,10-11"
+    # the GPU box of this pool: two sockets, 128 hardware threads each, GPUs 0-2 and 7 on node 0, 3-6 on node 1
+    # (gpurun_out host probe: /sys/class/drm/card*/device/numa_node = 0 0 0 1 1 1 1 0)
+    nodes = [0, 0, 0, 1, 1, 1, 1, 0]
+    cpus = {0: set(range(0, 64)) | set(range(128, 192)), 1: set(range(64, 128)) | set(range(192, 256))}
+    allowed = set(range(256))
+    for n in (1, 2, 4, 8):
+        plan = A.plan(nodes, cpus, allowed, n)
+        assert len(plan) == n and all(src == "numa" for _, src in plan)
+        for r, (cores, _) in enumerate(plan):
+            assert cores and set(cores) <= cpus[nodes[r]], (n, r)          # on the GPU's own node
+        for a in range(n):                                                   # ranks never share a core
+            for b in range(a + 1, n):
+                assert not set(plan[a][0]) & set(plan[b][0]), (n, a, b)
+        # the ranks of one node split its cores evenly
+        for node in (0, 1):
+            on = [len(plan[r][0]) for r in range(n) if nodes[r] == node]
+            assert not on or (max(on) - min(on) <= 1 and sum(on) == 128), (n, node, on)
+    assert len(A.plan(nodes, cpus, allowed, 8)[0][0]) == 32 and len(A.plan(nodes, cpus, allowed, 1)[0][0]) == 128
+    # a cgroup that leaves 16 cores, all on node 0: the ranks of node 1 fall back to an even deal of what is allowed
+    small = set(range(16))
+    plan = A.plan(nodes, cpus, small, 8)
+    assert [src for _, src in plan] == ["numa"] * 3 + ["even"] * 4 + ["numa"]
+    assert all(cores and set(cores) <= small for cores, _ in plan)
+    assert sorted(c for r in (0, 1, 2, 7) for c in plan[r][0]) == list(range(16))
+    # no topology at all (containers: numa_node = -1): an even deal, every core used once
+    plan = A.plan([-1] * 8, {}, allowed, 8)
+    assert all(src == "even" and len(cores) == 32 for cores, src in plan)
+    assert sorted(c for cores, _ in plan for c in cores) == list(range(256))
+    # more ranks than cores: ranks share, nobody is left without a core
+    plan = A.plan([-1] * 8, {}, {5, 6}, 8)
+    assert all(len(cores) == 1 and cores[0] in (5, 6) for cores, _ in plan)
+
+
+def test_bind_rank_applies_the_mask_in_a_child_process():
+    """bind_rank on this host (whatever its topology): the mask it reports is the mask the process has."""
+    import multiprocessing as mp
+    import os
+    from deeprecsys_amd.utils import affinity as A
+
+    def child(q, r, n):
+        info = A.bind_rank(r, n)
+        q.put((info, sorted(os.sched_getaffinity(0))))
+    ctx = mp.get_context("fork")
+    before = sorted(os.sched_getaffinity(0))
+    seen = []
+    for r in range(2):
+        q = ctx.Queue()
+        p = ctx.Process(target=child, args=(q, r, 2))
+        p.start()
+        info, mask = q.get(timeout=30)
+        p.join()
+        assert A.parse_cpulist(info["cpus"]) == set(mask) and info["n_cpus"] == len(mask)
+        assert set(mask) <= set(before)
+        seen.append(set(mask))
+    if len(before) >= 2:
+        assert not seen[0] & seen[1]
+    assert sorted(os.sched_getaffinity(0)) == before          # the parent is untouched
+    os.environ["DRS_NO_AFFINITY"] = "1"
+    try:
+        assert A.bind_rank(0, 2)["source"] == "unchanged"
+    finally:
+        del os.environ["DRS_NO_AFFINITY"]
