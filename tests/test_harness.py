@@ -67,26 +67,28 @@ def _write_mix_configs(tmp_path):
     return ",".join(files)
 
 
-@pytest.mark.parametrize("rate,req_batch", [(0.0, 16), (0.0, 1), (3.0, 16)])
-def test_load_generator_batches_back_to_back_requests(tmp_path, rate, req_batch):
+@pytest.mark.parametrize("rate,req_batch,accels", [(0.0, 16, 1), (0.0, 16, 2), (0.0, 1, 2), (3.0, 16, 2)])
+def test_load_generator_batches_back_to_back_requests(tmp_path, rate, req_batch, accels):
     """--accel_req_batch: accelerator requests generated back to back travel as ONE put of a list (the packets
     are the reference's, utils/packets.py:6-22); the list is flushed before every sleep, so when the
     inter-arrival gap is non-zero every request leaves at once; 1 = the reference's one packet per put.
+    Several engines on the one queue: lists of at most 8 (a list lands on ONE engine).
     Sentinels are always their own put (loadGenerator.py:208-214)."""
     import queue
     from deeprecsys_amd.loadGenerator import loadGenerator
     from deeprecsys_amd.utils.packets import ServiceRequest
-    a = _args(tmp_path, num_accels=2, nepochs=3, num_batches=8, avg_arrival_rate=rate, accel_req_batch=req_batch)
-    a.inference_engines = 2
+    a = _args(tmp_path, num_accels=accels, nepochs=3, num_batches=8, avg_arrival_rate=rate, accel_req_batch=req_batch)
+    a.inference_engines = accels
     np.random.seed(a.numpy_rand_seed)
     rq, ret, ready, pid, aq = (queue.Queue() for _ in range(5))
-    ready.put(True), ready.put(True)
+    for _ in range(accels):
+        ready.put(True)
     loadGenerator(a, rq, ret, ready, pid, aq)
     puts = []
     while not aq.empty():
         puts.append(aq.get())
-    assert puts[-2:] == [None, None] and rq.empty()
-    body = puts[:-2]
+    assert puts[-accels:] == [None] * accels and rq.empty()
+    body = puts[:-accels]
     flat = [r for p in body for r in (p if isinstance(p, list) else [p])]
     assert all(isinstance(r, ServiceRequest) for r in flat)
     assert [(r.epoch, r.batch_id) for r in flat] == [(e, b) for e in range(3) for b in range(8)]      # order kept
@@ -94,7 +96,7 @@ def test_load_generator_batches_back_to_back_requests(tmp_path, rate, req_batch)
     if req_batch == 1:
         assert len(body) == 24 and not any(isinstance(p, list) for p in body)
     elif rate == 0.0:
-        assert [len(p) for p in body] == [16, 8]
+        assert [len(p) for p in body] == ([16, 8] if accels == 1 else [8, 8, 8])
     else:
         # poisson(3 ms) is non-zero ~95 % of the time: (almost) every request is flushed on its own
         assert len(body) >= 20
