@@ -69,13 +69,12 @@ struct Tune {
   int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
   int din_nt = 1;                // fused DIN launch: non-temporal row loads ("din_nt": +2.5 % queries/s, 0.527 -> 0.545 of peak)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
-  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_stream_waves = 0, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, mlp_debug = 0;
+  int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, mlp_debug = 0;
   int gemm32 = 1;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel) ...
   int gemm32_small_blocks = 0;   // ... when that shape gives at least this many workgroups
   int gemm32_small = 0;          // ... and smaller launches this gemm32 shape (0 = gemm_kernel | 22 | 21 | 12 | 11)
   int gemm32_blocks = 512;       // ... when its 128 x 128 workgroups number at least this many (two per CU)
   int64_t mlp_rows32 = 0;        // stream4_kernel: launches of at least this many rows take 32 rows per workgroup (0 = never)
-  int64_t mlp_s4_rows = 0;       // "mlp_stream" 3 with four waves: launches of up to this many rows take stream4_kernel instead
   DispatchLog* log = nullptr;    // where the launch functions note what they chose (the slot being enqueued; may be null)
 };
 // Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs

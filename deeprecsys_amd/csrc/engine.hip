@@ -249,6 +249,7 @@ struct drs_engine {
   // overlapping GEMM launches), the latency-bound chain launches go on the slots' MLP streams beside them;
   // an event per change of stream orders a set's launches.  0: a set's MLP launches all on its own stream.
   int mlp_layout = 0;
+  int mlp_cu_mask = 0, gather_cu_complement = 1;   // "mlp_cu_mask": CUs reserved for the MLP streams (0: none)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
   // launch sets whose outputs are at least this many bytes (0: never) leave by a copy-engine transfer queued behind the
   // last kernel + a stream-ordered flag write, instead of the last workgroup's in-kernel copy: MT-WnD's 2 MB per
@@ -1790,7 +1791,10 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // launch sets only ("mlp_s4_rows").
     // Round 4: full sets (>= 2 048 rows) as stream4_kernel with 32 rows per workgroup where the slabs fit LDS
     // (RMC1: 139 KB) -- 96 workgroups per 12-query set instead of 192: +1.6 % queries/s (mlp.hip stream_plan)
-    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 3; e->tune.mlp_stream_waves = 4; e->tune.mlp_s4_rows = 1024; e->tune.mlp_rows32 = 2048; }
+    // Round 5: stream4_kernel for EVERY set size of gather-bound DLRM (sets of 5-7 queries, which stream3_kernel still
+    // served: 98.6 / 110.2 / 120.0 k -> 107.9 / 119.1 / 127.0 k queries/s, profiles/r05_stream3_vs_stream4/); stream3_kernel
+    // is gone.  Launches below 2 048 rows keep the one-workgroup-per-CU build ("mlp_stream_2cu" 0 for this class).
+    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 4; e->tune.mlp_rows32 = 2048; }
     // W&D and DIEN: their stream launches (512-256-1 tail; top MLP) as stream4_kernel compiled for two
     // workgroups per CU: 95.1 k -> 96.2 k and 168 k -> 172 k queries/s (MT-WnD -4 %, NCF -9 %, DIN, RM3: +-0)
     if (e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
@@ -1813,7 +1817,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // ... and the packed stream kernel in its 128-VGPR form, two workgroups per CU, for every model whose
     // MLP launches overlap each other (measured with 16-query sets: DIEN +8 %, W&D +5 %, MT-WnD +4 %, DIN +3 %,
     // RM3 +2 %; NCF -2 %: its launch is bound by its own 512 KB of outputs crossing PCIe)
-    e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF;
+    e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF && !(e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM);
   }
   apply_stream_mode(e);
   {
@@ -2490,17 +2494,38 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     e->mlp_streams = (int)value;
     apply_stream_mode(e);
   }
+  else if (!strcmp(key, "mlp_cu_mask") && value >= 0 && value <= 248) {
+    // experiment: the MLP side's streams run on `value` CUs only (bits 0 .. value-1 of the queue's CU
+    // mask; 0 = every CU, the default), the gather stream on the others ("gather_cu_complement" 1, default) or everywhere (0)
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    int ncu = 0;
+    HIP_TRY(e, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, e->device));
+    if (value >= ncu) return fail(e, DRS_ERR_BAD_ARG, "mlp_cu_mask %lld of %d CUs", (long long)value, ncu);
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> mlp((size_t)words, 0u), rest((size_t)words, 0u);
+    for (int c = 0; c < ncu; ++c) ((value == 0 || c < value) ? mlp : rest)[(size_t)c / 32] |= 1u << (c % 32);
+    if (value == 0 || !e->gather_cu_complement) rest = std::vector<uint32_t>((size_t)words, 0xffffffffu);
+    for (auto& s : e->slots) {
+      if (s.own_stream) { (void)hipStreamSynchronize(s.own_stream); (void)hipStreamDestroy(s.own_stream); s.own_stream = nullptr; }
+      HIP_TRY(e, hipExtStreamCreateWithCUMask(&s.own_stream, (uint32_t)words, mlp.data()));
+    }
+    if (e->stream_g) { (void)hipStreamSynchronize(e->stream_g); (void)hipStreamDestroy(e->stream_g); e->stream_g = nullptr; }
+    HIP_TRY(e, hipExtStreamCreateWithCUMask(&e->stream_g, (uint32_t)words, rest.data()));
+    e->mlp_cu_mask = (int)value;
+    apply_stream_mode(e);
+  }
+  else if (!strcmp(key, "gather_cu_complement") && (value == 0 || value == 1)) e->gather_cu_complement = (int)value;
   else if (!strcmp(key, "mlp_layout") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_layout = (int)value; }
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
-  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 4) e->tune.mlp_stream = (int)value;
+  else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 4 && value != 3) e->tune.mlp_stream = (int)value;
   else if (!strcmp(key, "mlp_stream_2cu") && (value == 0 || value == 1)) e->tune.mlp_stream_2cu = (int)value;
   else if (!strcmp(key, "mlp_gemm_2cu") && (value == 0 || value == 1)) e->tune.gemm_2cu = (int)value;
   else if (!strcmp(key, "launch_thread") && (value == 0 || value == 1)) e->launch_thread = (int)value;
-  else if (!strcmp(key, "mlp_stream_waves") && (value == 0 || value == 4 || value == 8)) e->tune.mlp_stream_waves = (int)value;
   else if (!strcmp(key, "mlp_gemm")) e->tune.mlp_gemm = value ? 1 : 0;
   else if (!strcmp(key, "mlp_gemm_tile") && (value == 0 || value == 22 || value == 12 || value == 21 || value == 11 || value == 214 || value == 322 || value == 321 || value == 312 || value == 311)) e->tune.gemm_tile = (int)value;
   else if (!strcmp(key, "mlp_gemm32") && (value == 0 || value == 1)) e->tune.gemm32 = (int)value;
@@ -2508,7 +2533,6 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_gemm32_small_blocks") && value >= 0 && value <= 65536) e->tune.gemm32_small_blocks = (int)value;
   else if (!strcmp(key, "mlp_gemm32_blocks") && value >= 1 && value <= 65536) e->tune.gemm32_blocks = (int)value;
   else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
-  else if (!strcmp(key, "mlp_s4_rows") && value >= 0) e->tune.mlp_s4_rows = value;
   else if (!strcmp(key, "mlp_rows32") && value >= 0) e->tune.mlp_rows32 = value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
   else if (!strcmp(key, "table_placement")) {
@@ -2720,8 +2744,8 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
-      {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_stream_waves", t.mlp_stream_waves}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_s4_rows", t.mlp_s4_rows}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
+      {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
+      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"mlp_cu_mask", e->mlp_cu_mask}, {"gather_cu_complement", e->gather_cu_complement},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
       {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
       {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},

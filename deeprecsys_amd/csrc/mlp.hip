@@ -1112,8 +1112,10 @@ __global__ __launch_bounds__(64 * NWV, RD3 ? 4 : 1) void stream_kernel(SArgs a, 
 }
 
 // ---------------------------------------------------------------------------
-// stream3_kernel ("mlp_stream" 3, the default since round 3): the packed form re-cut around what the
-// round-3 microbenchmarks (tools/ubench/) say about the fp32 matrix pipe of a SIMD:
+// The four-wave forms (round 3's stream3_kernel -- removed in round 5, when stream4_kernel below had overtaken it on
+// every launch size: 5-7 query sets +6-9 % queries/s, profiles/r05_stream3_vs_stream4/ -- and stream4_kernel, which
+// runs the same step table): the packed form re-cut around what the round-3 microbenchmarks (tools/ubench/) say
+// about the fp32 matrix pipe of a SIMD:
 //   * ONE wave keeps it busy: a dependent v_mfma_f32_16x16x4_f32 chain issues every 35 cycles, two or
 //     four independent chains every 33 (the pipe's rate is 32) -- a second wave per SIMD adds nothing;
 //   * a global_load_dwordx4 every 4 MFMAs and a ds_read_b128 every 8, placed BETWEEN the MFMAs, cost
@@ -1152,506 +1154,6 @@ __device__ __forceinline__ int lpos(int c) { return (c & ~15) | ((c & 3) << 2) |
 #define S3_OFF_2 "2048"
 #define S3_OFF_3 "3072"
 #define S3_OFF(Q) S3_OFF_##Q
-
-// NT = tiles per wave at most: 4 (four waves, one per SIMD) or 2 (eight waves, two per SIMD: a wave's
-// control instructions then run in the shadow of its SIMD partner's MFMAs without hand interleaving).
-template <int NT, int RD>
-__global__ __launch_bounds__(1024 / NT) void stream3_kernel(SArgs a, Done done, XSrc xs) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kThreads = 1024 / NT;
-  constexpr int kNewer = 4 * NT * (RD - 1) + 3 * NT;   // loads allowed in flight in front of a quarter (see above)
-  static_assert((NT == 4 || NT == 2) && RD == 2, "ring shape");   // (a ring of 3 needs more VGPRs than a wave has here: the
-  // compiler then spills into AGPRs -- among them the accumulators' fixed a[0:15]; measured before that was understood:
-  // no faster)
-  kernarg_burst();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  // byte offsets of this lane's float4 inside the 4-KB blocks of the wave's four tiles
-  const uint32_t lo0 = (uint32_t)lane * 16u, lo1 = lo0 + 4096u, lo2 = lo0 + 8192u, lo3 = lo0 + 12288u;
-  const int64_t m0 = (int64_t)blockIdx.x * 16;
-#ifdef DRS_TIMELINE
-  unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(smem + a.lds_floats);
-  if (threadIdx.x == 0) g_tl_lds[0] = 0;
-#endif
-  TL(1);
-  const float* zero = a.zero;
-  const int n_table = a.n_table;
-  const uint32_t* s_tab = reinterpret_cast<const uint32_t*>(smem + a.tab_off);
-  const uint32_t* s_lay = reinterpret_cast<const uint32_t*>(smem + a.lay_off);
-  const float* const wbase = a.wbase;
-
-  // What a wave requests for a step: the scalar base of its first tile's 4-KB block in chunk c of the
-  // twin, and how many of its (up to four) tiles exist there.
-  struct Req { const float* base; int nex; };
-  auto req_of = [&](uint32_t wp_off, int pstride, int info) {
-    Req q;
-    const int tpw = (info >> S3_TPW_SHIFT) & 7;
-    const int tile0 = info & 0xff, ntl = (info >> 8) & 0xff;
-    const int t0 = tile0 + tpw * wave;
-    q.nex = min(max(ntl - t0, 0), tpw);                    // tiles of mine that exist in the twin (tpw <= NT)
-    const int tb = q.nex > 0 ? t0 : 0;                     // (any valid address when nothing is loaded)
-    q.base = wbase + (wp_off + (uint32_t)(tb >> 3) * (uint32_t)pstride + (uint32_t)(tb & 7) * 1024u);
-    return q;
-  };
-  // the four loads of k-group Q of a step (float4 Q of each tile's block); tile k is requested with
-  // EXEC = 0 when the wave owns fewer than k + 1 tiles there
-#define S3_LOADQ4(RB, RQ, Q)                                                                      \
-  {                                                                                               \
-    uint64_t sv_;                                                                                 \
-    asm volatile(                                                                                 \
-        "s_mov_b64 %4, exec\n\t"                                                                  \
-        "s_cmp_gt_u32 %10, 0\n\ts_cselect_b64 exec, %4, 0\n\t"                                    \
-        "global_load_dwordx4 %0, %5, %9 offset:" S3_OFF(Q) "\n\t"                                 \
-        "s_cmp_gt_u32 %10, 1\n\ts_cselect_b64 exec, %4, 0\n\t"                                    \
-        "global_load_dwordx4 %1, %6, %9 offset:" S3_OFF(Q) "\n\t"                                 \
-        "s_cmp_gt_u32 %10, 2\n\ts_cselect_b64 exec, %4, 0\n\t"                                    \
-        "global_load_dwordx4 %2, %7, %9 offset:" S3_OFF(Q) "\n\t"                                 \
-        "s_cmp_gt_u32 %10, 3\n\ts_cselect_b64 exec, %4, 0\n\t"                                    \
-        "global_load_dwordx4 %3, %8, %9 offset:" S3_OFF(Q) "\n\t"                                 \
-        "s_mov_b64 exec, %4"                                                                      \
-        : "=&v"(RB[0][Q]), "=&v"(RB[1][Q]), "=&v"(RB[2][Q]), "=&v"(RB[3][Q]), "=&s"(sv_)          \
-        : "v"(lo0), "v"(lo1), "v"(lo2), "v"(lo3), "s"(RQ.base), "s"(RQ.nex)                       \
-        : "scc");                                                                                 \
-  }
-#define S3_LOADQ2(RB, RQ, Q)                                                                      \
-  {                                                                                               \
-    uint64_t sv_;                                                                                 \
-    asm volatile(                                                                                 \
-        "s_mov_b64 %2, exec\n\t"                                                                  \
-        "s_cmp_gt_u32 %6, 0\n\ts_cselect_b64 exec, %2, 0\n\t"                                     \
-        "global_load_dwordx4 %0, %3, %5 offset:" S3_OFF(Q) "\n\t"                                 \
-        "s_cmp_gt_u32 %6, 1\n\ts_cselect_b64 exec, %2, 0\n\t"                                     \
-        "global_load_dwordx4 %1, %4, %5 offset:" S3_OFF(Q) "\n\t"                                 \
-        "s_mov_b64 exec, %2"                                                                      \
-        : "=&v"(RB[0][Q]), "=&v"(RB[1][Q]), "=&s"(sv_)                                            \
-        : "v"(lo0), "v"(lo1), "s"(RQ.base), "s"(RQ.nex)                                           \
-        : "scc");                                                                                 \
-  }
-#define S3_LOADQ(RB, RQ, Q)                                                                       \
-  if constexpr (NT == 4) S3_LOADQ4(RB, RQ, Q) else S3_LOADQ2(RB, RQ, Q)
-#define S3_WAITQ(RB, Q)                                                                           \
-  if constexpr (NT == 4)                                                                          \
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(RB[0][Q]), "+v"(RB[1][Q]), "+v"(RB[2][Q]), "+v"(RB[3][Q]) : "n"(kNewer)); \
-  else                                                                                            \
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(RB[0][Q]), "+v"(RB[1][Q]) : "n"(kNewer))
-
-  // ---- prologue: ONE memory round trip.  The chain inputs (the critical path: cold misses all the
-  // way to HBM), the biases and the descriptor table are requested first, the weights of the first
-  // RD steps right behind them; nothing is waited for before all of it is in flight.
-  // A thread's role in the input copies is fixed: row tid / TPR, columns 4 (tid % TPR) + CG j -- no
-  // division, one 64-bit row pointer per input.
-  constexpr int TPR = kThreads / 16, CG = 4 * TPR;   // threads per row; columns one pass of them covers (64 | 128)
-  constexpr int PB = 512 / CG;                   // column groups per input and batch (512 columns)
-  const int prow = tid / TPR, pk0 = (tid % TPR) * 4;
-  const SInput& in0 = a.in[0];
-  const SInput& in1 = a.in[a.n_inputs > 1 ? 1 : 0];
-  const int nj0 = (in0.cols_pad + CG - 1) / CG, nj1 = a.n_inputs > 1 ? (in1.cols_pad + CG - 1) / CG : 0;
-  const float* base0 = in0.src;
-  int64_t row00 = m0, rows0 = a.M;
-  if (in0.use_xs) resolve_src(xs, in0.src, a.M, m0, &base0, &row00, &rows0);
-  const float* const rp0 = base0 + min(row00 + prow, rows0 - 1) * in0.ld + in0.col0;
-  const float* const rp1 = in1.src + min(m0 + prow, a.M - 1) * in1.ld + in1.col0;
-  const float* const rp2 = in1.src + min(m0 + prow, a.M - 1) * in1.ld + (in1.col2 >= 0 ? in1.col2 : in1.col0);
-  const int cols0 = in0.cols, cols1 = in1.cols, cpad0 = in0.cols_pad, cpad1 = in1.cols_pad;
-  const bool sum1 = in1.col2 >= 0;
-  float* const ld0 = smem + in0.lds_off + prow * in0.lds_ld;
-  float* const ld1 = smem + in1.lds_off + prow * in1.lds_ld;
-  const int lc0 = in0.lds_col0 + pk0, lc1 = in1.lds_col0 + pk0;
-  float* const gd1 = in1.g_dst && m0 + prow < a.M ? in1.g_dst + (m0 + prow) * in1.g_ldd : nullptr;
-  // (a load beyond the block's real columns reads the zero page: an address select keeps it unconditional)
-  auto issue = [&](const float* rp, int cols, int jb, int nj, float4 (&v)[PB]) {
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-      if (jb + j < nj) {                         // uniform
-        const int k = pk0 + CG * (jb + j);
-        int64_t off = k < cols ? (int64_t)k : (int64_t)(zero - rp);   // (offset, not pointer, select: the load stays a global_load)
-        asm("" : "+v"(off));
-        v[j] = *reinterpret_cast<const float4*>(rp + off);
-      }
-  };
-  auto store = [&](float* ld, int lc, int cpad, int jb, int nj, const float4 (&v)[PB]) {
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-      if (jb + j < nj) {
-        const int k = pk0 + CG * (jb + j);
-        if (k < cpad) {
-          // columns c .. c+3 (c a multiple of 4) sit 4 floats apart inside their 16-column block
-          const int c = lc + CG * (jb + j);
-          float* dst = ld + ((c & ~15) | ((c >> 2) & 3));
-          dst[0] = v[j].x; dst[4] = v[j].y; dst[8] = v[j].z; dst[12] = v[j].w;
-        }
-      }
-  };
-  const uint32_t* kp = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();   // SArgs is argument 0
-  uint32_t* dt = reinterpret_cast<uint32_t*>(smem + a.tab_off);
-  uint32_t* dl = reinterpret_cast<uint32_t*>(smem + a.lay_off);
-  const int n_tab_w = 4 * n_table, n_lay_w = a.n_layers * (int)(sizeof(SLayer) / 4);
-  float4 pv0[PB], pv1[PB], pv2[PB];
-  issue(rp0, cols0, 0, nj0, pv0);
-  issue(rp1, cols1, 0, nj1, pv1);
-  if (sum1) issue(rp2, cols1, 0, nj1, pv2);
-  // biases, descriptors and layer records ride on the same round trip
-  constexpr int NBV = 1024 / kThreads, NTV = 512 / kThreads;
-  float bias_v[NBV];
-  uint32_t tabv[NTV], layv[NTV];
-#pragma unroll
-  for (int j = 0; j < NBV; ++j) bias_v[j] = a.bias[min(tid + j * kThreads, a.n_bias - 1)];
-#pragma unroll
-  for (int j = 0; j < NTV; ++j) {
-    tabv[j] = kp[offsetof(SArgs, tiles) / 4 + min(tid + j * kThreads, n_tab_w - 1)];
-    layv[j] = kp[offsetof(SArgs, L) / 4 + min(tid + j * kThreads, n_lay_w - 1)];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  TL(2);
-  f32x4 rb0[NT][4], rb1[NT][4], rb2[NT][4], rb3[NT][4];
-  // L2 warm-up.  The workgroups of a launch walk the same weights in lock step and the gather that ran
-  // before has flushed them from every XCD's L2: without help EVERY weight load of EVERY workgroup
-  // waits for a fill from Infinity Cache / HBM (~7 k cycles measured: with two steps of lead a step
-  // took ~3.5 k cycles whatever its MFMA count; Little's law wants 54 KB in flight per wave to hide
-  // that, more than vmcnt can count).  So each workgroup touches ONE slice of the launch's packed
-  // weights here, 16 loads per lane, fire and forget: the ~16 workgroups of an XCD (block b runs on
-  // XCD b % 8 -- a speed hint only) together pull the whole set into their L2 while the inputs are in
-  // flight anyway, and the ring's loads become L2 hits.  The loads land in ring slot 1's registers,
-  // which the slot's real request -- issued after them, retiring after them -- overwrites.
-  {
-    const uint32_t nx = (gridDim.x + 7u) >> 3, rank = blockIdx.x >> 3;
-    const uint32_t bytes = (uint32_t)a.warm_bytes;               // a multiple of 4096
-    const uint32_t slice = ((bytes / nx) + 4095u) & ~4095u;
-    const uint32_t o0 = rank * slice + (uint32_t)tid * 16u, last = bytes - 16u;
-    const float* wb = wbase + a.warm_off;
-#define S3_WARM(R, I)                                                                             \
-    { const uint32_t o_ = min(o0 + (I) * 4096u, last);                                            \
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(R) : "v"(o_), "s"(wb)); }
-    S3_WARM(rb1[0][0], 0) S3_WARM(rb1[1][0], 1) S3_WARM(rb1[0][1], 2) S3_WARM(rb1[1][1], 3)
-    S3_WARM(rb1[0][2], 4) S3_WARM(rb1[1][2], 5) S3_WARM(rb1[0][3], 6) S3_WARM(rb1[1][3], 7)
-    if constexpr (NT == 4) {
-      S3_WARM(rb1[2][0], 8) S3_WARM(rb1[3][0], 9) S3_WARM(rb1[2][1], 10) S3_WARM(rb1[3][1], 11)
-      S3_WARM(rb1[2][2], 12) S3_WARM(rb1[3][2], 13) S3_WARM(rb1[2][3], 14) S3_WARM(rb1[3][3], 15)
-    }
-#undef S3_WARM
-  }
-  // the ring: weights of steps 0 .. RD-1 (descriptors straight from the arguments: their LDS copy is not
-  // there yet).  The compiler's own vmcnt for the loads above does not know these: it waits a little
-  // longer than it has to (loads retire in order), never too short.
-  {
-    const STile e0 = a.tiles[0], e1 = a.tiles[min(1, n_table - 1)];
-    const Req q0 = req_of(e0.wp_off, e0.in_ld, e0.info);
-    S3_LOADQ(rb0, q0, 0) S3_LOADQ(rb0, q0, 1) S3_LOADQ(rb0, q0, 2) S3_LOADQ(rb0, q0, 3)
-    const Req q1 = req_of(e1.wp_off, e1.in_ld, e1.info);
-    S3_LOADQ(rb1, q1, 0) S3_LOADQ(rb1, q1, 1) S3_LOADQ(rb1, q1, 2) S3_LOADQ(rb1, q1, 3)
-    if constexpr (RD >= 3) {
-      const STile e2 = a.tiles[min(2, n_table - 1)];
-      const Req q2 = req_of(e2.wp_off, e2.in_ld, e2.info);
-      S3_LOADQ(rb2, q2, 0) S3_LOADQ(rb2, q2, 1) S3_LOADQ(rb2, q2, 2) S3_LOADQ(rb2, q2, 3)
-    }
-    if constexpr (RD >= 4) {
-      const STile e3 = a.tiles[min(3, n_table - 1)];
-      const Req q3 = req_of(e3.wp_off, e3.in_ld, e3.info);
-      S3_LOADQ(rb3, q3, 0) S3_LOADQ(rb3, q3, 1) S3_LOADQ(rb3, q3, 2) S3_LOADQ(rb3, q3, 3)
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  store(ld0, lc0, cpad0, 0, nj0, pv0);
-  if (sum1) {
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-      pv1[j] = make_float4(pv1[j].x + pv2[j].x, pv1[j].y + pv2[j].y, pv1[j].z + pv2[j].z, pv1[j].w + pv2[j].w);
-  }
-  store(ld1, lc1, cpad1, 0, nj1, pv1);
-  if (gd1) {                                     // NCF: the summed block is also kept in global memory
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-      if (j < nj1 && pk0 + CG * j < cols1) *reinterpret_cast<float4*>(gd1 + pk0 + CG * j) = pv1[j];
-  }
-#pragma unroll
-  for (int j = 0; j < NBV; ++j)
-    if (tid + j * kThreads < a.n_bias) smem[a.bias_off + tid + j * kThreads] = bias_v[j];
-#pragma unroll
-  for (int j = 0; j < NTV; ++j) {
-    if (tid + j * kThreads < n_tab_w) dt[tid + j * kThreads] = tabv[j];
-    if (tid + j * kThreads < n_lay_w) dl[tid + j * kThreads] = layv[j];
-  }
-  // (inputs wider than 8 x 64 columns: further batches, one round trip each)
-  for (int jb = PB; jb < nj0; jb += PB) { issue(rp0, cols0, jb, nj0, pv0); store(ld0, lc0, cpad0, jb, nj0, pv0); }
-  for (int jb = PB; jb < nj1; jb += PB) {
-    issue(rp1, cols1, jb, nj1, pv1);
-    if (sum1) {
-      issue(rp2, cols1, jb, nj1, pv2);
-#pragma unroll
-      for (int j = 0; j < PB; ++j)
-        pv1[j] = make_float4(pv1[j].x + pv2[j].x, pv1[j].y + pv2[j].y, pv1[j].z + pv2[j].z, pv1[j].w + pv2[j].w);
-    }
-    store(ld1, lc1, cpad1, jb, nj1, pv1);
-    if (gd1) {
-#pragma unroll
-      for (int j = 0; j < PB; ++j)
-        if (jb + j < nj1 && pk0 + CG * (jb + j) < cols1) *reinterpret_cast<float4*>(gd1 + pk0 + CG * (jb + j)) = pv1[j];
-    }
-  }
-  for (int i0 = 1024; i0 < a.n_bias; i0 += kThreads)     // (more than 1024 bias words: not on any shipped config)
-    if (i0 + tid < a.n_bias) smem[a.bias_off + i0 + tid] = a.bias[i0 + tid];
-  for (int i = tid + 512; i < n_lay_w; i += kThreads) dl[i] = kp[offsetof(SArgs, L) / 4 + i];
-  TL(3);
-  __syncthreads();
-  TL(4);
-
-  // dot interaction between the chains: as stream_kernel's, on this form's slab layout
-  auto interact = [&]() {
-    const float* Ts = smem + a.t_off;
-    float* Rs = smem + a.r_off;
-    const int D = a.D, W = a.r_pad, off = a.itself ? 1 : 0;
-    for (int o = tid; o < 16 * W; o += kThreads) {
-      const int row = o / W, c = o - row * W;
-      const float* t = Ts + row * a.t_ld;
-      float v = 0.f;
-      if (c < D) {
-        v = t[lpos(c)];
-      } else if (c < D + a.P) {
-        continue;                                 // the pairs: on the matrix cores, below
-      }
-      Rs[row * a.r_ld + lpos(c)] = v;
-      if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
-    }
-    interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
-                          tid >> 6, tid & 63, [](int c, int) { return lpos(c); });
-    __syncthreads();
-  };
-
-  // The accumulators live in FIXED registers, a[0:15] (a[0:7] with two tiles per wave), written only by
-  // the asm blocks below: the MFMAs of a quarter sit under a (uniform) branch on the layer's tiles per
-  // wave, and accumulators held in C++ variables came out of every such branch through AGPR <-> VGPR
-  // copies + s_nop.  (Blocks without register outputs under a branch are harmless; blocks WITH
-  // outputs -- the ring's loads and waits -- stay in straight-line code.)
-#define S3_ACC_CLOBBER "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"
-  auto acc_zero = [&]() {
-    asm volatile(
-        "v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\t"
-        "v_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\t"
-        "v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\t"
-        "v_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\t"
-        "s_nop 4" ::: S3_ACC_CLOBBER);
-  };
-#define S3_ACC_READ(DST, A0, A1, A2, A3)                                                          \
-  asm volatile("v_accvgpr_read_b32 %0, " A0 "\n\tv_accvgpr_read_b32 %1, " A1 "\n\t"               \
-               "v_accvgpr_read_b32 %2, " A2 "\n\tv_accvgpr_read_b32 %3, " A3                      \
-               : "=v"(DST[0]), "=v"(DST[1]), "=v"(DST[2]), "=v"(DST[3]))
-  // the fields of a layer record the epilogue needs, from its LDS copy
-  struct Epi { int N, act, out_off, out_ld, out_pad, out_col0, b_off, g_sc1; float* g_out; int64_t g_ld; };
-  auto lds_epi = [&](int l) {
-    const uint32_t* src = s_lay + l * (int)(sizeof(SLayer) / 4);
-    auto w = [&](size_t byte_off) { return (int)__builtin_amdgcn_readfirstlane(src[byte_off / 4]); };
-    Epi e;
-    e.N = w(offsetof(SLayer, N)); e.act = w(offsetof(SLayer, act));
-    e.out_off = w(offsetof(SLayer, out_off)); e.out_ld = w(offsetof(SLayer, out_ld));
-    e.out_pad = w(offsetof(SLayer, out_pad)); e.out_col0 = w(offsetof(SLayer, out_col0));
-    e.b_off = w(offsetof(SLayer, b_off)); e.g_sc1 = w(offsetof(SLayer, g_sc1));
-    const uint64_t glo = (uint32_t)w(offsetof(SLayer, g_out)), ghi = (uint32_t)w(offsetof(SLayer, g_out) + 4);
-    e.g_out = reinterpret_cast<float*>(glo | (ghi << 32));
-    const uint64_t llo = (uint32_t)w(offsetof(SLayer, g_ld)), lhi = (uint32_t)w(offsetof(SLayer, g_ld) + 4);
-    e.g_ld = (int64_t)(llo | (lhi << 32));
-    return e;
-  };
-  // Epilogue of one tile: bias + activation -> the next layer's slab (columns past N inside the pad
-  // are zero filled) and / or global memory.  `lim`: columns that exist in the slab; `dst`: this lane's
-  // slab address of (row 4 g, its column); the four rows of a lane are out_ld apart.
-  auto epilogue = [&](const Epi& el, const float (&acc)[4], float bias_v, int col, int lim, float* dst) {
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = acc[i] + bias_v;
-    if (el.act == DRS_ACT_RELU) {                // (uniform)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-    } else if (el.act == DRS_ACT_SIGMOID) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], DRS_ACT_SIGMOID);
-    }
-    if (el.out_off >= 0 && col < lim) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i * el.out_ld] = col < el.N ? v[i] : 0.f;
-    }
-    if (el.g_out && col < el.N) {                // the last layer of a chain
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t row = m0 + g * 4 + i;
-        if (row < a.M) {
-          float* dstg = el.g_out + row * el.g_ld + col;
-          if (el.g_sc1) __hip_atomic_store(dstg, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *dstg = v[i];
-        }
-      }
-    }
-  };
-  auto read_a = [&](f32x4 (&av)[4], int a_off) {
-    const float* pa = smem + (a_off & 0xffff) + r * (a_off >> 16) + g * 4;
-    av[0] = *reinterpret_cast<const f32x4*>(pa); av[1] = *reinterpret_cast<const f32x4*>(pa + 16);
-    av[2] = *reinterpret_cast<const f32x4*>(pa + 32); av[3] = *reinterpret_cast<const f32x4*>(pa + 48);
-  };
-
-  // The MFMAs of one quarter (steps 4Q .. 4Q+3) for 4 / 2 / 1 tiles per wave; accumulators alternate.
-  // %0..%3: the four activation operands; then the tiles' weight operands, tile-major.
-#define S3_M(ACC, A, B) "v_mfma_f32_16x16x4_f32 " ACC ", " A ", " B ", " ACC "\n\t"
-#define S3_MFMA4(AV, RB, Q)                                                                       \
-  asm volatile(                                                                                   \
-      S3_M("a[0:3]", "%0", "%4") S3_M("a[4:7]", "%0", "%8") S3_M("a[8:11]", "%0", "%12") S3_M("a[12:15]", "%0", "%16") \
-      S3_M("a[0:3]", "%1", "%5") S3_M("a[4:7]", "%1", "%9") S3_M("a[8:11]", "%1", "%13") S3_M("a[12:15]", "%1", "%17") \
-      S3_M("a[0:3]", "%2", "%6") S3_M("a[4:7]", "%2", "%10") S3_M("a[8:11]", "%2", "%14") S3_M("a[12:15]", "%2", "%18") \
-      S3_M("a[0:3]", "%3", "%7") S3_M("a[4:7]", "%3", "%11") S3_M("a[8:11]", "%3", "%15") S3_M("a[12:15]", "%3", "%19") \
-      :: "v"(AV[Q][0]), "v"(AV[Q][1]), "v"(AV[Q][2]), "v"(AV[Q][3]),                              \
-         "v"(RB[0][Q][0]), "v"(RB[0][Q][1]), "v"(RB[0][Q][2]), "v"(RB[0][Q][3]),                  \
-         "v"(RB[1][Q][0]), "v"(RB[1][Q][1]), "v"(RB[1][Q][2]), "v"(RB[1][Q][3]),                  \
-         "v"(RB[2][Q][0]), "v"(RB[2][Q][1]), "v"(RB[2][Q][2]), "v"(RB[2][Q][3]),                  \
-         "v"(RB[3][Q][0]), "v"(RB[3][Q][1]), "v"(RB[3][Q][2]), "v"(RB[3][Q][3])                   \
-      : S3_ACC_CLOBBER)
-#define S3_MFMA2(AV, RB, Q)                                                                       \
-  asm volatile(                                                                                   \
-      S3_M("a[0:3]", "%0", "%4") S3_M("a[4:7]", "%0", "%8")                                       \
-      S3_M("a[0:3]", "%1", "%5") S3_M("a[4:7]", "%1", "%9")                                       \
-      S3_M("a[0:3]", "%2", "%6") S3_M("a[4:7]", "%2", "%10")                                      \
-      S3_M("a[0:3]", "%3", "%7") S3_M("a[4:7]", "%3", "%11")                                      \
-      :: "v"(AV[Q][0]), "v"(AV[Q][1]), "v"(AV[Q][2]), "v"(AV[Q][3]),                              \
-         "v"(RB[0][Q][0]), "v"(RB[0][Q][1]), "v"(RB[0][Q][2]), "v"(RB[0][Q][3]),                  \
-         "v"(RB[1][Q][0]), "v"(RB[1][Q][1]), "v"(RB[1][Q][2]), "v"(RB[1][Q][3])                   \
-      : S3_ACC_CLOBBER)
-#define S3_MFMA1(AV, RB, Q)                                                                       \
-  asm volatile(                                                                                   \
-      S3_M("a[0:3]", "%0", "%4") S3_M("a[0:3]", "%1", "%5") S3_M("a[0:3]", "%2", "%6") S3_M("a[0:3]", "%3", "%7") \
-      :: "v"(AV[Q][0]), "v"(AV[Q][1]), "v"(AV[Q][2]), "v"(AV[Q][3]),                              \
-         "v"(RB[0][Q][0]), "v"(RB[0][Q][1]), "v"(RB[0][Q][2]), "v"(RB[0][Q][3])                   \
-      : S3_ACC_CLOBBER)
-#define S3_MFMAS(AV, RB, Q)                                                                       \
-  if constexpr (NT == 4) {                                                                        \
-    if (tpw == 4) S3_MFMA4(AV, RB, Q);                                                            \
-    else if (tpw == 2) S3_MFMA2(AV, RB, Q);                                                       \
-    else S3_MFMA1(AV, RB, Q);                                                                     \
-  } else {                                                                                        \
-    if (tpw == 2) S3_MFMA2(AV, RB, Q);                                                            \
-    else S3_MFMA1(AV, RB, Q);                                                                     \
-  }
-  // One quarter of a step: wait for its operands, the MFMAs, then the reload of the registers they consumed.
-#ifdef DRS_TIMELINE
-// timing experiments ("mlp_debug", timeline build only; results are garbage while a bit is set):
-// 1 no vmcnt waits | 2 no MFMAs | 4 no weight loads in the loop | 8 no operand prefetch
-#define S3_QUARTER(RB, AV, RQ, Q)                                                                 \
-  if (!(a.dbg & 1)) { S3_WAITQ(RB, Q); }                                                          \
-  if (!(a.dbg & 2)) { S3_MFMAS(AV, RB, Q) }                                                       \
-  if (!(a.dbg & 4)) { S3_LOADQ(RB, RQ, Q) }
-#define S3_PREFETCH_A (!(a.dbg & 8))
-#else
-#define S3_QUARTER(RB, AV, RQ, Q)                                                                 \
-  S3_WAITQ(RB, Q);                                                                                \
-  S3_MFMAS(AV, RB, Q)                                                                             \
-  S3_LOADQ(RB, RQ, Q)
-#define S3_PREFETCH_A true
-#endif
-
-  // A step.  cur: its descriptor; nxt: the next step's (operand prefetch); fut: the one RD steps ahead,
-  // whose weights this step requests -- its raw words were read from LDS one step EARLIER (nothing in a
-  // step waits for an LDS round trip of control data).  AV / AN: operand sets.
-#define S3_STEP(RB, AV, AN)                                                                       \
-  {                                                                                               \
-    const int tpw = (cur.info >> S3_TPW_SHIFT) & 7;                                               \
-    if (__builtin_expect((cur.info & S3_INTERACT) != 0, 0)) { interact(); a_ready = false; }      \
-    if (!a_ready) read_a(AV, cur.a_off);        /* first step of a layer: after the barrier */    \
-    const Req rq = req_of(__builtin_amdgcn_readfirstlane(fut_raw.x), __builtin_amdgcn_readfirstlane(fut_raw.z), \
-                          __builtin_amdgcn_readfirstlane(fut_raw.w));                             \
-    const uint4 nxt_raw = *reinterpret_cast<const uint4*>(s_tab + 4 * min(ti + 2, n_table - 1));  \
-    fut_raw = *reinterpret_cast<const uint4*>(s_tab + 4 * min(ti + RD + 1, n_table - 1));         \
-    a_ready = (cur.info & S3_ANEXT) != 0;                                                         \
-    if (cur.info & S3_FIRST) acc_zero();        /* right in front of the pass's first MFMA */     \
-    S3_QUARTER(RB, AV, rq, 0)                                                                     \
-    if (S3_PREFETCH_A) read_a(AN, nxt.a_off);   /* (garbage when the next step opens a layer: re-read there) */ \
-    S3_QUARTER(RB, AV, rq, 1)                                                                     \
-    S3_QUARTER(RB, AV, rq, 2)                                                                     \
-    S3_QUARTER(RB, AV, rq, 3)                                                                     \
-    if (__builtin_expect((cur.info & S3_LAST) != 0, 0)) {                                         \
-      /* the accumulators first, straight behind the last MFMA: between asm blocks the compiler   */ \
-      /* is free to use a[0:15] (it spills VGPRs there when it runs short)                        */ \
-      float c0[4], c1[4], c2[4], c3[4];                                                           \
-      asm volatile("s_nop 15\n\ts_nop 7" ::: S3_ACC_CLOBBER);   /* the last MFMAs' results */       \
-      S3_ACC_READ(c0, "a0", "a1", "a2", "a3"); S3_ACC_READ(c1, "a4", "a5", "a6", "a7");           \
-      if constexpr (NT == 4) { S3_ACC_READ(c2, "a8", "a9", "a10", "a11"); S3_ACC_READ(c3, "a12", "a13", "a14", "a15"); } \
-      const Epi el = lds_epi((cur.info >> 24) & 0xff);                                            \
-      const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;                                 \
-      const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;                             \
-      float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);      \
-      const float b0 = smem[el.b_off + min(col0, el.N - 1)], b1 = smem[el.b_off + min(col0 + 16, el.N - 1)]; \
-      if constexpr (NT == 4) {                                                                    \
-        const float b2 = smem[el.b_off + min(col0 + 32, el.N - 1)], b3 = smem[el.b_off + min(col0 + 48, el.N - 1)]; \
-        if (tpw == 4) { epilogue(el, c2, b2, col0 + 32, lim, dst + 32); epilogue(el, c3, b3, col0 + 48, lim, dst + 48); } \
-      }                                                                                           \
-      epilogue(el, c0, b0, col0, lim, dst);                                                       \
-      if (tpw >= 2) epilogue(el, c1, b1, col0 + 16, lim, dst + 16);                               \
-    }                                                                                             \
-    if (__builtin_expect((cur.info & S3_BARRIER) != 0, 0)) { TL(13); __syncthreads(); TL(14); }   \
-    ++ti;                                                                                         \
-    cur = nxt;                                                                                    \
-    nxt.wp_off = __builtin_amdgcn_readfirstlane(nxt_raw.x); nxt.a_off = __builtin_amdgcn_readfirstlane(nxt_raw.y); \
-    nxt.in_ld = __builtin_amdgcn_readfirstlane(nxt_raw.z); nxt.info = __builtin_amdgcn_readfirstlane(nxt_raw.w); \
-  }
-  int ti = 0;
-  bool a_ready = false;
-  f32x4 avA[4], avB[4];
-  STile cur = a.tiles[0], nxt = a.tiles[min(1, n_table - 1)];
-  uint4 fut_raw = *reinterpret_cast<const uint4*>(s_tab + 4 * min(RD, n_table - 1));
-  if constexpr (RD == 2) {
-    for (int i = 0; i < n_table; i += 2) {
-      S3_STEP(rb0, avA, avB)
-      if (i + 1 >= n_table) break;
-      S3_STEP(rb1, avB, avA)
-    }
-  } else if constexpr (RD == 4) {
-    for (int i = 0; i < n_table; i += 4) {
-      S3_STEP(rb0, avA, avB)
-      if (i + 1 >= n_table) break;
-      S3_STEP(rb1, avB, avA)
-      if (i + 2 >= n_table) break;
-      S3_STEP(rb2, avA, avB)
-      if (i + 3 >= n_table) break;
-      S3_STEP(rb3, avB, avA)
-    }
-  } else {
-    for (int i = 0; i < n_table; i += 6) {
-      S3_STEP(rb0, avA, avB)
-      if (i + 1 >= n_table) break;
-      S3_STEP(rb1, avB, avA)
-      if (i + 2 >= n_table) break;
-      S3_STEP(rb2, avA, avB)
-      if (i + 3 >= n_table) break;
-      S3_STEP(rb0, avB, avA)
-      if (i + 4 >= n_table) break;
-      S3_STEP(rb1, avA, avB)
-      if (i + 5 >= n_table) break;
-      S3_STEP(rb2, avB, avA)
-    }
-  }
-#undef S3_STEP
-#undef S3_QUARTER
-#undef S3_PREFETCH_A
-#undef S3_MFMAS
-#undef S3_MFMA4
-#undef S3_MFMA2
-#undef S3_MFMA1
-#undef S3_M
-#undef S3_ACC_READ
-#undef S3_ACC_CLOBBER
-#undef S3_WAITQ
-#undef S3_LOADQ
-#undef S3_LOADQ4
-#undef S3_LOADQ2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing requests
-  TL(20);
-  signal_done(done, gridDim.x, smem);
-#ifdef DRS_TIMELINE
-  TL(21);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const unsigned n = (unsigned)g_tl_lds[0];
-    unsigned base = g_tl_n;
-    for (unsigned i = 0; i < n && base + i < 16384; ++i) g_tl[base + i] = g_tl_lds[i + 1];
-    g_tl_n = base + n;
-  }
-#endif
-}
 
 // stream4_kernel ("mlp_stream" 4): the 4-wave form with every SEGMENT -- all 64-k chunks of one
 // (layer, pass) for the 1 / 2 / 4 tiles a wave owns -- run by ONE asm statement (seg_asm.inc, generated
@@ -2234,8 +1736,6 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(stream_kernel<false, 8>);
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8>);
   if (e == hipSuccess) e = set_max_lds(stream_kernel<true, 8, true>);
-  if (e == hipSuccess) e = set_max_lds(stream3_kernel<4, 2>);
-  if (e == hipSuccess) e = set_max_lds(stream3_kernel<2, 2>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<true, false>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, true>);
@@ -2331,15 +1831,6 @@ static inline int pad64(int n) { return (n + 63) & ~63; }
 static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune, const XSrc& xs,
                         bool publish, SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr,
                         const SumArgs* sum = nullptr) {
-  // Gather-bound DLRM ("mlp_stream" 3 on four waves) with "mlp_rows32": launches of at least that many rows
-  // take stream4_kernel's 32-row form when its slabs fit -- half as many workgroups sit beside the next
-  // set's gather (RMC1, 12-query sets, same session, three runs each: stream3 130.7-132.1 k queries/s,
-  // stream4 with 16 rows 129.0-129.5 k, with 32 rows 133.3-133.4 k) -- and stream3_kernel otherwise.
-  if (tune.mlp_stream == 3 && tune.mlp_stream_waves == 4 && tune.mlp_rows32 > 0 && a.M >= tune.mlp_rows32 && !sum) {
-    Tune t4 = tune;
-    t4.mlp_stream = 4;
-    if (stream_plan(a, b, t4, xs, publish, out, lds_bytes, dot, sum) && out->packed == 6) return true;
-  }
   SArgs& p = *out;
   memset(&p, 0, sizeof p);
   const int na = a.n_layers, nb = b ? b->n_layers : 0;
@@ -2397,14 +1888,10 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     for (int l = 0; l < na; ++l) pk = pk && has_twin(a.W[l]);
     for (int l = 0; l < nb; ++l) pk = pk && has_twin(b->W[l]);
   }
-  // "mlp_stream" 3 (default): stream3_kernel -- two tiles per wave, b128 activation operands; its
-  // steps must fit the descriptor table
-  // stream3_kernel: 4 waves x up to 4 tiles ("mlp_stream_waves" 4) or 8 waves x up to 2 tiles (default)
-  // stream4_kernel: the 4-wave step table, run segment by segment ("mlp_stream" 4; with "mlp_stream" 3
-  // on four waves: launches of up to tune.mlp_s4_rows rows -- a single query -- where the launch's own
-  // latency counts, not what it takes from a gather beside it)
-  const bool f4 = tune.mlp_stream == 4 || (tune.mlp_stream == 3 && tune.mlp_stream_waves == 4 && a.M <= tune.mlp_s4_rows);
-  const int nt3 = (f4 || tune.mlp_stream_waves == 4) ? 4 : 2, nw3 = 16 / nt3;   // tiles per wave at most; waves (4 | 8)
+  // "mlp_stream" 4: stream4_kernel -- four waves x up to four tiles, b128 activation operands, the step table below
+  // run segment by segment; its steps must fit the descriptor table
+  const bool f4 = tune.mlp_stream == 4;
+  const int nt3 = 4, nw3 = 16 / nt3;   // tiles per wave at most; waves
   auto tpw3 = [&](int N, int out_pad) {       // tiles per wave of a layer: 1 / 2 (/ 4): a pass covers nw3 * tpw tiles
     const int etl = ((out_pad > N ? out_pad : N) + 15) / 16;
     int t = 1;
@@ -2415,7 +1902,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     const int etl = ((out_pad > N ? out_pad : N) + 15) / 16, tpp = nw3 * tpw3(N, out_pad);
     return ((etl + tpp - 1) / tpp) * ((K + 63) / 64);
   };
-  bool f3 = pk && (tune.mlp_stream == 3 || f4);
+  bool f3 = pk && f4;
   if (f3) {
     int st = 0;
     for (int l = 0; l < na; ++l) {
@@ -2431,7 +1918,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   if (sum && !f3 && pad64(b->width[0]) - sum->cols > ((d_out + 127) / 128) * 128) return false;   // zero pad must fall in an existing pass
   const int nwv = 8;
   const int passw = 16 * nwv;
-  p.packed = f3 ? (f4 ? 5 : nt3 == 4 ? 4 : 3) : pk ? 1 : 0;   // 3: stream3, 8 waves | 4: stream3, 4 waves | 5: stream4 (6: its 32-row form, set below)
+  p.packed = f3 ? 5 : pk ? 1 : 0;   // 1: stream_kernel on the packed twins | 5: stream4 (6: its 32-row form, set below)
   const int lpad = f3 ? 8 : 4;      // slab rows: 64 m + 8 floats apart in the b128 form, 64 m + 4 else
   // rows per workgroup: 16, or 32 for stream4_kernel's two-halves form ("mlp_rows32": launches of at
   // least that many rows, no summed input, slabs that still fit LDS)
@@ -2653,18 +2140,16 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
       const dim3 g3((unsigned)((a.M + 15) / 16));
       {
         // which form serves this launch (drs_last_dispatch; DESIGN.md dispatch table)
-        const char* form = sp.packed == 6 ? "stream4_kernel<rows32>" : sp.packed == 4 ? "stream3_kernel<4waves>" :
+        const char* form = sp.packed == 6 ? "stream4_kernel<rows32>" :
             sp.packed == 5 ? (sp.in[1].col2 >= 0 ? "stream4_kernel<sum>" : (tune.mlp_stream == 4 && tune.mlp_stream_2cu) ? "stream4_kernel<2cu>" : "stream4_kernel") :
-            sp.packed == 3 ? "stream3_kernel<8waves>" : sp.packed ? ((tune.mlp_stream_2cu && sp.n_table > 0) ? "stream_kernel<packed,2cu>" : "stream_kernel<packed>") : "stream_kernel<lds>";
+            sp.packed ? ((tune.mlp_stream_2cu && sp.n_table > 0) ? "stream_kernel<packed,2cu>" : "stream_kernel<packed>") : "stream_kernel<lds>";
         log_launch(tune.log, "%s[%u wg, %d layers%s, %zu B lds]", form, sp.packed == 6 ? (unsigned)((a.M + 31) / 32) : g3.x,
                    sp.n_layers, dot ? ", dot" : "", slds);
       }
       if (sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2>), dim3((unsigned)((a.M + 31) / 32)), dim3(256), slds, s, sp, d, xs);
-      else if (sp.packed == 4) hipLaunchKernelGGL((stream3_kernel<4, 2>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5) hipLaunchKernelGGL((stream4_kernel<false, false>), g3, dim3(256), slds, s, sp, d, xs);
-      else if (sp.packed == 3) hipLaunchKernelGGL((stream3_kernel<2, 2>), g3, dim3(512), slds, s, sp, d, xs);
       else if (sp.packed && tune.mlp_stream_2cu && sp.n_table > 0) hipLaunchKernelGGL((stream_kernel<true, 8, true>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else if (sp.packed) hipLaunchKernelGGL((stream_kernel<true, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else hipLaunchKernelGGL((stream_kernel<false, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);

@@ -215,12 +215,14 @@ class _HipNet(object):
             return None
         # only where it was measured to pay: gather-bound DLRM (one MLP stream).  The MLP-bound shapes have nothing to
         # gain (their gather is a tenth of a set), the one-lookup models' tables are cache resident.
-        if self.kind != N.MODEL_DLRM or int(eng.get_option("mlp_streams")) != 1:
+        # (round 5: DIN as well -- its fused gather + attention launch is its set's longest kernel; "din_nt" is its policy knob)
+        if not ((self.kind == N.MODEL_DLRM and int(eng.get_option("mlp_streams")) == 1) or self.kind == N.MODEL_DIN):
             return None
+        nt_key = "din_nt" if self.kind == N.MODEL_DIN else "sls_nt"
         co = max(1, min(int(eng.get_option("preferred_coalesce")), 16))
         bs = int(eng.max_batch)
         prev = eng.get_option("shared_stream")
-        nt0 = int(eng.get_option("sls_nt"))
+        nt0 = int(eng.get_option(nt_key))
 
         def gather_us():
             eng.set_option("shared_stream", 1)
@@ -242,7 +244,7 @@ class _HipNet(object):
         def both():
             out = []
             for p in policies:
-                eng.set_option("sls_nt", p)
+                eng.set_option(nt_key, p)
                 out.append(gather_us())
             return out
 
@@ -276,7 +278,7 @@ class _HipNet(object):
         finally:
             try:
                 eng.set_option("table_alloc", 0)
-                eng.set_option("sls_nt", best[2] if best else nt0)
+                eng.set_option(nt_key, best[2] if best else nt0)
                 if best:
                     eng.set_option("table_placement", best[1])
                 eng.set_option("table_placement", -2)

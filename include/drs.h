@@ -325,27 +325,18 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                "mlp_gemm32_small" names a gemm32 shape for them (22 | 21 | 12 | 11) that gives at least
  *                "mlp_gemm32_small_blocks" workgroups (defaults: 12 with 256 for MT-WnD and MLP-bound DLRM, 12 with 512 for
  *                W&D, else 0)
- *   "mlp_stream" 2 (default for MLP-bound models) chains run as the weight-tile stream kernel
- *                (tiles of all layers requested six rounds ahead, inputs resident in LDS) when every
- *                K % 4 == 0 and the slabs fit, the tiles read from the layers' PACKED twins (MFMA
- *                operand order, built by drs_set_fc) straight into the MFMA operand registers: no LDS
- *                staging of W, a workgroup barrier per layer instead of per 64-k chunk | 4 (default
- *                for gather-bound DLRM) stream4_kernel: four waves, every (layer, 64-column-per-wave
- *                pass) run by ONE hand-laid instruction stream (csrc/seg_asm.inc): MFMAs back to
- *                back with the weight reloads, operand prefetch and loop control between them, ring
- *                and accumulators in AGPRs under fixed names, the next segment's first chunk
- *                requested while the last one runs ("mlp_rows32" n: its launches of >= n rows take 32 rows per
- *                workgroup -- two halves sharing the weight operands; default 8192 for MLP-bound DLRM,
- *                2048 for gather-bound DLRM (whose full sets then take stream4_kernel in that form when its
- *                slabs fit LDS -- RMC1: 139 KB -- instead of stream3_kernel: half the workgroups beside the next
- *                set's gather), else 0 = never; "mlp_s4_rows" n: with "mlp_stream" 3 on four waves, launches of up to n
- *                rows take stream4_kernel; default 1024 for gather-bound DLRM) | 3 stream3_kernel: the same packed
- *                twins, activation operands as four ds_read_b128 per 64-k chunk, accumulators in fixed
- *                AGPRs, weight loads spread through the MFMA stream (EXEC-masked for tiles a wave does
- *                not own), one-round-trip prologue; "mlp_stream_waves" 4: four waves x up to four
- *                tiles (half the waves and LDS traffic beside a gather) | 8: eight waves x up to two |
- *                1 the first kernel with W staged through LDS | 0 always the per-layer chain kernel.
- *                Same bits in every form.
+ *   "mlp_stream" 2 (default for MT-WnD, NCF, DIN) chains run as the weight-tile stream kernel (tiles of all layers requested
+ *                six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and the slabs fit, the tiles read from
+ *                the layers' PACKED twins (MFMA operand order, built by drs_set_fc) straight into the MFMA operand
+ *                registers: no LDS staging of W, a workgroup barrier per layer instead of per 64-k chunk | 4 (default
+ *                for DLRM, W&D, DIEN) stream4_kernel: four waves, every (layer, 64-column-per-wave pass) run by ONE
+ *                hand-laid instruction stream (csrc/seg_asm.inc): MFMAs back to back with the weight reloads, operand
+ *                prefetch and loop control between them, ring and accumulators in AGPRs under fixed names, the next
+ *                segment's first chunk requested while the last one runs ("mlp_rows32" n: its launches of >= n rows take
+ *                32 rows per workgroup -- two halves sharing the weight operands; default 8192 for MLP-bound DLRM, 2048
+ *                for gather-bound DLRM, else 0 = never) | 1 the first kernel with W staged through LDS | 0 always the
+ *                per-layer chain kernel.  Same bits in every form.  (3 was stream3_kernel, removed in round 5: stream4_kernel
+ *                serves every launch size it served, faster -- DESIGN.md "Dispatch".)
  *                ("mlp_stream_2cu" 1 (default, except NCF) | 0: "mlp_stream" 2 with a ring of three
  *                register sets instead of six, compiled for 128 VGPRs, so that two of its workgroups
  *                share a CU and overlapping launches interleave on the same SIMDs)

@@ -399,9 +399,9 @@ def test_full_size_reference_shapes_match_oracle(name):
         for (bid, bs), o in zip(jobs16, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, "16 coalesced", bid, bs)
         # other launch structures of the same arithmetic: bit-identical
-        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_waves", "mlp_gemm", "mlp_gemm_2cu", "mlp_fuse", "shared_stream", "out_dma")}
-        for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=3, mlp_stream_waves=8),
-                     dict(mlp_stream=3, mlp_stream_waves=4), dict(mlp_gemm=0), dict(mlp_gemm_2cu=0), dict(mlp_gemm_2cu=1),
+        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_2cu", "mlp_gemm", "mlp_gemm_2cu", "mlp_fuse", "shared_stream", "out_dma")}
+        for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=4, mlp_stream_2cu=0),
+                     dict(mlp_stream=4, mlp_stream_2cu=1), dict(mlp_gemm=0), dict(mlp_gemm_2cu=0), dict(mlp_gemm_2cu=1),
                      dict(mlp_fuse=0), dict(shared_stream=1), dict(out_dma=1)):
             for key, val in opts.items():
                 eng.set_option(key, val)
@@ -836,9 +836,6 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "unfused_stream_packed": dict(mlp_stream=2, mlp_fuse=0, shared_stream=1),
             "pipelined_packed": dict(mlp_stream=2, mlp_fuse=1, shared_stream=2),
             "packed_ring3_2_per_cu": dict(mlp_stream=2, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),   # 128 VGPRs: two workgroups per CU
-            "stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=8),   # 8 waves x 2 tiles, b128 operands
-            "stream3_4_waves": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4, mlp_s4_rows=0),   # 4 waves x 4 tiles
-            "stream3_4_waves_small_sets_stream4": dict(mlp_stream=3, mlp_fuse=1, shared_stream=1, mlp_stream_waves=4, mlp_s4_rows=1 << 20),
             "stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1),               # 4 waves, one asm statement per (layer, pass)
             "unfused_stream4": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1),
             "stream4_2_per_cu": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_stream_2cu=1),
@@ -846,8 +843,6 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "unfused_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1, mlp_rows32=1),
             "pipelined_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_rows32=1),
             "pipelined_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2),
-            "unfused_stream3": dict(mlp_stream=3, mlp_fuse=0, shared_stream=1),
-            "pipelined_stream3": dict(mlp_stream=3, mlp_fuse=1, shared_stream=2),
             "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
             "unfused_chain": dict(mlp_stream=0, mlp_fuse=0, shared_stream=1),
             "standalone_layers": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1, mlp_wide_kn=1),
@@ -862,9 +857,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), name
             results[name] = outs[0]
             eng.set_option("mlp_wide_kn", 512 * 1024)
-            eng.set_option("mlp_stream_waves", 0)
             eng.set_option("mlp_stream_2cu", 0)
-            eng.set_option("mlp_s4_rows", 0)
             eng.set_option("mlp_rows32", 0)
         for name, got in results.items():
             assert np.array_equal(got, results["stream"]), name
@@ -1315,14 +1308,12 @@ def test_stream4_forms_on_every_model_kind(case):
         eng.set_option("mlp_stream_2cu", 0)
         want = run()
         for opts in (dict(mlp_stream=4, mlp_stream_2cu=0), dict(mlp_stream=4, mlp_stream_2cu=1),
-                     dict(mlp_stream=4, mlp_stream_2cu=0, mlp_rows32=1), dict(mlp_stream=3, mlp_stream_waves=4, mlp_s4_rows=1 << 20)):
+                     dict(mlp_stream=4, mlp_stream_2cu=0, mlp_rows32=1), dict(mlp_stream=4, mlp_stream_2cu=1, mlp_rows32=1)):
             for k, v in opts.items():
                 eng.set_option(k, v)
             got = run()
             assert all(np.array_equal(a_, b_) for a_, b_ in zip(got, want)), (case, opts)
             eng.set_option("mlp_rows32", 0)
-            eng.set_option("mlp_s4_rows", 0)
-            eng.set_option("mlp_stream_waves", 0)
     finally:
         eng.close()
 
@@ -1535,3 +1526,26 @@ def test_pipelined_engine_race_hunt(extra):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "--seconds", "20"] + extra,
                        capture_output=True, text=True, timeout=400, cwd=root)
     assert r.returncode == 0 and "stress OK" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+
+
+# ------------------------------------------------------------------------------------
+def test_dispatch_table_of_the_bench_workloads():
+    """Which kernel serves which shape: for the eleven bench workloads, a single query, a 4-query set
+    and the engine's preferred launch set take exactly the kernel forms DESIGN.md's dispatch table lists
+    (tests/golden/dispatch.json, written by tools/dispatch_table.py from drs_last_dispatch; grids left out -- they
+    follow from the row count).  Table SIZES do not enter the dispatch: the scalar-row workloads run with small tables."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import dispatch_table as DT
+    with open(os.path.join(H.GOLDEN, "dispatch.json")) as f:
+        want = json.load(f)
+    assert sorted(want) == sorted(DT.WORKLOADS)
+    got = DT.table(DT.WORKLOADS, small_rows=True)
+    for w in DT.WORKLOADS:
+        assert got[w]["preferred_coalesce"] == want[w]["preferred_coalesce"] and got[w]["mlp_streams"] == want[w]["mlp_streams"], w
+        for name, r in want[w]["sets"].items():
+            assert got[w]["sets"][name]["forms"] == r["forms"], (w, name, got[w]["sets"][name]["forms"], r["forms"])
+            streams = lambda t: t[t.index("gather on"):]
+            assert streams(got[w]["sets"][name]["set"]) == streams(r["set"]), (w, name)

@@ -81,10 +81,10 @@ run 600 $R3 --set mlp_gemm32=0 > "$OUT/rmc3_bench_gemm32_0.json" 2>/dev/null
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
-# the 8-wave packed MLP launch / stream4_kernel in place of stream3_kernel's 4-wave form (what each costs
+# the 8-wave packed MLP launch in place of stream4_kernel (what each costs
 # the gather beside it), and launch sets of 8 instead of 12 queries
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=2 > "$OUT/bench_mlp_stream2.json" 2>/dev/null
-run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=4 > "$OUT/bench_mlp_stream4.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream_2cu=1 > "$OUT/bench_mlp_stream4_2cu.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 8 > "$OUT/bench_coalesce8.json" 2>/dev/null
 # round 4: what the non-temporal row loads and the 32-row MLP form are worth on this box (same line, one option off)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set sls_nt=0 > "$OUT/bench_sls_nt0.json" 2>/dev/null
@@ -92,14 +92,12 @@ run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_rows32=
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 > "$OUT/bench_again.json" 2>/dev/null
 # the MLP launch ALONE (one stream, 8-query sets = 128 workgroups) in its three forms: durations from
 # rocprofv3, MFMA counters, and the in-kernel timeline of stream4_kernel (needs libdrs_hip_tl.so: make timeline)
-MA="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --coalesce 8 --set shared_stream=1 --set mlp_s4_rows=0"
+MA="python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --coalesce 8 --set shared_stream=1"
 trace mlp_alone_stream4 $MA --set mlp_stream=4 --set mlp_stream_2cu=0
-trace mlp_alone_stream3 $MA --set mlp_stream=3 --set mlp_stream_waves=4
 trace mlp_alone_stream2 $MA --set mlp_stream=2 --set mlp_stream_2cu=0
 # (2 048 rows take stream4_kernel's 32-row form by default since round 4: the two lines above both ran it; the
 #  16-row forms alone, for the record)
 trace mlp_alone_stream4_16rows $MA --set mlp_stream=4 --set mlp_stream_2cu=0 --set mlp_rows32=0
-trace mlp_alone_stream3_16rows $MA --set mlp_stream=3 --set mlp_stream_waves=4 --set mlp_rows32=0
 pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" $MA --set mlp_stream=4
 pmc "$OUT/mlp_alone_pmc_summary.txt" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" $MA --set mlp_stream=4
 [ -f deeprecsys_amd/libdrs_hip_tl.so ] && TL_ROWS=40 run 200 python tools/mlp_timeline.py --coalesce 8 --set mlp_stream=4 --set shared_stream=1 > "$OUT/mlp_timeline_stream4.txt" 2>&1
