@@ -12,7 +12,7 @@
 //            layer scratch, device output buffer, [flag | err | out] in host-mapped pinned
 //            memory, and a host-mapped pinned input block for per-call inputs
 // Streams: every gather on stream_g, the rest of each launch set on a second stream behind
-// an event (DESIGN.md 3.5); completion is a flag in pinned memory, not a stream sync.
+// an event (DESIGN.md 4.5); completion is a flag in pinned memory, not a stream sync.
 #include <immintrin.h>
 #include <sched.h>
 #include <stdarg.h>
@@ -165,7 +165,7 @@ struct Slot {
 
 // One copy of the table arena.  kind 0: a plain hipMalloc.  kind 1: built with the virtual-memory API --
 // a reserved address range of chosen alignment, physical memory created in chunks of a chosen size
-// (0: one handle for the whole arena) and mapped into it ("table_alloc" and friends, DESIGN.md 3.5:
+// (0: one handle for the whole arena) and mapped into it ("table_alloc" and friends, DESIGN.md 5:
 // what a table is, models/dlrm_s_caffe2.py:297-299, does not say where it lives).
 struct VaRange { void* base = nullptr; size_t reserved = 0; float* p = nullptr; };   // a reserved address range and the (aligned) arena address inside it
 struct Arena {
@@ -249,6 +249,7 @@ struct drs_engine {
   // overlapping GEMM launches), the latency-bound chain launches go on the slots' MLP streams beside them;
   // an event per change of stream orders a set's launches.  0: a set's MLP launches all on its own stream.
   int mlp_layout = 0;
+  int gather_priority = 0;
   int mlp_cu_mask = 0, gather_cu_complement = 1;   // "mlp_cu_mask": CUs reserved for the MLP streams (0: none)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
   // launch sets whose outputs are at least this many bytes (0: never) leave by a copy-engine transfer queued behind the
@@ -378,7 +379,7 @@ void arena_free(Arena& a) {
 // data_generator/dlrm_data_caffe2.py:105-110), the launch the engine would make for them.  *us = average
 // duration of a launch.  Why the real kernel: synthetic row-read probes that saturate the memory system read every
 // gigabyte of HBM equally fast; the gather kernels, with a handful of loads in flight per lane, do not
-// (DESIGN.md 3.5, profiles/r05_placement/).
+// (DESIGN.md 5, profiles/r05_placement/).
 hipError_t probe_gather(drs_engine* e, const float* base, size_t bytes, double* us) {
   *us = 0;
   const int D = e->D;
@@ -528,7 +529,7 @@ hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
   }
   if (e->table_alloc == 0 || e->table_alloc == 2 || e->table_alloc == 3) {
     // 2: physically contiguous device memory, best effort (hipDeviceMallocContiguous: the driver assembles the
-    // allocation from neighbouring free blocks instead of taking whatever blocks head its free lists -- DESIGN.md 3.5)
+    // allocation from neighbouring free blocks instead of taking whatever blocks head its free lists -- DESIGN.md 5)
     void* p = nullptr;
     hipError_t r = hipErrorOutOfMemory;
     if (e->table_alloc == 2) {
@@ -589,8 +590,9 @@ hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
 
 // The arena in use moves to another address range: "table_va_next" reserves one more range and maps the arena's
 // memory there (the ranges tried so far stay reserved -- address space only, no memory), "table_va_select" k goes
-// back to candidate k and gives the other ranges up.  Why an ADDRESS matters: DESIGN.md 3.5 (the gather's speed on
-// an arena follows the arena's virtual address, i.e. the page-table blocks behind it, not its memory).
+// back to candidate k and gives the other ranges up.  A lab instrument (tools/placement_lab.py): it showed that the
+// gather's speed on an arena does NOT depend on the address -- one arena read the same at 24-60 address ranges, and
+// fast / slow memory stayed fast / slow wherever it was mapped (profiles/r05_placement/README.md).
 int32_t arena_move(drs_engine* e, Arena& a, int64_t to /* -1: a fresh range */) {
   if (a.kind != 1) return fail(e, DRS_ERR_STATE, "the table arena was not built with the virtual-memory API (\"table_alloc\" 1)");
   if (to >= (int64_t)a.vas.size()) return fail(e, DRS_ERR_BAD_ARG, "address candidate %lld of %zu", (long long)to, a.vas.size());
@@ -2516,6 +2518,17 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     apply_stream_mode(e);
   }
   else if (!strcmp(key, "gather_cu_complement") && (value == 0 || value == 1)) e->gather_cu_complement = (int)value;
+  else if (!strcmp(key, "gather_priority") && value >= -1 && value <= 1) {
+    // experiment: the gather stream at the device's highest (1) or lowest (-1) queue priority, 0 = default
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    int lo = 0, hi = 0;
+    HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo, &hi));      // (numerically: hi <= lo)
+    if (e->stream_g) { (void)hipStreamSynchronize(e->stream_g); (void)hipStreamDestroy(e->stream_g); e->stream_g = nullptr; }
+    HIP_TRY(e, hipStreamCreateWithPriority(&e->stream_g, hipStreamNonBlocking, value > 0 ? hi : value < 0 ? lo : (lo + hi) / 2));
+    e->gather_priority = (int)value;
+    apply_stream_mode(e);
+  }
   else if (!strcmp(key, "mlp_layout") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_layout = (int)value; }
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
@@ -2537,7 +2550,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
   else if (!strcmp(key, "table_placement")) {
     // Where a multi-gigabyte allocation lands in HBM moves the gather by up to 6 % and stays for the allocation's
-    // lifetime (DESIGN.md 3.5): the feeder may try a few places with the model's own launch sets and keep the best.
+    // lifetime (DESIGN.md 5): the feeder may try a few places with the model's own launch sets and keep the best.
     //   -1: copy the tables into one more allocation and use that one (the earlier ones stay allocated, or the allocator
     //       hands the same pages out again) | k >= 0: use candidate k | -2: free every candidate but the one in use.
     // Refused (DRS_ERR_OOM, nothing changes) when one more copy would not leave 3/4 of the device's memory free.
@@ -2745,7 +2758,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"mlp_cu_mask", e->mlp_cu_mask}, {"gather_cu_complement", e->gather_cu_complement},
+      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"mlp_cu_mask", e->mlp_cu_mask}, {"gather_priority", e->gather_priority}, {"gather_cu_complement", e->gather_cu_complement},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
       {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
       {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},

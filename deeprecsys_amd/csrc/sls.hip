@@ -742,7 +742,7 @@ __global__ void fill_uniform_kernel(float* W, int64_t n, int32_t t, float lo, fl
 // ---------------------------------------------------------------------------
 // Row-read probe of a range of device memory: the access shape of the many-rows-per-bag gather (a wave =
 // 80 random 256-byte rows, 4 per load instruction, all 20 loads of a lane in flight, non-temporal) without
-// index arrays or outputs.  What it is for: DESIGN.md 3.5 -- the same gather runs up to 9 % faster on some
+// index arrays or outputs.  What it is for: DESIGN.md 5 -- the same gather runs up to 9 % faster on some
 // gigabytes of HBM than on others, and the arena builder keeps the gigabytes this probe reads fastest.
 __global__ __launch_bounds__(64) void probe_rows_kernel(const float4* __restrict__ base, uint32_t rows, uint32_t seed,
                                                         float4* __restrict__ sink, uint32_t windows, uint32_t stride_rows, int sorted) {

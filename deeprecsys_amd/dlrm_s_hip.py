@@ -200,7 +200,7 @@ class _HipNet(object):
         """Where the tables live in HBM, and with which cache policy their rows are read, moves the many-rows-per-bag
         gather by up to 9 % -- a property of the PHYSICAL memory (it follows the memory through address changes;
         gigabytes-wide regions of HBM are "fast" or "slow", and they are different regions for non-temporal and for
-        plain loads) that no synthetic probe sees, only the model's own launch sets (DESIGN.md 3.5,
+        plain loads) that no synthetic probe sees, only the model's own launch sets (DESIGN.md 5,
         profiles/r05_placement/README.md).  With the input sets staged, this times full launch sets of the engine's
         preferred size (one stream: the gather alone) on the arena drs_create made, under each load policy ("sls_nt"
         1 / 0), then on up to `candidates` - 1 further arenas taken from further on in HBM (virtual-memory API,
@@ -304,7 +304,7 @@ class _HipNet(object):
         """Enqueue one set of launches on `slot` and return at once; collect_staged_multi(slot,
         batch_sizes) hands the outputs over.  With several slots the engine process keeps the
         gather of one set, the MLP of the previous one and the host work of the next in flight
-        at the same time (DESIGN.md 3.5)."""
+        at the same time (DESIGN.md 4.5)."""
         self.engine.forward_multi_async(slot, [int(b) for b in batch_ids], [int(b) for b in batch_sizes])
 
     def collect_staged_multi(self, batch_sizes, slot):
