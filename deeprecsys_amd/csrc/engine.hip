@@ -374,6 +374,7 @@ void arena_free(Arena& a) {
   a = Arena();
 }
 
+#ifdef DRS_LAB
 // The model's OWN gather kernel on a one-table problem laid over [base, base + bytes): `bags` bags of L sorted,
 // distinct rows each (one row per L-th of the range, what np.unique leaves of a bag's draws,
 // data_generator/dlrm_data_caffe2.py:105-110), the launch the engine would make for them.  *us = average
@@ -519,14 +520,17 @@ hipError_t arena_alloc_selected(drs_engine* e, size_t bytes, Arena* out) {
   return hipSuccess;
 }
 
+#endif  // DRS_LAB
 // `bytes` of device memory for the tables, built as e->table_alloc / vmm_* say.  On failure nothing stays
 // allocated and *out is empty.
 hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
   *out = Arena();
+#ifdef DRS_LAB
   if (e->table_alloc == 3) {
     if (arena_alloc_selected(e, bytes, out) == hipSuccess) return hipSuccess;
     (void)hipGetLastError();           // (no room for a pool, no virtual-memory API ...: a plain allocation)
   }
+#endif  // DRS_LAB
   if (e->table_alloc == 0 || e->table_alloc == 2 || e->table_alloc == 3) {
     // 2: physically contiguous device memory, best effort (hipDeviceMallocContiguous: the driver assembles the
     // allocation from neighbouring free blocks instead of taking whatever blocks head its free lists -- DESIGN.md 5)
@@ -588,6 +592,7 @@ hipError_t arena_alloc(drs_engine* e, size_t bytes, Arena* out) {
   return hipSuccess;
 }
 
+#ifdef DRS_LAB
 // The arena in use moves to another address range: "table_va_next" reserves one more range and maps the arena's
 // memory there (the ranges tried so far stay reserved -- address space only, no memory), "table_va_select" k goes
 // back to candidate k and gives the other ranges up.  A lab instrument (tools/placement_lab.py): it showed that the
@@ -619,6 +624,7 @@ int32_t arena_move(drs_engine* e, Arena& a, int64_t to /* -1: a fresh range */) 
   return DRS_OK;
 }
 
+#endif  // DRS_LAB
 // ---- host-side worker pool for the per-call input pass ----------------------------------------
 // drs_forward_inputs converts 160 k indices per RMC1 query on the host; one thread doing that
 // (plus the Python call) capped the PCIe-inclusive path at 12 k queries/s.  The
@@ -1823,14 +1829,14 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
   }
   apply_stream_mode(e);
   {
-    // The table arena, last (its builder may run the gather kernels as a probe): one hipMalloc.  With
-    // DRS_TABLE_SELECT=1 in the environment, gather-bound DLRM with gigabytes of tables gets "table_alloc" 3
-    // (arena_alloc_selected: the fastest gigabytes of a pool by a one-table run of the model's gather kernel) -- an
-    // experiment that did NOT work: that probe reads every gigabyte equally fast (profiles/r05_placement/README.md);
-    // what does see the property is the model's own launch sets (DLRM_Net.tune_table_placement).
+    // The table arena, last: one hipMalloc (where it lands in HBM, and what DLRM_Net.tune_table_placement does about
+    // it: DESIGN.md 5).
+#ifdef DRS_LAB
+    // lab build, DRS_TABLE_SELECT=1: "table_alloc" 3 (arena_alloc_selected: the fastest gigabytes of a pool by a one-table
+    // run of the model's gather kernel) -- an experiment that did NOT work (profiles/r05_placement/README.md)
     const char* env = getenv("DRS_TABLE_SELECT");
-    const bool want = env ? atoi(env) != 0 : false;
-    if (want && e->kind == DRS_MODEL_DLRM && e->mlp_streams <= 2 && e->max_lookups >= 8 && e->tables_bytes >= ((size_t)1 << 30)) e->table_alloc = 3;
+    if (env && atoi(env) != 0 && e->kind == DRS_MODEL_DLRM && e->mlp_streams <= 2 && e->max_lookups >= 8 && e->tables_bytes >= ((size_t)1 << 30)) e->table_alloc = 3;
+#endif
     Arena first;
     CREATE_TRY(arena_alloc(e, e->tables_bytes, &first));
     e->tables = first.p;
@@ -2496,6 +2502,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     e->mlp_streams = (int)value;
     apply_stream_mode(e);
   }
+#ifdef DRS_LAB
   else if (!strcmp(key, "mlp_cu_mask") && value >= 0 && value <= 248) {
     // experiment: the MLP side's streams run on `value` CUs only (bits 0 .. value-1 of the queue's CU
     // mask; 0 = every CU, the default), the gather stream on the others ("gather_cu_complement" 1, default) or everywhere (0)
@@ -2529,6 +2536,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     e->gather_priority = (int)value;
     apply_stream_mode(e);
   }
+#endif  // DRS_LAB
   else if (!strcmp(key, "mlp_layout") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_layout = (int)value; }
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
@@ -2556,12 +2564,17 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     // Refused (DRS_ERR_OOM, nothing changes) when one more copy would not leave 3/4 of the device's memory free.
     int32_t rc = drs_sync(e);
     if (rc) return rc;
-    if (value == -1 || value == -3) {
+#ifdef DRS_LAB
+    const bool scan = value == -3;
+#else
+    const bool scan = false;
+#endif
+    if (value == -1 || scan) {
       // (-3, a lab's request: one more copy as long as it fits beside 4 GB of headroom -- tools/placement_lab.py scans
       // the whole of HBM with it)
       size_t free_b = 0, total_b = 0;
       if (e->arenas.size() >= 256 || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-          (value == -1 ? e->tables_bytes > free_b / 4 : e->tables_bytes + ((size_t)4 << 30) > free_b))
+          (!scan ? e->tables_bytes > free_b / 4 : e->tables_bytes + ((size_t)4 << 30) > free_b))
         return fail(e, DRS_ERR_OOM, "table_placement: no room for one more copy of the tables (%zu bytes)", e->tables_bytes);
       Arena fresh;
       hipError_t ar = arena_alloc(e, e->tables_bytes, &fresh);
@@ -2583,6 +2596,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
       return fail(e, DRS_ERR_BAD_ARG, "table_placement %lld (candidates: %zu)", (long long)value, e->arenas.size());
     }
   }
+#ifdef DRS_LAB
   else if (!strcmp(key, "table_va_next") || !strcmp(key, "table_va_select") || !strcmp(key, "table_va_goto")) {
     int32_t rc = drs_sync(e);
     if (rc) return rc;
@@ -2681,7 +2695,11 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     HIP_TRY(e, arena_map(a, a.p, e->device));
     HIP_TRY(e, arena_map(b, b.p, e->device));
   }
-  else if (!strcmp(key, "table_alloc") && value >= 0 && value <= 3) e->table_alloc = (int)value;
+#endif  // DRS_LAB
+#ifdef DRS_LAB
+  else if (!strcmp(key, "table_alloc") && value == 3) e->table_alloc = 3;
+#endif
+  else if (!strcmp(key, "table_alloc") && value >= 0 && value <= 2) e->table_alloc = (int)value;
   else if (!strcmp(key, "table_spacer") && value >= 0) {
     // `value` bytes of device memory are taken in 1 GiB pieces and never mapped: the next placement candidate comes from
     // further on in HBM.  "table_placement" -2 gives them back (as does drs_destroy).
@@ -2698,10 +2716,14 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
       e->spacers.push_back(h);
     }
   }
+#ifdef DRS_LAB
   else if (!strcmp(key, "table_select_pool") && value >= 0 && value <= 192) e->sel_want_pool = value;
+#endif  // DRS_LAB
   else if (!strcmp(key, "table_vmm_chunk") && value >= -1) e->vmm_chunk = value;
   else if (!strcmp(key, "table_vmm_align") && value >= 0) e->vmm_align = value;
+#ifdef DRS_LAB
   else if (!strcmp(key, "table_vmm_shuffle") && (value == 0 || value == 1)) e->vmm_shuffle = (int)value;
+#endif  // DRS_LAB
   else if (!strcmp(key, "out_dma") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->out_dma = value; }
   else if (!strcmp(key, "zero_copy")) { int32_t rc = drs_sync(e); if (rc) return rc; e->zero_copy = value ? 1 : 0; }
   else return fail(e, DRS_ERR_BAD_ARG, "unknown option %s=%lld", key, (long long)value);
@@ -2758,19 +2780,28 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"mlp_cu_mask", e->mlp_cu_mask}, {"gather_priority", e->gather_priority}, {"gather_cu_complement", e->gather_cu_complement},
+      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
       {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
       {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},
-      {"table_alloc", e->table_alloc}, {"table_vmm_chunk", e->vmm_chunk}, {"table_vmm_align", e->vmm_align}, {"table_vmm_shuffle", e->vmm_shuffle},
-      {"table_address", (int64_t)(uintptr_t)e->tables}, {"table_select_pool", e->sel_pool}, {"table_select_kept", e->sel_kept},
+      {"table_alloc", e->table_alloc}, {"table_vmm_chunk", e->vmm_chunk}, {"table_vmm_align", e->vmm_align},
+      {"table_address", (int64_t)(uintptr_t)e->tables}};
+  for (auto& kv : tab)
+    if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
+#ifdef DRS_LAB
+  struct { const char* k; int64_t v; } lab[] = {
+      {"table_select_pool", e->sel_pool}, {"table_select_kept", e->sel_kept},
       {"table_select_best_ns", e->sel_best_ns}, {"table_select_worst_ns", e->sel_worst_ns}, {"table_select_kept_worst_ns", e->sel_kept_worst_ns},
       {"table_select_ms", e->sel_ms}, {"table_probe_mbs", e->probe_mbs}, {"table_probe_gather_ns", e->probe_gather_ns}, {"table_probe_ps", e->probe_ps},
+      {"mlp_cu_mask", e->mlp_cu_mask}, {"gather_priority", e->gather_priority}, {"gather_cu_complement", e->gather_cu_complement},
+      {"table_vmm_shuffle", e->vmm_shuffle},
       {"table_kind", [&]() -> int64_t { for (const Arena& a : e->arenas) if (a.p == e->tables) return a.kind; return 0; }()},
       {"table_va_candidates", [&]() -> int64_t { for (const Arena& a : e->arenas) if (a.p == e->tables) return (int64_t)a.vas.size(); return 0; }()},
       {"table_va", [&]() -> int64_t { for (const Arena& a : e->arenas) if (a.p == e->tables) return a.va_cur; return 0; }()}};
-  for (auto& kv : tab)
+  for (auto& kv : lab)
     if (!strcmp(key, kv.k)) { *value = kv.v; return DRS_OK; }
+#endif
+
   return fail(e, DRS_ERR_BAD_ARG, "unknown option %s", key);
 }
 

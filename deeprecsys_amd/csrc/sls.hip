@@ -739,6 +739,7 @@ __global__ void fill_uniform_kernel(float* W, int64_t n, int32_t t, float lo, fl
   }
 }
 
+#ifdef DRS_LAB   // probes of tools/placement_lab.py (libdrs_hip_lab.so: make lab-lib); not in the product library
 // ---------------------------------------------------------------------------
 // Row-read probe of a range of device memory: the access shape of the many-rows-per-bag gather (a wave =
 // 80 random 256-byte rows, 4 per load instruction, all 20 loads of a lane in flight, non-temporal) without
@@ -834,6 +835,8 @@ hipError_t probe_latency(const void* base, size_t chunk_bytes, int n_chunks, int
                      (uint32_t)rows, steps, 12345u, d_ticks);
   return hipGetLastError();
 }
+
+#endif  // DRS_LAB
 
 hipError_t launch_fill_uniform(float* W, int64_t n, int32_t t, float lo, float hi, uint64_t seed,
                                hipStream_t s) {

@@ -396,10 +396,15 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                drs_set_table / drs_fill_table_uniform drop the candidates not in use (they would be stale).
  *                Results never depend on it.  (DLRM_Net.tune_table_placement times each with the model's own sets.)
  *   "table_alloc" how the NEXT arena is built (a "table_placement" -1 candidate): 0 hipMalloc | 1 the virtual-memory
- *                API -- an address range reserved with alignment "table_vmm_align" bytes (0: the allocation granularity),
- *                physical memory created in handles of "table_vmm_chunk" bytes (0: one handle for the whole arena)
- *                and mapped into it; "table_vmm_shuffle" 1 maps the chunks in a permuted order (an experiment:
- *                neighbouring addresses on distant memory).  "table_address" (read only): the arena's address.
+ *                API -- physical memory created in handles of "table_vmm_chunk" bytes (-1, the default: 1 GiB handles for
+ *                arenas of at least 1 GiB, one handle for smaller ones; 0: one handle) and mapped into an address range
+ *                aligned to "table_vmm_align" bytes (0: 2 MiB) | 2 hipDeviceMallocContiguous, best effort.
+ *                "table_spacer" n: n bytes of device memory are taken in 1 GiB pieces and never mapped, so that the next
+ *                candidate comes from further on in HBM ("table_placement" -2 and drs_destroy give them back).
+ *                "table_address" (read only): the arena's address.  What moves the gather is WHICH physical gigabytes
+ *                hold the tables x the load policy ("sls_nt"); DLRM_Net.tune_table_placement searches both.
+ *                (The lab's instruments -- memory probes, arenas moved between address ranges or built from a probed
+ *                pool, CU masks / priorities of the streams -- exist in the lab build only: make lab-lib, -DDRS_LAB.)
  *   "out_dma"    bytes (default 1 572 864; 0 = never): with "zero_copy" 1, launch sets with at least this many bytes of
  *                outputs hand them over by a copy-engine transfer queued behind the last kernel and a
  *                stream-ordered write of the completion flag behind that (MT-WnD's 2 MB per 16-query set);

@@ -26,6 +26,12 @@ sys.path.insert(0, ROOT)
 import bench as B  # noqa: E402
 from deeprecsys_amd import _native as N  # noqa: E402
 
+# the lab's options (probes, address moves, pool selection ...) live in the lab build of the library only
+_LAB = os.path.join(ROOT, "deeprecsys_amd", "libdrs_hip_lab.so")
+if not os.path.exists(_LAB):
+    sys.exit("tools/placement_lab.py needs deeprecsys_amd/libdrs_hip_lab.so: make -C deeprecsys_amd/csrc lab-lib")
+N.LIB_PATH = _LAB
+
 MB = 1 << 20
 RECIPES = [
     # (name, table_alloc, chunk bytes, align bytes, shuffle)
