@@ -19,7 +19,8 @@ def test_stream4_kernel_keeps_agprs_to_its_asm_statements():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "deeprecsys_amd", "csrc"), "check-agpr"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("AGPR uses outside asm: 0") == 4 and "occupancy 2" in r.stdout      # three instantiations, one of them two per CU
+    # four instantiations, one of them two per CU (the report appears twice when make had to rebuild the listing first)
+    assert r.stdout.count("AGPR uses outside asm: 0") in (4, 8) and "occupancy 2" in r.stdout
 
 
 def test_generated_segment_streams_wait_for_exactly_what_they_consume():
