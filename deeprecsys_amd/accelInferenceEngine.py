@@ -59,8 +59,10 @@ def _build_hip_model(args, engine_id):
     # this engine process onto the cores next to its GPU (utils/affinity.py) before anything is pinned or any worker
     # thread starts; engines that share a GPU share its cores
     from .utils import affinity
+    # (more engines than GPUs: engine k drives GPU k % ndev -- two to four engine processes per GPU are what it takes to
+    #  keep one MI355X busy through the Python queues, DESIGN.md 8 -- and takes that GPU's cores)
     n_acc = max(1, int(getattr(args, "num_accels", 1)))
-    if not getattr(args, "_drs_bound", False) and n_acc <= ndev:
+    if not getattr(args, "_drs_bound", False):
         args._drs_binding = affinity.bind_rank(args._drs_device, min(n_acc + int(getattr(args, "accel_device_offset", 0)), ndev))
         args._drs_bound = True
     if args.model_type not in M.WRAPPERS:
