@@ -1811,6 +1811,10 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     // chip: RM3 config 3's 416-512-256-1 top chain 80 -> 67 us, 31.5 k -> 32.1 k queries/s.  At 4 096 rows
     // (128 workgroups) the form loses: W&D 96.1 k -> 94.5 k.
     if (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1) { e->tune.mlp_stream = 4; e->tune.mlp_rows32 = 8192; }
+    // ... and the in-between class (a gather-bound DLRM that got two MLP streams because its MLP launch outlasts its
+    // gather: the reference's own dlrm_rm1.json) from 4 096 rows on -- its full 16-query set as 128 workgroups beside
+    // the gather instead of 256: 237.6 k -> 241.8 k queries/s, gather 0.671 -> 0.682 (round 5, same session, three forms)
+    if (e->kind == DRS_MODEL_DLRM && e->mlp_streams == 2 && flop / bytes <= 20.0) e->tune.mlp_rows32 = 4096;
     // wide layers as two 64 x 64 GEMM workgroups per CU (gemm.hip) where that measured faster
     e->tune.gemm_2cu = e->kind == DRS_MODEL_DLRM || e->kind == DRS_MODEL_WND;
     // Wide layers that do not reach 512 tiles of 128 x 128 take gemm32_kernel's 64 x 128 workgroups instead of
