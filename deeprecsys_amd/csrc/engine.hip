@@ -1514,6 +1514,73 @@ int32_t drs_device_count(int32_t* out_count) {
 
 const char* drs_last_error(drs_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// ---- which launch forms a model's sets take ------------------------------------------------------------
+// Decided ONCE per engine, here and nowhere else, from the model's shape; what each launch then becomes also depends
+// on its row count (mlp.hip stream_plan, gemm.hip launch_gemm, sls.hip flat_plan) -- the resulting table is
+// DESIGN.md 3 / profiles/r05_dispatch.md, read back through drs_last_dispatch and asserted by
+// test_dispatch_table_of_the_bench_workloads.  The numbers behind every choice are same-session A/Bs
+// (docs/DESIGN_rounds_1-4.md).
+//
+//   class (MLP FLOP per gathered byte, per sample)     MLP streams  stream kernel              rows32 from   GEMM forms
+//   gather-bound DLRM (RMC1 2, RM2 0.6)                1            stream4, one WG per CU     2 048 rows    --
+//   in-between DLRM (dlrm_rm1.json: MLP launch         2            stream4, two WGs per CU    4 096 rows    --
+//     outlasts its gather)
+//   MLP-bound DLRM (RM3 230)                           up to 4      stream4, two WGs per CU    8 192 rows    2cu; gemm32 64 x 128 from 256 tiles
+//   W&D (440), DIEN (200)                              up to 4      stream4, two WGs per CU    never         W&D: 2cu; gemm32 64 x 128 from 512 tiles
+//   MT-WnD                                             up to 4      stream_kernel, two per CU  --            gemm32 64 x 128 from 256 tiles
+//   DIN                                                1            stream_kernel, two per CU  --            --
+//   NCF (145)                                          up to 4      stream_kernel, one per CU  --            --
+static void choose_launch_forms(drs_engine* e) {
+  const int T = e->T, D = e->D;
+  // A wave of the wave-split gather takes 256/D rows per load instruction: a bag shorter than 8 such instructions cannot
+  // fill its load rings, and a lane group per bag (the sequential variant, which is also bit-exact) is faster: RM3
+  // (D=32, L=20) 16.9 -> 11.6 us, W&D / NCF (L=1) 2x; RM1 (L=80) stays wave-split.
+  e->sls_short_bag = 2048 / D;
+  // Which side bounds a launch set?  Gather-bound models keep ONE MLP stream (more only takes CUs from the gather that sets
+  // the pace); MLP-bound ones let the MLP launches of consecutive sets overlap on one stream per slot (W&D 57 k -> 68 k q/s,
+  // RM3 39 k -> 50 k, NCF 128 k -> 200 k; RM1 122 k -> 100 k, hence the rule).
+  double flop = 0;
+  for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
+    for (size_t i = 0; i + 1 < mm->ln.size(); ++i) flop += 2.0 * mm->ln[i] * (mm->ln[i + 1] > 0 ? mm->ln[i + 1] : 64);
+  // (DIEN: the recurrence, (T - 3) steps of two layers)
+  for (const Mlp& rn : e->rnn) flop += 2.0 * (T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
+  const double bytes = (double)T * e->max_lookups * D * 4.0;
+  const bool mlp_bound = flop / bytes > 20.0;
+  e->mlp_streams = mlp_bound ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
+  // In between: a gather-bound DLRM whose full launch set gathers FASTER than its latency-bound MLP launch runs (the
+  // reference's own dlrm_rm1.json, D = 32: 33 us of gather against a 40 us launch): two MLP streams hand the pace back to
+  // the gather (186 k -> 200 k queries/s; RMC1 BASELINE within noise; DIN 158 k -> 147 k, hence an estimate instead of a
+  // blanket 2: gather at 5.5 TB/s, MLP launch 12 us + 1 us per 4 500 weights).
+  bool in_between = false;
+  if (!mlp_bound && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
+    double weights = 0;
+    for (const Mlp* mm : {&e->bot, &e->top})
+      for (size_t i = 0; i + 1 < mm->ln.size(); ++i) weights += (double)mm->ln[i] * mm->ln[i + 1];
+    const double gather_us = 2048.0 * bytes / 5.5e6, mlp_us = 12.0 + weights / 4500.0;
+    if (mlp_us > gather_us) { e->mlp_streams = 2; in_between = true; }
+  }
+  const bool dlrm = e->kind == DRS_MODEL_DLRM;
+  const bool gather_bound_dlrm = dlrm && !mlp_bound && !in_between;
+  // stream kernel: stream4_kernel for DLRM, W&D and DIEN (W&D 95.1 k -> 96.2 k, DIEN 168 k -> 172 k; MT-WnD -4 %, NCF -9 %,
+  // DIN +-0 keep stream_kernel on the packed twins)
+  if (dlrm || e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
+  // 32 rows per workgroup: gather-bound DLRM from 2 048 rows (96 workgroups beside the next set's gather instead of 192:
+  // +1.6-4 %), in-between DLRM from 4 096 (237.6 k -> 241.8 k), MLP-bound DLRM from 8 192 (RM3 config 3's top chain 80 -> 67 us;
+  // at 4 096 rows the form loses: W&D 96.1 k -> 94.5 k)
+  if (gather_bound_dlrm) e->tune.mlp_rows32 = 2048;
+  else if (in_between) e->tune.mlp_rows32 = 4096;
+  else if (dlrm) e->tune.mlp_rows32 = 8192;
+  // two workgroups per CU (the 128-VGPR builds) for every model whose MLP launches overlap each other (DIEN +8 %, W&D +5 %,
+  // MT-WnD +4 %, DIN +3 %, RM3 +2 %; NCF -2 %; gather-bound DLRM keeps one per CU: 54.6 k against 53.4 k at one query per set)
+  e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF && !gather_bound_dlrm;
+  // wide layers: two 64 x 64 gemm_kernel workgroups per CU where that measured faster; gemm32_kernel's 64 x 128 workgroups
+  // for launches below 512 tiles of 128 x 128 when they number at least "mlp_gemm32_small_blocks" (k queries/s, off | >= 0 | >= 512:
+  // MT-WnD 69.2 | 71.8 | 66.4; RM3 reference JSON 66.5 | 68.1 | 72.2; RM3 config 3 34.8 | 35.2 | 34.7; W&D 96.0 | 94.7 | 97.0)
+  e->tune.gemm_2cu = dlrm || e->kind == DRS_MODEL_WND;
+  if (e->kind == DRS_MODEL_MTWND || (dlrm && e->mlp_streams > 1)) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 256; }
+  if (e->kind == DRS_MODEL_WND) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 512; }
+}
+
 int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out) {
   if (!cfg || !out) return fail(nullptr, DRS_ERR_BAD_ARG, "null cfg/out");
   *out = nullptr;
@@ -1751,86 +1818,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     }
   }
   CREATE_TRY(hipStreamCreateWithFlags(&e->stream_g, hipStreamNonBlocking));
-  // A wave of the wave-split gather takes 256/D rows per load instruction: a bag shorter than 8
-  // such instructions cannot fill its load rings, and a lane group per bag (the sequential
-  // variant, which is also bit-exact) is faster: measured on RM3 (D=32, L=20) 16.9 -> 11.6 us,
-  // W&D / NCF (L=1) 2x; RM1 (L=80, D=64 or 32) stays wave-split.
-  e->sls_short_bag = 2048 / D;
-  {
-    // Which side bounds a launch set?  FLOP of the MLPs per byte the gather moves, per sample.
-    // Gather-bound models (RM1: 2 FLOP/B, RM2: 0.6) keep ONE MLP stream: more only takes CUs
-    // from the gather that sets the pace.  MLP-bound models (RM3: 230, W&D: 440, NCF: 145) let
-    // the MLP launches of consecutive sets overlap on one stream per slot: their kernels are
-    // latency-bound and half of them cover only 128 CUs (measured: W&D 57 k -> 68 k q/s, RM3
-    // 39 k -> 50 k, NCF 128 k -> 200 k; RM1 122 k -> 100 k, hence the rule).
-    double flop = 0;
-    for (const Mlp* mm : {&e->bot, &e->top, &e->fin})
-      for (size_t i = 0; i + 1 < mm->ln.size(); ++i) flop += 2.0 * mm->ln[i] * (mm->ln[i + 1] > 0 ? mm->ln[i + 1] : 64);
-    // (DIEN: the recurrence, (T - 3) steps of two layers -- 1.1 MFLOP per sample at 40 x 32 -> 64 -> 64,
-    // and its 16-sample workgroups cover half the chip for a full launch set)
-    for (const Mlp& rn : e->rnn) flop += 2.0 * (T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
-    const double bytes = (double)T * e->max_lookups * D * 4.0;
-    e->mlp_streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
-    // In between: a gather-bound model whose full launch set (2 048 rows) gathers FASTER than its
-    // latency-bound MLP launch runs -- the reference's own dlrm_rm1.json (D = 32: 175 MB per set,
-    // 33 us, against a 40 us stream-kernel launch that covers half the chip).  Two MLP streams let
-    // consecutive MLP launches overlap and hand the pace back to the gather (measured: RM1
-    // reference JSON 186 k -> 200 k queries/s; RMC1 BASELINE 128 k -> 134 k, within noise; DIN,
-    // whose top MLP is a 20 us launch, 158 k -> 147 k -- hence the estimate instead of a blanket 2).
-    // Estimates fitted to those three launches: gather at 5.5 TB/s, MLP launch 12 us + 1 us per
-    // 4 500 weights.
-    if (e->mlp_streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
-      double weights = 0;
-      for (const Mlp* mm : {&e->bot, &e->top})
-        for (size_t i = 0; i + 1 < mm->ln.size(); ++i) weights += (double)mm->ln[i] * mm->ln[i + 1];
-      const double gather_us = 2048.0 * bytes / 5.5e6, mlp_us = 12.0 + weights / 4500.0;
-      if (mlp_us > gather_us) e->mlp_streams = 2;
-    }
-    // Gather-bound DLRM whose MLP launch hides under the next set's gather (RMC1 BASELINE: one MLP
-    // stream): what matters there is how little the MLP launch takes from the gather beside it.
-    // stream3_kernel with four waves per workgroup (half the waves, a third of the LDS traffic, the
-    // launch itself within 3 % of the 8-wave forms) leaves the gather at 0.75-0.77 of peak instead of
-    // 0.68-0.70 (measured round 3, same session A/B: 127 k -> 132 k queries/s).  MLP-bound models keep
-    // the 8-wave packed form, which is faster alone (NCF 43 vs 53 us).
-    // Later in round 3: stream4_kernel, the same four waves with every (layer, pass) run by one
-    // hand-laid instruction stream -- the launch alone 30.6 instead of 33-36 us, one query per
-    // launch set 52.8 k instead of 50.1 k queries/s; beside a full set's gather it costs the gather
-    // 1.5-4 % more than stream3_kernel does (same-session A/B on two boxes), so it takes the small
-    // launch sets only ("mlp_s4_rows").
-    // Round 4: full sets (>= 2 048 rows) as stream4_kernel with 32 rows per workgroup where the slabs fit LDS
-    // (RMC1: 139 KB) -- 96 workgroups per 12-query set instead of 192: +1.6 % queries/s (mlp.hip stream_plan)
-    // Round 5: stream4_kernel for EVERY set size of gather-bound DLRM (sets of 5-7 queries, which stream3_kernel still
-    // served: 98.6 / 110.2 / 120.0 k -> 107.9 / 119.1 / 127.0 k queries/s, profiles/r05_stream3_vs_stream4/); stream3_kernel
-    // is gone.  Launches below 2 048 rows keep the one-workgroup-per-CU build ("mlp_stream_2cu" 0 for this class).
-    if (e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM) { e->tune.mlp_stream = 4; e->tune.mlp_rows32 = 2048; }
-    // W&D and DIEN: their stream launches (512-256-1 tail; top MLP) as stream4_kernel compiled for two
-    // workgroups per CU: 95.1 k -> 96.2 k and 168 k -> 172 k queries/s (MT-WnD -4 %, NCF -9 %, DIN, RM3: +-0)
-    if (e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
-    // MLP-bound DLRM (RM3): the same, and launches of >= 8 192 rows (a 16-query set at batch 512) with 32
-    // rows per workgroup -- two 16-row halves share every weight operand, 256 workgroups still cover the
-    // chip: RM3 config 3's 416-512-256-1 top chain 80 -> 67 us, 31.5 k -> 32.1 k queries/s.  At 4 096 rows
-    // (128 workgroups) the form loses: W&D 96.1 k -> 94.5 k.
-    if (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1) { e->tune.mlp_stream = 4; e->tune.mlp_rows32 = 8192; }
-    // ... and the in-between class (a gather-bound DLRM that got two MLP streams because its MLP launch outlasts its
-    // gather: the reference's own dlrm_rm1.json) from 4 096 rows on -- its full 16-query set as 128 workgroups beside
-    // the gather instead of 256: 237.6 k -> 241.8 k queries/s, gather 0.671 -> 0.682 (round 5, same session, three forms)
-    if (e->kind == DRS_MODEL_DLRM && e->mlp_streams == 2 && flop / bytes <= 20.0) e->tune.mlp_rows32 = 4096;
-    // wide layers as two 64 x 64 GEMM workgroups per CU (gemm.hip) where that measured faster
-    e->tune.gemm_2cu = e->kind == DRS_MODEL_DLRM || e->kind == DRS_MODEL_WND;
-    // Wide layers that do not reach 512 tiles of 128 x 128 take gemm32_kernel's 64 x 128 workgroups instead of
-    // gemm_kernel when those number at least "mlp_gemm32_small_blocks" (same session, two runs each; k queries/s):
-    //   MT-WnD (1888 x 1024 and 1024 x 512 at 4 096 rows: 512 and 256 tiles)   off 69.2 | >= 0: 71.8 | >= 512: 66.4
-    //   RM3 reference JSON (2560 x 1024, 1024 x 256 at 4 096 rows: 512, 128)   off 66.5 | >= 0: 68.1 | >= 512: 72.2
-    //   RM3 config 3 (1024 x 256 at 8 192 rows: 256 tiles)                     off 34.8 | >= 0: 35.2 | >= 512: 34.7
-    //   W&D (1376 x 1024 and 1024 x 512 at 4 096 rows: 512, 256)               off 96.0 | >= 0: 94.7 | >= 512: 97.0
-    // i.e. 256 for MT-WnD and MLP-bound DLRM (a 128-tile launch leaves half the chip idle), 512 for W&D.
-    if (e->kind == DRS_MODEL_MTWND || (e->kind == DRS_MODEL_DLRM && e->mlp_streams > 1)) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 256; }
-    if (e->kind == DRS_MODEL_WND) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 512; }
-    // ... and the packed stream kernel in its 128-VGPR form, two workgroups per CU, for every model whose
-    // MLP launches overlap each other (measured with 16-query sets: DIEN +8 %, W&D +5 %, MT-WnD +4 %, DIN +3 %,
-    // RM3 +2 %; NCF -2 %: its launch is bound by its own 512 KB of outputs crossing PCIe)
-    e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF && !(e->mlp_streams == 1 && e->kind == DRS_MODEL_DLRM);
-  }
+  choose_launch_forms(e);
   apply_stream_mode(e);
   {
     // The table arena, last: one hipMalloc (where it lands in HBM, and what DLRM_Net.tune_table_placement does about

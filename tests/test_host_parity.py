@@ -446,3 +446,68 @@ def test_bind_rank_applies_the_mask_in_a_child_process():
         assert A.bind_rank(0, 2)["source"] == "unchanged"
     finally:
         del os.environ["DRS_NO_AFFINITY"]
+
+
+def test_tune_table_placement_search_logic_on_a_scripted_engine():
+    """DLRM_Net.tune_table_placement against an engine whose gather time is scripted per
+    (arena, load policy): it times both policies on every arena, stops as soon as one arena is a level (5 %)
+    faster than another, keeps the best (arena, policy), releases everything else, and leaves the
+    allocation mode as it found it."""
+    from deeprecsys_amd import dlrm_s_hip as M
+
+    class Eng:
+        max_batch = 256
+
+        def __init__(self, us):
+            self.us = us                       # us[arena][policy index: nt, plain]
+            self.opt = {"mlp_streams": 1, "preferred_coalesce": 12, "shared_stream": 2, "sls_nt": 1, "table_bytes": 2 << 30,
+                        "table_alloc": 0, "table_vmm_chunk": -1}
+            self.arenas, self.cur, self.log = 1, 0, []
+
+        def get_option(self, k):
+            return self.opt[k]
+
+        def set_option(self, k, v):
+            self.log.append((k, v))
+            if k == "table_placement":
+                if v == -1:
+                    if self.arenas >= len(self.us):
+                        raise M.N.DrsError(-2, "drs_set_option", "no room")
+                    self.arenas += 1
+                    self.cur = self.arenas - 1
+                elif v == -2:
+                    self.kept, self.arenas, self.cur = self.cur, 1, 0
+                else:
+                    self.cur = v
+            else:
+                self.opt[k] = v
+
+        def forward_multi_async(self, *a): pass
+        def wait(self, *a): pass
+        def reset_kernel_time(self): pass
+        def set_profiling(self, *a): pass
+
+        def kernel_time(self, _k):
+            return self.us[self.cur][0 if self.opt["sls_nt"] else 1] * 1e-3, 1
+
+    def run(us, candidates=6):
+        net = M.DLRM_Net.__new__(M.DLRM_Net)
+        net.engine, net._n_staged = Eng(us), 4
+        return net.tune_table_placement(candidates, sets=4), net.engine
+
+    # the third arena is a level faster under plain loads: the search stops there and keeps (arena 2, plain)
+    res, eng = run([[86.5, 87.5], [86.6, 87.9], [85.0, 81.0], [80.0, 80.0]])
+    assert res["kept"] == 2 and res["sls_nt"] == 0 and res["candidates"] == 3 and res["losers"] == "freed"
+    assert eng.kept == 2 and eng.arenas == 1 and eng.opt["sls_nt"] == 0 and eng.opt["table_alloc"] == 0
+    assert ("table_spacer", 2 << 30) in eng.log                      # a spacer of the arena's size between candidates
+    # no spread anywhere: every candidate is tried, the (marginally) best one stays
+    res, eng = run([[86.0, 87.0]] * 3 + [[85.8, 87.0]] + [[86.0, 87.0]] * 2)
+    assert res["candidates"] == 6 and res["kept"] == 3 and res["sls_nt"] == 1 and eng.kept == 3
+    # no room for a second arena: the policies of the first one still compete
+    res, eng = run([[86.0, 84.0]])
+    assert res["candidates"] == 1 and res["kept"] == 0 and res["sls_nt"] == 0 and eng.arenas == 1
+    # MLP-bound models are left alone
+    net = M.DLRM_Net.__new__(M.DLRM_Net)
+    net.engine, net._n_staged = Eng([[1, 1]]), 4
+    net.engine.opt["mlp_streams"] = 4
+    assert net.tune_table_placement(6) is None and net.engine.log == []
