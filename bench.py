@@ -75,6 +75,9 @@ WORKLOADS = {
     # behaviour tables -> two BasicRNN layers 32 -> 64 -> 64 (--hidden_size default), top 160-200-80-2
     "dien": dict(kind="dien", rows=[500_000] * 41 + [5_000_000] * 2, T=43, D=32, L=1, bot="512", top="200-80-2",
                  hidden=64, op="cat"),
+    # tools/placement_lab.py: RMC1 with 128-byte and 512-byte rows (does the placement effect depend on the row size?)
+    "lab_d32": dict(rows=1_000_000, T=8, D=32, L=80, bot="128-64-32", top="256-64-1", op="cat"),
+    "lab_d128": dict(rows=1_000_000, T=8, D=128, L=80, bot="128-64-128", top="256-64-1", op="cat"),
     # CPU-test size (tests/test_harness.py drives the rank entry through the CPU restatement of the ABI)
     "tiny": dict(rows=1000, T=4, D=16, L=4, bot="16-16", top="32-1", op="cat"),
 }

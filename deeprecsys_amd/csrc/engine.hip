@@ -249,6 +249,7 @@ struct drs_engine {
   // overlapping GEMM launches), the latency-bound chain launches go on the slots' MLP streams beside them;
   // an event per change of stream orders a set's launches.  0: a set's MLP launches all on its own stream.
   int mlp_layout = 0;
+  int gather_bound = 0;             // set by choose_launch_forms (read only for callers)
   int gather_priority = 0;
   int mlp_cu_mask = 0, gather_cu_complement = 1;   // "mlp_cu_mask": CUs reserved for the MLP streams (0: none)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
@@ -1561,6 +1562,9 @@ static void choose_launch_forms(drs_engine* e) {
   }
   const bool dlrm = e->kind == DRS_MODEL_DLRM;
   const bool gather_bound_dlrm = dlrm && !mlp_bound && !in_between;
+  // ("gather_bound", read only: the models whose set period is their gather launch -- where the tables live and which
+  //  policy their rows are read with is worth a search, DLRM_Net.tune_table_placement)
+  e->gather_bound = (dlrm && !mlp_bound) || e->kind == DRS_MODEL_DIN;
   // stream kernel: stream4_kernel for DLRM, W&D and DIEN (W&D 95.1 k -> 96.2 k, DIEN 168 k -> 172 k; MT-WnD -4 %, NCF -9 %,
   // DIN +-0 keep stream_kernel on the packed twins)
   if (dlrm || e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
@@ -2772,7 +2776,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout},
+      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"gather_bound", e->gather_bound},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
       {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
       {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},

@@ -377,6 +377,8 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "preferred_coalesce" (read only) queries per launch set the engine asks its feeder for: 12
  *                for gather-bound DLRM (the gap between two gather launches is amortised over
  *                more bytes), 8 for DIN, 16 (DRS_MAX_COALESCE) for MLP-bound models
+ *   "gather_bound" (read only) 1 for the models whose set period is their gather launch (DLRM with fewer than 20 MLP FLOP
+ *                per gathered byte, DIN): where the tables live and the rows' load policy are worth a search
  *   "device"     (read only) the HIP device index the engine was created on
  *   "preferred_slots" (read only) launch sets the engine asks its feeder to keep in flight: 3
  *                (gather | MLP | enqueue), 6 for NCF (one short latency-bound launch per set: 414 k ->

@@ -460,7 +460,7 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
 
         def __init__(self, us):
             self.us = us                       # us[arena][policy index: nt, plain]
-            self.opt = {"mlp_streams": 1, "preferred_coalesce": 12, "shared_stream": 2, "sls_nt": 1, "table_bytes": 2 << 30,
+            self.opt = {"mlp_streams": 1, "gather_bound": 1, "preferred_coalesce": 12, "shared_stream": 2, "sls_nt": 1, "table_bytes": 2 << 30,
                         "table_alloc": 0, "table_vmm_chunk": -1}
             self.arenas, self.cur, self.log = 1, 0, []
 
@@ -500,8 +500,10 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
     assert res["kept"] == 2 and res["sls_nt"] == 0 and res["candidates"] == 3 and res["losers"] == "freed"
     assert eng.kept == 2 and eng.arenas == 1 and eng.opt["sls_nt"] == 0 and eng.opt["table_alloc"] == 0
     assert ("table_spacer", 2 << 30) in eng.log                      # a spacer of the arena's size between candidates
-    # no spread anywhere: every candidate is tried, the (marginally) best one stays
+    # no spread anywhere: every candidate is tried, and the first arena stays (another must be 2 % faster to replace it)
     res, eng = run([[86.0, 87.0]] * 3 + [[85.8, 87.0]] + [[86.0, 87.0]] * 2)
+    assert res["candidates"] == 6 and res["kept"] == 0 and res["sls_nt"] == 1 and eng.kept == 0
+    res, eng = run([[86.0, 87.0]] * 3 + [[83.8, 87.0]] + [[86.0, 87.0]] * 2)
     assert res["candidates"] == 6 and res["kept"] == 3 and res["sls_nt"] == 1 and eng.kept == 3
     # no room for a second arena: the policies of the first one still compete
     res, eng = run([[86.0, 84.0]])
@@ -509,5 +511,5 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
     # MLP-bound models are left alone
     net = M.DLRM_Net.__new__(M.DLRM_Net)
     net.engine, net._n_staged = Eng([[1, 1]]), 4
-    net.engine.opt["mlp_streams"] = 4
+    net.engine.opt["mlp_streams"], net.engine.opt["gather_bound"] = 4, 0
     assert net.tune_table_placement(6) is None and net.engine.log == []
