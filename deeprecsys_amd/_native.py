@@ -43,7 +43,7 @@ SYMBOLS = [
                                     C.POINTER(_i32p)]),
     ("drs_forward", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p]),
     ("drs_forward_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    ("drs_forward_multi_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p]),
+    ("drs_forward_multi_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("drs_wait", C.c_int32, [C.c_void_p, C.c_int32, _f32p, C.c_int64]),
     ("drs_sync", C.c_int32, [C.c_void_p]),
     ("drs_forward_inputs_async", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _f32p, C.POINTER(_i64p), _i64p,
@@ -166,6 +166,7 @@ class Engine(object):
         self.m_den = int(self._ln_bot[0]) if kind in (MODEL_DLRM, MODEL_WND, MODEL_MTWND) else 0
         self.num_slots = int(num_slots)
         self.device = int(device)
+        self._marsh = ((C.c_int32 * 64)(), (C.c_int32 * 64)())
 
     # -- helpers ------------------------------------------------------------------
     def _check(self, rc, what):
@@ -255,10 +256,15 @@ class Engine(object):
     def forward_multi_async(self, slot, batch_ids, bss):
         """Coalesce several queries into one set of launches; wait(slot, sum(bss)) returns
         their outputs back to back."""
-        ids = np.ascontiguousarray(batch_ids, dtype=np.int32)
-        bs = np.ascontiguousarray(bss, dtype=np.int32)
-        self._check(lib().drs_forward_multi_async(self._h, slot, ids.size, ids.ctypes.data_as(_i32p),
-                                                  bs.ctypes.data_as(_i32p)), "drs_forward_multi_async")
+        # (two preallocated ctypes arrays: 0.7 us to fill against 6.5 us for two numpy conversions + pointer casts,
+        #  on a call an engine process makes ~15 000 times a second)
+        n = len(batch_ids)
+        if n > 64 or n != len(bss):          # (the library enforces DRS_MAX_COALESCE itself)
+            raise ValueError("one size per query, at most 64 entries")
+        a = self._marsh
+        a[0][:n] = batch_ids
+        a[1][:n] = bss
+        self._check(lib().drs_forward_multi_async(self._h, slot, n, a[0], a[1]), "drs_forward_multi_async")
 
     def wait(self, slot, bs=None):
         """bs = total samples submitted on the slot (sum over coalesced queries); the library
