@@ -20,6 +20,7 @@ import numpy as np
 from .accelInferenceEngine import accelInferenceEngine
 from .loadGenerator import accel_engine_count, loadGenerator
 from .stats import ResponseAggregator
+from .utils.packets import ResponseBlock
 from .utils.utils import cli, mix_models
 
 
@@ -116,6 +117,12 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
                     finished += 1
                     say("Joined ", finished, " inference engines")
                     sys.stdout.flush()
+                    continue
+                if isinstance(item, ResponseBlock):
+                    # --accel_response_blocks: many whole-query responses of one engine as columns, booked at once
+                    running_p95 = agg.add_block(item)
+                    if running_p95 is not None:
+                        pidQueue.put(running_p95)
                     continue
                 # an accelerator engine returns the responses of one launch set in one put (a list)
                 for response in (item if isinstance(item, list) else (item,)):

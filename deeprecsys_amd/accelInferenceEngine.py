@@ -31,7 +31,7 @@ import time
 
 import numpy as np
 
-from .utils.packets import ServiceResponse
+from .utils.packets import ResponseBlock, ServiceResponse
 from .utils.utils import debugPrint, mix_models
 
 SIM_MODELS = ("wnd", "rm1", "rm2", "rm3", "ncf", "din", "dien", "mtwnd")   # reference omits "ncf"
@@ -143,6 +143,15 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
     stats = {"pull": 0.0, "submit": 0.0, "collect": 0.0, "respond": 0.0, "sets": 0, "queries": 0} \
         if os.environ.get("DRS_ENGINE_STATS") else None
 
+    block_n = int(getattr(args, "accel_response_blocks", 0)) if model is not None else 0
+    blk = [[] for _ in range(8)]
+
+    def flush_block():
+        if blk[0]:
+            responseQueue.put(ResponseBlock(engine_id, *blk))
+            for col in blk:
+                del col[:]
+
     def finish_oldest():
         mid, slot, requests, start_time = inflight.pop(0)
         t_c = time.perf_counter() if stats else 0.0
@@ -157,12 +166,23 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
         free[mid].append(slot)
         # the responses of a launch set leave in one put (a list) unless --accel_req_batch 1 asks for the
         # reference's one packet per put; the packets themselves are the reference's (utils/packets.py:32-59)
-        resp = [_respond(r, engine_id, start_time, end_time, o.shape[0]) for r, o in zip(requests, outs)]
-        if batched and len(resp) > 1:
-            responseQueue.put(resp)
+        if block_n > 0:
+            # --accel_response_blocks: the set's responses join the engine's open block (columns); it leaves when full
+            # -- or, at the latest, when the engine finds nothing more to do (flush_block below)
+            for r in requests:
+                blk[0].append(r.epoch); blk[1].append(r.batch_id); blk[2].append(r.batch_size); blk[3].append(r.arrival_time)
+                blk[4].append(start_time); blk[5].append(end_time); blk[6].append(bool(r.exp_packet))
+                blk[7].append(getattr(r, "model_id", 0))
+            if len(blk[0]) >= block_n:
+                flush_block()
+            resp = requests
         else:
-            for x in resp:
-                responseQueue.put(x)
+            resp = [_respond(r, engine_id, start_time, end_time, o.shape[0]) for r, o in zip(requests, outs)]
+            if batched and len(resp) > 1:
+                responseQueue.put(resp)
+            else:
+                for x in resp:
+                    responseQueue.put(x)
         if stats:
             stats["respond"] += time.perf_counter() - t_c
             stats["sets"] += 1
@@ -190,6 +210,8 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
         if not shutdown and len(backlog) < coalesce:
             debugPrint(args, "Accel", "Trying to pull request")
             try:
+                if block_n > 0 and not (inflight or backlog):
+                    flush_block()            # about to sleep on the queue: what has been answered leaves first
                 take(requestQueue.get() if not (inflight or backlog) else requestQueue.get_nowait())
             except pyqueue.Empty:
                 pass
@@ -241,6 +263,7 @@ def accelInferenceEngine(args, requestQueue=None, engine_id=None, responseQueue=
     if stats:
         print("[Accel %s] DRS_ENGINE_STATS %s" % (engine_id, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}))
         sys.stdout.flush()
+    flush_block()
     debugPrint(args, "Accel", "Sending final done signal")
     responseQueue.put(None)
     if model is not None:

@@ -20,12 +20,18 @@ class ResponseAggregator(object):
         self.final_response_latencies = []   # completed non-experimental queries
         self._raw = []                       # the responses as they arrived; turned into dicts when somebody asks
         self._dicts = []
+        self._blocks = []                    # ResponseBlocks not unrolled yet (add_block)
+        self.keep_records = False            # True: unroll every block as it arrives (tests that read responses_list mid-run)
 
     @property
     def responses_list(self):
         """per-response dicts, arrival order (what the orchestrator logs, reference `response.__dict__`).  Built on
         demand: with eight MI355X answering ~1.5 M queries/s the per-response dict was a third of the orchestrator's
         4.4 us per response, and nobody reads the list before the run is over."""
+        if self._blocks:
+            for b in self._blocks:
+                self._raw.extend(b.responses())
+            self._blocks = []
         if len(self._dicts) < len(self._raw):
             wm = self.with_model
             self._dicts.extend(r.as_dict(wm) if hasattr(r, "as_dict") else dict(r.__dict__)
@@ -61,7 +67,22 @@ class ResponseAggregator(object):
                             * 1000.)
         return latency, running
 
+    def add_block(self, block):
+        """a ResponseBlock (utils/packets.py): n whole-query responses of one engine, booked at once.
+        -> running_p95_ms of the block's last `request_granularity` queries, or None for a shorter block"""
+        lat = block.inference_end_time - block.arrival_time
+        self._raw.extend(block.responses()) if self.keep_records else self._blocks.append(block)
+        self.response_latencies.extend(lat.tolist())
+        self.final_response_latencies.extend(lat[~block.exp_packet].tolist())
+        if len(lat) >= self.request_granularity:
+            return float(np.percentile(lat[-self.request_granularity:], 95) * 1000.)
+        return None
+
     def summary(self):
+        if self._blocks:            # (blocks are unrolled into records once, after the run)
+            for b in self._blocks:
+                self._raw.extend(b.responses())
+            self._blocks = []
         out = summarize(self.responses_list, self.final_response_latencies)
         if self.with_model:
             per = {}

@@ -72,3 +72,44 @@ class ServiceResponse(object):
         return "Response[%s] -> arrival %s start %s end %s inference_end %s" % (
             (self.epoch, self.batch_id, self.batch_size, self.consumer_id), self.arrival_time,
             self.queue_start_time, self.queue_end_time, self.inference_end_time)
+
+
+class ResponseBlock(object):
+    """Many whole-query responses of ONE engine in one put (this build, `--accel_response_blocks n`): the fields of the
+    reference's ServiceResponse as columns.  What an accelerator engine sends instead of n ServiceResponse objects when
+    the orchestrator would otherwise be the bottleneck (eight MI355X answer ~1.5 M queries/s; a Python process
+    unpickles and books ~0.5 M packets/s): the orchestrator books a block with a handful of numpy operations and turns
+    it back into per-response records only for its log.  Every response in a block is a whole query
+    (total_sub_batches 1, sub_id 0), which is all an accelerator engine ever answers."""
+    __slots__ = ("consumer_id", "epoch", "batch_id", "batch_size", "arrival_time", "queue_start_time",
+                 "inference_end_time", "exp_packet", "model_id")
+
+    def __init__(self, consumer_id, epoch, batch_id, batch_size, arrival_time, queue_start_time, inference_end_time,
+                 exp_packet, model_id):
+        import numpy as np
+        self.consumer_id = consumer_id
+        self.epoch = np.asarray(epoch, dtype=np.int32)
+        self.batch_id = np.asarray(batch_id, dtype=np.int32)
+        self.batch_size = np.asarray(batch_size, dtype=np.int32)
+        self.arrival_time = np.asarray(arrival_time, dtype=np.float64)
+        self.queue_start_time = np.asarray(queue_start_time, dtype=np.float64)
+        self.inference_end_time = np.asarray(inference_end_time, dtype=np.float64)
+        self.exp_packet = np.asarray(exp_packet, dtype=np.bool_)
+        self.model_id = np.asarray(model_id, dtype=np.int32)
+
+    def __len__(self):
+        return int(self.epoch.size)
+
+    def __reduce__(self):
+        return (ResponseBlock, (self.consumer_id, self.epoch, self.batch_id, self.batch_size, self.arrival_time,
+                                self.queue_start_time, self.inference_end_time, self.exp_packet, self.model_id))
+
+    def responses(self):
+        """the block as the ServiceResponse objects it stands for (the orchestrator's log)"""
+        for i in range(len(self)):
+            end = float(self.inference_end_time[i])
+            yield ServiceResponse(consumer_id=self.consumer_id, epoch=int(self.epoch[i]), batch_id=int(self.batch_id[i]),
+                                  batch_size=int(self.batch_size[i]), arrival_time=float(self.arrival_time[i]),
+                                  process_start_time=float(self.queue_start_time[i]), queue_end_time=end,
+                                  inference_end_time=end, out_batch_size=int(self.batch_size[i]), sub_id=0,
+                                  total_sub_batches=1, exp_packet=bool(self.exp_packet[i]), model_id=int(self.model_id[i]))

@@ -72,6 +72,7 @@ EXTRA_FLAGS = [
     ("accel_table_placements", _I, 6),  # places in HBM tried for the table arena at engine start (1 = wherever hipMalloc put it)
     ("accel_slots", _I, 0),           # launch sets in flight per accel engine; 0 = the engine's preference (3: gather | MLP | enqueue; NCF 6)
     ("accel_req_batch", _I, 16),      # requests per put on accelRequestQueue / responses per put back (1 = the reference's one packet per put)
+    ("accel_response_blocks", _I, 0),  # > 0: an accel engine answers in ResponseBlocks of up to this many responses (columns, one put) instead of ServiceResponse packets
     ("accel_coalesce", _I, 0),        # queued requests an accel engine may serve per launch set (0 = what the engine prefers for the model: 12 | 16 | 8)
     ("mp_start_method", _S, "spawn"),  # engine/loadgen processes: spawn (HIP-safe) | fork
     # mixed-model stream (BASELINE config 4: W&D + NCF on the same accelerators): several model

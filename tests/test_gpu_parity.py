@@ -429,6 +429,19 @@ def test_full_size_reference_shapes_match_oracle(name):
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after freeing the others")
             with pytest.raises(Exception):
                 eng.set_option("table_placement", 3)
+            # the other ways to build an arena (round 5): the virtual-memory API in 1 GiB handles, best-effort contiguous
+            # memory, and a spacer of untouched memory in front of a candidate -- same tables, same bits
+            for alloc in (1, 2):
+                eng.set_option("table_alloc", alloc)
+                eng.set_option("table_spacer", 1 << 30)
+                eng.set_option("table_placement", -1)
+                assert eng.get_option("table_placements") == 2 and eng.get_option("table_placement") == 1
+                assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "table_alloc", alloc)
+                assert np.array_equal(net.run_staged(0, 165), ref[(0, 165)]), (name, "table_alloc", alloc)
+                eng.set_option("table_placement", 0)
+                eng.set_option("table_placement", -2)
+                assert eng.get_option("table_placements") == 1
+            eng.set_option("table_alloc", 0)
             tuned = net.tune_table_placement(3, sets=16)      # (gather-bound DLRM only: rm2 here)
             assert (tuned is None) == (name != "rm2"), (name, tuned)
             if tuned is not None:      # up to three arenas x two load policies timed, the best kept, every other arena released

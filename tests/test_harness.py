@@ -443,6 +443,19 @@ def test_two_real_accel_engines_share_the_queue(tmp_path):
     lines = [eval(l) for l in open(b.log_file).read().strip().splitlines()]
     share = sum(1 for l in lines if l["consumer_id"] == 0) / float(n)
     assert 0.35 <= share <= 0.65, share
+    # ... and the same run answering in ResponseBlocks (--accel_response_blocks, round 5): the log holds the same
+    # records, one per query, with plausible stamps
+    c = _args(tmp_path, accel_backend="hip", num_accels=2, arch_sparse_feature_size=16,
+              arch_embedding_size="2000-3000-1000", arch_mlp_bot="13-32-16", arch_mlp_top="32-1",
+              arch_interaction_op="dot", num_indices_per_lookup=10, model_type="dlrm", nepochs=16,
+              avg_arrival_rate=0.05, accel_response_blocks=64, log_file=str(tmp_path / "blocks.log"))
+    s = DeepRecSys(c, quiet=True)
+    n = c.nepochs * c.num_batches
+    assert s["accel_requests"] == n and s["responses"] == n and s["measured_queries"] == n and s["qps"] > 0
+    lines = [eval(l) for l in open(c.log_file).read().strip().splitlines()]
+    assert sorted((l["epoch"], l["batch_id"]) for l in lines) == sorted((e, b) for e in range(c.nepochs) for b in range(c.num_batches))
+    assert all(l["arrival_time"] <= l["queue_start_time"] <= l["inference_end_time"] and l["out_batch_size"] == l["batch_size"]
+               and l["total_sub_batches"] == 1 and l["sub_id"] == 0 for l in lines)
 
 
 def test_bench_cpu_baseline_has_the_reference_serving_shape_leg(tmp_path):
@@ -556,3 +569,47 @@ def test_load_generator_ceiling_one_and_sharded(tmp_path, capsys):
         print("\n[load generator ceiling] 1 generator: %.0f queries/s; 8 generators on %d cores: %.0f queries/s" % (one, cores, eight))
     assert one < 1.1e6                       # the reason the sharding exists
     assert eight > 1.5 * one or cores < 6    # more generators offer more (8 generators + 8 consumers share this host's cores)
+
+
+def test_response_blocks_book_like_packets(tmp_path):
+    """--accel_response_blocks: a ResponseBlock (columns, one put) books exactly like the ServiceResponse packets it
+    stands for -- same latencies, same per-response log records, same summary -- and survives pickling."""
+    import pickle
+    from deeprecsys_amd.utils.packets import ResponseBlock, ServiceResponse
+    rng = np.random.RandomState(5)
+    n = 300
+    arr = np.cumsum(rng.rand(n)) * 1e-4 + 100.0
+    end = arr + 1e-3 + rng.rand(n) * 1e-3
+    cols = dict(epoch=rng.randint(0, 4, n), batch_id=rng.randint(0, 32, n), batch_size=rng.randint(1, 256, n),
+                arrival_time=arr, queue_start_time=arr + 1e-4, inference_end_time=end, exp_packet=rng.rand(n) < 0.1,
+                model_id=rng.randint(0, 2, n))
+    packets = [ServiceResponse(consumer_id=3, epoch=int(cols["epoch"][i]), batch_id=int(cols["batch_id"][i]),
+                               batch_size=int(cols["batch_size"][i]), arrival_time=float(arr[i]),
+                               process_start_time=float(arr[i] + 1e-4), queue_end_time=float(end[i]),
+                               inference_end_time=float(end[i]), out_batch_size=int(cols["batch_size"][i]), sub_id=0,
+                               total_sub_batches=1, exp_packet=bool(cols["exp_packet"][i]), model_id=int(cols["model_id"][i]))
+               for i in range(n)]
+    a, b = stats.ResponseAggregator(64, with_model=True), stats.ResponseAggregator(64, with_model=True)
+    for p in packets:
+        a.add(p)
+    for lo in range(0, n, 128):
+        blk = ResponseBlock(3, *(cols[k][lo:lo + 128] for k in ("epoch", "batch_id", "batch_size", "arrival_time",
+                                                                  "queue_start_time", "inference_end_time", "exp_packet", "model_id")))
+        blk = pickle.loads(pickle.dumps(blk))
+        assert len(blk) == min(128, n - lo)
+        p95 = b.add_block(blk)
+        assert (p95 is None) == (len(blk) < 64)
+    assert a.response_latencies == pytest.approx(b.response_latencies) and len(a.final_response_latencies) == len(b.final_response_latencies)
+    assert a.responses_list == b.responses_list
+    assert a.summary() == b.summary()
+
+
+def test_harness_with_response_blocks(tmp_path):
+    """the sim engines keep the reference's one packet per request; the flag is honoured by the HIP engines only --
+    the orchestrator must take both kinds from one queue (here: packets), and the flag must not disturb a sim run"""
+    root = str(tmp_path / "accel") + "/"
+    os.makedirs(root)
+    _write_sim_tables(root)
+    a = _args(tmp_path, accel_backend="sim", num_accels=2, accel_root_dir=root, model_name="rm1", accel_response_blocks=64)
+    s = DeepRecSys(a, quiet=True)
+    assert s["accel_requests"] == 16 and s["responses"] == 16 and s["measured_queries"] == 16
