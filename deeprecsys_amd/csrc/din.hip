@@ -508,6 +508,235 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
   }
 }
 
+// PIPELINED form of the fused launch: hidden width 1 (the shipped attention unit 96-1-32) and launch sets whose
+// bags all have one fixed length <= 3 (FusedShape::C == 3; din.json: 3 lookups).
+// din_fused_kernel above walks a lane group's ~U / NGB units one dependent round trip after the other
+// (indices -> rows -> unit), and the launch is a single wave of workgroups: its time is the length of
+// that chain, not the bytes (profiles/r05_din/).  Here the workgroup first stages what the chain would
+// fetch on the way -- the indices of every (table, sample) bag and the tables' bases -- in LDS with ONE
+// round trip (thread t takes table t), after which a row load depends on nothing in HBM.  Each lane
+// group then keeps P units in flight: slot j holds the row pieces AND the weights of one unit; a slot is
+// refilled with the unit P places on as soon as its unit is applied.  Same work split, same summation
+// order as din_fused_kernel: the two forms give the same bits (tests/test_gpu_parity.py).
+template <int G, int S, int NW, int P, bool NT>
+__global__ __launch_bounds__(64 * NW, 2) void din_pipe_kernel(SlsArgs a, const float* __restrict__ packed,
+                                                              int64_t stride, const float* __restrict__ zero,
+                                                              float* __restrict__ R, int64_t ldr) {
+  constexpr int NG = 64 / G, NGB = NW * NG, D = 4 * G, C = 3;
+  constexpr uint32_t kNone = 0xffffffffu;            // staged "no row here": the load reads the zero page
+  static_assert(S <= NW, "wave s finishes sample s");
+  __shared__ float4 s_z[S][NW][G];
+  extern __shared__ int64_t s_dyn[];
+  const int T = a.T;
+  int64_t* s_off = s_dyn;                                         // [T] element offset of the table
+  uint32_t* s_r = reinterpret_cast<uint32_t*>(s_off + T);         // [T][S * C] row numbers (kNone past the bag's end)
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / G, gl = lane - g * G, gg = wave * NG + g;
+  const int n_smp = a.q.cum[a.q.n_q];
+  const int U = T - 3;
+  const int col = gl * 4;
+
+  // (sample groups dealt to the XCDs in contiguous runs: din_fused_kernel)
+  const unsigned nb_ = gridDim.x, xcd_ = blockIdx.x & 7u, per_ = nb_ >> 3, rem_ = nb_ & 7u;
+  const unsigned grp = xcd_ * per_ + (xcd_ < rem_ ? xcd_ : rem_) + (blockIdx.x >> 3);
+  bool live[S];
+  int vrow[S];
+  {
+    // ---- stage: thread t takes table t (the owners of the S samples are only needed here) ----------
+    Owner ow[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int smp = (int)grp * S + s;
+      live[s] = smp < n_smp;
+      ow[s] = owner_of(a, live[s] ? smp : 0);
+      vrow[s] = ow[s].vrow;
+    }
+    bool bad = false;
+    for (int t = threadIdx.x; t < T; t += 64 * NW) {
+      const uint32_t rows = (uint32_t)a.tab_rows[t];
+      s_off[t] = a.tab_off[t];
+      uint32_t r[S][C];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int len = live[s] ? ow[s].ulen : 0;
+        const int32_t* ip = ow[s].idx + (int64_t)t * a.idx_stride;
+        if (len == C) {                        // (uniform per sample) the whole bag with one 12-byte load
+          typedef int32_t I3 __attribute__((ext_vector_type(3), aligned(4)));
+          const I3 i3 = *reinterpret_cast<const I3*>(ip + ow[s].b * C);
+          r[s][0] = (uint32_t)i3.x; r[s][1] = (uint32_t)i3.y; r[s][2] = (uint32_t)i3.z;
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) r[s][c] = (uint32_t)ip[c < len ? ow[s].b * ow[s].ulen + c : 0];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int len = live[s] ? ow[s].ulen : 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const bool in = c < len;
+          bad |= in && r[s][c] >= rows;
+          s_r[t * (S * C) + s * C + c] = !in ? kNone : r[s][c] < rows ? r[s][c] : 0u;
+        }
+      }
+    }
+    if (bad) atomicOr(a.err, 1);
+  }
+  __syncthreads();
+
+  const float* zcol = zero + col;
+  // the staged rows of the S bags of table t -> v
+  auto issue_rows = [&](int t, bool have, float4 (&v)[S][C]) {
+    const float* __restrict__ W = a.tables + s_off[t] + col;
+    uint32_t r[S * C];
+#pragma unroll
+    for (int x = 0; x < S * C; ++x) r[x] = s_r[t * (S * C) + x];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const uint32_t rr = r[s * C + c];
+        v[s][c] = ld4row<NT>(have && rr != kNone ? W + ((uint64_t)(rr * ((uint32_t)D >> 2)) << 2) : zcol);
+      }
+  };
+  auto pool = [&](const float4 (&v)[S][C], float4 (&acc)[S]) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) add4(acc[s], v[s][c]);
+    }
+  };
+  // one unit's weights, this lane's pieces: [ W1 : 3D | W2 : D | b2 : D | b1 ] (h = 1)
+  struct Wt {
+    float4 w1u, w1a, w1s, w2, b2;
+    float b1;
+  };
+  auto issue_w = [&](int i, Wt& w) {
+    const float* __restrict__ wp = packed + (int64_t)i * stride;
+    w.w1u = ld4(wp + col);
+    w.w1a = ld4(wp + D + col);
+    w.w1s = ld4(wp + 2 * D + col);
+    w.w2 = ld4(wp + 3 * D + col);
+    w.b2 = ld4(wp + 4 * D + col);
+    w.b1 = wp[5 * D];
+  };
+
+  // slots: the candidate ad goes out together with the group's first P units
+  const int K = (U + NGB - 1) / NGB;        // units per lane group (the last one may be missing: `have`)
+  float4 v[P][S][C];
+  Wt w[P];
+  float4 ad[S];
+  {
+    float4 vad[S][C];
+    issue_rows(T - 2, true, vad);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int i = gg + j * NGB;
+      const bool have = j < K && i < U;
+      issue_rows(have ? 1 + i : T - 2, have, v[j]);
+      issue_w(have ? i : 0, w[j]);
+    }
+    pool(vad, ad);
+  }
+
+  // pass-through features of the top MLP's input row: lane group 0 of waves 0..2 takes one each
+  // (profile, candidate ad, context)
+  if (wave < 3 && g == 0) {
+    const int dst = wave == 0 ? 0 : wave == 1 ? 2 * D : 3 * D;
+    float4 pv[S];
+    if (wave == 1) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) pv[s] = ad[s];
+    } else {
+      float4 vp[S][C];
+      issue_rows(wave == 0 ? 0 : T - 1, true, vp);
+      pool(vp, pv);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (live[s]) *reinterpret_cast<float4*>(R + (int64_t)vrow[s] * ldr + dst + col) = pv[s];
+  }
+
+  float4 z[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) z[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // unit k of this lane group out of slot j; then the slot takes unit k + P (into the SAME registers, after the
+  // unit's arithmetic: refilled before it, the compiler lands the loads in fresh registers and copies them over
+  // at the end of the iteration, which waits for every load in flight)
+  auto step = [&](int j, int k, bool refill) {
+    // (the steps stay in program order: the scheduler otherwise pools the next slot's rows ahead of this slot's
+    // refill -- every load consumed, then every load reissued, nothing in flight in between)
+    __builtin_amdgcn_sched_barrier(0);
+    const bool have = gg + k * NGB < U;
+    float4 u[S];
+    pool(v[j], u);
+    const Wt& wt = w[j];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float4 sum = make_float4(u[s].x + ad[s].x, u[s].y + ad[s].y, u[s].z + ad[s].z, u[s].w + ad[s].w);
+      float pd = dot4(u[s], wt.w1u, 0.f);
+      pd = dot4(ad[s], wt.w1a, pd);
+      pd = dot4(sum, wt.w1s, pd);
+#pragma unroll
+      for (int m = 1; m < G; m <<= 1) pd += __shfl_xor(pd, m);
+      const float y = fmaxf(pd + wt.b1, 0.f);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      o.x = fmaf(y, wt.w2.x, o.x); o.y = fmaf(y, wt.w2.y, o.y);
+      o.z = fmaf(y, wt.w2.z, o.z); o.w = fmaf(y, wt.w2.w, o.w);
+      add4(o, wt.b2);
+      o = relu4(o);
+      z[s].x += have ? o.x : 0.f; z[s].y += have ? o.y : 0.f;
+      z[s].z += have ? o.z : 0.f; z[s].w += have ? o.w : 0.f;
+    }
+    if (refill) {
+      const int in_ = gg + (k + P) * NGB;
+      const bool hn = in_ < U;
+      issue_rows(hn ? 1 + in_ : T - 2, hn, v[j]);
+      issue_w(hn ? in_ : 0, w[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // rounds in which every slot is refilled (no branch around the loads: with one, the wait counts after it must
+  // assume the loads were skipped, and wait for everything) ...
+  int k0 = 0;
+  for (; k0 + 2 * P <= K; k0 += P) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) step(j, k0 + j, true);
+  }
+  // ... and the last ones
+  for (; k0 < K; k0 += P) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int k = k0 + j;
+      if (k >= K) break;                       // (uniform)
+      step(j, k, k + P < K);
+    }
+  }
+  // partial sums: the lane groups of a wave over the cross-lane network, the waves through LDS
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) add4(z[s], shfl_xor4(z[s], m));
+    if (g == 0) s_z[s][wave][gl] = z[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (wave == s && g == 0 && live[s]) {          // wave s finishes sample s (S <= NW)
+      float4 t = s_z[s][0][gl];
+#pragma unroll
+      for (int w_ = 1; w_ < NW; ++w_) add4(t, s_z[s][w_][gl]);
+      *reinterpret_cast<float4*>(R + (int64_t)vrow[s] * ldr + D + col) = t;
+    }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
 struct FusedShape { int S, C; };
 // Waves per workgroup.  FIXED for every launch size: it decides which units a lane group sums, i.e.
 // the association of the fp32 Sum over the units -- a query's bits must not depend on how many
@@ -546,6 +775,32 @@ void launch_fused_s(const FusedShape& f, const SlsArgs& a, int h, const float* p
   if (f.S == 4) launch_fused_h<G, 4>(f, a, h, packed, stride, zero, R, ldr, grid, s, stop);
   else if (f.S == 2) launch_fused_h<G, 2>(f, a, h, packed, stride, zero, R, ldr, grid, s, stop);
   else launch_fused_h<G, 1>(f, a, h, packed, stride, zero, R, ldr, grid, s, stop);
+}
+
+// The pipelined form keeps kPipe units in flight per lane group.  Measured on din.json (12-query sets; one query):
+// S = 4: depth 2 -> 40.5 us alone; S = 2: depth 2 / 3 / 4 -> 46.5 / 45.8 / 46.5 us alone, 147.8 / 138.9 / 138.3 k queries/s
+// beside the MLP launches; S = 1 (one query): 2 / 4 / 6 -> 10.15 / 10.18 / 12.1 us.  The main phase already runs at
+// ~0.77 of the HBM peak: deeper does not help, more registers hurt (profiles/r05_din/).
+constexpr int kPipe = 2;
+size_t din_pipe_lds(int T, int S) { return (size_t)T * (8 + (size_t)S * 3 * 4); }
+template <int G, int S>
+void launch_pipe_k(const SlsArgs& a, const float* packed, int64_t stride, const float* zero, float* R, int64_t ldr,
+                   unsigned grid, hipStream_t s, hipEvent_t stop) {
+  const size_t lds = din_pipe_lds(a.T, S);
+  if (a.nt) {
+    if (stop) hipExtLaunchKernelGGL((din_pipe_kernel<G, S, kWaves, kPipe, true>), dim3(grid), dim3(64 * kWaves), lds, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
+    else hipLaunchKernelGGL((din_pipe_kernel<G, S, kWaves, kPipe, true>), dim3(grid), dim3(64 * kWaves), lds, s, a, packed, stride, zero, R, ldr);
+  } else {
+    if (stop) hipExtLaunchKernelGGL((din_pipe_kernel<G, S, kWaves, kPipe, false>), dim3(grid), dim3(64 * kWaves), lds, s, nullptr, stop, 0, a, packed, stride, zero, R, ldr);
+    else hipLaunchKernelGGL((din_pipe_kernel<G, S, kWaves, kPipe, false>), dim3(grid), dim3(64 * kWaves), lds, s, a, packed, stride, zero, R, ldr);
+  }
+}
+template <int G>
+void launch_pipe_s(const FusedShape& f, const SlsArgs& a, const float* packed, int64_t stride, const float* zero,
+                   float* R, int64_t ldr, unsigned grid, hipStream_t s, hipEvent_t stop) {
+  if (f.S == 4) launch_pipe_k<G, 4>(a, packed, stride, zero, R, ldr, grid, s, stop);
+  else if (f.S == 2) launch_pipe_k<G, 2>(a, packed, stride, zero, R, ldr, grid, s, stop);
+  else launch_pipe_k<G, 1>(a, packed, stride, zero, R, ldr, grid, s, stop);
 }
 
 // Samples per workgroup (the units' weights are read once per workgroup; fewer for small launches
@@ -1135,6 +1390,13 @@ hipError_t launch_din_fused(const SlsArgs& a_in, int32_t h, const float* packed,
   const int64_t stride = din_unit_stride(a.D, h);
   const FusedShape f = fused_shape(a, tune);
   const unsigned grid = (unsigned)din_fused_grid(a, tune);
+  // hidden width 1, fixed bag length <= 3, the staged indices fit LDS: the pipelined form (same bits)
+  if (tune.din_pipe && h == 1 && f.C == 3 && din_pipe_lds(a.T, f.S) <= 48 * 1024) {
+    log_launch(tune.log, "din_pipe_kernel<%d,S%d,P%d%s>[%u wg]", a.D == 32 ? 8 : 16, f.S, kPipe, a.nt ? ",nt" : "", grid);
+    if (a.D == 32) launch_pipe_s<8>(f, a, packed, stride, tune.zero, R, ldr, grid, s, stop);
+    else launch_pipe_s<16>(f, a, packed, stride, tune.zero, R, ldr, grid, s, stop);
+    return hipGetLastError();
+  }
   log_launch(tune.log, "din_fused_kernel<%d,S%d,h%d,C%d%s>[%u wg]", a.D == 32 ? 8 : 16, f.S, h, f.C, a.nt ? ",nt" : "", grid);
   if (a.D == 32) launch_fused_s<8>(f, a, h, packed, stride, tune.zero, R, ldr, grid, s, stop);
   else launch_fused_s<16>(f, a, h, packed, stride, tune.zero, R, ldr, grid, s, stop);

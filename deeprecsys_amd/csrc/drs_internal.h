@@ -68,6 +68,7 @@ struct Tune {
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
   int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
   int din_nt = 1;                // fused DIN launch: non-temporal row loads ("din_nt": +2.5 % queries/s, 0.527 -> 0.545 of peak)
+  int din_pipe = 1;              // fused DIN launch, hidden width 1: indices staged in LDS, units pipelined (din_pipe_kernel)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)
   int mlp_preload = 0, mlp_kc = 0, mlp_stream = 2, mlp_stream_2cu = 0, mlp_gemm = 1, gemm_tile = 0, gemm_2cu = 0, mlp_debug = 0;
   int gemm32 = 1;                // wide layers through the v_mfma_f32_32x32x2_f32 kernel (gemm.hip gemm32_kernel) ...

@@ -2479,6 +2479,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "din_s") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.din_s = (int)value;
   else if (!strcmp(key, "sls_nt")) e->tune.sls_nt = value ? 1 : 0;
   else if (!strcmp(key, "din_nt")) e->tune.din_nt = value ? 1 : 0;
+  else if (!strcmp(key, "din_pipe")) e->tune.din_pipe = value ? 1 : 0;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
@@ -2769,7 +2770,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"din_pipe", t.din_pipe}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},

@@ -297,6 +297,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                of its own behind it.  Same bits.
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
+ *   "din_pipe"   1 (default) | 0: hidden width 1 and launch sets whose bags all have one fixed length <= 3 (din.json)
+ *                take the pipelined form of that launch (din_pipe_kernel: the set's indices staged in LDS with one
+ *                round trip, two units in flight per lane group); 0: the chained form for every shape.  Same bits.
  *   "sls_nt"     1 (default) | 0: the many-rows-per-bag gather kernels read table rows with non-temporal
  *                loads (rows are read once per launch; same bits either way; the one-lookup models' gather
  *                keeps plain loads: their tables are cache-resident).  "din_nt" 1 (default) | 0: the same for

@@ -645,14 +645,18 @@ def test_engine_ragged_bags_and_device_error_path():
 
 
 @pytest.mark.parametrize("D,h,U,ragged", [(32, 1, 6, False), (32, 1, 70, True), (64, 2, 9, True), (32, 4, 130, False),
-                                          (16, 1, 5, False), (32, 3, 5, True)])
+                                          (16, 1, 5, False), (32, 3, 5, True), (32, 1, 251, False), (64, 1, 70, False),
+                                          (32, 1, 33, False)])
 def test_din_fused_and_two_launch_forms_match_oracle(D, h, U, ragged):
     """DIN's default launch fuses gather, attention units and Concat (din.hip); "sls_exact" 1 and
     "din_fused" 0 take the two-launch form.  Both against the oracle: two-launch + sequential
     gather bitwise on the top MLP's input row, the fused form within the default-mode tolerance
     -- over ragged bags (incl. empty ones and samples past a workgroup's last), hidden widths
     with and without a fused instance (3: falls back), D without one (16), more units than one
-    round of lane groups, and 8 coalesced queries whose samples share workgroups."""
+    round of lane groups, and 8 coalesced queries whose samples share workgroups.  Hidden width 1 with
+    fixed-length bags of <= 3 rows takes the PIPELINED fused form (din_pipe_kernel: indices staged in
+    LDS, units in flight per lane group): the dispatch log says so, and its bits equal the chained
+    form's ("din_pipe" 0) at every samples-per-workgroup setting."""
     rng = np.random.RandomState(D + h + U)
     rows = [500] + [300] * U + [700, 400]
     T, B, Lmax = len(rows), 150, 5
@@ -704,9 +708,18 @@ def test_din_fused_and_two_launch_forms_match_oracle(D, h, U, ragged):
             # a query's bits do not depend on what it was coalesced with, nor on how many samples
             # share a workgroup
             if mode == "fused":
+                piped = fused_instance and h == 1 and not ragged
                 for S_ in (1, 2, 4):
                     eng.set_option("din_s", S_)
                     assert np.array_equal(net.run_staged(1, B), ref[(mode, 1, B)]), S_
+                    assert ("din_pipe_kernel" in " ".join(eng.last_dispatch())) == piped, eng.last_dispatch()
+                    if piped:
+                        eng.set_option("din_pipe", 0)
+                        for bs in (B, 77, 1):
+                            assert np.array_equal(net.run_staged(1, bs), ref[(mode, 1, bs)]), (S_, bs)
+                        assert "din_fused_kernel" in " ".join(eng.last_dispatch())
+                        eng.set_option("din_pipe", 1)
+                        assert np.array_equal(net.run_staged(1, 77), ref[(mode, 1, 77)]), S_
                 eng.set_option("din_s", 0)
             jobs = [(0, B), (1, 77), (0, 1), (1, B), (0, 77), (1, 1), (0, B), (1, B)]
             outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
