@@ -241,6 +241,10 @@ struct drs_engine {
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+#ifdef DRS_LAB
+  hipStream_t stream_g2 = nullptr;  // lab ("gather_streams" 2): the gathers of consecutive slots alternate between two streams
+  int gather_streams = 1;
+#endif
   hipStream_t stream_h2d = nullptr; // input copies of drs_run_queues_multi_async (created on first use)
   int mlp_streams = 1;              // pipelined mode: streams the MLP launches alternate between (set in drs_create)
   // "mlp_layout" 1 (MLP-bound models, pipelined mode): streams by KERNEL TYPE instead of by launch set -- the
@@ -1001,6 +1005,9 @@ void apply_stream_mode(drs_engine* e) {
     else s.stream = e->shared_stream ? e->slots[0].own_stream : s.own_stream;
     s.base_stream = s.stream;
     s.gather_stream = e->shared_stream == 2 ? e->stream_g : s.stream;
+#ifdef DRS_LAB
+    if (e->shared_stream == 2 && e->gather_streams == 2 && e->stream_g2 && (k & 1)) s.gather_stream = e->stream_g2;
+#endif
     ++k;
   }
 }
@@ -1852,6 +1859,9 @@ int32_t drs_destroy(drs_handle e) {
   DTR("launcher gone");
   (void)hipSetDevice(e->device);
   if (e->stream_g) { (void)hipStreamSynchronize(e->stream_g); (void)hipStreamDestroy(e->stream_g); }
+#ifdef DRS_LAB
+  if (e->stream_g2) { (void)hipStreamSynchronize(e->stream_g2); (void)hipStreamDestroy(e->stream_g2); }
+#endif
   if (e->stream_h2d) { (void)hipStreamSynchronize(e->stream_h2d); (void)hipStreamDestroy(e->stream_h2d); }
   DTR("g and h2d streams gone");
   for (auto& s : e->slots) {
@@ -2500,6 +2510,14 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     apply_stream_mode(e);
   }
 #ifdef DRS_LAB
+  else if (!strcmp(key, "gather_streams") && (value == 1 || value == 2)) {
+    // experiment: does a second gather stream close the ~1.4 us between back-to-back gather launches?
+    int32_t rc = drs_sync(e);
+    if (rc) return rc;
+    if (value == 2 && !e->stream_g2) HIP_TRY(e, hipStreamCreateWithFlags(&e->stream_g2, hipStreamNonBlocking));
+    e->gather_streams = (int)value;
+    apply_stream_mode(e);
+  }
   else if (!strcmp(key, "mlp_cu_mask") && value >= 0 && value <= 248) {
     // experiment: the MLP side's streams run on `value` CUs only (bits 0 .. value-1 of the queue's CU
     // mask; 0 = every CU, the default), the gather stream on the others ("gather_cu_complement" 1, default) or everywhere (0)

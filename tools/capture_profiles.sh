@@ -30,6 +30,7 @@ trace() { # name, command...
   [ -n "$T" ] && run 120 python tools/trace_stats.py "$T" > "$OUT/${n}_kernel_trace_by_grid.txt"
   [ -n "$T" ] && run 120 python tools/trace_overlap.py "$T" > "$OUT/${n}_kernel_overlap.txt"
   [ -n "$T" ] && run 120 python tools/trace_timeline.py "$T" 30 > "$OUT/${n}_kernel_timeline.txt"
+  [ -n "$T" ] && run 120 python tools/trace_ramp.py "$T" > "$OUT/${n}_duration_by_position.txt"
   rm -rf "$d"
 }
 
@@ -66,10 +67,13 @@ pmc "$OUT/wnd_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
     python bench.py --workload wnd --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 2048 --set shared_stream=1
 # the wide-layer GEMM alone (tools/gemm_bench.py): durations + MFMA-busy; at 2 048 rows (every shape) and, for
 # RM3 config 3's real launch, 8 192 rows (gemm32_kernel's 128 x 128 form) against gemm_kernel on the same box
-trace gemm python tools/gemm_bench.py --iters 50
+trace gemm python tools/gemm_bench.py --iters 2000
 pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --iters 20
-trace gemm_8192 python tools/gemm_bench.py --rows 8192 --iters 30 --shapes 2560x1024,1024x256
-trace gemm_8192_gemm_kernel python tools/gemm_bench.py --rows 8192 --iters 30 --shapes 2560x1024,1024x256 --gemm32 0
+# (sustained runs: a GPU that was idle needs some hundred launches to reach its sustained shader clock -- a
+#  30-launch trace of an MFMA-bound kernel reads 10-15 % slow; tools/trace_ramp.py prints duration by position)
+trace gemm_8192 python tools/gemm_bench.py --rows 8192 --iters 3000 --shapes 2560x1024,1024x256
+trace gemm_8192_gemm_kernel python tools/gemm_bench.py --rows 8192 --iters 3000 --shapes 2560x1024,1024x256 --gemm32 0
+run 200 python tools/clock_trace.py --out "$OUT/gemm_8192_clock_trace.txt" --hz 20 -- python tools/gemm_bench.py --rows 8192 --iters 15000 --shapes 2560x1024 > /dev/null 2>&1
 pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --rows 8192 --iters 10 --shapes 2560x1024
 pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --rows 8192 --iters 10 --shapes 2560x1024 --gemm32 0
 # per-workgroup phase stamps, shader clock and bit check of the same launch (tools/ubench/gemm_lab.hip, built by `make lab`)
