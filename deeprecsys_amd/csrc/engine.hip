@@ -1572,9 +1572,9 @@ static void choose_launch_forms(drs_engine* e) {
   // ("gather_bound", read only: the models whose set period is their gather launch -- where the tables live and which
   //  policy their rows are read with is worth a search, DLRM_Net.tune_table_placement)
   e->gather_bound = (dlrm && !mlp_bound) || e->kind == DRS_MODEL_DIN;
-  // stream kernel: stream4_kernel for DLRM, W&D and DIEN (W&D 95.1 k -> 96.2 k, DIEN 168 k -> 172 k; MT-WnD -4 %, NCF -9 %,
-  // DIN +-0 keep stream_kernel on the packed twins)
-  if (dlrm || e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN) e->tune.mlp_stream = 4;
+  // stream kernel: stream4_kernel for DLRM, W&D, DIEN and DIN (W&D 95.1 k -> 96.2 k, DIEN 168 k -> 172 k, DIN beside the
+  // pipelined fused launch 170.6 k -> 172.7 k; MT-WnD -4 %, NCF -9 % keep stream_kernel on the packed twins)
+  if (dlrm || e->kind == DRS_MODEL_WND || e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_DIN) e->tune.mlp_stream = 4;
   // 32 rows per workgroup: gather-bound DLRM from 2 048 rows (96 workgroups beside the next set's gather instead of 192:
   // +1.6-4 %), in-between DLRM from 4 096 (237.6 k -> 241.8 k), MLP-bound DLRM from 8 192 (RM3 config 3's top chain 80 -> 67 us;
   // at 4 096 rows the form loses: W&D 96.1 k -> 94.5 k)
