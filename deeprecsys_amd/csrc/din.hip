@@ -976,9 +976,9 @@ __global__ __launch_bounds__(256) void dien_rnn_kernel(const float* __restrict__
 // hidden units [16 w, 16 w + 16) of BOTH layers.  Per step and layer the pre-activations are two
 // v_mfma_f32_16x16x4_f32 chains (bit-for-bit k-ordered fp32 fma chains, as in mlp.hip): A = the
 // wave's 16 weight rows (registers for the whole launch: (D + 3 H) / 4 VGPRs), B = the step's input
-// [k][sample] -- the embeddings straight from the gather's buffer (fetched a step ahead), the
-// states from LDS ([hidden][sample], double-buffered so ONE workgroup barrier per step orders
-// everything) -- D[m = hidden 4 g + q][n = sample r].  Same bits as dien_rnn_kernel.
+// [k][sample] -- the embeddings through LDS (one coalesced fetch of the 16 rows per workgroup and step,
+// four steps ahead: round 5), the states from LDS ([hidden][sample], double-buffered so ONE workgroup
+// barrier per step orders everything) -- D[m = hidden 4 g + q][n = sample r].  Same bits as dien_rnn_kernel.
 // Cost: (D + 3 H) / 4 = 56 MFMAs of 32 cycles per wave and step at D 32 / H 64, 16 samples at a
 // time, against 2 x 112 dependent VALU fmas per SAMPLE in the one-wave-per-sample form.
 // Measured on dien.json's shape (40 steps, 2048 samples per launch = 128 workgroups): every wave
@@ -1004,6 +1004,10 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
   // measured as well: 130 us on half as many CUs instead of 76 us, no gain in queries/s.)
   constexpr int NW = H / 16, NT = 64 * (SPLIT ? 2 : 1) * NW;
   __shared__ float s0[2][H][16], s1[2][H][16];
+  // x_t of the 16 samples, [sample][k] with rows 4 floats apart from a multiple of 64: the B operand read
+  // sx[.][r][4 s + g] touches 64 different banks, the loaders' 16-byte writes are aligned
+  constexpr int XLD = D + 4;
+  __shared__ __attribute__((aligned(16))) float sx[2][16][XLD];
   extern __shared__ __attribute__((aligned(16))) float dien_top_lds[];   // fused top MLP: 2 x [kmax][16] (none otherwise)
   const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NW, role = (threadIdx.x >> 6) / NW;
   const bool do1 = !SPLIT || role == 0, do2 = !SPLIT || role == 1;   // (wave-uniform)
@@ -1062,51 +1066,94 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
   }
   // B operand of the input product: x_t[sample r][k = 4 s + g]; step t of "sample" b is embedding
   // n % U of sample n / U, n = t * bs + b (the reference's Reshape, models/dien.py:316-320).
-  // Fetched NB steps ahead into a register ring: a step lasts ~1 us, a load from the gather's
-  // buffer (L2 / MALL / HBM) about as long -- one step of distance left the MFMAs waiting for it.
-  // (Round 4, read off the ISA: across the loop's back edge the compiler's counter model forgets the ring and
-  // every step waits vmcnt(7)..(0) -- for the set requested ONE step earlier: the effective lead is one step,
-  // not four.  An inline-asm ring with an explicit vmcnt(24) was tried: the compiler copies ring registers whose
-  // loads are still in flight (at the joins of the per-role branches and for operand placement), the recurrent
-  // state came out wrong.  A second form with the ring in fixed accumulation registers (loads and the input
-  // product's MFMAs through inline asm) ran no faster -- 165 k against 172 k queries/s -- before it was even
-  // right: the wait is not what bounds the step, the two waves of a SIMD already cover it for each other.)
+  // Round 5: the 16 rows of a step (D floats each, contiguous in the gather's buffer) are fetched ONCE per
+  // workgroup, 16 bytes per lane (loader lane f takes piece f % (D/4) of sample f / (D/4): a row per 128-byte
+  // line), NB steps ahead into a register ring, and handed to the layer-1 waves through sx -- until then every
+  // layer-1 wave fetched the operand itself, a dword per lane and MFMA step: 8 requests of 16 lines each per wave
+  // and step, 32 per workgroup, and the texture path of a CU with two workgroups was the bound (the recurrence
+  // with the fetch compiled out: 179 k -> 203 k queries/s; with a second workgroup on the CU a launch took twice
+  // as long).  (Rounds 3-4 on the wait counters across the loop's back edge: docs/DESIGN_rounds_1-4.md.)
   constexpr int NB = 4;
-  float xr[NB][D / 4];
-  auto fetch_x = [&](int t, float (&xb)[D / 4]) {
+  constexpr int NF = 16 * D / 4;                                  // float4 pieces of a step
+  constexpr int NLD = 64 * NW;                                    // loader lanes: the waves that run layer 1
+  constexpr int NL = (NF + NLD - 1) / NLD;
+  f32x4_ xr[NB][NL];
+  const float* xsrc[NL];                                          // this loader lane's sample: row 0 of its query ...
+  int xb_[NL], xbs[NL];                                           // ... its number in the query, the query's size
+  if (do1) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int f = min(wave * 64 + lane + i * NLD, NF - 1);
+      const int ls = f / (D / 4), piece = f - ls * (D / 4);
+      const int sm = min(smp_base + ls, n_smp - 1);
+      int bb = sm, bsz = q.bs[0], vv = q.vstart[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        const bool in = k < q.n_q && sm >= q.cum[k];
+        bb = in ? sm - q.cum[k] : bb;
+        bsz = in ? q.bs[k] : bsz;
+        vv = in ? q.vstart[k] : vv;
+      }
+      if (q.n_q > 8) {
+#pragma unroll
+        for (int k = 8; k < DRS_MAX_COALESCE; ++k) {
+          const bool in = k < q.n_q && sm >= q.cum[k];
+          bb = in ? sm - q.cum[k] : bb;
+          bsz = in ? q.bs[k] : bsz;
+          vv = in ? q.vstart[k] : vv;
+        }
+      }
+      xb_[i] = bb; xbs[i] = bsz;
+      xsrc[i] = T + (int64_t)vv * ldt + D + 4 * piece;
+    }
+  }
+  auto fetch_x = [&](int t, f32x4_ (&xq)[NL]) {
     if (!do1) return;
     const int tt = min(t, U - 1);
-    const int n = tt * bs + b;
-    const int src = n / U, unit = n - src * U;
-    const float* x = T + (int64_t)(v0 + src) * ldt + (int64_t)(1 + unit) * D + g;
 #pragma unroll
-    for (int s = 0; s < D / 4; ++s) xb[s] = x[4 * s];
+    for (int i = 0; i < NL; ++i) {
+      const int n = tt * xbs[i] + xb_[i];
+      const int src = n / U, unit = n - src * U;
+      xq[i] = *reinterpret_cast<const f32x4_*>(xsrc[i] + (int64_t)src * ldt + (int64_t)unit * D);
+    }
+  };
+  auto stash_x = [&](int buf, const f32x4_ (&xq)[NL]) {            // ring slot -> sx[buf]
+    if (!do1) return;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int f = wave * 64 + lane + i * NLD;
+      if (f < NF) {
+        const int ls = f / (D / 4), piece = f - ls * (D / 4);
+        *reinterpret_cast<f32x4_*>(&sx[buf][ls][4 * piece]) = xq[i];
+      }
+    }
   };
 #pragma unroll
   for (int j = 0; j < NB; ++j) fetch_x(j, xr[j]);              // slot j % NB holds x_j
+  stash_x(0, xr[0]);
+  stash_x(1, xr[1 % NB]);
+  fetch_x(NB, xr[0]);
+  fetch_x(NB + 1, xr[1 % NB]);
   __syncthreads();
   // Layer 2 runs one step behind layer 1: an iteration holds layer 2 of step t and layer 1 of step
   // t + 1, which do not depend on each other, and ONE barrier per iteration orders the
   // double-buffered state exchange.
   //   s0[t & 1] = layer-1 state after step t,  s1[t & 1] = layer-2 state after step t
-  auto layer1 = [&](int rd, int wr, const float (&xb)[D / 4]) {   // x_t, state s0[rd] -> s0[wr]
+  auto layer1 = [&](int rd, int wr, int xbuf) {   // x_t in sx[xbuf], state s0[rd] -> s0[wr]
     f32x4_ aa = {0.f, 0.f, 0.f, 0.f}, ag = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < H / 4; ++s) {
       ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wga[s], s0[rd][4 * s + g][r], ag, 0, 0, 0);
-      if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
+      if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], sx[xbuf][r][4 * s + g], aa, 0, 0, 0);
     }
 #pragma unroll
-    for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
+    for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], sx[xbuf][r][4 * s + g], aa, 0, 0, 0);
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd)
       s0[wr][16 * wave + 4 * g + qd][r] = tanh_rnn((ag[qd] + bga[qd]) + (aa[qd] + bia[qd]));
   };
   f32x4_ h1v = {0.f, 0.f, 0.f, 0.f};
-  if (do1) {
-    layer1(1, 0, xr[0]);            // step 0 of layer 1: its previous state is the zero buffer s0[1]
-    fetch_x(NB, xr[0]);
-  }
+  if (do1) layer1(1, 0, 0);         // step 0 of layer 1: its previous state is the zero buffer s0[1]
   __syncthreads();
   for (int t0 = 0; t0 < U; t0 += NB) {
 #pragma unroll
@@ -1114,14 +1161,16 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
       const int t = t0 + j;
       if (t >= U) break;                                 // (uniform)
       const int cur = t & 1, prv = cur ^ 1;
-      float (&xb)[D / 4] = xr[(j + 1) % NB];             // x_{t+1}: t0 is a multiple of NB
+      f32x4_ (&xn)[NL] = xr[(j + 2) % NB];               // x_{t+2} (t0 is a multiple of NB): into sx[t & 1], whose x_t
+                                                         // was read an iteration ago; x_{t+1} sits in sx[prv]
       // layer 2, step t: input = layer-1 state of step t (s0[cur]), previous own state s1[prv];
       // layer 1, step t + 1: input x_{t+1}, previous state s0[cur]; writes s0[prv].  (After the last
       // step layer 1 computes one step too many into the unused buffer: cheaper than a divergent tail.)
       if (SPLIT) {
         if (role == 0) {
-          layer1(cur, prv, xb);
-          fetch_x(t + 1 + NB, xb);
+          layer1(cur, prv, prv);
+          stash_x(cur, xn);
+          fetch_x(t + 2 + NB, xn);
         } else {
           f32x4_ ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1145,11 +1194,12 @@ __global__ __launch_bounds__(64 * (SPLIT ? 2 : 1) * (H / 16)) void dien_rnn_mfma
           ba = __builtin_amdgcn_mfma_f32_16x16x4f32(wib[s], h0k, ba, 0, 0, 0);
           bg = __builtin_amdgcn_mfma_f32_16x16x4f32(wgb[s], s1[prv][4 * s + g][r], bg, 0, 0, 0);
           ag = __builtin_amdgcn_mfma_f32_16x16x4f32(wga[s], h0k, ag, 0, 0, 0);
-          if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
+          if (s < D / 4) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], sx[prv][r][4 * s + g], aa, 0, 0, 0);
         }
 #pragma unroll
-        for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], xb[s], aa, 0, 0, 0);
-        fetch_x(t + 1 + NB, xb);
+        for (int s = H / 4; s < D / 4; ++s) aa = __builtin_amdgcn_mfma_f32_16x16x4f32(wia[s], sx[prv][r][4 * s + g], aa, 0, 0, 0);
+        stash_x(cur, xn);
+        fetch_x(t + 2 + NB, xn);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           h1v[qd] = tanh_rnn((bg[qd] + bgb[qd]) + (ba[qd] + bib[qd]));
