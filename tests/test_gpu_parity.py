@@ -445,7 +445,7 @@ def test_full_size_reference_shapes_match_oracle(name):
             tuned = net.tune_table_placement(3, sets=16)      # (gather-bound DLRM only: rm2 here)
             assert (tuned is None) == (name != "rm2"), (name, tuned)
             if tuned is not None:      # up to three arenas x two load policies timed, the best kept, every other arena released
-                assert 1 <= len(tuned["gather_alone_us"]) <= 3 and all(len(t) == 2 for t in tuned["gather_alone_us"])
+                assert 1 <= len(tuned["gather_us"]) <= 3 and all(len(t) == 2 for t in tuned["gather_us"])
                 assert tuned["losers"] == "freed" and eng.get_option("table_placements") == 1 and eng.get_option("table_placement") == 0
                 assert eng.get_option("sls_nt") == tuned["sls_nt"] and eng.get_option("table_alloc") == 0
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, "after tuning")

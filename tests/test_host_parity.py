@@ -450,7 +450,7 @@ def test_bind_rank_applies_the_mask_in_a_child_process():
 
 def test_tune_table_placement_search_logic_on_a_scripted_engine():
     """DLRM_Net.tune_table_placement against an engine whose gather time is scripted per
-    (arena, load policy): it times both policies on every arena, stops as soon as one arena is a level (5 %)
+    (arena, load policy): it times both policies on every arena, stops as soon as one arena is a level (8 %)
     faster than another, keeps the best (arena, policy), releases everything else, and leaves the
     allocation mode as it found it."""
     from deeprecsys_amd import dlrm_s_hip as M
@@ -460,9 +460,9 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
 
         def __init__(self, us):
             self.us = us                       # us[arena][policy index: nt, plain]
-            self.opt = {"mlp_streams": 1, "gather_bound": 1, "preferred_coalesce": 12, "shared_stream": 2, "sls_nt": 1, "table_bytes": 2 << 30,
+            self.opt = {"mlp_streams": 1, "gather_bound": 1, "preferred_coalesce": 12, "preferred_slots": 3, "shared_stream": 2, "sls_nt": 1, "table_bytes": 2 << 30,
                         "table_alloc": 0, "table_vmm_chunk": -1}
-            self.arenas, self.cur, self.log = 1, 0, []
+            self.arenas, self.cur, self.log, self.busy = 1, 0, [], {}
 
         def get_option(self, k):
             return self.opt[k]
@@ -482,8 +482,16 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
             else:
                 self.opt[k] = v
 
-        def forward_multi_async(self, *a): pass
-        def wait(self, *a): pass
+        num_slots = 3
+
+        def forward_multi_async(self, slot, *a):
+            assert 0 <= slot < 3 and not self.busy.get(slot), "a slot is waited for before it is reused"
+            self.busy[slot] = True
+
+        def wait(self, slot, *a):
+            assert self.busy.get(slot)
+            self.busy[slot] = False
+
         def reset_kernel_time(self): pass
         def set_profiling(self, *a): pass
 
@@ -496,7 +504,7 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
         return net.tune_table_placement(candidates, sets=4), net.engine
 
     # the third arena is a level faster under plain loads: the search stops there and keeps (arena 2, plain)
-    res, eng = run([[86.5, 87.5], [86.6, 87.9], [85.0, 81.0], [80.0, 80.0]])
+    res, eng = run([[86.5, 87.5], [86.6, 87.9], [85.0, 79.0], [78.0, 78.0]])
     assert res["kept"] == 2 and res["sls_nt"] == 0 and res["candidates"] == 3 and res["losers"] == "freed"
     assert eng.kept == 2 and eng.arenas == 1 and eng.opt["sls_nt"] == 0 and eng.opt["table_alloc"] == 0
     assert ("table_spacer", 2 << 30) in eng.log                      # a spacer of the arena's size between candidates
