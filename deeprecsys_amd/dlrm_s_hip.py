@@ -196,7 +196,7 @@ class _HipNet(object):
             self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
         self._n_staged = len(lS_l)
 
-    def tune_table_placement(self, candidates=6, sets=128, spacer_gb=None, policies=(1, 0)):
+    def tune_table_placement(self, candidates=8, sets=128, spacer_gb=None, policies=(1, 0)):
         """Where the tables live in HBM, and with which cache policy their rows are read, moves the many-rows-per-bag
         gather by up to 9 % -- a property of the PHYSICAL memory (it follows the memory through address changes;
         gigabytes-wide regions of HBM are "fast" or "slow", and they are different regions for non-temporal and for
