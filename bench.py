@@ -818,7 +818,8 @@ def main():
     lX, lS_l, lS_i = data
     L = WORKLOADS[opt.workload]["L"]
     host_n, host_el, host_bytes, bus_bytes = 0, 1.0, 0, 0
-    if extra:
+    # (ragged bags -- `--trace_unique` -- are served from the staged sets only: the leg below hands over [T, bs * L] arrays)
+    if extra and not getattr(opt, "trace_unique", False):
         # what the reference's feeder passes: ids [T, bs*L] int64, lengths [T, bs] int32, fc [bs, m_den]
         host_sets = [(np.stack([np.asarray(t[:bs * L], dtype=np.int64) for t in lS_i[b]]),
                       np.stack([np.asarray(t[:bs], dtype=np.int32) for t in lS_l[b]]),
@@ -957,7 +958,7 @@ def main():
                              "bytes": int(one_bytes / one_n), "avg_launch_us": round(one_ms / one_n * 1e3, 3),
                              "frac": round(one / HBM_PEAK_GBS, 4)}},
         }
-        if extra:
+        if extra and host_n:
             out["host_inputs_leg"] = {
                 "value": round(host_n / host_el, 1), "unit": "queries/s", "queries": host_n,
                 # what actually crosses the bus per query: the NARROWED int32 indices and the fp32 dense rows
