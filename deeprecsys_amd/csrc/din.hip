@@ -508,6 +508,23 @@ __global__ __launch_bounds__(64 * NW) void din_fused_kernel(SlsArgs a, const flo
   }
 }
 
+// Sum over the G lanes of a lane group, every lane ends with the total: the butterfly of __shfl_xor(., 1 / 2 / 4 / 8) --
+// same pairs, same bits -- on the DPP network instead of ds_bpermute (xor 1 and 2 as quad permutes; after them the four
+// lanes of a quad agree, so the mirror of 8 (16) lanes delivers the partner quad's (half-row's) sum).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(G == 8 || G == 16, "lane groups of 8 or 16");
+  v += dpp_f<0xB1>(v);                     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);                    // row_half_mirror
+  if (G == 16) v += dpp_f<0x140>(v);       // row_mirror
+  return v;
+}
+
 // PIPELINED form of the fused launch: hidden width 1 (the shipped attention unit 96-1-32) and launch sets whose
 // bags all have one fixed length <= 3 (FusedShape::C == 3; din.json: 3 lookups).
 // din_fused_kernel above walks a lane group's ~U / NGB units one dependent round trip after the other
@@ -679,8 +696,7 @@ __global__ __launch_bounds__(64 * NW, 2) void din_pipe_kernel(SlsArgs a, const f
       float pd = dot4(u[s], wt.w1u, 0.f);
       pd = dot4(ad[s], wt.w1a, pd);
       pd = dot4(sum, wt.w1s, pd);
-#pragma unroll
-      for (int m = 1; m < G; m <<= 1) pd += __shfl_xor(pd, m);
+      pd = group_sum<G>(pd);
       const float y = fmaxf(pd + wt.b1, 0.f);
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       o.x = fmaf(y, wt.w2.x, o.x); o.y = fmaf(y, wt.w2.y, o.y);
