@@ -93,7 +93,7 @@ def parse(argv=None):
     ap.add_argument("--workload", default="rmc1", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--num_batches", type=int, default=32)
-    ap.add_argument("--table_placements", type=int, default=8,
+    ap.add_argument("--table_placements", type=int, default=12,
                     help="places in HBM tried for the table arena before the warm-up (the engine's own launch sets time "
                          "each, the fastest stays: DLRM_Net.tune_table_placement); 1 = wherever hipMalloc put it")
     ap.add_argument("--slots", type=int, default=0,

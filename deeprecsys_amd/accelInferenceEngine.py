@@ -75,7 +75,7 @@ def _build_hip_model(args, engine_id):
     model.net.stage_batches(lX, lS_l, lS_i)
     # where the table arena lands in HBM moves the gather by a few per cent for the engine's lifetime: try a few places
     # with the model's own launch sets (about 30 ms each) and keep the fastest (--accel_table_placements, 1 = off)
-    n_place = int(getattr(args, "accel_table_placements", 8))
+    n_place = int(getattr(args, "accel_table_placements", 12))
     if n_place > 1:
         model.net.tune_table_placement(n_place)
     return model

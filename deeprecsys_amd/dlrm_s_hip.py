@@ -196,7 +196,7 @@ class _HipNet(object):
             self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
         self._n_staged = len(lS_l)
 
-    def tune_table_placement(self, candidates=8, sets=128, spacer_gb=None, policies=(1, 0)):
+    def tune_table_placement(self, candidates=12, sets=128, spacer_gb=None, policies=(1, 0)):
         """Where the tables live in HBM, and with which cache policy their rows are read, moves the many-rows-per-bag
         gather by up to 9 % -- a property of the PHYSICAL memory (it follows the memory through address changes;
         gigabytes-wide regions of HBM are "fast" or "slow", and they are different regions for non-temporal and for
@@ -265,6 +265,8 @@ class _HipNet(object):
             return out
 
         times, best = [], None          # best = (us, arena index, policy)
+        import time as _time
+        t_begin = _time.perf_counter()
         try:
             t = both()
             if t[0] is None:
@@ -292,7 +294,8 @@ class _HipNet(object):
             if best[1] != 0 and best[0] > 0.98 * first[0]:
                 best = first
             return {"gather_us": [[round(u, 2) for u in tt] for tt in times], "timed": "pipelined, %d sets in flight" % n_slots, "policies": ["nt" if p else "plain" for p in policies],
-                    "kept": best[1], "sls_nt": best[2], "candidates": len(times), "losers": "freed"}
+                    "kept": best[1], "sls_nt": best[2], "candidates": len(times), "losers": "freed",
+                    "seconds": round(_time.perf_counter() - t_begin, 2)}
         except N.DrsError:
             return None                                 # (staged sets smaller than a full batch, ...: serve from where it is)
         finally:
