@@ -328,11 +328,11 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                "mlp_gemm32_small" names a gemm32 shape for them (22 | 21 | 12 | 11) that gives at least
  *                "mlp_gemm32_small_blocks" workgroups (defaults: 12 with 256 for MT-WnD and MLP-bound DLRM, 12 with 512 for
  *                W&D, else 0)
- *   "mlp_stream" 2 (default for MT-WnD, NCF, DIN) chains run as the weight-tile stream kernel (tiles of all layers requested
+ *   "mlp_stream" 2 (default for MT-WnD, NCF) chains run as the weight-tile stream kernel (tiles of all layers requested
  *                six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and the slabs fit, the tiles read from
  *                the layers' PACKED twins (MFMA operand order, built by drs_set_fc) straight into the MFMA operand
  *                registers: no LDS staging of W, a workgroup barrier per layer instead of per 64-k chunk | 4 (default
- *                for DLRM, W&D, DIEN) stream4_kernel: four waves, every (layer, 64-column-per-wave pass) run by ONE
+ *                for DLRM, W&D, DIEN, DIN) stream4_kernel: four waves, every (layer, 64-column-per-wave pass) run by ONE
  *                hand-laid instruction stream (csrc/seg_asm.inc): MFMAs back to back with the weight reloads, operand
  *                prefetch and loop control between them, ring and accumulators in AGPRs under fixed names, the next
  *                segment's first chunk requested while the last one runs ("mlp_rows32" n: its launches of >= n rows take
