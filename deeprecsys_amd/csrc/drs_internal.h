@@ -123,6 +123,11 @@ struct Done {
 struct XSrc {
   QTable q;
   const float* x[DRS_MAX_COALESCE];
+  // > 0 (gemm32_kernel's scalar-base forms only, launch_gemm): columns [0, ksplit) of an input row come from the
+  // queries' own staged arrays (rows ksplit floats apart), columns from ksplit on from `x` at the VIRTUAL row -- W&D's and
+  // MT-WnD's first layer reads Concat(dense, pooled embeddings) without the dense rows ever being copied next to the
+  // embeddings (models/wide_and_deep.py:271-281).  A multiple of 32, >= 64, < K.
+  int32_t ksplit;
 };
 
 hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W,
@@ -130,6 +135,9 @@ hipError_t launch_fc(const float* x, int64_t ldx, int64_t M, int32_t K, const fl
                      const Tune& tune, hipStream_t stream, const Done* done = nullptr,
                      const XSrc* xs = nullptr);
 
+// would launch_gemm take a form that reads a split input row (XSrc::ksplit) for this layer?  (gemm.hip)
+bool gemm_split_applicable(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, int32_t N, const XSrc& xs,
+                           const Tune& tune);
 // Register-blocked GEMM for wide layers (gemm.hip); false = not applicable, use launch_fc's
 // own kernel.  zero_page: 16 B of zeros in device memory.
 bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,

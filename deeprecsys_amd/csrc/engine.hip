@@ -109,6 +109,7 @@ struct Batch {
 };
 
 struct Slot {
+  bool split_last = false;        // the set in flight read its dense columns in place ("gemm_split"): s.T holds none
   hipStream_t stream = nullptr;   // the stream the job in flight launches its MLP side on
   hipStream_t base_stream = nullptr;   // ... as assigned by apply_stream_mode (shared or own)
   hipStream_t own_stream = nullptr;
@@ -254,6 +255,7 @@ struct drs_engine {
   // an event per change of stream orders a set's launches.  0: a set's MLP launches all on its own stream.
   int mlp_layout = 0;
   int gather_bound = 0;             // set by choose_launch_forms (read only for callers)
+  int gemm_split = 1;               // W&D / MT-WnD: the first top layer reads the dense columns from the queries' arrays (no copy launch)
   int gather_priority = 0;
   int mlp_cu_mask = 0, gather_cu_complement = 1;   // "mlp_cu_mask": CUs reserved for the MLP streams (0: none)
   int sls_short_bag = 8;            // uniform bag length up to which the lane-group-per-bag gather is used (drs_create: 2048 / D)
@@ -1250,6 +1252,10 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     }
   } else {
     bool fused = false;
+    bool split_top = false;      // the first top layer reads the dense columns in place (xs_top)
+    s.split_last = false;
+    XSrc xs_top;
+    memset(&xs_top, 0, sizeof xs_top);
     if (!e->bot.layers.empty()) {
       if (fused_applicable(e, s, Mv, &xs)) HIP_TRY(e, join());
       fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
@@ -1258,8 +1264,20 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     if (fused) {
       // nothing else to launch
     } else if (e->bot.layers.empty()) {
-      log_launch(&s.dlog, "copy_rows_multi_kernel");
-      HIP_TRY(e, launch_copy_rows_multi(xs, e->m_den, s.T, e->ldT, s.stream));
+      // W&D / MT-WnD: Concat(dense, pooled embeddings) feeds the first top layer.  When that layer goes to a GEMM form
+      // that can read a split row ("gemm_split", launch_gemm) it takes the dense columns from the queries' own arrays;
+      // otherwise the dense rows are copied in front of the embeddings first.
+      XSrc xsp = xs;
+      xsp.ksplit = e->m_den;
+      if (e->gemm_split && !e->top.layers.empty() && is_wide(e, e->top, 0) &&
+          gemm_split_applicable(s.T, e->ldT, Mv, e->top.ln[0], e->top.layers[0].W, e->top.ln[1], xsp, e->tune)) {
+        xs_top = xsp;
+        split_top = true;
+        s.split_last = true;
+      } else {
+        log_launch(&s.dlog, "copy_rows_multi_kernel");
+        HIP_TRY(e, launch_copy_rows_multi(xs, e->m_den, s.T, e->ldT, s.stream));
+      }
     } else {
       if ((rc = run_mlp(e, s, e->bot, nullptr, e->m_den, Mv, s.T, e->ldT, nullptr, &xs))) return rc;
     }
@@ -1277,12 +1295,12 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       // shared top MLP (all ReLU) -> H3, then every task head reads H3 and writes its block of
       // the output row; the last head's last launch carries the completion hand-off
       const int wt = e->top.ln.back(), wo = e->tasks[0].ln.back();
-      if ((rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, s.H3, wt))) return rc;
+      if ((rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, s.H3, wt, nullptr, split_top ? &xs_top : nullptr))) return rc;
       for (size_t k = 0; k < e->tasks.size(); ++k)
         if ((rc = run_mlp(e, s, e->tasks[k], s.H3, wt, Mv, out + k * wo, e->n_out,
                           k + 1 == e->tasks.size() ? dp : nullptr)))
           return rc;
-    } else if (!fused && (rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp))) return rc;
+    } else if (!fused && (rc = run_mlp(e, s, e->top, top_in, ld_top, Mv, out, e->n_out, dp, split_top ? &xs_top : nullptr))) return rc;
   }
   HIP_TRY(e, rejoin_stream(e, s));     // ("mlp_layout" 1: the tail below is ordered behind a last launch on the gather's stream)
   if (evts) {
@@ -2382,7 +2400,11 @@ int32_t drs_fetch_interaction(drs_handle e, int32_t slot, int32_t bs, float* h_R
   if (e->kind == DRS_MODEL_NCF) { src = s.H2; ld = e->num_int; }
   else if (e->kind == DRS_MODEL_DIN || e->kind == DRS_MODEL_DIEN) { src = s.R; ld = e->ldR; }
   else if (e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) { src = s.R; ld = e->ldR; }
-  else { src = s.T; ld = e->ldT; }
+  else {
+    if (s.split_last)
+      return fail(e, DRS_ERR_STATE, "the set's dense columns were read in place (\"gemm_split\" 1): set it to 0 to materialise the interaction tensor");
+    src = s.T; ld = e->ldT;
+  }
   HIP_TRY(e, hipMemcpy2D(h_R, sizeof(float) * e->num_int, src, sizeof(float) * ld,
                          sizeof(float) * e->num_int, bs, hipMemcpyDeviceToHost));
   return DRS_OK;
@@ -2490,6 +2512,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_nt")) e->tune.sls_nt = value ? 1 : 0;
   else if (!strcmp(key, "din_nt")) e->tune.din_nt = value ? 1 : 0;
   else if (!strcmp(key, "din_pipe")) e->tune.din_pipe = value ? 1 : 0;
+  else if (!strcmp(key, "gemm_split")) e->gemm_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_bpw") && (value == 0 || value == 1 || value == 2 || value == 4)) e->tune.sls_bpw = (int)value;
   else if (!strcmp(key, "mlp_split")) e->mlp_split = value ? 1 : 0;
   else if (!strcmp(key, "sls_uniform")) e->sls_uniform = value ? 1 : 0;
@@ -2788,7 +2811,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   const Tune& t = e->tune;
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
-      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"din_pipe", t.din_pipe}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
+      {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"din_pipe", t.din_pipe}, {"gemm_split", e->gemm_split}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},

@@ -363,7 +363,10 @@ __device__ unsigned long long g_gtl[8 * 8192];
 // 8 192 rows 377 -> 367 us, 4 096 rows -- one workgroup per CU, nobody to fill the gap -- 198 -> 185 us)
 // (DBG, tools/ubench/gemm_lab.hip only: timing experiments that drop a part of the loop -- 2 no LDS stash, 4 no
 // barrier, 8 no global requests; the results are then not the GEMM's)
-template <int WTM, int WTN, int SPREAD = 1, int DBG = 0>
+// XSPLIT: the input row is split between two sources (XSrc::ksplit): chunks below ksplit from the query's own dense
+// array, the others from a.x at the virtual row -- a second set of row offsets (and, SPREAD == 2, a second descriptor
+// and lane offsets that replace the first at the one chunk where the source changes).
+template <int WTM, int WTN, int SPREAD = 1, int DBG = 0, bool XSPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc xs) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
   constexpr int NA = 2 * WTM, NB = 2 * WTN;      // float4 per thread per chunk (rows frow + 32 j)
@@ -390,6 +393,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
   // dense array, XSrc), so every 64-row half resolves its source on its own
   const float* xb[WTM];
   int64_t offA[NA], offB[NB];
+  const int ksp = XSPLIT ? xs.ksplit : 0;                 // first column that comes from a.x (XSPLIT)
+  int64_t offT[XSPLIT ? NA : 1];                          // ... and the offsets of the virtual rows there
 #pragma unroll
   for (int hm = 0; hm < WTM; ++hm) {
     int64_t row0, rows;
@@ -399,7 +404,11 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
       // rows past the end are clamped: they only feed outputs that are never stored
       const int64_t rr = row0 + frow + 32 * jj;
       // (an empty source -- rows == 0, which the engine's query table never holds -- reads its row 0 slot: never row -1)
-      offA[2 * hm + jj] = (rr < rows ? rr : (rows > 0 ? rows - 1 : 0)) * a.ldx + fk;
+      offA[2 * hm + jj] = (rr < rows ? rr : (rows > 0 ? rows - 1 : 0)) * (XSPLIT ? (int64_t)ksp : a.ldx) + fk;
+      if constexpr (XSPLIT) {
+        const int64_t vr = m0 + 64 * hm + frow + 32 * jj;
+        offT[2 * hm + jj] = (vr < a.M ? vr : a.M - 1) * a.ldx + fk;
+      }
     }
   }
 #pragma unroll
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const float* p = in ? xb[j >> 1] + offA[j] + k0 : a.zero;
+      if constexpr (XSPLIT) { if (in && k0 >= ksp) p = a.x + offT[j] + k0; }
       asm("" : "+v"(p));
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[j]) : "v"(p));
     }
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     const bool in = k0 + fk < K;
     if (q < NA) {
       const float* p = in ? xb[q >> 1] + offA[q] + k0 : a.zero;
+      if constexpr (XSPLIT) { if (in && k0 >= ksp) p = a.x + offT[q] + k0; }
       asm("" : "+v"(p));
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[q]) : "v"(p));
     } else {
@@ -455,9 +466,21 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     rsrc_t r = {(int)lo, (int)(hi & 0xffffu), (int)0xfffff000u, 0x00020000};
     return r;
   };
+  uint32_t voT[XSPLIT ? NA : 1];
+  rsrc_t rsT = {0, 0, 0, 0};
+  bool switched = false;
   auto set_chunk = [&]() {
     s_k0 = (uint32_t)f_c * (G3KC * 4u);
     s_nrec = f_c < nch ? 0xfffff000u : 0u;
+    if constexpr (XSPLIT) {
+      if (!switched && f_c * G3KC >= ksp) {      // (uniform) the next request is the first one past the dense columns
+        switched = true;
+#pragma unroll
+        for (int j2 = 0; j2 < NA; ++j2) voA[j2] = voT[j2];
+#pragma unroll
+        for (int hm = 0; hm < WTM; ++hm) rsA[hm] = rsT;
+      }
+    }
   };
   if constexpr (SPREAD == 2) {
 #pragma unroll
@@ -468,6 +491,11 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(GArgs a, Done done, XSrc
     for (int hm = 0; hm < WTM; ++hm)
       rsA[hm] = mk_rsrc(xb[hm]);
     rsB = mk_rsrc(a.W);
+    if constexpr (XSPLIT) {
+#pragma unroll
+      for (int j2 = 0; j2 < NA; ++j2) voT[j2] = (uint32_t)(offT[j2] * 4);
+      rsT = mk_rsrc(a.x);
+    }
   }
   auto fetch_one_s = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], int q) {
     rsrc_t r = q < NA ? rsA[q >> 1] : rsB;
@@ -634,7 +662,8 @@ hipError_t gemm_set_attrs() {
   for (const void* k : {reinterpret_cast<const void*>(gemm32_kernel<2, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 2>),
                         reinterpret_cast<const void*>(gemm32_kernel<2, 1>), reinterpret_cast<const void*>(gemm32_kernel<1, 1>),
                         reinterpret_cast<const void*>(gemm32_kernel<2, 2, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 2, 2>),
-                        reinterpret_cast<const void*>(gemm32_kernel<2, 1, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 1, 2>)}) {
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 1, 2>), reinterpret_cast<const void*>(gemm32_kernel<1, 1, 2>),
+                        reinterpret_cast<const void*>(gemm32_kernel<2, 2, 2, 0, true>), reinterpret_cast<const void*>(gemm32_kernel<1, 2, 2, 0, true>)}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
   }
@@ -644,9 +673,9 @@ hipError_t gemm_set_attrs() {
 // tune.mlp_gemm ("mlp_gemm"): wide layers through gemm_kernel; tune.gemm_tile ("mlp_gemm_tile"):
 // force TM*10+TN (22 | 12 | 21 | 11), 0 = by block count
 // false = not applicable (caller falls back to fc_kernel)
-bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
-                 int32_t N, int32_t act, float* y, int64_t ldy, const Tune& tune,
-                 hipStream_t s, const Done& d, const XSrc& xs, hipError_t* err) {
+static bool launch_gemm_impl(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
+                             int32_t N, int32_t act, float* y, int64_t ldy, const Tune& tune,
+                             hipStream_t s, const Done& d, const XSrc& xs, hipError_t* err, bool dry) {
   *err = hipSuccess;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   const float* zero_page = tune.zero;
@@ -696,6 +725,19 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
       // scalar-base requests when K is whole 32-k chunks and the row offsets fit 32 bits (gemm32_kernel, SPREAD == 2)
       // (offsets + a row's bytes stay below the descriptors' num_records of 0xfffff000)
       const bool sbase = !(K & 31) && ((uint64_t)M * (uint64_t)ldx + (uint64_t)K) * 4u < 0xfffff000ull && ((uint64_t)N + 1) * (uint64_t)K * 4u < 0xfffff000ull;
+      if (xs.ksplit > 0) {
+        // a split input row: the scalar-base forms 2 x 2 and 1 x 2 only (what W&D's and MT-WnD's first layer takes at
+        // full launch sets); the dense arrays' row offsets fit 32 bits like the others
+        const bool ok = sbase && (w == 22 || w == 12) && !(xs.ksplit & 31) && xs.ksplit >= 64 && xs.ksplit < K;
+        if (dry) return ok;
+        if (!ok) { *err = hipErrorInvalidValue; return true; }
+        log_launch(tune.log, "gemm32_kernel<%d,%d,sbase,split%d>[%u x %u wg, %dx%d]", wm_, wn_, xs.ksplit, grid.x, grid.y, K, N);
+        if (w == 22) hipLaunchKernelGGL((gemm32_kernel<2, 2, 2, 0, true>), grid, dim3(256), lds, s, a, d, xs);
+        else hipLaunchKernelGGL((gemm32_kernel<1, 2, 2, 0, true>), grid, dim3(256), lds, s, a, d, xs);
+        *err = hipGetLastError();
+        return true;
+      }
+      if (dry) return false;
       log_launch(tune.log, "gemm32_kernel<%d,%d%s>[%u x %u wg, %dx%d]", wm_, wn_, sbase ? ",sbase" : "", grid.x, grid.y, K, N);
 #define DRS_G3LAUNCH(WM_, WN_)                                                                              \
       if (sbase) hipLaunchKernelGGL((gemm32_kernel<WM_, WN_, 2>), grid, dim3(256), lds, s, a, d, xs);          \
@@ -706,6 +748,8 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
       return true;
     }
   }
+  if (dry) return false;
+  if (xs.ksplit > 0) { *err = hipErrorInvalidValue; return true; }   // (callers ask gemm_split_applicable first)
   const dim3 grid((unsigned)((M + 32 * tm - 1) / (32 * tm)), (unsigned)((N + 64 * tn - 1) / (64 * tn)));
   const size_t lds = sizeof(float) * 2 * (32 * tm + 64 * tn) * GLD;
   log_launch(tune.log, "gemm_kernel<%d,%d%s>[%u x %u wg, %dx%d]", tm, tn, two_per_cu ? ",2cu" : "", grid.x, grid.y, K, N);
@@ -716,6 +760,24 @@ bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float*
 #undef DRS_GLAUNCH
   *err = hipGetLastError();
   return true;
+}
+
+bool launch_gemm(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, const float* b,
+                 int32_t N, int32_t act, float* y, int64_t ldy, const Tune& tune,
+                 hipStream_t s, const Done& d, const XSrc& xs, hipError_t* err) {
+  return launch_gemm_impl(x, ldx, M, K, W, b, N, act, y, ldy, tune, s, d, xs, err, false);
+}
+
+// the same decisions without a launch: true when the layer would go to a gemm32_kernel form that reads a split row
+bool gemm_split_applicable(const float* x, int64_t ldx, int64_t M, int32_t K, const float* W, int32_t N, const XSrc& xs,
+                           const Tune& tune) {
+  if (xs.ksplit <= 0 || N < 64 || K < 64) return false;
+  hipError_t err = hipSuccess;
+  Done d;
+  memset(&d, 0, sizeof d);
+  DispatchLog* keep = tune.log;
+  (void)keep;
+  return launch_gemm_impl(x, ldx, M, K, W, nullptr, N, 0, nullptr, 0, tune, nullptr, d, xs, &err, true) && err == hipSuccess;
 }
 
 }  // namespace drs

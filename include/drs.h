@@ -297,6 +297,10 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *                of its own behind it.  Same bits.
  *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
  *                (results do not depend on it)
+ *   "gemm_split" 1 (default) | 0: DRS_MODEL_WND / DRS_MODEL_MTWND: when the first top layer runs as a scalar-base
+ *                gemm32_kernel (full launch sets), it reads the dense columns of Concat(dense, embeddings) from the
+ *                queries' own arrays; 0 (and every other launch form): the dense rows are copied in front of the
+ *                embeddings first (copy_rows_multi_kernel).  Same bits.
  *   "din_pipe"   1 (default) | 0: hidden width 1 and launch sets whose bags all have one fixed length <= 3 (din.json)
  *                take the pipelined form of that launch (din_pipe_kernel: the set's indices staged in LDS with one
  *                round trip, two units in flight per lane group); 0: the chained form for every shape.  Same bits.

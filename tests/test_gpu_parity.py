@@ -343,6 +343,64 @@ FULL_SIZE = {
 }
 
 
+@pytest.mark.parametrize("name", ["wnd", "mtwnd"])
+def test_first_top_layer_reads_the_dense_rows_in_place(name):
+    """W&D / MT-WnD (models/wide_and_deep.py:271-281: Concat(dense, pooled embeddings) -> top MLP) at full size, launch
+    sets of 16 queries: the first top layer goes to a scalar-base gemm32_kernel that reads the dense columns from the
+    queries' own arrays ("gemm_split" 1, the default -- no copy_rows_multi_kernel launch, the dispatch log says so).
+    Same bits as with the dense rows copied in front of the embeddings first ("gemm_split" 0), every query against
+    the oracle; a set of mixed query sizes (the 64-row padding between queries) as well; the interaction tensor is
+    only materialised in the copy form, and drs_fetch_interaction says so."""
+    from deeprecsys_amd.data_generator.dlrm_data import generate_fast_input_data
+    w = FULL_SIZE[name]
+    B, seed, nb = 256, 78, 4
+    rows, D, L, T = w["rows"], w["D"], w["L"], len(w["rows"])
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_bot=w["bot"], arch_mlp_top=w["top"], arch_interaction_op="cat",
+                       num_indices_per_lookup=L, num_batches=nb, max_mini_batch_size=B, mini_batch_size=B,
+                       numpy_rand_seed=seed, accel_table_init="device", model_type=w["kind"], accel_slots=2)
+    if "tasks" in w:
+        args.arch_mlp_tasks, args.num_multi_tasks = w["tasks"], w["num_tasks"]
+    np.random.seed(seed)
+    net = H.NET_CLS[w["kind"]](args)
+    m_den = int(w["bot"].split("-")[0])
+    _, lX, lS_l, lS_i = generate_fast_input_data(nb, B, m_den, rows, L, seed)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    eng = net.engine
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        net.emb_w = [orc.fill_table_uniform(rows[t], D, t, -float(np.sqrt(1 / rows[t])), float(np.sqrt(1 / rows[t])),
+                                            seed, nthreads=0) for t in range(T)]
+        om = H.oracle_model(net)
+        full = [(k % nb, B) for k in range(16)]
+        mixed = [(k % nb, (B, 165, 200, 256, 77, 256, 1, 250)[k % 8]) for k in range(16)]
+        outs = {}
+        for split in (1, 0):
+            eng.set_option("gemm_split", split)
+            for tag, jobs in (("full", full), ("mixed", mixed)):
+                outs[(split, tag)] = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+                disp = " ".join(eng.last_dispatch(0))
+                if tag == "full":
+                    assert ("split%d" % m_den in disp) == bool(split), disp
+                    assert ("copy_rows_multi_kernel" in disp) == (not split), disp
+                    if split:
+                        with pytest.raises(N.DrsError) as ei:
+                            eng.fetch_interaction(B)
+                        assert ei.value.code == N.ERR_STATE
+                    else:
+                        R = eng.fetch_interaction(B)
+                        _, R_exp = om.forward(lX[0], lS_i[0], lS_l[0], bs=B, want_R=True, nthreads=0)
+                        assert np.array_equal(R, R_exp)
+        for tag, jobs in (("full", full), ("mixed", mixed)):
+            for k, (b, n) in enumerate(jobs):
+                assert np.array_equal(outs[(1, tag)][k], outs[(0, tag)][k]), (name, tag, k)
+                if k < 6:
+                    exp = om.forward(lX[b], lS_i[b], lS_l[b], bs=n, nthreads=0)
+                    assert H.close(outs[(1, tag)][k], exp, rtol=1e-6, atol=1e-7), (name, tag, k)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("name", sorted(FULL_SIZE))
 def test_full_size_reference_shapes_match_oracle(name):
     """The shapes BASELINE configs 4 and 5 serve, at FULL size and batch 256, against the oracle
