@@ -205,7 +205,7 @@ class _HipNet(object):
         preferred size (served as they will be: pipelined, the gather beside the previous set's MLP launch) on the arena drs_create made, under each load policy ("sls_nt"
         1 / 0), then on up to `candidates` - 1 further arenas taken from further on in HBM (`spacer_gb` of untouched
         memory between two candidates, default = the arena's size), and keeps the fastest (arena, policy) -- the first
-        arena unless another is at least 2 % faster.  It stops as soon as one arena's best reading is 8 % under another's (the
+        arena unless another is at least 1 % faster.  It stops as soon as one arena's best reading is 8 % under another's (the
         fast level is reached).  Every other arena and the spacers are released before it returns: one copy of the
         tables, nothing held.  Returns {"gather_us": [[nt, plain], ...], "kept": k, "sls_nt": p, ...} or
         None when the engine has nothing to time.  ~70 ms per candidate."""
@@ -289,9 +289,10 @@ class _HipNet(object):
                 times.append(both())
             flat = [(u, k, policies[i]) for k, tt in enumerate(times) for i, u in enumerate(tt)]
             best = min(flat)
-            # the arena drs_create made stays unless another one is at least 2 % faster (1 % is the measurement's noise)
+            # the arena drs_create made stays unless another one is at least 1 % faster (timed as served, the readings repeat
+            # to +-0.2 %; at 2 % a run kept an 84.6 us arena with 83.5 us ones on the list)
             first = min((u, 0, policies[i]) for i, u in enumerate(times[0]))
-            if best[1] != 0 and best[0] > 0.98 * first[0]:
+            if best[1] != 0 and best[0] > 0.99 * first[0]:
                 best = first
             return {"gather_us": [[round(u, 2) for u in tt] for tt in times], "timed": "pipelined, %d sets in flight" % n_slots, "policies": ["nt" if p else "plain" for p in policies],
                     "kept": best[1], "sls_nt": best[2], "candidates": len(times), "losers": "freed",

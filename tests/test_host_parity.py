@@ -508,7 +508,7 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
     assert res["kept"] == 2 and res["sls_nt"] == 0 and res["candidates"] == 3 and res["losers"] == "freed"
     assert eng.kept == 2 and eng.arenas == 1 and eng.opt["sls_nt"] == 0 and eng.opt["table_alloc"] == 0
     assert ("table_spacer", 2 << 30) in eng.log                      # a spacer of the arena's size between candidates
-    # no spread anywhere: every candidate is tried, and the first arena stays (another must be 2 % faster to replace it)
+    # no spread anywhere: every candidate is tried, and the first arena stays (another must be 1 % faster to replace it)
     res, eng = run([[86.0, 87.0]] * 3 + [[85.8, 87.0]] + [[86.0, 87.0]] * 2)
     assert res["candidates"] == 6 and res["kept"] == 0 and res["sls_nt"] == 1 and eng.kept == 0
     res, eng = run([[86.0, 87.0]] * 3 + [[83.8, 87.0]] + [[86.0, 87.0]] * 2)
