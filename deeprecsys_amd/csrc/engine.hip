@@ -268,6 +268,7 @@ struct drs_engine {
   int64_t mlp_wide_kn = 256 * 1024;   // K*N from which a layer gets its own 2-D launch (RM3's 1024x256 included)
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   int64_t mlp_small_rows = 1024;      // launch sets up to this many rows: MLP side on the slot's own stream
+  int small_piped = 0;                // ... and their gather: 0 = on the slot's own stream too, 1 = on the shared gather stream
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
   double k_ms[DRS_KERNEL_COUNT] = {0, 0, 0};
@@ -1022,7 +1023,7 @@ hipStream_t job_stream(const drs_engine* e, const Slot& s, int64_t Mv) {
 // cross-stream event; short gathers of different slots may overlap -- they are latency-bound,
 // by PCIe when the inputs are read in place from host memory)
 hipStream_t job_gather_stream(const drs_engine* e, const Slot& s, int64_t Mv) {
-  return (e->shared_stream == 2 && Mv <= e->mlp_small_rows) ? s.own_stream : s.gather_stream;
+  return (e->shared_stream == 2 && Mv <= e->mlp_small_rows && !e->small_piped) ? s.own_stream : s.gather_stream;
 }
 
 // Enqueue n >= 1 coalesced queries (query i = first bs[i] samples of *bts[i]) as ONE set of
@@ -2579,6 +2580,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
+  else if (!strcmp(key, "small_piped") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->small_piped = (int)value; }
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
   else if (!strcmp(key, "mlp_stream") && value >= 0 && value <= 4 && value != 3) e->tune.mlp_stream = (int)value;
@@ -2813,7 +2815,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"din_pipe", t.din_pipe}, {"gemm_split", e->gemm_split}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"small_piped", e->small_piped}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
