@@ -115,6 +115,11 @@ struct Done {
   const float* dev_out;
   float* host_out;
   uint32_t out_words;
+  // early start (stream4_kernel, "mlp_early"): the launch does NOT wait for the gather on its stream; it runs its
+  // prologue and the first chain, then polls `wait_flag` for `wait_val` (a stream-ordered 32-bit write queued behind the
+  // gather) before it fetches the second chain's pooled rows.  nullptr: the stream orders the launch behind the gather.
+  uint32_t wait_val;
+  const uint32_t* wait_flag;
 };
 
 // y[M, N] (ld = ldy) = act(x[M, K] (ld = ldx) . W[N, K]^T + b), k-ordered fp32 MFMA chain
@@ -191,7 +196,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
 // would launch_chain2(a, &b, ..., dot) run as the stream kernel?  (With a dot interaction in
 // between it is the only kernel that can.)
 bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const Tune& tune, const XSrc* xs,
-                       const DotArgs* dot, const SumArgs* sum = nullptr);
+                       const DotArgs* dot, const SumArgs* sum = nullptr, bool* can_defer = nullptr);
 size_t chain2_lds_bytes(const ChainArgs& a, const ChainArgs& b, const Tune& tune);
 
 // T [B, F, D] (sample stride ldt) -> R [B, D + P] (ld = ldr), see drs_interact_dot

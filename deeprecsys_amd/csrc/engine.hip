@@ -113,6 +113,8 @@ struct Slot {
   hipStream_t stream = nullptr;   // the stream the job in flight launches its MLP side on
   hipStream_t base_stream = nullptr;   // ... as assigned by apply_stream_mode (shared or own)
   hipStream_t own_stream = nullptr;
+  hipStream_t early_stream = nullptr;    // "mlp_early": the MLP launch of a small set whose gather runs on own_stream
+  uint32_t* d_gflag = nullptr;           // ... and the word that launch polls: seq, written by a stream-ordered write behind the gather
   hipStream_t gather_stream = nullptr;   // where the gather is launched (== stream unless pipelined)
   hipStream_t cur = nullptr;             // "mlp_layout" 1: the stream the set's latest MLP launch went on
   hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // ... events that order a set's launches across the two kinds of stream
@@ -268,6 +270,7 @@ struct drs_engine {
   int64_t mlp_wide_kn = 256 * 1024;   // K*N from which a layer gets its own 2-D launch (RM3's 1024x256 included)
   int64_t mlp_fuse_rows = 0;          // fuse bottom+top only from this many rows on
   int64_t mlp_small_rows = 1024;      // launch sets up to this many rows: MLP side on the slot's own stream
+  int mlp_early = 0;                  // small sets of staged DLRM queries: the fused MLP launch starts beside the gather (Done::wait_flag)
   int small_piped = 0;                // ... and their gather: 0 = on the slot's own stream too, 1 = on the shared gather stream
   // profiling
   int profiling = 0;             // 0 off | 1 device clock stamps | 2 stamps + HIP events
@@ -958,7 +961,8 @@ struct FusedPlan {
   bool has_dot = false;
 };
 
-FusedPlan fused_plan(const drs_engine* e, const Slot& s, int64_t Mv, float* out, const XSrc* xs) {
+FusedPlan fused_plan(const drs_engine* e, const Slot& s, int64_t Mv, float* out, const XSrc* xs, bool* can_defer = nullptr) {
+  if (can_defer) *can_defer = false;
   FusedPlan p;
   if (!e->mlp_fuse || Mv < e->mlp_fuse_rows || e->kind != DRS_MODEL_DLRM) return p;
   const int nb = (int)e->bot.layers.size(), nt = (int)e->top.layers.size();
@@ -968,13 +972,14 @@ FusedPlan fused_plan(const drs_engine* e, const Slot& s, int64_t Mv, float* out,
   fill_chain(p.a, e->bot, 0, nb, nullptr, e->m_den, Mv, s.T, e->ldT);
   if (e->interaction_op == DRS_INTERACT_CAT) {
     fill_chain(p.b, e->top, 0, nt, s.T, e->ldT, Mv, out, e->n_out);
-    p.ok = chain2_lds_bytes(p.a, p.b, e->tune) <= kChainLds || stream_applicable(p.a, p.b, e->tune, xs, nullptr);
+    p.ok = can_defer ? (stream_applicable(p.a, p.b, e->tune, xs, nullptr, nullptr, can_defer) || chain2_lds_bytes(p.a, p.b, e->tune) <= kChainLds)
+                     : (chain2_lds_bytes(p.a, p.b, e->tune) <= kChainLds || stream_applicable(p.a, p.b, e->tune, xs, nullptr));
   } else {
     fill_chain(p.b, e->top, 0, nt, s.R, e->ldR, Mv, out, e->n_out);
     p.dot.T = s.T; p.dot.ldt = e->ldT; p.dot.F = e->T + 1; p.dot.D = e->D; p.dot.itself = e->itself;
     p.dot.R = s.R; p.dot.ldr = e->ldR;
     p.has_dot = true;
-    p.ok = stream_applicable(p.a, p.b, e->tune, xs, &p.dot);   // only the stream kernel has the interaction
+    p.ok = stream_applicable(p.a, p.b, e->tune, xs, &p.dot, nullptr, can_defer);   // only the stream kernel has the interaction
   }
   return p;
 }
@@ -1258,6 +1263,27 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     XSrc xs_top;
     memset(&xs_top, 0, sizeof xs_top);
     if (!e->bot.layers.empty()) {
+      // "mlp_early": a small set of staged queries (gather on the slot's own stream, nothing else of the set there) whose
+      // bottom + top MLP is ONE stream4_kernel launch: the launch goes on a second stream WITHOUT waiting for the gather,
+      // runs its prologue and the bottom chain beside it and polls the slot's flag -- a 32-bit write queued behind the
+      // gather -- before it fetches the pooled rows (mlp.hip, Done::wait_flag).  <= 512 rows: at most 32 workgroups spin.
+      bool early = false;
+      if (e->mlp_early && e->shared_stream == 2 && !piped && gstream == s.own_stream && Mv <= 512 && dp && s.early_stream &&
+          e->kind == DRS_MODEL_DLRM) {
+        bool staged = true;
+        for (int i = 0; i < q.n_q; ++i)
+          staged = staged && qb[i] >= e->batches.data() && qb[i] < e->batches.data() + e->batches.size();
+        if (staged) {
+          FusedPlan fp = fused_plan(e, s, Mv, out, &xs, &early);
+          early = early && fp.ok;
+        }
+      }
+      if (early) {
+        HIP_TRY(e, hipStreamWriteValue32(gstream, s.d_gflag, s.seq, 0));
+        done.wait_flag = s.d_gflag; done.wait_val = s.seq;
+        s.stream = s.early_stream;
+        log_launch(&s.dlog, "early");
+      }
       if (fused_applicable(e, s, Mv, &xs)) HIP_TRY(e, join());
       fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
       if (rc) return rc;
@@ -1804,6 +1830,9 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipMalloc(&s.d_out, sizeof(float) * out_words));
     CREATE_TRY(hipMalloc(&s.d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&s.d_counter, sizeof(uint32_t)));
+    CREATE_TRY(hipStreamCreateWithFlags(&s.early_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&s.d_gflag, sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(s.d_gflag, 0, sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s.d_err, 0, sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s.d_counter, 0, sizeof(uint32_t)));
     // coherent (fine-grained) pinned memory: device stores become visible to a polling CPU
@@ -1890,6 +1919,8 @@ int32_t drs_destroy(drs_handle e) {
     s.mq.clear();
     DTR("multi freed");
     if (s.own_stream) { (void)hipStreamSynchronize(s.own_stream); (void)hipStreamDestroy(s.own_stream); }
+    if (s.early_stream) { (void)hipStreamSynchronize(s.early_stream); (void)hipStreamDestroy(s.early_stream); }
+    if (s.d_gflag) (void)hipFree(s.d_gflag);
     DTR("own stream gone");
     if (s.ev_sls) (void)hipEventDestroy(s.ev_sls);
     if (s.ev_in) (void)hipEventDestroy(s.ev_in);
@@ -2580,6 +2611,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "sls_short_bag") && value >= -1 && value <= 1 << 20) e->sls_short_bag = (int)value;
   else if (!strcmp(key, "mlp_wide_kn") && value > 0) e->mlp_wide_kn = value;
   else if (!strcmp(key, "mlp_fuse_rows") && value >= 0) e->mlp_fuse_rows = value;
+  else if (!strcmp(key, "mlp_early") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_early = (int)value; }
   else if (!strcmp(key, "small_piped") && (value == 0 || value == 1)) { int32_t rc = drs_sync(e); if (rc) return rc; e->small_piped = (int)value; }
   else if (!strcmp(key, "mlp_small_rows") && value >= 0) { int32_t rc = drs_sync(e); if (rc) return rc; e->mlp_small_rows = value; }
   else if (!strcmp(key, "mlp_preload")) e->tune.mlp_preload = value ? 1 : 0;
@@ -2815,7 +2847,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"din_pipe", t.din_pipe}, {"gemm_split", e->gemm_split}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
       {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
-      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"small_piped", e->small_piped}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
+      {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"small_piped", e->small_piped}, {"mlp_early", e->mlp_early}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident

@@ -498,6 +498,8 @@ struct STile {
 struct SArgs {
   int32_t n_layers, n_tiles, sB_off, n_inputs;
   int32_t dbg, lds_floats;
+  int32_t wait_tile, pad0_;   // wait_tile: first step of the second chain (where a launch with Done::wait_flag waits
+                              // for the gather and fetches its second input), -1: the form has no such point
   // dot interaction between the chains (DotArgs): at tile `inter_tile` the T slab (F x D per
   // row) becomes the R slab (D + P per row, zero padded to r_pad) the second chain reads
   int32_t inter_on, inter_tile, F, D, itself, P;
@@ -1277,8 +1279,12 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   uint32_t* dl = reinterpret_cast<uint32_t*>(smem + a.lay_off);
   const int n_tab_w = 4 * n_table, n_lay_w = a.n_layers * (int)(sizeof(SLayer) / 4);
   float4 pv0[PB], pv1[PB], pv2[PB];
+  // early start ("mlp_early", plain 16-row form only): the second input -- the gather's pooled rows -- is fetched at the
+  // first step of the second chain, once the gather's flag has been seen; everything before runs beside the gather
+  constexpr bool kCanDefer = !SUM1 && !TWO && R == 1;
+  const bool defer1 = kCanDefer && done.wait_flag != nullptr && a.wait_tile > 0;   // (uniform)
   issue(rp0, cols0, 0, nj0, pv0);
-  issue(rp1, cols1, 0, nj1, pv1);
+  if (!defer1) issue(rp1, cols1, 0, nj1, pv1);
   if constexpr (sum1) issue(rp2, cols1, 0, nj1, pv2);
   // biases, descriptors and layer records ride on the same round trip
   constexpr int NBV = 1024 / kThreads, NTV = 512 / kThreads;
@@ -1322,7 +1328,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     for (int j = 0; j < PB; ++j)
       pv1[j] = make_float4(pv1[j].x + pv2[j].x, pv1[j].y + pv2[j].y, pv1[j].z + pv2[j].z, pv1[j].w + pv2[j].w);
   }
-  store(ld1, lc1, cpad1, 0, nj1, pv1);
+  if (!defer1) store(ld1, lc1, cpad1, 0, nj1, pv1);
   if (gd1) {                                     // NCF: the summed block is also kept in global memory
 #pragma unroll
     for (int j = 0; j < PB; ++j)
@@ -1338,7 +1344,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   }
   // (inputs wider than 8 x 64 columns: further batches, one round trip each)
   for (int jb = PB; jb < nj0; jb += PB) { issue(rp0, cols0, jb, nj0, pv0); store(ld0, lc0, cpad0, jb, nj0, pv0); }
-  for (int jb = PB; jb < nj1; jb += PB) {
+  for (int jb = PB; jb < (defer1 ? 0 : nj1); jb += PB) {
     issue(rp1, cols1, jb, nj1, pv1);
     if constexpr (sum1) {
       issue(rp2, cols1, jb, nj1, pv2);
@@ -1451,6 +1457,21 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     // reads complete under its MFMAs instead of after them
     const STile nx = desc(min(nti, n_table - 1));
     const Seg sn = seg_of(nx.wp_off, nx.in_ld, nx.info);
+    if constexpr (kCanDefer) {
+      if (__builtin_expect(defer1 && ti == a.wait_tile, 0)) {
+        // the gather's flag (a stream-ordered write queued behind it: its rows are in memory), then the rows
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(done.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != done.wait_val &&
+                 ++spins < (1 << 22))
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int jb = 0; jb < nj1; jb += PB) { issue(rp1, cols1, jb, nj1, pv1); store(ld1, lc1, cpad1, jb, nj1, pv1); }
+        __syncthreads();
+      }
+    }
     if (__builtin_expect((cur.info & S3_INTERACT) != 0, 0)) interact();
     TL(10);
     const Epi el = lds_epi((last_info >> 24) & 0xff);
@@ -2017,6 +2038,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   p.n_layers = n;
   p.n_tiles = tiles;
   p.n_table = 0;
+  p.wait_tile = -1; p.pad0_ = 0;
   if (f3) {
     // one descriptor per STEP of stream3_kernel: (layer, pass of nw3 x TPW tiles, 64-k chunk).
     // wp_off: chunk c of the twin's first 128-column pass; in_ld: floats between two such passes;
@@ -2030,6 +2052,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
       const int etl = (opad + 15) / 16, tpw = tpw3(L.N, opad);
       const int tpp = nw3 * tpw, npass = (etl + tpp - 1) / tpp;
       if (dot && l < na) inter_at += npass * nch;
+      if (b && !sum && l == na) p.wait_tile = ti;
       for (int ps = 0; ps < npass; ++ps)
         for (int c = 0; c < nch; ++c) {
           STile& t = p.tiles[ti];
@@ -2116,14 +2139,17 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
 }
 
 bool stream_applicable(const ChainArgs& a, const ChainArgs& b, const Tune& tune, const XSrc* xsrc,
-                       const DotArgs* dot, const SumArgs* sum) {
+                       const DotArgs* dot, const SumArgs* sum, bool* can_defer) {
   if (!tune.mlp_stream || !tune.zero) return false;
   XSrc xs;
   memset(&xs, 0, sizeof xs);
   if (xsrc) xs = *xsrc;
   SArgs sp;
   size_t lds = 0;
-  return stream_plan(a, &b, tune, xs, true, &sp, &lds, dot, sum);
+  const bool ok = stream_plan(a, &b, tune, xs, true, &sp, &lds, dot, sum);
+  // (the 16-row one-workgroup-per-CU form only: the 2cu / 32-row builds have no registers to spare for the late fetch)
+  if (can_defer) *can_defer = ok && sp.packed == 5 && sp.wait_tile > 0 && !(tune.mlp_stream == 4 && tune.mlp_stream_2cu);
+  return ok;
 }
 
 hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tune, hipStream_t s,
@@ -2153,6 +2179,10 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
         log_launch(tune.log, "%s[%u wg, %d layers%s, %zu B lds]", form, sp.packed == 6 ? (unsigned)((a.M + 31) / 32) : g3.x,
                    sp.n_layers, dot ? ", dot" : "", slds);
       }
+      if (d.wait_flag) {   // early start: only the plain stream4_kernel form has the late fetch (callers ask stream_applicable)
+        const bool plain = sp.packed == 5 && sp.in[1].col2 < 0 && !(tune.mlp_stream == 4 && tune.mlp_stream_2cu) && sp.wait_tile > 0;
+        if (!plain) return hipErrorInvalidValue;
+      }
       if (sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2>), dim3((unsigned)((a.M + 31) / 32)), dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs);
       else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs);
@@ -2163,7 +2193,7 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
       return hipGetLastError();
     }
   }
-  if (dot || sum) return hipErrorInvalidValue;   // only the stream kernel has these joins (callers check stream_applicable)
+  if (dot || sum || d.wait_flag) return hipErrorInvalidValue;   // only the stream kernel has these joins (callers check stream_applicable)
   int kc = 64, nbuf = 2, lda = 0;
   size_t lds = 0;
   if (!chain_plan(a, b, tune, &kc, &nbuf, &lds, &lda)) return hipErrorInvalidValue;

@@ -927,6 +927,9 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "unfused_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1, mlp_rows32=1),
             "pipelined_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_rows32=1),
             "pipelined_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2),
+            # early start: the launch runs its prologue and the bottom chain beside the gather and polls the slot's flag
+            # before it fetches the pooled rows (Done::wait_flag)
+            "early_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_early=1),
             "unfused_stream": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1),
             "unfused_chain": dict(mlp_stream=0, mlp_fuse=0, shared_stream=1),
             "standalone_layers": dict(mlp_stream=1, mlp_fuse=0, shared_stream=1, mlp_wide_kn=1),
@@ -940,6 +943,12 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             outs = [eng.wait(slot, sum(bs for _, bs in jobs)) for slot in (0, 1, 2)]
             assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), name
             results[name] = outs[0]
+            # (the early start is taken when the set is ONE plain stream4_kernel launch: the RMC1-class widths)
+            took_early = "early" in eng.last_dispatch(0)
+            assert not took_early or name == "early_stream4", (name, eng.last_dispatch(0))
+            if name == "early_stream4" and (D, T) == (64, 8):
+                assert took_early, eng.last_dispatch(0)
+            eng.set_option("mlp_early", 0)
             eng.set_option("mlp_wide_kn", 512 * 1024)
             eng.set_option("mlp_stream_2cu", 0)
             eng.set_option("mlp_rows32", 0)
@@ -1597,6 +1606,8 @@ def test_options_are_per_handle_and_engines_coexist():
                                    # consecutive sets overlap each other
                                    ["--workload", "rmc3_ref", "--batch", "128"], ["--workload", "wnd", "--batch", "128"],
                                    ["--set", "sls_exact=1"],
+                                   # small sets start their MLP launch beside the gather (flag poll inside the kernel)
+                                   ["--set", "mlp_early=1"],
                                    # the LDS-staged form of the stream kernel (the default reads packed twins)
                                    ["--set", "mlp_stream=1"],
                                    # DIN: the fused gather + attention launch, 1..8 queries per set (its
