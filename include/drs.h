@@ -393,6 +393,13 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
  *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
  *                MLP launches of consecutive small sets overlap each other
+ *   "small_piped" 0 (default) | 1: ... and their gather on the shared gather stream instead of the slot's own (one query
+ *                per set, 6 sets in flight: 57 k -> 64 k queries/s at p99 0.115 ms; 3 in flight: 53 k -> 47 k)
+ *   "mlp_early"  0 (default) | 1: a small set (<= 512 rows) of staged DLRM queries whose bottom + top MLP is one plain
+ *                stream4_kernel launch starts that launch beside its gather: prologue and bottom chain run, then the
+ *                launch polls a per-slot flag (a stream-ordered write behind the gather) before it fetches the pooled
+ *                rows.  Same bits; measured slower with HIP's stream-ordered write (a kernel of its own), see
+ *                profiles/r05_single_query/README.md
  *   "table_placement" where the table arena lives.  A multi-gigabyte allocation's place in HBM moves the gather by
  *                up to 6 % and stays for the allocation's lifetime; a feeder that has staged its input sets can
  *                try a few: -1 = copy the tables into one more allocation and use that one (the earlier ones stay

@@ -946,7 +946,7 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             # (the early start is taken when the set is ONE plain stream4_kernel launch: the RMC1-class widths)
             took_early = "early" in eng.last_dispatch(0)
             assert not took_early or name == "early_stream4", (name, eng.last_dispatch(0))
-            if name == "early_stream4" and (D, T) == (64, 8):
+            if name == "early_stream4" and (D, T, op) == (64, 8, "cat"):
                 assert took_early, eng.last_dispatch(0)
             eng.set_option("mlp_early", 0)
             eng.set_option("mlp_wide_kn", 512 * 1024)
