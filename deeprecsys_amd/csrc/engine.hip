@@ -1520,9 +1520,11 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out, int64_t h_cap = -1) {
     s.ts_blocks = 0;
   }
   if (s.last_bs > 0 && s.h_out[1] != 0) {
+    const uint32_t bits = s.h_out[1];
     s.h_out[1] = 0;
     HIP_TRY(e, hipMemsetAsync(s.d_err, 0, sizeof(uint32_t), s.stream));
     HIP_TRY(e, hipStreamSynchronize(s.stream));
+    if (bits & 2u) return fail(e, DRS_ERR_HIP, "mlp_early: the gather's flag never reached the MLP launch");
     return fail(e, DRS_ERR_INDEX_RANGE, "an embedding index was out of range on the device");
   }
   if (h_out && s.last_bs > 0) {

@@ -1465,6 +1465,9 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
           while (__hip_atomic_load(done.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != done.wait_val &&
                  ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(4);
+          // (bounded: a flag that never comes must not hang the GPU -- bit 1 of the device error word makes the
+          // host fail the set instead of handing out sums over rows that were not there yet)
+          if (spins >= (1 << 22) && done.dev_err) atomicOr(const_cast<uint32_t*>(done.dev_err), 2u);
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
