@@ -77,6 +77,15 @@ struct Tune {
   int gemm32_blocks = 512;       // ... when its 128 x 128 workgroups number at least this many (two per CU)
   int64_t mlp_rows32 = 0;        // stream4_kernel: launches of at least this many rows take 32 rows per workgroup (0 = never)
   DispatchLog* log = nullptr;    // where the launch functions note what they chose (the slot being enqueued; may be null)
+  // stream4_kernel's column-split form (mlp.hip SArgs::ns): launches of at most mlp_nsplit_rows rows spread the first
+  // layer of the second chain over mlp_nsplit (0 = never | 2 | 4) workgroups per slab of rows.  xbuf / xcnt: the
+  // exchange buffer ([xbuf_rows, xbuf_cols] floats) and ticket words of the slot being enqueued (like `log`).
+  int mlp_nsplit = 0;
+  int64_t mlp_nsplit_rows = 0;
+  float* xbuf = nullptr;
+  uint32_t* xcnt = nullptr;
+  int64_t xbuf_rows = 0;
+  int32_t xbuf_cols = 0;
 };
 // Once per DEVICE (thread-safe): the > 64 KB dynamic-LDS attribute of every kernel that needs
 // it (HIP function attributes are per device) and the device's zero page.

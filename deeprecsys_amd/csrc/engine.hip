@@ -131,6 +131,10 @@ struct Slot {
   float* d_out = nullptr;    // [max_batch*n_out] device outputs (copy path only)
   uint32_t* d_err = nullptr; // device error word (bit0: index out of range)
   uint32_t* d_counter = nullptr;  // arrival counter of the completion hand-off
+  float* xbuf = nullptr;          // stream4_kernel's column-split form: exchange buffer [xrows, xcols] of the split layer's outputs ...
+  uint32_t* xcnt = nullptr;       // ... and one arrival ticket per 16-row slab (zero between launches)
+  int64_t xrows = 0;
+  int32_t xcols = 0;
   uint32_t* h_out = nullptr; // pinned host: [flag | err | outputs...]
   uint32_t* dm_out = nullptr;// the same memory as seen from the device (zero-copy path)
   uint32_t seq = 0;          // sequence number of the query in flight on this slot
@@ -1112,6 +1116,9 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   s.cur = nullptr;               // (the set's first MLP launch needs no event: join() orders it behind the gather)
   s.dlog.len = 0; s.dlog.text[0] = 0;
   e->tune.log = &s.dlog;         // the launch functions note what they choose for this set (drs_last_dispatch)
+  e->tune.xbuf = s.xbuf; e->tune.xcnt = s.xcnt; e->tune.xbuf_rows = s.xrows; e->tune.xbuf_cols = s.xcols;
+  // (both belong to THIS slot: launches made outside this function -- the operator-level entry points -- must not see them)
+  struct TuneScope { Tune& t; ~TuneScope() { t.log = nullptr; t.xbuf = nullptr; t.xcnt = nullptr; } } tune_scope{e->tune};
   log_launch(&s.dlog, "set[%d queries, %d rows, gather on %s, mlp on %s]", q.n_q, (int)Mv,
              job_gather_stream(e, s, Mv) == e->stream_g ? "stream_g" : "own", s.stream == s.own_stream ? "own" : "shared");
   const hipStream_t gstream = job_gather_stream(e, s, Mv);
@@ -1631,6 +1638,11 @@ static void choose_launch_forms(drs_engine* e) {
   // two workgroups per CU (the 128-VGPR builds) for every model whose MLP launches overlap each other (DIEN +8 %, W&D +5 %,
   // MT-WnD +4 %, DIN +3 %, RM3 +2 %; NCF -2 %; gather-bound DLRM keeps one per CU: 54.6 k against 53.4 k at one query per set)
   e->tune.mlp_stream_2cu = e->kind != DRS_MODEL_NCF && !gather_bound_dlrm;
+  // column-split form of the fused DLRM launch (mlp.hip NSplit): launch sets of one or two queries spread their widest
+  // layer over four workgroups per slab of rows (RMC1, one query per set: 54.3 k -> 59.5 k queries/s, two: 84.7 k ->
+  // 87-91 k, three: equal, four: 103 k -> 89 k -- 256 workgroups that each repeat the bottom chain; profiles/r06_nsplit/)
+  e->tune.mlp_nsplit_rows = 512;
+  e->tune.mlp_nsplit = dlrm ? 4 : 0;      // (dlrm_rm1.json: 65.0 k -> 73.5 k, 111.9 k -> 120.0 k; dot interaction: equal, +5 %)
   // wide layers: two 64 x 64 gemm_kernel workgroups per CU where that measured faster; gemm32_kernel's 64 x 128 workgroups
   // for launches below 512 tiles of 128 x 128 when they number at least "mlp_gemm32_small_blocks" (k queries/s, off | >= 0 | >= 512:
   // MT-WnD 69.2 | 71.8 | 66.4; RM3 reference JSON 66.5 | 68.1 | 72.2; RM3 config 3 34.8 | 35.2 | 34.7; W&D 96.0 | 94.7 | 97.0)
@@ -1837,6 +1849,14 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipMemset(s.d_gflag, 0, sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s.d_err, 0, sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s.d_counter, 0, sizeof(uint32_t)));
+    // column-split MLP launches (mlp.hip NSplit; DLRM's first top layer): up to 4 096 rows of that layer's outputs
+    if (e->kind == DRS_MODEL_DLRM && e->top.ln.size() >= 3 && e->top.ln[1] >= 128 && e->top.ln[1] <= 1024 && !(e->top.ln[1] & 63)) {
+      s.xrows = e->max_rows < 4096 ? e->max_rows : 4096;
+      s.xcols = e->top.ln[1];
+      CREATE_TRY(hipMalloc(&s.xbuf, sizeof(float) * (size_t)s.xrows * s.xcols));
+      CREATE_TRY(hipMalloc(&s.xcnt, sizeof(uint32_t) * (size_t)(s.xrows / 16 + 1)));
+      CREATE_TRY(hipMemset(s.xcnt, 0, sizeof(uint32_t) * (size_t)(s.xrows / 16 + 1)));
+    }
     // coherent (fine-grained) pinned memory: device stores become visible to a polling CPU
     CREATE_TRY(hipHostMalloc(&s.h_out, sizeof(uint32_t) * out_words, hipHostMallocMapped | hipHostMallocCoherent));
     memset(s.h_out, 0, sizeof(uint32_t) * out_words);
@@ -1939,6 +1959,8 @@ int32_t drs_destroy(drs_handle e) {
     if (s.h_span) (void)hipHostFree(s.h_span);
     if (s.d_span_acc) (void)hipFree(s.d_span_acc);
     if (s.d_counter) (void)hipFree(s.d_counter);
+    if (s.xbuf) (void)hipFree(s.xbuf);
+    if (s.xcnt) (void)hipFree(s.xcnt);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_stage) (void)hipHostFree(s.h_stage);
     if (s.d_stage) (void)hipFree(s.d_stage);
@@ -2629,6 +2651,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   else if (!strcmp(key, "mlp_gemm32_blocks") && value >= 1 && value <= 65536) e->tune.gemm32_blocks = (int)value;
   else if (!strcmp(key, "mlp_debug")) e->tune.mlp_debug = (int)value;
   else if (!strcmp(key, "mlp_rows32") && value >= 0) e->tune.mlp_rows32 = value;
+  else if (!strcmp(key, "mlp_nsplit") && (value == 0 || value == 2 || value == 4)) e->tune.mlp_nsplit = (int)value;
+  else if (!strcmp(key, "mlp_nsplit_rows") && value >= 0) e->tune.mlp_nsplit_rows = value;
   else if (!strcmp(key, "mlp_kc") && (value == 0 || value == 64 || value == 128 || value == 192 || value == 256)) e->tune.mlp_kc = (int)value;
   else if (!strcmp(key, "table_placement")) {
     // Where a multi-gigabyte allocation lands in HBM moves the gather by up to 6 % and stays for the allocation's
@@ -2854,7 +2878,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
       // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
       {"preferred_slots", e->kind == DRS_MODEL_NCF ? 6 : 3}, {"mlp_stream", t.mlp_stream}, {"mlp_preload", t.mlp_preload}, {"mlp_kc", t.mlp_kc},
-      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"gather_bound", e->gather_bound},
+      {"mlp_debug", t.mlp_debug}, {"mlp_rows32", t.mlp_rows32}, {"mlp_nsplit", t.mlp_nsplit}, {"mlp_nsplit_rows", t.mlp_nsplit_rows}, {"shared_stream", e->shared_stream}, {"mlp_streams", e->mlp_streams}, {"mlp_layout", e->mlp_layout}, {"gather_bound", e->gather_bound},
       {"zero_copy_inputs", e->zero_copy_inputs}, {"host_threads", e->host_threads}, {"launch_thread", e->launch_thread}, {"zero_copy", e->zero_copy}, {"out_dma", e->out_dma}, {"device", e->device},
       {"table_placement", (int64_t)(std::find_if(e->arenas.begin(), e->arenas.end(), [&](const Arena& a) { return a.p == e->tables; }) - e->arenas.begin())},
       {"table_placements", (int64_t)e->arenas.size()}, {"table_bytes", (int64_t)e->tables_bytes},

@@ -38,8 +38,8 @@ __device__ unsigned g_tl_n;
 // stamps go to a spare 8 KB at the very end of the dynamic LDS (no global traffic while the
 // kernel runs); thread 0 of workgroup 0 flushes them at the end
 #define TL_SLOTS 1000
-__device__ __forceinline__ void tl_stamp(unsigned long long* tl, unsigned tag) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+__device__ __forceinline__ void tl_stamp(unsigned long long* tl, unsigned tag, bool on) {
+  if (on && threadIdx.x == 0) {
     const unsigned i = (unsigned)tl[0];
     if (i + 1 < TL_SLOTS) {
       tl[i + 1] = ((unsigned long long)tag << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull);
@@ -47,7 +47,8 @@ __device__ __forceinline__ void tl_stamp(unsigned long long* tl, unsigned tag) {
     }
   }
 }
-#define TL(tag) tl_stamp(g_tl_lds, tag)
+#define TL_ON (blockIdx.x == 0 && blockIdx.y == 0)      // (stream4_kernel: every workgroup of slab 0 stamps, the one that signs off flushes)
+#define TL(tag) tl_stamp(g_tl_lds, tag, TL_ON)
 #define TL_DECL unsigned long long* g_tl_lds
 #define TL_ARG , g_tl_lds
 #define TL_PARAM , unsigned long long* g_tl_lds
@@ -498,8 +499,9 @@ struct STile {
 struct SArgs {
   int32_t n_layers, n_tiles, sB_off, n_inputs;
   int32_t dbg, lds_floats;
-  int32_t wait_tile, pad0_;   // wait_tile: first step of the second chain (where a launch with Done::wait_flag waits
+  int32_t wait_tile, ns;      // wait_tile: first step of the second chain (where a launch with Done::wait_flag waits
                               // for the gather and fetches its second input), -1: the form has no such point
+                              // ns: column slices of the split layer (stream4_kernel<..., SPL>; 0: none), see below
   // dot interaction between the chains (DotArgs): at tile `inter_tile` the T slab (F x D per
   // row) becomes the R slab (D + P per row, zero padded to r_pad) the second chain reads
   int32_t inter_on, inter_tile, F, D, itself, P;
@@ -522,6 +524,20 @@ struct SArgs {
   int32_t n_table, warm_bytes;   // warm_off / warm_bytes: the arena range holding this launch's packed twins (stream3_kernel's L2 warm-up)
   int32_t tab_off, lay_off;   // LDS float offsets of the copies of tiles[] and L[] the loop reads
   STile tiles[DRS_MAX_STREAM_TILES];
+};
+// Column-split form of stream4_kernel (SArgs::ns = 2 | 4): `ns` workgroups share a slab of rows.  Each runs everything up
+// to the split layer (steps [t0, t1) of the table: the first layer of the second chain, RMC1's 576 -> 256) for ALL of the
+// slab's rows, but only `tps` of that layer's column tiles (tiles tps y ...: one pass, 4 waves x tps / 4 tiles); it
+// publishes its [rows, 16 tps] piece of the layer's output slab (LDS offset `off`, leading dimension `ld`, `n` columns)
+// write-through in xbuf and takes a ticket on xcnt[slab]; the last arriver fetches the other pieces and runs the
+// remaining layers.  The split is over N: every output keeps its k-ordered chain -- same bits.
+// A kernel argument of its own BEHIND the others: grown into SArgs, it moved tiles[], Done and XSrc inside the argument
+// block, the compiler cut its scalar loads differently and the 32-row build -- 106 SGPRs, 17 more in VGPR lanes -- came
+// out with a (never accessed) 36-byte private segment, i.e. a launch that needs scratch set up.
+struct NSplit {
+  int32_t t0, t1, tps, n, off, ld;
+  float* xbuf;                // [launch rows, n] in the slab's column order
+  uint32_t* xcnt;             // [slabs] arrival tickets, zero between launches
 };
 
 
@@ -1175,19 +1191,36 @@ __device__ __forceinline__ int lpos(int c) { return (c & ~15) | ((c & 3) << 2) |
 // R: 16-row slabs per workgroup (1 | 2).  R = 2: a workgroup owns 32 rows as two halves that share every
 // weight operand -- twice the MFMAs per byte of weights streamed from L2 and per fixed cost of a
 // workgroup; taken for launches of many rows whose slabs still fit LDS ("mlp_rows32").
-template <bool SUM1, bool TWO, int R = 1>
-__global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done done, XSrc xs) {
+// SPL: the column-split form (SArgs::ns): blockIdx.x = slab of rows * ns + column slice.  Consecutive workgroups go to
+// consecutive XCDs, so slice y of every slab runs on the XCDs k with k % ns == y: an XCD's L2 holds only its slice of
+// the split layer's weights (a speed matter only: nothing depends on the placement).
+template <bool SUM1, bool TWO, int R = 1, bool SPL = false>
+__global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done done, XSrc xs, NSplit sp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kThreads = 256;
+  if constexpr (SPL) {          // (NSplit's line of the argument block rides on the burst below)
+    static_assert(sizeof(SArgs) + sizeof(Done) + sizeof(XSrc) == 0xd00, "offset of the NSplit argument");
+    uint32_t t_;
+    asm volatile("s_load_dword %0, %1, 0xd00" : "=&s"(t_) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+  }
   kernarg_burst();
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   static_assert(R == 1 || (R == 2 && !TWO && !SUM1), "32-row form: one workgroup per CU, no summed input");
-  const int64_t m0 = (int64_t)blockIdx.x * (16 * R);
+  static_assert(!SPL || (!TWO && !SUM1), "column-split form: one workgroup per CU, no summed input");
+  const int ns_y = SPL ? (int)(blockIdx.x % (unsigned)a.ns) : 0;            // my column slice of the split layer
+  const unsigned slab = SPL ? blockIdx.x / (unsigned)a.ns : blockIdx.x;     // my slab of 16 R rows
+  const int64_t m0 = (int64_t)slab * (16 * R);
+  // stores of the chains' outputs to GLOBAL memory: one workgroup per slab makes them (slice 0 before the split layer,
+  // the last arriver behind it)
+  bool gw = !SPL || ns_y == 0;
 #ifdef DRS_TIMELINE
   unsigned long long* g_tl_lds = reinterpret_cast<unsigned long long*>(smem + a.lds_floats);
   if (threadIdx.x == 0) g_tl_lds[0] = 0;
+  const bool tl_on = slab == 0;
+#undef TL_ON
+#define TL_ON tl_on
 #endif
   TL(1);
   const float* zero = a.zero;
@@ -1198,11 +1231,13 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   // A wave's tiles in a segment: byte offsets (from the arena) of their 4-KB blocks in chunk 0, + 16 lane;
   // nex = how many of its tpw tiles exist in the twin (the others are requested from tile 0's address)
   struct Seg { uint32_t off[4]; int nex, tpw, nch; };
-  auto seg_of = [&](uint32_t wp_off, int pstride, int info) {
+  // (tadd: the split layer's steps name slice 0's tiles; slice y works ns_tps y tiles further on)
+  auto tadd_of = [&](int i) { return SPL && i >= sp.t0 && i < sp.t1 ? ns_y * sp.tps : 0; };
+  auto seg_of = [&](uint32_t wp_off, int pstride, int info, int tadd) {
     Seg q;
     q.tpw = (info >> S3_TPW_SHIFT) & 7;
     q.nch = pstride >> 13;
-    const int tile0 = info & 0xff, ntl = (info >> 8) & 0xff;
+    const int tile0 = (info & 0xff) + tadd, ntl = (info >> 8) & 0xff;
     const int t0 = tile0 + q.tpw * wave;
     q.nex = min(max(ntl - t0, 0), q.tpw);
 #pragma unroll
@@ -1249,7 +1284,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   float* const ld0 = smem + in0.lds_off + prow * in0.lds_ld;
   float* const ld1 = smem + in1.lds_off + prow * in1.lds_ld;
   const int lc0 = in0.lds_col0 + pk0, lc1 = in1.lds_col0 + pk0;
-  float* const gd1 = in1.g_dst && m0 + prow < a.M ? in1.g_dst + (m0 + prow) * in1.g_ldd : nullptr;
+  float* const gd1 = in1.g_dst && m0 + prow < a.M && !SPL ? in1.g_dst + (m0 + prow) * in1.g_ldd : nullptr;
   // (a load beyond the block's real columns reads the zero page: an address select keeps it unconditional)
   auto issue = [&](const float* rp, int cols, int jb, int nj, float4 (&v)[PB]) {
 #pragma unroll
@@ -1281,7 +1316,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   float4 pv0[PB], pv1[PB], pv2[PB];
   // early start ("mlp_early", plain 16-row form only): the second input -- the gather's pooled rows -- is fetched at the
   // first step of the second chain, once the gather's flag has been seen; everything before runs beside the gather
-  constexpr bool kCanDefer = !SUM1 && !TWO && R == 1;
+  constexpr bool kCanDefer = !SUM1 && !TWO && R == 1 && !SPL;
   const bool defer1 = kCanDefer && done.wait_flag != nullptr && a.wait_tile > 0;   // (uniform)
   issue(rp0, cols0, 0, nj0, pv0);
   if (!defer1) issue(rp1, cols1, 0, nj1, pv1);
@@ -1319,7 +1354,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   // chunk 0 of the first segment (descriptor straight from the arguments: its LDS copy is not there yet)
   {
     const STile e0 = a.tiles[0];
-    prefetch(seg_of(e0.wp_off, e0.in_ld, e0.info), 0);
+    prefetch(seg_of(e0.wp_off, e0.in_ld, e0.info, tadd_of(0)), 0);
   }
   __builtin_amdgcn_sched_barrier(0);
   store(ld0, lc0, cpad0, 0, nj0, pv0);
@@ -1381,9 +1416,9 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
         continue;                                 // the pairs: on the matrix cores, below
       }
       Rs[row * a.r_ld + lpos(c)] = v;
-      if (a.g_R && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
+      if (a.g_R && gw && c < D + a.P && m0 + row < a.M) a.g_R[(m0 + row) * a.g_ldr + c] = v;
     }
-    interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16 * R, a.F, D, a.itself, a.g_R, a.g_ldr, m0, a.M, kThreads / 64,
+    interact_pairs_mfma(Ts, a.t_ld, Rs, a.r_ld, 16 * R, a.F, D, a.itself, gw ? a.g_R : nullptr, a.g_ldr, m0, a.M, kThreads / 64,
                           tid >> 6, tid & 63, [](int c, int) { return lpos(c); });
     __syncthreads();
   };
@@ -1422,7 +1457,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
 #pragma unroll
       for (int i = 0; i < 4; ++i) dst[i * el.out_ld] = col < el.N ? v[i] : 0.f;
     }
-    if (el.g_out && col < el.N) {                // the last layer of a chain
+    if (el.g_out && gw && col < el.N) {          // the last layer of a chain
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t row = m0 + rowoff + g * 4 + i;
@@ -1448,7 +1483,9 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
   };
   int ti = 0, par = 0;          // par: the ring slot this wave's chunk 0 of the segment was requested into
   STile cur = desc(0);
-  Seg sg = seg_of(cur.wp_off, cur.in_ld, cur.info);
+  int tadd = tadd_of(0);
+  Seg sg = seg_of(cur.wp_off, cur.in_ld, cur.info, tadd);
+  bool alive = true;            // (column-split form: false once another workgroup has taken my slab over)
   while (ti < n_table) {
     const int nti = ti + sg.nch;
     const int last_info = __builtin_amdgcn_readfirstlane(s_tab[4 * (nti - 1) + 3]);
@@ -1456,7 +1493,8 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     // and everything the epilogue needs from LDS -- layer record, biases -- BEFORE the statement: the
     // reads complete under its MFMAs instead of after them
     const STile nx = desc(min(nti, n_table - 1));
-    const Seg sn = seg_of(nx.wp_off, nx.in_ld, nx.info);
+    const int tadd_n = tadd_of(min(nti, n_table - 1));
+    const Seg sn = seg_of(nx.wp_off, nx.in_ld, nx.info, tadd_n);
     if constexpr (kCanDefer) {
       if (__builtin_expect(defer1 && ti == a.wait_tile, 0)) {
         // the gather's flag (a stream-ordered write queued behind it: its rows are in memory), then the rows
@@ -1479,7 +1517,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
     TL(10);
     const Epi el = lds_epi((last_info >> 24) & 0xff);
     const int tpw = sg.tpw;
-    const int col0 = ((cur.info & 0xff) + tpw * wave) * 16 + r;
+    const int col0 = ((cur.info & 0xff) + tadd + tpw * wave) * 16 + r;
     const int lim = el.out_off >= 0 ? max(el.out_pad, el.N) : el.N;
     float* const dst = smem + el.out_off + (g * 4) * el.out_ld + lpos(col0 + el.out_col0);
     if (sg.nex > 0) {
@@ -1561,17 +1599,75 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
       prefetch(sn, par);
     }
     if (last_info & S3_BARRIER) { TL(13); __syncthreads(); TL(14); }
+    if constexpr (SPL) {
+      if (nti == sp.t1) {      // (uniform) the split layer is done: my piece of its output slab is in LDS
+        // ---- the seam (cdna guide G16 R1, "splitk-seam"): piece -> exchange buffer by 16-byte write-through stores,
+        // every wave drains, one lane takes the slab's ticket; whoever draws the last one has every piece visible.
+        // The buffer keeps the slab's own column order (lpos permutes inside 16-column blocks; a piece is whole blocks).
+        const int cw4 = sp.tps * 4;                       // float4 per row of a piece
+        const int n4 = sp.n >> 2;                         // ... of the whole row
+        float* const xrow = sp.xbuf + (size_t)m0 * sp.n;
+        const float* const sl = smem + sp.off;
+        for (int i = tid; i < 16 * R * cw4; i += kThreads) {
+          const int row = i / cw4, c4 = ns_y * cw4 + (i - row * cw4);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sl + row * sp.ld + 4 * c4);
+          float* dstx = xrow + (size_t)row * sp.n + 4 * c4;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dstx), "v"(v) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory", SEG_AGPR_CLOBBER);
+        __syncthreads();
+        TL(15);
+        // (the chains' first input slab sits at LDS offset 0 and is dead since layer 0: its first word carries the verdict)
+        unsigned* const s_last = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) {
+          const unsigned old = __hip_atomic_fetch_add(sp.xcnt + slab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == (unsigned)a.ns - 1) __hip_atomic_store(sp.xcnt + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_last[0] = old == (unsigned)a.ns - 1;
+        }
+        __syncthreads();
+        alive = s_last[0] != 0;
+        TL(16);
+        if (!alive) break;
+        // last arriver: the other pieces, device-coherent loads (the producers stored write-through), four in flight
+        const int o4 = n4 - cw4;                            // float4 per row that are not mine
+        for (int i0 = 0; i0 < 16 * R * o4; i0 += 4 * kThreads) {
+          f32x4 v[4];
+          int at[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = min(i0 + tid + j * kThreads, 16 * R * o4 - 1);
+            const int row = i / o4, c = i - row * o4;
+            const int c4 = c < ns_y * cw4 ? c : c + cw4;    // skip my own piece
+            at[j] = row * sp.ld + 4 * c4;
+            const float* src = xrow + (size_t)row * sp.n + 4 * c4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[j]) : "v"(src));
+          }
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i0 + tid + j * kThreads < 16 * R * o4)
+              *reinterpret_cast<float4*>(smem + sp.off + at[j]) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
+        __syncthreads();
+        TL(17);
+        gw = true;
+      }
+    }
     ti = nti;
     cur = nx;
+    tadd = tadd_n;
     sg = sn;
   }
 #undef S4_ACC_READ
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory", SEG_AGPR_CLOBBER);   // the trailing request
   TL(20);
+  if constexpr (SPL) {
+    if (alive) signal_done(done, gridDim.x / (unsigned)a.ns, smem, (int)slab);
+  } else
   signal_done(done, gridDim.x, smem);
 #ifdef DRS_TIMELINE
   TL(21);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (tl_on && alive && threadIdx.x == 0) {
     const unsigned n = (unsigned)g_tl_lds[0];
     unsigned base = g_tl_n;
     for (unsigned i = 0; i < n && base + i < 16384; ++i) g_tl[base + i] = g_tl_lds[i + 1];
@@ -1580,6 +1676,10 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void stream4_kernel(SArgs a, Done
 #endif
 }
 
+#ifdef DRS_TIMELINE
+#undef TL_ON
+#define TL_ON (blockIdx.x == 0 && blockIdx.y == 0)
+#endif
 // The packed twin of a layer's weights (stream_kernel<true>): tile (pass p, chunk c) = 8192 floats,
 // wave w's block = 1024, float4 q of lane (r, g) = { W[128 p + 16 w + r][64 c + 16 q + 4 j + g] : j = 0..3 },
 // i.e. element j of float4 q is the B operand of MFMA step s = 4 q + j (k = 64 c + 4 s + g: natural
@@ -1771,6 +1871,8 @@ hipError_t mlp_set_attrs() {
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<true, false>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, true>);
   if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false, 2>);
+  if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false, 1, true>);
+  if (e == hipSuccess) e = set_max_lds(stream4_kernel<false, false, 2, true>);
   if (e == hipSuccess) e = set_max_lds(interact_dot_kernel);
   return e;
 }
@@ -1861,8 +1963,10 @@ static inline int pad64(int n) { return (n + 63) & ~63; }
 // Lay the chain(s) out for stream_kernel.  false = not applicable (caller uses chain_kernel).
 static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune, const XSrc& xs,
                         bool publish, SArgs* out, size_t* lds_bytes, const DotArgs* dot = nullptr,
-                        const SumArgs* sum = nullptr) {
+                        const SumArgs* sum = nullptr, bool d_wait = false /* the launch polls Done::wait_flag */,
+                        NSplit* nsp = nullptr) {
   SArgs& p = *out;
+  if (nsp) memset(nsp, 0, sizeof *nsp);
   memset(&p, 0, sizeof p);
   const int na = a.n_layers, nb = b ? b->n_layers : 0;
   if (na + nb > DRS_MAX_STREAM_LAYERS) return false;
@@ -1934,6 +2038,17 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
     return ((etl + tpp - 1) / tpp) * ((K + 63) / 64);
   };
   bool f3 = pk && f4;
+  // Column-split form ("mlp_nsplit"; SArgs::ns): the first layer of the second chain over ns workgroups per slab of rows.
+  // A slice is ONE pass of the four waves: N / ns in {64, 128, 256} columns (1 / 2 / 4 tiles per wave), N a multiple of
+  // 64 (no zero pad in the slab), and the layer must hand its outputs on through LDS (not the chain's last).
+  int ns = 0;
+  if (f3 && b && !sum && nb >= 2 && tune.mlp_nsplit >= 2 && tune.xbuf && tune.xcnt && !d_wait &&
+      a.M <= tune.mlp_nsplit_rows && a.M <= tune.xbuf_rows && b->width[1] <= tune.xbuf_cols && !(b->width[1] & 63)) {
+    for (int S = tune.mlp_nsplit >= 4 ? 4 : 2; S >= 2 && !ns; S >>= 1) {
+      const int cw = b->width[1] / S;
+      if (b->width[1] % S == 0 && (cw == 64 || cw == 128 || cw == 256)) ns = S;
+    }
+  }
   if (f3) {
     int st = 0;
     for (int l = 0; l < na; ++l) {
@@ -1941,7 +2056,9 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
       if (l == na - 1 && b && sum) op = pad64(b->width[0]) - sum->cols;
       st += steps3(a.width[l], a.width[l + 1], op);
     }
-    for (int l = 0; l < nb; ++l) st += steps3(b->width[l], b->width[l + 1], l == nb - 1 ? b->width[l + 1] : pad64(b->width[l + 1]));
+    for (int l = 0; l < nb; ++l)
+      st += l == 0 && ns ? (b->width[0] + 63) / 64
+                         : steps3(b->width[l], b->width[l + 1], l == nb - 1 ? b->width[l + 1] : pad64(b->width[l + 1]));
     for (int l = 0; l < na; ++l) f3 = f3 && a.width[l + 1] <= 4080 && a.width[l] <= 4096;
     for (int l = 0; l < nb; ++l) f3 = f3 && b->width[l + 1] <= 4080 && b->width[l] <= 4096;
     f3 = f3 && st <= DRS_MAX_STREAM_TILES;
@@ -2041,7 +2158,7 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
   p.n_layers = n;
   p.n_tiles = tiles;
   p.n_table = 0;
-  p.wait_tile = -1; p.pad0_ = 0;
+  p.wait_tile = -1; p.ns = 0;
   if (f3) {
     // one descriptor per STEP of stream3_kernel: (layer, pass of nw3 x TPW tiles, 64-k chunk).
     // wp_off: chunk c of the twin's first 128-column pass; in_ld: floats between two such passes;
@@ -2052,10 +2169,16 @@ static bool stream_plan(const ChainArgs& a, const ChainArgs* b, const Tune& tune
       const SLayer& L = p.L[l];
       const int nch = (L.K + 63) / 64, ntl = (L.N + 15) / 16;
       const int opad = L.out_off >= 0 && L.out_pad > L.N ? L.out_pad : L.N;
-      const int etl = (opad + 15) / 16, tpw = tpw3(L.N, opad);
-      const int tpp = nw3 * tpw, npass = (etl + tpp - 1) / tpp;
+      const bool split = ns && l == na;      // this launch's split layer: the table names slice 0's tiles (one pass)
+      const int etl = (opad + 15) / 16, tpw = split ? L.N / ns / 64 : tpw3(L.N, opad);
+      const int tpp = nw3 * tpw, npass = split ? 1 : (etl + tpp - 1) / tpp;
       if (dot && l < na) inter_at += npass * nch;
       if (b && !sum && l == na) p.wait_tile = ti;
+      if (split) {
+        p.ns = ns;
+        if (nsp) { nsp->t0 = ti; nsp->t1 = ti + nch; nsp->tps = tpp; nsp->n = L.N; nsp->off = L.out_off; nsp->ld = L.out_ld;
+                   nsp->xbuf = tune.xbuf; nsp->xcnt = tune.xcnt; }
+      }
       for (int ps = 0; ps < npass; ++ps)
         for (int c = 0; c < nch; ++c) {
           STile& t = p.tiles[ti];
@@ -2169,27 +2292,32 @@ hipError_t launch_chain2(const ChainArgs& a, const ChainArgs* b, const Tune& tun
   if (tune.mlp_stream && tune.zero) {
     SArgs sp;
     size_t slds = 0;
-    if (stream_plan(a, b, tune, xs, d.counter != nullptr, &sp, &slds, dot, sum)) {
+    NSplit nsp;
+    if (stream_plan(a, b, tune, xs, d.counter != nullptr, &sp, &slds, dot, sum, d.wait_flag != nullptr, &nsp)) {
 #ifdef DRS_TIMELINE
       slds += 8192;
 #endif
       const dim3 g3((unsigned)((a.M + 15) / 16));
       {
         // which form serves this launch (drs_last_dispatch; DESIGN.md dispatch table)
-        const char* form = sp.packed == 6 ? "stream4_kernel<rows32>" :
+        const char* form = sp.ns ? (sp.packed == 6 ? (sp.ns == 4 ? "stream4_kernel<rows32,nsplit4>" : "stream4_kernel<rows32,nsplit2>")
+                                                    : (sp.ns == 4 ? "stream4_kernel<nsplit4>" : "stream4_kernel<nsplit2>")) :
+            sp.packed == 6 ? "stream4_kernel<rows32>" :
             sp.packed == 5 ? (sp.in[1].col2 >= 0 ? "stream4_kernel<sum>" : (tune.mlp_stream == 4 && tune.mlp_stream_2cu) ? "stream4_kernel<2cu>" : "stream4_kernel") :
             sp.packed ? ((tune.mlp_stream_2cu && sp.n_table > 0) ? "stream_kernel<packed,2cu>" : "stream_kernel<packed>") : "stream_kernel<lds>";
-        log_launch(tune.log, "%s[%u wg, %d layers%s, %zu B lds]", form, sp.packed == 6 ? (unsigned)((a.M + 31) / 32) : g3.x,
+        log_launch(tune.log, "%s[%u wg, %d layers%s, %zu B lds]", form, (sp.packed == 6 ? (unsigned)((a.M + 31) / 32) : g3.x) * (sp.ns ? sp.ns : 1),
                    sp.n_layers, dot ? ", dot" : "", slds);
       }
       if (d.wait_flag) {   // early start: only the plain stream4_kernel form has the late fetch (callers ask stream_applicable)
         const bool plain = sp.packed == 5 && sp.in[1].col2 < 0 && !(tune.mlp_stream == 4 && tune.mlp_stream_2cu) && sp.wait_tile > 0;
         if (!plain) return hipErrorInvalidValue;
       }
-      if (sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2>), dim3((unsigned)((a.M + 31) / 32)), dim3(256), slds, s, sp, d, xs);
-      else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs);
-      else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs);
-      else if (sp.packed == 5) hipLaunchKernelGGL((stream4_kernel<false, false>), g3, dim3(256), slds, s, sp, d, xs);
+      if (sp.ns && sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2, true>), dim3((unsigned)((a.M + 31) / 32) * sp.ns), dim3(256), slds, s, sp, d, xs, nsp);
+      else if (sp.ns) hipLaunchKernelGGL((stream4_kernel<false, false, 1, true>), dim3(g3.x * sp.ns), dim3(256), slds, s, sp, d, xs, nsp);
+      else if (sp.packed == 6) hipLaunchKernelGGL((stream4_kernel<false, false, 2>), dim3((unsigned)((a.M + 31) / 32)), dim3(256), slds, s, sp, d, xs, nsp);
+      else if (sp.packed == 5 && sp.in[1].col2 >= 0) hipLaunchKernelGGL((stream4_kernel<true, false>), g3, dim3(256), slds, s, sp, d, xs, nsp);
+      else if (sp.packed == 5 && tune.mlp_stream == 4 && tune.mlp_stream_2cu) hipLaunchKernelGGL((stream4_kernel<false, true>), g3, dim3(256), slds, s, sp, d, xs, nsp);
+      else if (sp.packed == 5) hipLaunchKernelGGL((stream4_kernel<false, false>), g3, dim3(256), slds, s, sp, d, xs, nsp);
       else if (sp.packed && tune.mlp_stream_2cu && sp.n_table > 0) hipLaunchKernelGGL((stream_kernel<true, 8, true>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else if (sp.packed) hipLaunchKernelGGL((stream_kernel<true, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);
       else hipLaunchKernelGGL((stream_kernel<false, 8>), dim3((unsigned)((a.M + 15) / 16)), dim3(kThreads), slds, s, sp, d, xs);

@@ -54,12 +54,13 @@ __device__ __forceinline__ float4 mask4(const float4 v, int k, int K) {
 // see Done in drs_internal.h.  Every thread fences its own output stores at system
 // scope, the workgroup joins, then one lane takes a ticket; the workgroup that draws
 // the last ticket knows all outputs are visible and publishes the flag.
-__device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, void* lds_scratch) {
+// bid_in >= 0: this workgroup's rank among the n_blocks that sign off (the column-split form: one per slab of rows).
+__device__ __forceinline__ void signal_done(const Done d, unsigned n_blocks, void* lds_scratch, int bid_in = -1) {
   if (!d.counter) return;
   unsigned* s_u = reinterpret_cast<unsigned*>(lds_scratch);   // dynamic LDS is free by now
   if (d.ts) {
     // every workgroup folds its slice of the gather's clock stamps into (min start, max end)
-    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned bid = bid_in >= 0 ? (unsigned)bid_in : blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned per = (d.ts_blocks + n_blocks - 1) / n_blocks;
     const unsigned end = min(d.ts_blocks, (bid + 1) * per);
     unsigned long long lo = ~0ull, hi = 0ull;

@@ -927,6 +927,13 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "unfused_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=0, shared_stream=1, mlp_rows32=1),
             "pipelined_stream4_32_rows": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_rows32=1),
             "pipelined_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2),
+            # column-split form: the first top layer's columns over 4 / 2 workgroups per slab of rows, the pieces exchanged
+            # through L2, the last arriver runs the remaining layers (taken when that layer is 128 ... 1024 wide in 64s)
+            "stream4_nsplit4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_nsplit=4, mlp_nsplit_rows=1 << 20),
+            "stream4_nsplit2": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_nsplit=2, mlp_nsplit_rows=1 << 20),
+            "stream4_32_rows_nsplit2": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_rows32=1, mlp_nsplit=2, mlp_nsplit_rows=1 << 20),
+            "stream4_32_rows_nsplit4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=1, mlp_rows32=1, mlp_nsplit=4, mlp_nsplit_rows=1 << 20),
+            "pipelined_stream4_nsplit4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_nsplit=4, mlp_nsplit_rows=1 << 20),
             # early start: the launch runs its prologue and the bottom chain beside the gather and polls the slot's flag
             # before it fetches the pooled rows (Done::wait_flag)
             "early_stream4": dict(mlp_stream=4, mlp_fuse=1, shared_stream=2, mlp_early=1),
@@ -948,6 +955,9 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             assert not took_early or name == "early_stream4", (name, eng.last_dispatch(0))
             if name == "early_stream4" and (D, T, op) == (64, 8, "cat"):
                 assert took_early, eng.last_dispatch(0)
+            took_split = any("nsplit" in d for d in eng.last_dispatch(0))
+            assert took_split == ("nsplit" in name and top.startswith("256-")), (name, eng.last_dispatch(0))
+            eng.set_option("mlp_nsplit", 0)
             eng.set_option("mlp_early", 0)
             eng.set_option("mlp_wide_kn", 512 * 1024)
             eng.set_option("mlp_stream_2cu", 0)

@@ -184,3 +184,87 @@ def test_oracle_dien_matches_torch_rnn_fp64():
         for W, b in net.top_w:
             x = torch.relu(x @ torch.from_numpy(W.astype(np.float64)).t() + torch.from_numpy(b.astype(np.float64)))
     assert H.close(out, x.numpy(), rtol=1e-5, atol=1e-6), np.abs(out - x.numpy()).max()
+
+
+def _torch_forward(net, model_type, dense, idx, lens):
+    """The whole forward on torch-CPU operators only -- embedding_bag(sum), addmm, bmm + tril gather,
+    relu / sigmoid / tanh -- written against the reference's graph builders (file:line below), NOT
+    against the oracle: a second, independent restatement of the same graph on the same weights."""
+    import torch
+    import torch.nn.functional as F
+    T = len(net.emb_w)
+    D = int(net.m_spa)
+    tables = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)) for w in net.emb_w]
+    emb = []
+    for t in range(T):                                   # SparseLengthsSum per table (models/dlrm_s_caffe2.py:281-329)
+        le = torch.from_numpy(np.asarray(lens[t], dtype=np.int64))
+        offs = torch.cumsum(le, 0) - le
+        emb.append(F.embedding_bag(torch.from_numpy(np.asarray(idx[t], dtype=np.int64)), tables[t], offs, mode="sum"))
+
+    def mlp(x, layers, sigmoid_layer=-1):                # create_mlp: FC + Relu, Sigmoid at layer index sigmoid_layer (:223-279)
+        for i, (W, b) in enumerate(layers):
+            x = torch.addmm(torch.from_numpy(b), x, torch.from_numpy(W).t())
+            x = torch.sigmoid(x) if i + 1 == sigmoid_layer else torch.relu(x)
+        return x
+
+    x = None if dense is None else torch.from_numpy(np.ascontiguousarray(dense, dtype=np.float32))
+    if model_type == "ncf":                              # models/ncf.py:301-346: Sum | Concat -> MLP | Concat -> FC + Relu
+        mf = emb[0] + emb[1]
+        z = mlp(torch.cat([emb[2], emb[3]], 1), net.top_w)
+        return mlp(torch.cat([mf, z], 1), net.final_w).numpy()
+    if model_type == "din":                              # models/din.py:246-330
+        ad, z = emb[T - 2], None
+        for u, unit in enumerate(net.att_w):
+            y = mlp(torch.cat([emb[1 + u], ad, emb[1 + u] + ad], 1), unit)
+            z = y if z is None else z + y
+        return mlp(torch.cat([emb[0], z, ad, emb[T - 1]], 1), net.top_w).numpy()
+    if model_type == "dien":                             # models/dien.py:308-432 (Reshape = reinterpretation, two BasicRNN layers)
+        U, Hs = T - 3, int(net.hidden_size)
+        X = torch.stack(emb[1:T - 2], 1).reshape(U, -1, D)
+        rnn = torch.nn.RNN(D, Hs, num_layers=2, nonlinearity="tanh")
+        with torch.no_grad():
+            for l in (0, 1):
+                (iw, ib), (gw, gb) = net.rnn_w[l]
+                getattr(rnn, "weight_ih_l%d" % l).copy_(torch.from_numpy(iw))
+                getattr(rnn, "bias_ih_l%d" % l).copy_(torch.from_numpy(ib))
+                getattr(rnn, "weight_hh_l%d" % l).copy_(torch.from_numpy(gw))
+                getattr(rnn, "bias_hh_l%d" % l).copy_(torch.from_numpy(gb))
+            _, hn = rnn(X)
+        return mlp(torch.cat([hn[1], emb[0], emb[T - 2], emb[T - 1]], 1), net.top_w).numpy()
+    if model_type == "wnd":                              # models/wide_and_deep.py:271-305
+        return mlp(torch.cat([x] + emb, 1), net.top_w, net.sigmoid_top).numpy()
+    if model_type == "mtwnd":                            # models/multi_task_wnd.py:286-316: all-ReLU trunk, Sigmoid in the heads
+        shared = mlp(torch.cat([x] + emb, 1), net.top_w)
+        return torch.cat([mlp(shared, head, net.sigmoid_top) for head in net.task_w], 1).numpy()
+    d = mlp(x, net.bot_w, net.sigmoid_bot)               # models/dlrm_s_caffe2.py:331-386
+    if net.arch_interaction_op == "cat":
+        R = torch.cat([d] + emb, 1)
+    else:
+        Tt = torch.stack([d] + emb, 1)
+        Z = torch.bmm(Tt, Tt.transpose(1, 2))
+        Fn = T + 1
+        off = 0 if net.arch_interaction_itself else -1
+        li, lj = torch.tril_indices(Fn, Fn, off)
+        R = torch.cat([d, Z[:, li, lj]], 1)
+    return mlp(R, net.top_w, net.sigmoid_top).numpy()
+
+
+@pytest.mark.parametrize("case", H.MODEL_CASES)
+def test_torch_cpu_forward_second_opinion(case):
+    """the fixtures' expected outputs are the recorded op list run by oracle/c2ops.py; here the
+    same weights and inputs go through torch-CPU operators end to end (embedding_bag(sum) + addmm + bmm /
+    tril + sigmoid / relu, nn.RNN for DIEN) -- a restatement that shares no code with c2ops.py or the C
+    oracle.  It must agree with the golden output AND with the C oracle: the pin is two independent
+    restatements deep on OUTPUTS, not only op by op."""
+    import torch
+    meta, z = H.load_fixture(case)
+    args = H.args_from(meta["args"])
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    dense = None if args.model_type in H.NO_DENSE else lX[0]
+    with torch.no_grad():
+        got = _torch_forward(net, args.model_type, dense, lS_i[0], lS_l[0])
+    exp = H.golden_output(meta, z)
+    assert got.shape == exp.shape
+    assert H.close(got, exp, rtol=2e-5, atol=1e-6), np.abs(got - exp).max()
+    out = H.oracle_model(net).forward(dense, lS_i[0], lS_l[0])
+    assert H.close(got, out, rtol=2e-5, atol=1e-6), np.abs(got - out).max()

@@ -12,7 +12,8 @@ import numpy as np
 import bench
 
 NAMES = {1: "pass start", 2: "fetch0 issued", 3: "stash0 done", 4: "barrier0", 10: "round start",
-         11: "fetch issued", 12: "mfma done", 13: "stash done", 14: "barrier", 20: "loop end", 21: "signal done"}
+         11: "fetch issued", 12: "mfma done", 13: "stash done", 14: "barrier", 15: "seam: piece published", 16: "seam: ticket", 17: "seam: pieces fetched",
+         20: "loop end", 21: "signal done"}
 # (stream3_kernel: 2 = inputs requested, 3 = ring requested + inputs in LDS, 10 = step start (previous step's
 # epilogue / barrier before it), 12 = the step's MFMA stream issued, 14 = epilogue + barrier)
 
