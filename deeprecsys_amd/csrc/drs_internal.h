@@ -264,10 +264,10 @@ hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t
 int64_t stream_packed_floats(int K, int N);
 hipError_t launch_pack_stream_weights(const float* W, int32_t K, int32_t N, float* Wp, hipStream_t stream);
 
-// random 256-byte row reads over [base, base + bytes) in the gather's access shape, timed with events on `s`
+// random 128- / 256- / 512-byte row reads over [base, base + bytes) in the gather's access shape, timed with events on `s`
 // (sls.hip probe_rows_kernel); sink: >= 1 KiB of device memory nobody reads
 hipError_t probe_rows(const void* base, size_t bytes, int waves, int reps, float* sink, hipStream_t s, double* gbs,
-                      int windows = 0, int sorted = 0);
+                      int windows = 0, int sorted = 0, int row_bytes = 256, int nt = 1, int loads = 20);
 
 // dependent-load walk through each of n_chunks chunks of chunk_bytes (one lane per chunk); d_ticks[k] = 100 MHz ticks
 hipError_t probe_latency(const void* base, size_t chunk_bytes, int n_chunks, int steps, uint64_t* d_ticks, hipStream_t s);

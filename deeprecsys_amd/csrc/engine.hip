@@ -216,7 +216,7 @@ struct drs_engine {
   int64_t sel_pool = 0, sel_kept = 0, sel_best_ns = 0, sel_worst_ns = 0, sel_kept_worst_ns = 0, sel_ms = 0;
   int64_t probe_gather_ns = 0;      // result of the last "table_probe_gather"
   int64_t probe_mbs = 0;            // result of the last "table_probe"
-  int probe_windows = 0, probe_sorted = 0;
+  int probe_windows = 0, probe_sorted = 0, probe_row_bytes = 256, probe_nt = 1, probe_loads = 20;
   int64_t probe_ps = 0;             // result of the last "table_probe_latency": picoseconds per dependent load
   int vmm_shuffle = 0;              // lab: map the chunks in a permuted order (neighbouring addresses, distant memory)
   int64_t* d_tab_off = nullptr;
@@ -2729,6 +2729,9 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "table_probe_windows") && value >= 0 && value <= 4096) e->probe_windows = (int)value;
   else if (!strcmp(key, "table_probe_sorted") && (value == 0 || value == 1)) e->probe_sorted = (int)value;
+  else if (!strcmp(key, "table_probe_row_bytes") && (value == 128 || value == 256 || value == 512)) e->probe_row_bytes = (int)value;
+  else if (!strcmp(key, "table_probe_nt") && (value == 0 || value == 1)) e->probe_nt = (int)value;
+  else if (!strcmp(key, "table_probe_loads") && (value == 10 || value == 20)) e->probe_loads = (int)value;
   else if (!strcmp(key, "table_probe_gather")) {
     // lab: the selection's probe (the model's own gather kernel on a one-table problem) over arena `value` as a whole;
     // result "table_probe_gather_ns"
@@ -2771,8 +2774,8 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
       bytes = std::min((size_t)1 << 30, e->tables_bytes - off);
     } else return fail(e, DRS_ERR_BAD_ARG, "table_probe %lld", (long long)value);
     double gbs = 0;
-    HIP_TRY(e, probe_rows(base, bytes, 24576, 64, e->slots[0].d_out, e->slots[0].own_stream, &gbs, e->probe_windows, e->probe_sorted));   // warm-up pass
-    HIP_TRY(e, probe_rows(base, bytes, 24576, 24, e->slots[0].d_out, e->slots[0].own_stream, &gbs, e->probe_windows, e->probe_sorted));
+    HIP_TRY(e, probe_rows(base, bytes, 24576, 64, e->slots[0].d_out, e->slots[0].own_stream, &gbs, e->probe_windows, e->probe_sorted, e->probe_row_bytes, e->probe_nt, e->probe_loads));   // warm-up pass
+    HIP_TRY(e, probe_rows(base, bytes, 24576, 24, e->slots[0].d_out, e->slots[0].own_stream, &gbs, e->probe_windows, e->probe_sorted, e->probe_row_bytes, e->probe_nt, e->probe_loads));
     e->probe_mbs = (int64_t)(gbs * 1e3);
   }
   else if (!strcmp(key, "table_vmm_swap")) {

@@ -745,61 +745,83 @@ __global__ void fill_uniform_kernel(float* W, int64_t n, int32_t t, float lo, fl
 // 80 random 256-byte rows, 4 per load instruction, all 20 loads of a lane in flight, non-temporal) without
 // index arrays or outputs.  What it is for: DESIGN.md 5 -- the same gather runs up to 9 % faster on some
 // gigabytes of HBM than on others, and the arena builder keeps the gigabytes this probe reads fastest.
+// G lanes per row (16 bytes each): 16 = RMC1's 256-byte rows (a wave = 80 rows), 8 = 128-byte rows (dlrm_rm1.json / RM3:
+// a wave = 160 rows, eight per load instruction), 32 = 512-byte rows; NT: non-temporal loads (a compile-time property).
+template <int G, bool NT, int NLD>
 __global__ __launch_bounds__(64) void probe_rows_kernel(const float4* __restrict__ base, uint32_t rows, uint32_t seed,
                                                         float4* __restrict__ sink, uint32_t windows, uint32_t stride_rows, int sorted) {
   // windows == 0: the wave's 80 rows anywhere in [0, rows).  windows > 0: wave w reads inside window w % windows
   // (window k = rows [k * stride_rows, k * stride_rows + rows)), like a bag of one table; sorted: ascending, one row per
   // eightieth of the window (what np.unique leaves of a bag's indices)
-  const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+  constexpr int NG = 64 / G;                       // rows per load instruction
+  constexpr uint32_t RW = NLD * NG;                 // rows per wave
+  const int lane = threadIdx.x, g = lane / G, gl = lane % G;
   const uint64_t w0 = windows ? (uint64_t)(blockIdx.x % windows) * stride_rows : 0;
-  uint32_t r[20];
+  uint32_t r[NLD];
 #pragma unroll
-  for (int u = 0; u < 20; ++u) {
-    uint32_t z = (blockIdx.x * 80u + (uint32_t)(4 * u + g)) * 0x9E3779B1u + seed;
+  for (int u = 0; u < NLD; ++u) {
+    uint32_t z = (blockIdx.x * RW + (uint32_t)(NG * u + g)) * 0x9E3779B1u + seed;
     z = (z ^ (z >> 16)) * 0x85EBCA6Bu;
     z = (z ^ (z >> 13)) * 0xC2B2AE35u;
     z ^= z >> 16;
     if (sorted) {
-      const uint32_t lo = (uint32_t)(((uint64_t)(4 * u + g) * rows) / 80), hi = (uint32_t)(((uint64_t)(4 * u + g + 1) * rows) / 80);
+      const uint32_t lo = (uint32_t)(((uint64_t)(NG * u + g) * rows) / RW), hi = (uint32_t)(((uint64_t)(NG * u + g + 1) * rows) / RW);
       r[u] = lo + (uint32_t)(((uint64_t)z * (hi > lo ? hi - lo : 1)) >> 32);
     } else {
       r[u] = (uint32_t)(((uint64_t)z * rows) >> 32);
     }
   }
-  float4 v[20];
+  float4 v[NLD];
 #pragma unroll
-  for (int u = 0; u < 20; ++u) v[u] = ld_nt(base + (w0 + r[u]) * 16 + gl);
+  for (int u = 0; u < NLD; ++u) {
+    if constexpr (NT) v[u] = ld_nt(base + (w0 + r[u]) * G + gl);
+    else v[u] = base[(w0 + r[u]) * G + gl];
+  }
   float4 acc = vzero4();
 #pragma unroll
-  for (int u = 0; u < 20; ++u) vadd(acc, v[u]);
+  for (int u = 0; u < NLD; ++u) vadd(acc, v[u]);
   if (acc.x == 1.2345e-30f) sink[lane] = acc;      // (keeps the loads alive; never true for table data)
 }
 
 // time `reps` launches of `waves` waves over [base, base + bytes); GB/s of row bytes in *gbs
 hipError_t probe_rows(const void* base, size_t bytes, int waves, int reps, float* sink, hipStream_t s, double* gbs,
-                      int windows, int sorted) {
+                      int windows, int sorted, int row_bytes, int nt, int loads) {
   *gbs = 0;
-  uint64_t rows = bytes / 256, stride = 0;
+  if (row_bytes != 128 && row_bytes != 256 && row_bytes != 512) return hipErrorInvalidValue;
+  uint64_t rows = bytes / (uint64_t)row_bytes, stride = 0;
   if (windows > 0) { stride = rows / (uint64_t)windows; rows = stride; }
-  if (rows < 80 || rows > 0xffffffffull) return hipErrorInvalidValue;
+  if (loads != 10 && loads != 20) return hipErrorInvalidValue;
+  const int G = row_bytes / 16, rw = loads * (64 / G);
+  if (rows < (uint64_t)rw || rows > 0xffffffffull) return hipErrorInvalidValue;
+  auto launch = [&](uint32_t seed) {
+#define DRS_PROBE(G_, NT_)                                                                                                               \
+  do {                                                                                                                                     \
+    if (loads == 10) hipLaunchKernelGGL((probe_rows_kernel<G_, NT_, 10>), dim3((unsigned)waves), dim3(64), 0, s, static_cast<const float4*>(base), \
+                                        (uint32_t)rows, seed, reinterpret_cast<float4*>(sink), (uint32_t)windows, (uint32_t)stride, sorted); \
+    else hipLaunchKernelGGL((probe_rows_kernel<G_, NT_, 20>), dim3((unsigned)waves), dim3(64), 0, s, static_cast<const float4*>(base),       \
+                            (uint32_t)rows, seed, reinterpret_cast<float4*>(sink), (uint32_t)windows, (uint32_t)stride, sorted);            \
+  } while (0)
+    if (G == 8) { if (nt) DRS_PROBE(8, true); else DRS_PROBE(8, false); }
+    else if (G == 16) { if (nt) DRS_PROBE(16, true); else DRS_PROBE(16, false); }
+    else { if (nt) DRS_PROBE(32, true); else DRS_PROBE(32, false); }
+#undef DRS_PROBE
+  };
   hipEvent_t e0, e1;
   hipError_t r = hipEventCreate(&e0);
   if (r != hipSuccess) return r;
   r = hipEventCreate(&e1);
   if (r != hipSuccess) { (void)hipEventDestroy(e0); return r; }
-  hipLaunchKernelGGL(probe_rows_kernel, dim3((unsigned)waves), dim3(64), 0, s, static_cast<const float4*>(base), (uint32_t)rows, 1u,
-                     reinterpret_cast<float4*>(sink), (uint32_t)windows, (uint32_t)stride, sorted);
+  launch(1u);
   r = hipEventRecord(e0, s);
   for (int i = 0; i < reps && r == hipSuccess; ++i) {
-    hipLaunchKernelGGL(probe_rows_kernel, dim3((unsigned)waves), dim3(64), 0, s, static_cast<const float4*>(base), (uint32_t)rows,
-                       0x51ED27u * (uint32_t)(i + 2), reinterpret_cast<float4*>(sink), (uint32_t)windows, (uint32_t)stride, sorted);
+    launch(0x51ED27u * (uint32_t)(i + 2));
     r = hipGetLastError();
   }
   if (r == hipSuccess) r = hipEventRecord(e1, s);
   if (r == hipSuccess) r = hipEventSynchronize(e1);
   float ms = 0.f;
   if (r == hipSuccess) r = hipEventElapsedTime(&ms, e0, e1);
-  if (r == hipSuccess && ms > 0.f) *gbs = (double)waves * 80.0 * 256.0 * reps / (ms * 1e-3) / 1e9;
+  if (r == hipSuccess && ms > 0.f) *gbs = (double)waves * (double)rw * (double)row_bytes * reps / (ms * 1e-3) / 1e9;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return r;
