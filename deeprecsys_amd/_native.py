@@ -167,6 +167,11 @@ class Engine(object):
         self.num_slots = int(num_slots)
         self.device = int(device)
         self._marsh = ((C.c_int32 * 64)(), (C.c_int32 * 64)())
+        self.user_options = set()        # option keys the caller set (set_option)
+        # the per-slot record of the kernel forms a launch set took (last_dispatch) costs the host ~1 us per set: off
+        # unless asked for -- DRS_DISPATCH_LOG=1 (tests/conftest.py sets it) or set_option("dispatch_log", 1)
+        if os.environ.get("DRS_DISPATCH_LOG", "0") not in ("", "0"):
+            self.set_option("dispatch_log", 1)
 
     # -- helpers ------------------------------------------------------------------
     def _check(self, rc, what):
@@ -381,8 +386,12 @@ class Engine(object):
                     "drs_interact_dot")
 
     # -- tuning / measurement -------------------------------------------------------
-    def set_option(self, key, value):
+    def set_option(self, key, value, user=True):
+        """user=False: a setting the host code makes on its own behalf (DLRM_Net.tune_table_placement) -- keys set with
+        user=True are remembered in `user_options`, and the search leaves those alone."""
         self._check(lib().drs_set_option(self._h, key.encode(), int(value)), "drs_set_option")
+        if user:
+            self.user_options.add(key)
 
     def get_option(self, key):
         v = C.c_int64(0)

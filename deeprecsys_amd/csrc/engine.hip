@@ -247,6 +247,7 @@ struct drs_engine {
   int64_t* d_op_tab = nullptr;   // [2]: tab_off, tab_rows for drs_sls
   // options
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
+  int dispatch_log = 0;             // "dispatch_log": keep the per-slot record of the kernel forms chosen (drs_last_dispatch)
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
 #ifdef DRS_LAB
   hipStream_t stream_g2 = nullptr;  // lab ("gather_streams" 2): the gathers of consecutive slots alternate between two streams
@@ -1115,11 +1116,13 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   s.stream = job_stream(e, s, Mv);
   s.cur = nullptr;               // (the set's first MLP launch needs no event: join() orders it behind the gather)
   s.dlog.len = 0; s.dlog.text[0] = 0;
-  e->tune.log = &s.dlog;         // the launch functions note what they choose for this set (drs_last_dispatch)
+  // ("dispatch_log" 1: the launch functions note what they choose for this set -- drs_last_dispatch; off by default: four
+  //  to eight vsnprintf per set are ~1 us of the ~11 us a small set costs the host)
+  e->tune.log = e->dispatch_log ? &s.dlog : nullptr;
   e->tune.xbuf = s.xbuf; e->tune.xcnt = s.xcnt; e->tune.xbuf_rows = s.xrows; e->tune.xbuf_cols = s.xcols;
   // (both belong to THIS slot: launches made outside this function -- the operator-level entry points -- must not see them)
   struct TuneScope { Tune& t; ~TuneScope() { t.log = nullptr; t.xbuf = nullptr; t.xcnt = nullptr; } } tune_scope{e->tune};
-  log_launch(&s.dlog, "set[%d queries, %d rows, gather on %s, mlp on %s]", q.n_q, (int)Mv,
+  log_launch(e->tune.log, "set[%d queries, %d rows, gather on %s, mlp on %s]", q.n_q, (int)Mv,
              job_gather_stream(e, s, Mv) == e->stream_g ? "stream_g" : "own", s.stream == s.own_stream ? "own" : "shared");
   const hipStream_t gstream = job_gather_stream(e, s, Mv);
   const bool prof = e->profiling >= 1;
@@ -1224,7 +1227,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       }
       tp.kmax = dien_top_kmax(nt, e->top.ln.data());
     }
-    log_launch(&s.dlog, "%s<%d,%d%s>[%d wg]", e->dien_mfma && Hh % 16 == 0 ? "dien_rnn_mfma_kernel" : "dien_rnn_kernel", e->D, Hh,
+    log_launch(e->tune.log, "%s<%d,%d%s>[%d wg]", e->dien_mfma && Hh % 16 == 0 ? "dien_rnn_mfma_kernel" : "dien_rnn_kernel", e->D, Hh,
                tp.n ? ",top" : "", e->dien_mfma && Hh % 16 == 0 ? (c + 15) / 16 : (c + 3) / 4);
     HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, Hh, e->d_att_packed, rw, e->dien_mfma, s.R,
                                e->ldR, s.stream, tp.n ? &tp : nullptr, dp));
@@ -1232,7 +1235,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   } else if (e->kind == DRS_MODEL_DIN) {
     // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
     HIP_TRY(e, join());
-    if (!din_fused) log_launch(&s.dlog, "din_attention_kernel[%lld wg]", (long long)((Mv + 3) / 4));
+    if (!din_fused) log_launch(e->tune.log, "din_attention_kernel[%lld wg]", (long long)((Mv + 3) / 4));
     if (!din_fused)
       HIP_TRY(e, launch_din_attention(s.T, e->ldT, Mv, e->T, e->D, e->att[0].ln[1], e->d_att_packed, s.R, e->ldR, s.stream));
     if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
@@ -1258,7 +1261,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       }
     }
     if (!fused) {
-      log_launch(&s.dlog, "add_rows_kernel");
+      log_launch(e->tune.log, "add_rows_kernel");
       HIP_TRY(e, launch_add_rows(s.T, e->ldT, s.T + D, e->ldT, s.H2, ldc, Mv, D, s.stream));
       if ((rc = run_mlp(e, s, e->top, s.T + 2 * D, e->ldT, Mv, s.H2 + D, ldc))) return rc;
       if ((rc = run_mlp(e, s, e->fin, s.H2, ldc, Mv, out, e->n_out, dp))) return rc;
@@ -1289,7 +1292,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
         HIP_TRY(e, hipStreamWriteValue32(gstream, s.d_gflag, s.seq, 0));
         done.wait_flag = s.d_gflag; done.wait_val = s.seq;
         s.stream = s.early_stream;
-        log_launch(&s.dlog, "early");
+        log_launch(e->tune.log, "early");
       }
       if (fused_applicable(e, s, Mv, &xs)) HIP_TRY(e, join());
       fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
@@ -1309,8 +1312,9 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
         split_top = true;
         s.split_last = true;
       } else {
-        log_launch(&s.dlog, "copy_rows_multi_kernel");
+        log_launch(e->tune.log, "copy_rows_multi_kernel");
         HIP_TRY(e, launch_copy_rows_multi(xs, e->m_den, s.T, e->ldT, s.stream));
+        s.cur = s.stream;          // ("mlp_layout" 1: a wide first layer routed to the gather's stream must wait for this copy)
       }
     } else {
       if ((rc = run_mlp(e, s, e->bot, nullptr, e->m_den, Mv, s.T, e->ldT, nullptr, &xs))) return rc;
@@ -1320,7 +1324,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     int64_t ld_top = e->ldT;
     if (!fused && e->kind == DRS_MODEL_DLRM && e->interaction_op == DRS_INTERACT_DOT) {
       HIP_TRY(e, rejoin_stream(e, s));
-      log_launch(&s.dlog, "interact_dot_kernel[%lld wg]", (long long)((Mv + 3) / 4));
+      log_launch(e->tune.log, "interact_dot_kernel[%lld wg]", (long long)((Mv + 3) / 4));
       HIP_TRY(e, launch_interact_dot(s.T, e->ldT, Mv, e->T + 1, e->D, e->itself, s.R, e->ldR, s.stream));
       top_in = s.R;
       ld_top = e->ldR;
@@ -1347,7 +1351,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     HIP_TRY(e, hipMemcpyAsync(s.h_out + 1, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
   }
   if (out_dma) {
-    log_launch(&s.dlog, "out_dma[%lld B]", (long long)(sizeof(float) * (size_t)Mv * e->n_out));
+    log_launch(e->tune.log, "out_dma[%lld B]", (long long)(sizeof(float) * (size_t)Mv * e->n_out));
     HIP_TRY(e, hipMemcpyAsync(s.h_out + kOutOffset, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
                               hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(e, hipStreamWriteValue32(s.stream, s.dm_out, s.seq, 0));
@@ -2580,6 +2584,7 @@ int32_t drs_set_option(drs_handle e, const char* key, int64_t value) {
     apply_stream_mode(e);
   }
   else if (!strcmp(key, "mlp_fuse")) e->mlp_fuse = value ? 1 : 0;
+  else if (!strcmp(key, "dispatch_log")) e->dispatch_log = value ? 1 : 0;
   else if (!strcmp(key, "zero_copy_inputs") && value >= 0 && value <= 3) e->zero_copy_inputs = (int)value;
   else if (!strcmp(key, "host_threads") && value >= -1 && value <= 64) { e->host_threads = (int)value; e->pool.reset(); }
   else if (!strcmp(key, "mlp_streams") && value >= 1 && value <= 8) {
@@ -2875,7 +2880,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   struct { const char* k; int64_t v; } tab[] = {
       {"sls_exact", e->sls_exact}, {"sls_flat", t.sls_flat},
       {"sls_bpw", t.sls_bpw}, {"din_fused", e->din_fused}, {"dien_mfma", e->dien_mfma}, {"dien_fuse_top", e->dien_fuse_top}, {"din_s", t.din_s}, {"sls_nt", t.sls_nt}, {"din_nt", t.din_nt}, {"din_pipe", t.din_pipe}, {"gemm_split", e->gemm_split}, {"sls_uniform", e->sls_uniform}, {"sls_short_bag", e->sls_short_bag},
-      {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse},
+      {"mlp_split", e->mlp_split}, {"mlp_wide_kn", e->mlp_wide_kn}, {"mlp_fuse", e->mlp_fuse}, {"dispatch_log", e->dispatch_log},
       {"mlp_fuse_rows", e->mlp_fuse_rows}, {"mlp_small_rows", e->mlp_small_rows}, {"small_piped", e->small_piped}, {"mlp_early", e->mlp_early}, {"mlp_gemm", t.mlp_gemm}, {"mlp_gemm_tile", t.gemm_tile}, {"mlp_gemm_2cu", t.gemm_2cu}, {"mlp_gemm32", t.gemm32}, {"mlp_gemm32_blocks", t.gemm32_blocks}, {"mlp_gemm32_small", t.gemm32_small}, {"mlp_gemm32_small_blocks", t.gemm32_small_blocks}, {"mlp_stream_2cu", t.mlp_stream_2cu}, 
       {"preferred_coalesce", e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8)},
       // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
@@ -2909,6 +2914,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
 int32_t drs_last_dispatch(drs_handle e, int32_t slot, char* buf, int64_t cap) {
   if (!e || !buf || cap < 1) return DRS_ERR_BAD_ARG;
   if (slot < 0 || slot >= e->n_slots) return fail(e, DRS_ERR_BAD_ARG, "slot %d of %d", slot, e->n_slots);
+  if (!e->dispatch_log) return fail(e, DRS_ERR_STATE, "drs_last_dispatch: the record is off (drs_set_option \"dispatch_log\" 1 before the launch set)");
   if (e->launcher) e->launcher->drain();
   const Slot& s = e->slots[slot];
   const int64_t n = s.dlog.len < cap - 1 ? s.dlog.len : cap - 1;

@@ -196,7 +196,7 @@ class _HipNet(object):
             self.engine.stage_batch(j, None if lX is None else lX[j], lS_i[j], lS_l[j])
         self._n_staged = len(lS_l)
 
-    def tune_table_placement(self, candidates=12, sets=128, spacer_gb=None, policies=(1, 0)):
+    def tune_table_placement(self, candidates=12, sets=128, spacer_gb=None, policies=(1, 0), max_extra_gb=48, sharers=1):
         """Where the tables live in HBM, and with which cache policy their rows are read, moves the many-rows-per-bag
         gather by up to 9 % -- a property of the PHYSICAL memory (it follows the memory through address changes;
         gigabytes-wide regions of HBM are "fast" or "slow", and they are different regions for non-temporal and for
@@ -208,7 +208,11 @@ class _HipNet(object):
         arena unless another is at least 1 % faster.  It stops as soon as one arena's best reading is 8 % under another's (the
         fast level is reached).  Every other arena and the spacers are released before it returns: one copy of the
         tables, nothing held.  Returns {"gather_us": [[nt, plain], ...], "kept": k, "sls_nt": p, ...} or
-        None when the engine has nothing to time.  ~70 ms per candidate."""
+        None when the engine has nothing to time.  ~70 ms per candidate.
+        While it runs every candidate and spacer stays allocated (a freed loser's pages would be handed out again as the
+        next candidate): the search's transient footprint is bounded by `max_extra_gb` / `sharers` (engine processes
+        that share the GPU) beside the engine's own guards (a quarter of the free memory per copy, 8 GB left free).
+        A load policy the caller set with set_option is kept (only the arena is searched); "table_alloc" is restored."""
         eng = self.engine
         nb = int(getattr(self, "_n_staged", 0))
         if nb < 1 or candidates < 1:
@@ -223,6 +227,10 @@ class _HipNet(object):
         co = max(1, min(int(eng.get_option("preferred_coalesce")), 16))
         bs = int(eng.max_batch)
         nt0 = int(eng.get_option(nt_key))
+        ta0 = int(eng.get_option("table_alloc"))
+        if nt_key in getattr(eng, "user_options", ()):     # the caller pinned the policy: search the arenas only
+            policies = (nt0,)
+        budget_gb = float(max_extra_gb) / max(1, int(sharers))
 
         # The sets are timed AS THEY WILL BE SERVED: the engine's stream mode, `preferred_slots` sets in flight, the gather
         # launches stamped by their own workgroups while the previous set's MLP launch runs beside them.  (Until the end of
@@ -260,7 +268,7 @@ class _HipNet(object):
         def both():
             out = []
             for p in policies:
-                eng.set_option(nt_key, p)
+                eng.set_option(nt_key, p, user=False)
                 out.append(gather_us())
             return out
 
@@ -274,19 +282,24 @@ class _HipNet(object):
             times.append(t)
             size_gb = max(1, -(-int(eng.get_option("table_bytes")) // (1 << 30)))
             gap = size_gb if spacer_gb is None else int(spacer_gb)
-            eng.set_option("table_alloc", 0)            # (plain hipMalloc candidates: arenas of the virtual-memory API read as
+            eng.set_option("table_alloc", 0, user=False)  # (plain hipMalloc candidates: arenas of the virtual-memory API read as
             for _ in range(1, candidates):              #  fast alone but measured 2 % slower beside two MLP streams, dlrm_rm1.json)
+                if len(times) * (size_gb + max(gap, 0)) + size_gb > budget_gb:
+                    break                               # the next candidate (and its spacer) would pass the footprint bound
                 per_arena = [min(tt) for tt in times]
                 if min(per_arena) <= 0.92 * max(per_arena):
                     break                               # an arena 8 % under the slowest one: the fast level has been seen (beside the MLP
                                                         # launch the levels read 90 / 88 / 85-86 / 82 us on RMC1; stopping at 5 % kept an 84.6)
                 try:
                     if gap > 0:
-                        eng.set_option("table_spacer", gap << 30)
-                    eng.set_option("table_placement", -1)
+                        eng.set_option("table_spacer", gap << 30, user=False)
+                    eng.set_option("table_placement", -1, user=False)
                 except N.DrsError:
                     break                               # no room for one more copy: the ones so far compete
-                times.append(both())
+                t = both()
+                if any(u is None for u in t):
+                    break                               # (nothing was timed on this one: it does not compete)
+                times.append(t)
             flat = [(u, k, policies[i]) for k, tt in enumerate(times) for i, u in enumerate(tt)]
             best = min(flat)
             # the arena drs_create made stays unless another one is at least 1 % faster (timed as served, the readings repeat
@@ -301,11 +314,11 @@ class _HipNet(object):
             return None                                 # (staged sets smaller than a full batch, ...: serve from where it is)
         finally:
             try:
-                eng.set_option("table_alloc", 0)
-                eng.set_option(nt_key, best[2] if best else nt0)
+                eng.set_option("table_alloc", ta0, user=False)
+                eng.set_option(nt_key, best[2] if best else nt0, user=False)
                 if best:
-                    eng.set_option("table_placement", best[1])
-                eng.set_option("table_placement", -2)
+                    eng.set_option("table_placement", best[1], user=False)
+                eng.set_option("table_placement", -2, user=False)
             except N.DrsError:
                 pass
 

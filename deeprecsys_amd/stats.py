@@ -18,9 +18,9 @@ class ResponseAggregator(object):
         self.response_sets = {}
         self.response_latencies = []         # every completed query (feeds the scheduler)
         self.final_response_latencies = []   # completed non-experimental queries
-        self._raw = []                       # the responses as they arrived; turned into dicts when somebody asks
+        self._raw = []                       # responses AND ResponseBlocks in arrival order; turned into dicts when somebody asks
         self._dicts = []
-        self._blocks = []                    # ResponseBlocks not unrolled yet (add_block)
+        self._n_unrolled = 0                 # entries of _raw already turned into dicts
         self.keep_records = False            # True: unroll every block as it arrives (tests that read responses_list mid-run)
 
     @property
@@ -28,14 +28,13 @@ class ResponseAggregator(object):
         """per-response dicts, arrival order (what the orchestrator logs, reference `response.__dict__`).  Built on
         demand: with eight MI355X answering ~1.5 M queries/s the per-response dict was a third of the orchestrator's
         4.4 us per response, and nobody reads the list before the run is over."""
-        if self._blocks:
-            for b in self._blocks:
-                self._raw.extend(b.responses())
-            self._blocks = []
-        if len(self._dicts) < len(self._raw):
-            wm = self.with_model
-            self._dicts.extend(r.as_dict(wm) if hasattr(r, "as_dict") else dict(r.__dict__)
-                               for r in self._raw[len(self._dicts):])
+        wm = self.with_model
+        for item in self._raw[self._n_unrolled:]:
+            # (blocks and single packets stay in ONE arrival-ordered list: the first / last entries bound the qps
+            #  window, reference DeepRecSys.py:168-173, also when CPU and accelerator engines answer side by side)
+            for r in (item.responses() if hasattr(item, "responses") else (item,)):
+                self._dicts.append(r.as_dict(wm) if hasattr(r, "as_dict") else dict(r.__dict__))
+        self._n_unrolled = len(self._raw)
         return self._dicts
 
     def add(self, response):
@@ -58,31 +57,36 @@ class ResponseAggregator(object):
             if remain != 0:
                 return None, None
             latency = inf - arr
-        running = None
+        before = len(self.response_latencies)
         self.response_latencies.append(latency)
         if not response.exp_packet:
             self.final_response_latencies.append(latency)
-        if len(self.response_latencies) % self.request_granularity == 0:
-            running = float(np.percentile(self.response_latencies[-self.request_granularity:], 95)
-                            * 1000.)
-        return latency, running
+        return latency, self._running_p95(before)
+
+    def _running_p95(self, before):
+        """p95 (ms) over the last `request_granularity` completed queries whenever their count has just crossed a
+        multiple of it (reference DeepRecSys.py:118-122: every request_granularity-th completion feeds pidQueue) --
+        one rule for single packets and for blocks, whatever their sizes."""
+        g = self.request_granularity
+        if len(self.response_latencies) // g == before // g:
+            return None
+        return float(np.percentile(self.response_latencies[-g:], 95) * 1000.)
 
     def add_block(self, block):
         """a ResponseBlock (utils/packets.py): n whole-query responses of one engine, booked at once.
-        -> running_p95_ms of the block's last `request_granularity` queries, or None for a shorter block"""
+        -> running_p95_ms over the last `request_granularity` completed queries when the block took their count across a
+        multiple of it (as add() does: the tuning loops then see a value however small the blocks are), else None"""
         lat = block.inference_end_time - block.arrival_time
-        self._raw.extend(block.responses()) if self.keep_records else self._blocks.append(block)
+        if self.keep_records:
+            self._raw.extend(block.responses())
+        else:
+            self._raw.append(block)
+        before = len(self.response_latencies)
         self.response_latencies.extend(lat.tolist())
         self.final_response_latencies.extend(lat[~block.exp_packet].tolist())
-        if len(lat) >= self.request_granularity:
-            return float(np.percentile(lat[-self.request_granularity:], 95) * 1000.)
-        return None
+        return self._running_p95(before)
 
     def summary(self):
-        if self._blocks:            # (blocks are unrolled into records once, after the run)
-            for b in self._blocks:
-                self._raw.extend(b.responses())
-            self._blocks = []
         out = summarize(self.responses_list, self.final_response_latencies)
         if self.with_model:
             per = {}

@@ -10,6 +10,7 @@ try:
 except ImportError:
     pass
 
+os.environ.setdefault("DRS_DISPATCH_LOG", "1")     # engines keep the record drs_last_dispatch returns (off by default)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

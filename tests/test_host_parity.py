@@ -463,12 +463,15 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
             self.opt = {"mlp_streams": 1, "gather_bound": 1, "preferred_coalesce": 12, "preferred_slots": 3, "shared_stream": 2, "sls_nt": 1, "table_bytes": 2 << 30,
                         "table_alloc": 0, "table_vmm_chunk": -1}
             self.arenas, self.cur, self.log, self.busy = 1, 0, [], {}
+            self.user_options = set()
 
         def get_option(self, k):
             return self.opt[k]
 
-        def set_option(self, k, v):
+        def set_option(self, k, v, user=True):
             self.log.append((k, v))
+            if user:
+                self.user_options.add(k)
             if k == "table_placement":
                 if v == -1:
                     if self.arenas >= len(self.us):
@@ -498,10 +501,12 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
         def kernel_time(self, _k):
             return self.us[self.cur][0 if self.opt["sls_nt"] else 1] * 1e-3, 1
 
-    def run(us, candidates=6):
+    def run(us, candidates=6, prepare=None, **kw):
         net = M.DLRM_Net.__new__(M.DLRM_Net)
         net.engine, net._n_staged = Eng(us), 4
-        return net.tune_table_placement(candidates, sets=4), net.engine
+        if prepare:
+            prepare(net.engine)
+        return net.tune_table_placement(candidates, sets=4, **kw), net.engine
 
     # the third arena is a level faster under plain loads: the search stops there and keeps (arena 2, plain)
     res, eng = run([[86.5, 87.5], [86.6, 87.9], [85.0, 79.0], [78.0, 78.0]])
@@ -513,6 +518,19 @@ def test_tune_table_placement_search_logic_on_a_scripted_engine():
     assert res["candidates"] == 6 and res["kept"] == 0 and res["sls_nt"] == 1 and eng.kept == 0
     res, eng = run([[86.0, 87.0]] * 3 + [[83.8, 87.0]] + [[86.0, 87.0]] * 2)
     assert res["candidates"] == 6 and res["kept"] == 3 and res["sls_nt"] == 1 and eng.kept == 3
+    assert not eng.user_options                                      # (the search's own settings are not the caller's)
+    # a load policy the caller pinned is kept: only the arenas are searched -- and the caller's allocation mode comes back
+    def pin(e):
+        e.set_option("sls_nt", 1)
+        e.set_option("table_alloc", 1)
+    res, eng = run([[86.5, 70.0], [86.6, 70.0], [79.0, 70.0]], prepare=pin)
+    assert res["kept"] == 2 and res["sls_nt"] == 1 and res["policies"] == ["nt"] and eng.opt["sls_nt"] == 1 and eng.opt["table_alloc"] == 1
+    # the transient footprint is bounded: 2 GB arenas + 2 GB spacers, 9 GB for this engine -> two candidates; a GPU shared
+    # by four engine processes -> none beside the first arena
+    res, eng = run([[86.0, 87.0]] * 6, max_extra_gb=9)
+    assert res["candidates"] == 2
+    res, eng = run([[86.0, 87.0]] * 6, max_extra_gb=9, sharers=4)
+    assert res["candidates"] == 1 and res["kept"] == 0
     # no room for a second arena: the policies of the first one still compete
     res, eng = run([[86.0, 84.0]])
     assert res["candidates"] == 1 and res["kept"] == 0 and res["sls_nt"] == 0 and eng.arenas == 1

@@ -19,8 +19,10 @@ def test_stream4_kernel_keeps_agprs_to_its_asm_statements():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "deeprecsys_amd", "csrc"), "check-agpr"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    # four instantiations, one of them two per CU (the report appears twice when make had to rebuild the listing first)
-    assert r.stdout.count("AGPR uses outside asm: 0") in (4, 8) and "occupancy 2" in r.stdout
+    # six instantiations (16 / 32 rows, summed input, two per CU, and the two column-split forms), one of them two per CU
+    # (the report appears twice when make had to rebuild the listing first)
+    assert r.stdout.count("AGPR uses outside asm: 0") in (6, 12) and "occupancy 2" in r.stdout
+    assert r.stdout.count("scratch 0,") == r.stdout.count("AGPR uses outside asm: 0")
 
 
 def test_generated_segment_streams_wait_for_exactly_what_they_consume():

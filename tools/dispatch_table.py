@@ -13,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DRS_DISPATCH_LOG", "1")
 import bench as B  # noqa: E402
 
 WORKLOADS = ["rmc1", "rmc1_dot", "rmc1_ref", "rmc2_ref", "rmc3_ref", "rmc3", "wnd", "ncf", "mtwnd", "din", "dien"]

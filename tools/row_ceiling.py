@@ -18,6 +18,7 @@ except Exception:  # noqa: BLE001
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DRS_DISPATCH_LOG", "1")
 import bench as B  # noqa: E402
 from deeprecsys_amd import _native as N  # noqa: E402
 
