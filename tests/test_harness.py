@@ -510,6 +510,33 @@ def test_sharded_load_generators_serve_every_query_once(tmp_path):
         DeepRecSys(bad, quiet=True)
 
 
+def test_n8_serving_layout_starts_serves_and_joins_on_the_cpu_abi(tmp_path):
+    """The serving shape eight MI355X imply (one engine process per GPU delivers 0.66 of a GPU on the
+    run scripts' query sizes, four per GPU 0.88): 32 REAL accelerator engine processes -- accelInferenceEngine.py with
+    the engine behind the C ABI, here its CPU restatement -- behind 8 sharded load generators.  Every process starts
+    (32 ready tokens), every query is answered exactly once by an engine of its generator's group, every engine gets
+    its sentinel and joins.  (The GPU suite runs the same harness on libdrs_hip.so with one and two engines.)"""
+    from deeprecsys_amd import _native
+    from tests.cpu_abi_entry import bind_cpu_abi
+    prev = _native._lib
+    bind_cpu_abi()                   # (forked children inherit the binding; restored below)
+    try:
+        a = _args(tmp_path, accel_backend="hip", num_accels=32, load_generators=8, arch_sparse_feature_size=8,
+                  arch_embedding_size="200-300-100", arch_mlp_bot="13-16-8", arch_mlp_top="16-1",
+                  arch_interaction_op="dot", num_indices_per_lookup=4, model_type="dlrm", nepochs=6, num_batches=32,
+                  avg_arrival_rate=0, accel_req_batch=2, log_file=str(tmp_path / "log" / "n8.log"), mp_start_method="fork")
+        s = DeepRecSys(a, quiet=True)
+    finally:
+        _native._lib = prev
+    n = a.nepochs * a.num_batches
+    assert s["accel_requests"] == n and s["responses"] == n and s["measured_queries"] == n
+    rows = [eval(l) for l in open(a.log_file).read().strip().splitlines()]
+    assert sorted((r["epoch"], r["batch_id"]) for r in rows) == sorted((e, b) for e in range(a.nepochs) for b in range(a.num_batches))
+    assert all(0 <= r["consumer_id"] < 32 and r["consumer_id"] % 8 == r["batch_id"] % 8 for r in rows)
+    assert all(r["out_batch_size"] == r["batch_size"] for r in rows)
+    assert len({r["consumer_id"] for r in rows}) >= 8        # (at least one engine of every generator's group served)
+
+
 def _drain(q, out):
     import time
     n, t_first = 0, None
