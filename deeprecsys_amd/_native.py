@@ -104,6 +104,12 @@ class DrsError(RuntimeError):
 _lib = None
 
 
+def is_lab():
+    """the lab build of the library (make -C deeprecsys_amd/csrc lab-lib; -DDRS_LAB) is bound: it also takes the lab's
+    instruments and the options of the forms that lost their measurement (docs/OPTIONS.md, last section)"""
+    return os.path.basename(LIB_PATH).startswith("libdrs_hip_lab")
+
+
 def lib():
     """Load libdrs_hip.so (built by __graft_entry__.build() / csrc/Makefile)."""
     global _lib

@@ -266,169 +266,24 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
                          int32_t itself, float* d_R);
 
 /* ---- tuning ------------------------------------------------------------------
- * integer knobs, for A/B measurements inside one process (bench.py --sweep):
- *   "sls_exact"  0 (default) wave-split gather: a wave per bag, rows spread over its lane
- *                groups, wave-wide butterfly at the end (fp32 sum order differs from the
- *                reference: compare with a tolerance) | 1 sequential-order gather,
- *                bit-identical to the Caffe2 CPU SparseLengthsSum (same speed alone, 4-8% slower
- *                beside an MLP launch)
- *   "sls_short_bag" fixed-length batches with at most this many lookups per bag (default
- *                2048 / D: RM3's 20 and W&D's / NCF's 1 qualify, RM1's 80 does not) always take
- *                the sequential-order variant: a lane group per bag instead of a mostly idle
- *                wave per bag | -1 never
- *   "sls_flat"   1 (default) batches whose bags all have one length L >= 2 (every shipped
- *                reference config) run the flat variant when sls_exact is 0: a wave owns 1, 2 or 4
- *                consecutive bags of a sample, reads their indices with one coalesced load and has
- *                ALL of its row loads (up to 20 x 16 B per lane) in flight at once; same tolerance
- *                as the wave-split variant | 0 ring-walk kernels only
- *   "sls_bpw"    bags per wave of the flat variant: 0 (default: as many of 4 | 2 | 1 as divide the
- *                table count and keep a lane at <= 10 loads) | 1 | 2 | 4
- *   "din_fused"  1 (default) DRS_MODEL_DIN with sls_exact 0, D in {32, 64} and hidden width in
- *                {1, 2, 4}: ONE launch gathers the bags, applies the attention units and writes the top
- *                MLP's input row (the [rows, T*D] pooled tensor never exists) | 0 gather launch +
- *                attention launch (what sls_exact 1 always does; bit-identical to the oracle there)
- *   "dien_mfma"  2 (default) DRS_MODEL_DIEN with hidden_size a multiple of 16: the recurrence runs on the
- *                matrix cores, 16 samples per workgroup, one set of waves per layer (layer 2 a step behind
- *                layer 1) | 1 every wave runs both layers of its 16 hidden units | 0 one wave per sample on
- *                the VALU.  Same bits in all three.
- *   "dien_fuse_top" 1 (default) | 0: DRS_MODEL_DIEN, matrix-core recurrence: the top MLP of a workgroup's 16
- *                samples runs in the recurrence's own launch when it fits (<= 4 layers, every input width a
- *                multiple of 4 and <= 256), which then signs off the launch set; 0: a stream-kernel launch
- *                of its own behind it.  Same bits.
- *   "din_s"      samples per workgroup of that launch: 0 (default: 4 | 2 | 1 by launch size) | 1 | 2 | 4
- *                (results do not depend on it)
- *   "gemm_split" 1 (default) | 0: DRS_MODEL_WND / DRS_MODEL_MTWND: when the first top layer runs as a scalar-base
- *                gemm32_kernel (full launch sets), it reads the dense columns of Concat(dense, embeddings) from the
- *                queries' own arrays; 0 (and every other launch form): the dense rows are copied in front of the
- *                embeddings first (copy_rows_multi_kernel).  Same bits.
- *   "din_pipe"   1 (default) | 0: hidden width 1 and launch sets whose bags all have one fixed length <= 3 (din.json)
- *                take the pipelined form of that launch (din_pipe_kernel: the set's indices staged in LDS with one
- *                round trip, two units in flight per lane group); 0: the chained form for every shape.  Same bits.
- *   "sls_nt"     1 (default) | 0: the many-rows-per-bag gather kernels read table rows with non-temporal
- *                loads (rows are read once per launch; same bits either way; the one-lookup models' gather
- *                keeps plain loads: their tables are cache-resident).  "din_nt" 1 (default) | 0: the same for
- *                the fused DIN launch
- *   "sls_uniform" 1 (default) batches whose bags all have one length skip the offset
- *                read (bag b starts at b*L) | 0 always read the staged prefix sums
- *   "mlp_split"  1 (default) a layer with K*N >= "mlp_wide_kn" weights (RM3's 2560x1024)
- *                runs as its own 2-D launch | 0 chain everything that fits LDS
- *   "mlp_wide_kn" that threshold (default 256K weights: RM3's 2560x1024 and 1024x256, W&D's
- *                1376x1024 and 1024x512)
- *   "mlp_fuse"   1 (default) DLRM/"cat": bottom and top MLP of a 16-row slab in ONE launch
- *                | 0 one launch per MLP;  "mlp_fuse_rows": fuse only from this many rows on
- *   "mlp_gemm"   1 (default) stand-alone wide layers run as the register-blocked gemm_kernel
- *                (gemm.hip) | 0 fc_kernel;  "mlp_gemm_tile" 0 (default: by workgroup count)
- *                | 22 | 12 | 21 | 11 forces the per-wave tile shape, 214 = the 2 x 1 shape compiled for TWO
- *                workgroups per CU (ring of two chunks, <= 128 VGPRs, 70 KB of LDS);
- *                "mlp_gemm_2cu" 1 (default for DLRM and W&D) | 0: take that shape by itself whenever
- *                it gives >= 512 workgroups (W&D +5 %, RM3 +5 %; MT-WnD -5 %: off there)
- *                (the full 2 x 2 tile is kept while it still gives 128 workgroups);
- *                "mlp_gemm_tile" 322 | 321 | 312 | 311: gemm32_kernel, the same GEMM on
- *                v_mfma_f32_32x32x2_f32 (four waves, each 2 x 2 | 2 x 1 | 1 x 2 | 1 x 1 tiles of 32 x 32:
- *                workgroup tiles of 128 x 128 .. 64 x 64, operands by ds_read_b128, two workgroups per CU);
- *                "mlp_gemm32" 1 (default) | 0: wide layers whose 128 x 128 tiles number at least
- *                "mlp_gemm32_blocks" (default 512: two workgroups per CU) take the 2 x 2 form (RM3 config 3's
- *                2560 x 1024 layer at 8 192 rows), smaller launches keep gemm_kernel unless
- *                "mlp_gemm32_small" names a gemm32 shape for them (22 | 21 | 12 | 11) that gives at least
- *                "mlp_gemm32_small_blocks" workgroups (defaults: 12 with 256 for MT-WnD and MLP-bound DLRM, 12 with 512 for
- *                W&D, else 0)
- *   "mlp_stream" 2 (default for MT-WnD, NCF) chains run as the weight-tile stream kernel (tiles of all layers requested
- *                six rounds ahead, inputs resident in LDS) when every K % 4 == 0 and the slabs fit, the tiles read from
- *                the layers' PACKED twins (MFMA operand order, built by drs_set_fc) straight into the MFMA operand
- *                registers: no LDS staging of W, a workgroup barrier per layer instead of per 64-k chunk | 4 (default
- *                for DLRM, W&D, DIEN, DIN) stream4_kernel: four waves, every (layer, 64-column-per-wave pass) run by ONE
- *                hand-laid instruction stream (csrc/seg_asm.inc): MFMAs back to back with the weight reloads, operand
- *                prefetch and loop control between them, ring and accumulators in AGPRs under fixed names, the next
- *                segment's first chunk requested while the last one runs ("mlp_rows32" n: its launches of >= n rows take
- *                32 rows per workgroup -- two halves sharing the weight operands; default 8192 for MLP-bound DLRM, 2048
- *                for gather-bound DLRM, else 0 = never) | 1 the first kernel with W staged through LDS | 0 always the
- *                per-layer chain kernel.  Same bits in every form.  (3 was stream3_kernel, removed in round 5: stream4_kernel
- *                serves every launch size it served, faster -- DESIGN.md "Dispatch".)
- *                ("mlp_stream_2cu" 1 (default, except NCF) | 0: "mlp_stream" 2 with a ring of three
- *                register sets instead of six, compiled for 128 VGPRs, so that two of its workgroups
- *                share a CU and overlapping launches interleave on the same SIMDs)
- *   "mlp_preload" 0 (default) | 1 chain kernel only: pull a chain's 16 x K0 input slab into
- *                LDS in one round instead of streaming it per K chunk
- *   "mlp_kc"     chain kernel only: force the K chunk (0 auto | 64 | 128 | 192 | 256)
- *   "mlp_debug"  timing experiments on the stream kernel, honoured by the `make timeline`
- *                build only (bit 0: always fetch the first tile, bit 1: skip the MFMAs;
- *                results are garbage while set)
- *   "shared_stream" how the launch sets of the slots are put on HIP streams:
- *                2 (default) pipelined: every gather on one stream, back to back; the rest of
- *                  each set (MLPs, interaction, completion) behind an event on a second
- *                  stream, so the HBM-bound gather of set i+1 runs beside the latency-bound
- *                  MLP of set i and gathers never overlap each other
- *                  ("mlp_streams" n: alternate the MLP side over n streams; default 1 for
- *                  gather-bound models, one per slot (up to 4) for MLP-bound ones, decided in
- *                  drs_create from MLP FLOP per gathered byte;
- *                  "mlp_layout" 0 (default) the MLP side's streams are dealt by launch set | 1 by
- *                  kernel type: wide-layer GEMM launches go on the GATHER's stream, serialised with it,
- *                  chains on the MLP streams, an event per kernel -- RM3 config 3: the gather runs at
- *                  0.63 instead of 0.26 of the HBM peak, the model 3-10 % slower, so it is not the default)
- *                1 one stream: sets strictly back to back, each kernel has the chip to itself
- *                0 one stream per slot: whole sets overlap freely
- *   "zero_copy_inputs" how drs_forward_inputs' converted inputs (one packed, pinned block per slot:
- *                dense | int32 indices | prefix sums) reach the kernels: 1 read in place over PCIe
- *                (default: no copy; kernel-issued PCIe reads top out near 20-25 GB/s) | 2 ONE DMA
- *                copy of the block's used prefix into its HBM twin, on the job's gather stream
- *                (same throughput at 3 calls in flight, 20 us more latency per query) | 3: 2 for
- *                queries of >= 128 KB, else 1 | 0 one copy per array (first version)
- *   "host_threads" workers of the per-call input pass (int64 -> int32 + ENFORCEs, one table per
- *                work item, the dense rows' copy one more) beside the calling thread:
- *                -1 (default) min(T, 7) | 0 the caller alone | n.  They spin ~50 us after a call and
- *                then sleep; they do not exist until the first per-call-input query.
- *   "launch_thread" 0 (default) | 1: per-call inputs: the caller converts a query's arrays (they are
- *                consumed before the call returns) and hands the HIP calls -- DMA copy, events,
- *                launches -- to a launcher thread; errors of those calls surface at drs_wait.  Cuts
- *                the caller's time per call from 20 to 14 us; throughput is PCIe-bound either way.
- *   "preferred_coalesce" (read only) queries per launch set the engine asks its feeder for: 12
- *                for gather-bound DLRM (the gap between two gather launches is amortised over
- *                more bytes), 8 for DIN, 16 (DRS_MAX_COALESCE) for MLP-bound models
- *   "gather_bound" (read only) 1 for the models whose set period is their gather launch (DLRM with fewer than 20 MLP FLOP
- *                per gathered byte, DIN): where the tables live and the rows' load policy are worth a search
- *   "device"     (read only) the HIP device index the engine was created on
- *   "preferred_slots" (read only) launch sets the engine asks its feeder to keep in flight: 3
- *                (gather | MLP | enqueue), 6 for NCF (one short latency-bound launch per set: 414 k ->
- *                480-492 k queries/s; nothing for the other models, whose p99 only doubles)
- *   "mlp_small_rows" pipelined mode: launch sets of up to this many rows (default 1024; a single
- *                query is 256) put their MLP side on the slot's own stream, so the latency-bound
- *                MLP launches of consecutive small sets overlap each other
- *   "small_piped" 0 (default) | 1: ... and their gather on the shared gather stream instead of the slot's own (one query
- *                per set, 6 sets in flight: 57 k -> 64 k queries/s at p99 0.115 ms; 3 in flight: 53 k -> 47 k)
- *   "mlp_early"  0 (default) | 1: a small set (<= 512 rows) of staged DLRM queries whose bottom + top MLP is one plain
- *                stream4_kernel launch starts that launch beside its gather: prologue and bottom chain run, then the
- *                launch polls a per-slot flag (a stream-ordered write behind the gather) before it fetches the pooled
- *                rows.  Same bits; measured slower with HIP's stream-ordered write (a kernel of its own), see
- *                profiles/r05_single_query/README.md
- *   "table_placement" where the table arena lives.  A multi-gigabyte allocation's place in HBM moves the gather by
- *                up to 6 % and stays for the allocation's lifetime; a feeder that has staged its input sets can
- *                try a few: -1 = copy the tables into one more allocation and use that one (the earlier ones stay
- *                allocated; DRS_ERR_OOM, nothing changed, when one more copy would take more than a quarter of the
- *                free memory or 256 exist) | k >= 0 = use candidate k | -2 = free every candidate but the one in use.
- *                Reading it gives the index in use, "table_placements" (read only) the number of candidates,
- *                "table_bytes" (read only) the size of one.  Freeing gigabytes has a price of its own: the runtime's
- *                copy-engine transfers (and, by a per cent or two, the gather) are slower for the rest of the process
- *                after it, so a feeder may prefer to leave small losers allocated until drs_destroy.
- *                drs_set_table / drs_fill_table_uniform drop the candidates not in use (they would be stale).
- *                Results never depend on it.  (DLRM_Net.tune_table_placement times each with the model's own sets.)
- *   "table_alloc" how the NEXT arena is built (a "table_placement" -1 candidate): 0 hipMalloc | 1 the virtual-memory
- *                API -- physical memory created in handles of "table_vmm_chunk" bytes (-1, the default: 1 GiB handles for
- *                arenas of at least 1 GiB, one handle for smaller ones; 0: one handle) and mapped into an address range
- *                aligned to "table_vmm_align" bytes (0: 2 MiB) | 2 hipDeviceMallocContiguous, best effort.
- *                "table_spacer" n: n bytes of device memory are taken in 1 GiB pieces and never mapped, so that the next
- *                candidate comes from further on in HBM ("table_placement" -2 and drs_destroy give them back).
- *                "table_address" (read only): the arena's address.  What moves the gather is WHICH physical gigabytes
- *                hold the tables x the load policy ("sls_nt"); DLRM_Net.tune_table_placement searches both.
- *                (The lab's instruments -- memory probes, arenas moved between address ranges or built from a probed
- *                pool, CU masks / priorities of the streams -- exist in the lab build only: make lab-lib, -DDRS_LAB.)
- *   "out_dma"    bytes (default 1 572 864; 0 = never): with "zero_copy" 1, launch sets with at least this many bytes of
- *                outputs hand them over by a copy-engine transfer queued behind the last kernel and a
- *                stream-ordered write of the completion flag behind that (MT-WnD's 2 MB per 16-query set);
- *                smaller sets by the last workgroup's own system-scope stores
- *   "zero_copy"  1 (default) last kernel writes outputs + completion flag into
- *                host-mapped pinned memory (no D2H copy, no stream sync) | 0 memcpy
- * unknown key -> DRS_ERR_BAD_ARG.  Options belong to the handle: two engines in one process
- * (the mixed-model accelerator engine) keep their own values.                    */
+ * Integer options of a handle; every key, its values, default and the measurement behind it: docs/OPTIONS.md.
+ * Results never depend on an option except where noted (sls_exact: the gather's fp32 summation order).
+ * The product library takes the keys below; unknown key or value -> DRS_ERR_BAD_ARG.
+ *   gather        "sls_exact" 0|1 (1: sequential order, bit-identical to Caffe2's SparseLengthsSum)
+ *                 "sls_flat" 0|1|2   "sls_bpw" 0|1|2|4   "sls_nt" 0|1
+ *                 "din_fused" 0|1   "din_pipe" 0|1   "din_s" 0|1|2|4   "din_nt" 0|1
+ *                 "dien_mfma" 0|1|2   "dien_fuse_top" 0|1
+ *   MLP side      "mlp_fuse" 0|1   "mlp_split" 0|1   "mlp_wide_kn" n   "gemm_split" 0|1
+ *                 "mlp_stream" 2|4   "mlp_stream_2cu" 0|1   "mlp_rows32" n
+ *                 "mlp_nsplit" 0|2|4   "mlp_nsplit_rows" n   "mlp_gemm_tile" 0|22|12|21|11|214|322|321|312|311
+ *   streams, host "shared_stream" 0|1|2   "mlp_streams" 1..8   "host_threads" -1..64
+ *                 "zero_copy_inputs" 1|2|3   "out_dma" bytes   "dispatch_log" 0|1
+ *   table arena   "table_placement" -1|-2|k   "table_alloc" 0|1|2   "table_spacer" bytes
+ *   read only     "preferred_coalesce"  "preferred_slots"  "gather_bound"  "device"
+ *                 "table_placements"  "table_bytes"  "table_address"
+ * Options belong to the handle: two engines in one process (the mixed-model accelerator engine) keep their own.
+ * The lab build (make -C deeprecsys_amd/csrc lab-lib, -DDRS_LAB) also takes the lab's instruments and the options
+ * of every form that lost its measurement (docs/OPTIONS.md, last section); the product library refuses them.      */
 int32_t drs_set_option(drs_handle h, const char* key, int64_t value);
 int32_t drs_get_option(drs_handle h, const char* key, int64_t* value);
 
@@ -461,7 +316,8 @@ int32_t drs_debug_gather_stamps(drs_handle h, int32_t slot, uint64_t* out, int64
  * stream4_kernel<rows32>[96 wg, 5 layers, 142400 B lds]".  The reference has one operator list per model
  * (models/dlrm_s_caffe2.py:223-389); here the launch form depends on the set's row count, and this is how a
  * caller (tests, tools/dispatch_table.py -> DESIGN.md's dispatch table) sees which one ran.  buf receives at
- * most cap - 1 characters and a terminating 0.                                                        */
+ * most cap - 1 characters and a terminating 0.  The record is kept only while "dispatch_log" is 1
+ * (off by default: DRS_ERR_STATE).                                                                      */
 int32_t drs_last_dispatch(drs_handle h, int32_t slot, char* buf, int64_t cap);
 /* algorithmic bytes of the gather for a query of `bs` samples of `batch_id`:
  * sum over bags of len*D*4 + len*4 + 4 + D*4  (SURVEY.md 8d / BASELINE.md 2)   */

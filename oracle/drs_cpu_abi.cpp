@@ -626,9 +626,9 @@ int32_t drs_kernel_bytes(drs_handle e, int32_t, int64_t* bytes) {
 int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   if (!e || !key || !value) return DRS_ERR_BAD_ARG;
   *value = 0;
-  if (!strcmp(key, "preferred_slots")) { *value = e->kind == DRS_MODEL_NCF ? 6 : 3; return DRS_OK; }   // (csrc/engine.hip drs_get_option)
+  if (!strcmp(key, "preferred_slots")) { *value = e->kind == DRS_MODEL_NCF ? 6 : 3; return DRS_OK; }   // (csrc/engine_options.hip kOptions)
   if (!strcmp(key, "preferred_coalesce")) {
-    // the engine's own rule (csrc/engine.hip drs_create / drs_get_option), so the host code above the ABI
+    // the engine's own rule (csrc/engine_create.hip choose_launch_forms, engine_options.hip), so the host code above the ABI
     // runs with the launch-set sizes the product uses: 16 when the model's MLP launches overlap each
     // other (MLP FLOP per gathered byte > 20, or a DLRM whose MLP launch outlasts its gather), 12 for
     // gather-bound DLRM, 8 otherwise

@@ -16,6 +16,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# DRS_TEST_LAB=1: the GPU suite on the LAB build of the library (libdrs_hip_lab.so: make -C deeprecsys_amd/csrc lab-lib) --
+# the same kernels plus the options of the forms that lost their measurement (mlp_stream 0 / 1, mlp_early, launch_thread,
+# zero_copy_inputs 0, ...), which the product library refuses; the tests run those entries only then (H.LAB).
+if os.environ.get("DRS_TEST_LAB", "0") not in ("", "0"):
+    from deeprecsys_amd import _native as _N
+    _lab = os.path.join(ROOT, "deeprecsys_amd", "libdrs_hip_lab.so")
+    if not os.path.exists(_lab):
+        raise RuntimeError("DRS_TEST_LAB=1 needs %s (make -C deeprecsys_amd/csrc lab-lib)" % _lab)
+    _N.LIB_PATH = _lab
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

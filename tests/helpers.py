@@ -20,6 +20,20 @@ NET_CLS = {"dlrm": M.DLRM_Net, "wnd": M.Wide_and_Deep, "ncf": M.NCF, "mtwnd": M.
 NO_DENSE = ("ncf", "din", "dien")     # model types whose queries are sparse features only
 
 
+LAB = M.N.is_lab()        # the lab build is bound (DRS_TEST_LAB=1, tests/conftest.py): entries that need its options run
+# what the lab build accepts beyond the product (docs/OPTIONS.md): whole keys, and values of two product keys
+_LAB_KEYS = {"mlp_early", "small_piped", "mlp_layout", "mlp_preload", "mlp_kc", "launch_thread", "mlp_debug", "mlp_small_rows",
+             "mlp_fuse_rows", "sls_short_bag", "sls_uniform", "mlp_gemm", "mlp_gemm_2cu", "mlp_gemm32", "mlp_gemm32_small",
+             "mlp_gemm32_small_blocks", "mlp_gemm32_blocks", "zero_copy", "table_vmm_chunk", "table_vmm_align"}
+
+
+def runs_here(opts):
+    """does the bound library take this option dict?  (product: no lab keys, mlp_stream in {2, 4}, zero_copy_inputs >= 1)"""
+    if LAB:
+        return True
+    return not (set(opts) & _LAB_KEYS or opts.get("mlp_stream", 2) in (0, 1) or opts.get("zero_copy_inputs", 1) == 0)
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 

@@ -265,7 +265,7 @@ def test_stand_alone_model_entry_prints_the_reference_table_lines(cpu_abi, case,
 
 def test_cpu_abi_answers_the_engines_launch_set_preference(cpu_abi):
     """the CPU restatement used to answer 8 for every model, so the host code ran with other
-    launch-set sizes off-GPU than on it.  It now restates the engine's rule (csrc/engine.hip): 12 for
+    launch-set sizes off-GPU than on it.  It now restates the engine's rule (csrc/engine_options.hip): 12 for
     gather-bound DLRM, 16 where MLP launches overlap each other, 8 otherwise."""
     def pref(kind, rows, D, bot, top, L, key="preferred_coalesce", **kw):
         e = N.Engine(kind, rows, D, bot, top, max_batch=16, max_lookups=L, num_staged_batches=1, num_slots=3, **kw)

@@ -100,7 +100,7 @@ def test_queue_requests_from_reference_engine(case):
             # per-call inputs read in place from pinned host memory (default) == copied to HBM
             # however the converted inputs reach the kernels (per-array copies, read in place over
             # PCIe, one DMA copy of the packed block; default: by size): the same bits
-            for mode in (0, 1, 2):
+            for mode in ((0, 1, 2) if H.LAB else (1, 2)):
                 net.engine.set_option("zero_copy_inputs", mode)
                 assert np.array_equal(out, w.run_queues(ids, lens, z["req/%d/fc_inputs" % r], bs)), mode
             net.engine.set_option("zero_copy_inputs", 1)
@@ -206,15 +206,16 @@ def test_gemm_kernel_every_tile_shape_is_bitwise(op_engine, tile, M, K, N_):
     finally:
         op_engine.set_option("mlp_gemm_tile", 0)
     assert np.array_equal(y.cpu().numpy(), exp)
-    # and the kernel it replaces agrees
-    op_engine.set_option("mlp_gemm", 0)
-    try:
-        y2 = torch.full((M, N_), float("nan"), device="cuda")
-        torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
-        op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, N.ACT_RELU, y2.data_ptr())
-    finally:
-        op_engine.set_option("mlp_gemm", 1)
-    assert np.array_equal(y2.cpu().numpy(), exp)
+    # and the kernel it replaces agrees (fc_kernel; "mlp_gemm" 0 is a lab option: narrow layers reach it by themselves)
+    if H.LAB:
+        op_engine.set_option("mlp_gemm", 0)
+        try:
+            y2 = torch.full((M, N_), float("nan"), device="cuda")
+            torch.cuda.synchronize()   # inputs/outputs were produced on torch's stream, the op runs on the engine's
+            op_engine.fc(dx.data_ptr(), M, K, dW.data_ptr(), db.data_ptr(), N_, N.ACT_RELU, y2.data_ptr())
+        finally:
+            op_engine.set_option("mlp_gemm", 1)
+        assert np.array_equal(y2.cpu().numpy(), exp)
 
 
 @pytest.mark.parametrize("F,D,itself", [(4, 8, False), (4, 8, True), (9, 32, False), (9, 64, True),
@@ -457,10 +458,13 @@ def test_full_size_reference_shapes_match_oracle(name):
         for (bid, bs), o in zip(jobs16, outs):
             assert np.array_equal(o, ref[(bid, bs)]), (name, "16 coalesced", bid, bs)
         # other launch structures of the same arithmetic: bit-identical
-        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_2cu", "mlp_gemm", "mlp_gemm_2cu", "mlp_fuse", "shared_stream", "out_dma")}
+        defaults = {k: eng.get_option(k) for k in ("mlp_stream", "mlp_stream_2cu", "mlp_fuse", "shared_stream", "out_dma") +
+                    (("mlp_gemm", "mlp_gemm_2cu") if H.LAB else ())}
         for opts in (dict(mlp_stream=0), dict(mlp_stream=1), dict(mlp_stream=2), dict(mlp_stream=4, mlp_stream_2cu=0),
                      dict(mlp_stream=4, mlp_stream_2cu=1), dict(mlp_gemm=0), dict(mlp_gemm_2cu=0), dict(mlp_gemm_2cu=1),
                      dict(mlp_fuse=0), dict(shared_stream=1), dict(out_dma=1)):
+            if not H.runs_here(opts):
+                continue                                    # (a lab option: DRS_TEST_LAB=1 runs it)
             for key, val in opts.items():
                 eng.set_option(key, val)
             assert np.array_equal(net.run_staged(1, B), ref[(1, B)]), (name, opts)
@@ -943,6 +947,8 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             "pipelined": dict(mlp_stream=1, mlp_fuse=1, shared_stream=2),
             "per_slot_streams": dict(mlp_stream=1, mlp_fuse=1, shared_stream=0),
         }.items():
+            if not H.runs_here(opts):
+                continue                                    # (a lab option: DRS_TEST_LAB=1 runs it)
             for k, v in opts.items():
                 eng.set_option(k, v)
             for slot in (0, 1, 2):      # keep several launch sets in flight
@@ -958,13 +964,14 @@ def test_mlp_launch_structures_are_bit_identical(D, T, bot, top, op):
             took_split = any("nsplit" in d for d in eng.last_dispatch(0))
             assert took_split == ("nsplit" in name and top.startswith("256-")), (name, eng.last_dispatch(0))
             eng.set_option("mlp_nsplit", 0)
-            eng.set_option("mlp_early", 0)
+            if H.LAB:
+                eng.set_option("mlp_early", 0)
             eng.set_option("mlp_wide_kn", 512 * 1024)
             eng.set_option("mlp_stream_2cu", 0)
             eng.set_option("mlp_rows32", 0)
         for name, got in results.items():
-            assert np.array_equal(got, results["stream"]), name
-        assert H.close(results["stream"], exp, rtol=1e-6, atol=1e-7)
+            assert np.array_equal(got, results["stream_packed"]), name
+        assert H.close(results["stream_packed"], exp, rtol=1e-6, atol=1e-7)
         # the interaction tensor the top MLP saw (cat layout / dot triangle), default structure
         for k, v in dict(mlp_stream=2, mlp_fuse=1, shared_stream=2).items():
             eng.set_option(k, v)
@@ -1222,13 +1229,17 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
             eng.stage_batch(0, dense[:bs], [r.copy() for r in ids], [r.copy() for r in lens])
             ref = eng.forward(0, bs)
             for workers, mode, lt in ((0, 3, 1), (1, 1, 0), (3, 2, 1), (-1, 0, 0), (-1, 3, 1), (-1, 1, 1), (-1, 2, 0)):
+                if not H.LAB and (mode == 0 or lt == 1):
+                    continue                             # (per-array copies and the launcher thread: lab options)
                 eng.set_option("host_threads", workers)
                 eng.set_option("zero_copy_inputs", mode)
-                eng.set_option("launch_thread", lt)      # launches on the calling thread (0) or handed to the launcher thread (1)
+                if H.LAB:
+                    eng.set_option("launch_thread", lt)  # launches on the calling thread (0) or handed to the launcher thread (1)
                 assert np.array_equal(eng.forward_inputs(dense[:bs], ids, lens, bs), ref), (bs, workers, mode, lt)
                 assert np.array_equal(eng.forward_inputs(dense[:bs], list(ids), list(lens), bs), ref)
-            eng.set_option("launch_thread", 1)
-            # calls handed to the launcher thread, mixed with staged submits on the other slots (every
+            if H.LAB:
+                eng.set_option("launch_thread", 1)
+            # calls handed to the launcher thread (lab build; the calling thread in the product), mixed with staged submits on the other slots (every
             # other entry point first lets that thread finish)
             for rep in range(20):
                 eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=0)
@@ -1243,14 +1254,14 @@ def test_per_call_inputs_2d_arrays_worker_pool_and_enforces():
                 assert np.array_equal(eng.wait(s_, bs), ref)
             # "sls_uniform" 0: the kernels read the prefix sums even for fixed-length bags, so every
             # copy mode has to ship them (the one-DMA-copy modes used to skip that upload)
-            eng.set_option("sls_uniform", 0)
-            for mode in (0, 1, 2, 3):
+            for mode in ((0, 1, 2, 3) if H.LAB else ()):
+                eng.set_option("sls_uniform", 0)
                 eng.set_option("zero_copy_inputs", mode)
                 for s_ in range(3):
                     eng.forward_inputs_async(dense[:bs], ids, lens, bs, slot=s_)
                 for s_ in range(3):
                     assert np.array_equal(eng.wait(s_, bs), ref), (bs, mode, "sls_uniform=0")
-            eng.set_option("sls_uniform", 1)
+                eng.set_option("sls_uniform", 1)
         with pytest.raises(ValueError):          # lengths narrower than bs: a Python error, not a host out-of-bounds read
             eng.forward_inputs(dense, big_ids[:, :B * L], big_len[:, :B - 1], B)
         with pytest.raises(ValueError):          # dense rows of the wrong width
@@ -1466,7 +1477,7 @@ def test_per_call_inputs_of_the_sparse_only_models(case):
         for bs in sorted({n, max(1, n // 2), 1}):
             ref = net.run_staged(0, bs)
             ids, lens = ids2[:, :bs * L], len2[:, :bs]
-            for workers, mode in ((0, 3), (1, 1), (3, 2), (-1, 0)):
+            for workers, mode in ((0, 3), (1, 1), (3, 2), (-1, 0 if H.LAB else 3)):
                 eng.set_option("host_threads", workers)
                 eng.set_option("zero_copy_inputs", mode)
                 assert np.array_equal(eng.forward_inputs(None, ids, lens, bs), ref), (case, bs, workers, mode)
@@ -1582,12 +1593,13 @@ def test_options_are_per_handle_and_engines_coexist():
         return e
     a, b = make(64, 8, 20), make(32, 4, 20)
     try:
-        defaults = {k: a.get_option(k) for k in ("sls_exact", "sls_flat", "sls_bpw", "sls_nt", "mlp_stream",
-                                                 "mlp_gemm", "mlp_gemm_tile", "mlp_kc", "mlp_preload")}
+        defaults = {k: a.get_option(k) for k in ("sls_exact", "sls_flat", "sls_bpw", "sls_nt", "mlp_stream", "mlp_gemm_tile") +
+                    (("mlp_gemm", "mlp_kc", "mlp_preload") if H.LAB else ())}
         assert defaults == {k: b.get_option(k) for k in defaults}
         ref_a, ref_b = a.forward(0, 64), b.forward(0, 64)
-        changed = {"sls_exact": 1, "sls_flat": 0, "sls_bpw": 2, "sls_nt": 0, "mlp_stream": 0, "mlp_gemm": 0,
-                   "mlp_gemm_tile": 11, "mlp_kc": 64, "mlp_preload": 1}
+        changed = {"sls_exact": 1, "sls_flat": 0, "sls_bpw": 2, "sls_nt": 0, "mlp_stream": 0 if H.LAB else 2, "mlp_gemm_tile": 11}
+        if H.LAB:
+            changed.update({"mlp_gemm": 0, "mlp_kc": 64, "mlp_preload": 1})
         for k, v in changed.items():
             a.set_option(k, v)
         assert {k: a.get_option(k) for k in changed} == changed
@@ -1616,10 +1628,10 @@ def test_options_are_per_handle_and_engines_coexist():
                                    # consecutive sets overlap each other
                                    ["--workload", "rmc3_ref", "--batch", "128"], ["--workload", "wnd", "--batch", "128"],
                                    ["--set", "sls_exact=1"],
-                                   # small sets start their MLP launch beside the gather (flag poll inside the kernel)
-                                   ["--set", "mlp_early=1"],
-                                   # the LDS-staged form of the stream kernel (the default reads packed twins)
-                                   ["--set", "mlp_stream=1"],
+                                   # small sets start their MLP launch beside the gather (flag poll inside the kernel; lab build)
+                                   pytest.param(["--set", "mlp_early=1"], marks=pytest.mark.skipif(not H.LAB, reason="lab option")),
+                                   # the LDS-staged form of the stream kernel (the default reads packed twins; lab build)
+                                   pytest.param(["--set", "mlp_stream=1"], marks=pytest.mark.skipif(not H.LAB, reason="lab option")),
                                    # DIN: the fused gather + attention launch, 1..8 queries per set (its
                                    # samples-per-workgroup shape changes with the set size, its bits must not)
                                    ["--workload", "din", "--batch", "96"], ["--workload", "dien", "--batch", "64"]])

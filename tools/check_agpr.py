@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """check_agpr.py <file.s> <kernel name substring>: fails when the compiler-generated part of the
 kernel (everything outside ;;#ASMSTART ... ;;#ASMEND) names an accumulation register, or when the kernel
-uses scratch memory (a spill).  stream4_kernel (mlp.hip) keeps live data in AGPRs between its asm statements."""
+uses scratch memory (a spill).  stream4_kernel (mlp_stream4.hip) keeps live data in AGPRs between its asm statements."""
 import re
 import sys
 

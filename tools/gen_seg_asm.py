@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates deeprecsys_amd/csrc/seg_asm.inc: the instruction streams of stream4_kernel (mlp.hip).
+"""Generates deeprecsys_amd/csrc/seg_asm.inc: the instruction streams of stream4_kernel (mlp_stream4.hip).
 
 One asm statement runs a whole SEGMENT -- every 64-k chunk of one (layer, pass) for the T = 4 / 2 / 1
 column tiles a wave owns -- as an unbroken run of MFMAs with the weight reloads, the operand prefetch

@@ -14,6 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 import bench
+if os.environ.get("DRS_TEST_LAB", "0") not in ("", "0"):      # the lab build (its options: mlp_early, mlp_stream 0 / 1, ...)
+    from deeprecsys_amd import _native as _N
+    _N.LIB_PATH = os.path.join(os.path.dirname(_N.LIB_PATH), "libdrs_hip_lab.so")
 
 
 def main():
