@@ -193,6 +193,9 @@ def trace_inputs(opt, args, m_den, rows, L):
     return nb, lX, lS_l, lS_i
 
 
+MID_SETS = 16     # launch sets of the timed region whose outputs are kept for the oracle (beside the last `slots` ones)
+
+
 def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1, tail=None, mid=None):
     """Closed loop: exactly n queries, `coalesce` of them per launch set, `slots` launch
     sets in flight.  Every query's latency runs from the submit of its launch set to the
@@ -200,21 +203,22 @@ def run_queries(eng, n, bs, nb, slots, lat=None, start_id=0, coalesce=1, tail=No
     tail (a list): the launch sets still in flight when the last query has been submitted -- the
     last `slots` sets of the region -- are waited for WITH an output buffer and appended as
     (batch ids, outputs [sum(bs), n_out]): what verify_tail() checks against the oracle.
-    mid (a list): the launch set submitted half-way through the region is collected WITH its outputs as well
-    (one host copy of bs * coalesce * n_out floats at the moment its slot is reused) and appended the same way:
-    a sample from the middle of the pipelined stream, not only from its drain."""
+    mid (a list): MID_SETS launch sets spread evenly over the region are collected WITH their outputs as well
+    (one host copy of bs * coalesce * n_out floats each, at the moment the set's slot is reused) and appended the
+    same way: samples from all along the pipelined stream, not only from its drain."""
     t_submit = [0.0] * slots
     in_slot = [0] * slots
     ids_in = [None] * slots
     t0 = time.perf_counter()
     i = g = 0
-    g_mid = (n // max(1, coalesce)) // 2 if mid is not None else -1
+    n_sets = -(-n // max(1, coalesce))
+    g_mid = {int((k + 0.5) * n_sets / MID_SETS) for k in range(MID_SETS)} if mid is not None else ()
     set_no = [-1] * slots
     while i < n:
         c = min(coalesce, n - i)
         s = g % slots
         if in_slot[s]:
-            if set_no[s] == g_mid:
+            if set_no[s] in g_mid:
                 mid.append((ids_in[s], eng.wait(s, bs * in_slot[s])))
             else:
                 eng.wait(s)
@@ -1003,7 +1007,7 @@ def main():
             try:
                 os.sched_setaffinity(0, job_mask)    # (the oracle check runs on every core of the host; the timed region is over)
                 out["verified"] = verify_tail(opt, net, data, mid + tail, bs)
-                out["verified"]["what"] = ("outputs of %d launch set(s) from the MIDDLE of the timed region and of its last %d "
+                out["verified"]["what"] = ("outputs of %d launch set(s) spread evenly over the timed region and of its last %d "
                                            "vs oracle/drs_oracle.c on the same inputs" % (len(mid), len(tail)))
                 out["verified"]["mid_region_sets"] = len(mid)
             except Exception as e:      # noqa: BLE001  (the line must still come out; "ok" is then absent)

@@ -72,19 +72,29 @@ pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 # (sustained runs: a GPU that was idle needs some hundred launches to reach its sustained shader clock -- a
 #  30-launch trace of an MFMA-bound kernel reads 10-15 % slow; tools/trace_ramp.py prints duration by position)
 trace gemm_8192 python tools/gemm_bench.py --rows 8192 --iters 3000 --shapes 2560x1024,1024x256
-trace gemm_8192_gemm_kernel python tools/gemm_bench.py --rows 8192 --iters 3000 --shapes 2560x1024,1024x256 --gemm32 0
+# (gemm_kernel on the same launch: "mlp_gemm32" 0 is a lab option since round 6 -- profiles/r05_gemm_sustained/ holds the pair)
 run 200 python tools/clock_trace.py --out "$OUT/gemm_8192_clock_trace.txt" --hz 20 -- python tools/gemm_bench.py --rows 8192 --iters 15000 --shapes 2560x1024 > /dev/null 2>&1
 pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --rows 8192 --iters 10 --shapes 2560x1024
-pmc "$OUT/gemm_pmc_summary.txt" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" python tools/gemm_bench.py --rows 8192 --iters 10 --shapes 2560x1024 --gemm32 0
 # per-workgroup phase stamps, shader clock and bit check of the same launch (tools/ubench/gemm_lab.hip, built by `make lab`)
 [ -x tools/ubench/gemm_lab ] && run 200 tools/ubench/gemm_lab 8192 2560 1024 > "$OUT/gemm_lab.txt" 2>&1
 [ -x tools/ubench/gemm_lab ] && run 200 tools/ubench/gemm_lab 4096 2560 1024 >> "$OUT/gemm_lab.txt" 2>&1
-# RM3: streams by launch set (default) against streams by kernel type ("mlp_layout" 1): both gather fractions, both rates
-run 600 $R3 --set mlp_layout=1 > "$OUT/rmc3_bench_layout1.json" 2>/dev/null
-run 600 $R3 --set mlp_gemm32=0 > "$OUT/rmc3_bench_gemm32_0.json" 2>/dev/null
+# (round 6: "mlp_layout" 1 and "mlp_gemm32" 0 are lab options; their RM3 lines are profiles/r05_rmc3_bench_layout1.json / _gemm32_0.json)
 # 5. other operating points and shapes (one line each)
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set shared_stream=1 > "$OUT/bench_single_stream.json" 2>/dev/null
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --coalesce 1 > "$OUT/bench_coalesce1.json" 2>/dev/null
+# round 6: small launch sets with and without the column-split MLP launch ("mlp_nsplit" 4, the default for DLRM), the arms alternating
+for rep in 1 2; do
+  for c in 1 2 4; do
+    for ns in 0 4; do
+      run 300 python bench.py --no_cpu_baseline --timed_only --steps 4 --warmup 2 --queries_per_step 20480 --coalesce $c --set mlp_nsplit=$ns > "$OUT/bench_coalesce${c}_nsplit${ns}_$rep.json" 2>/dev/null
+    done
+  done
+done
+run 300 python bench.py --no_cpu_baseline --timed_only --steps 4 --warmup 2 --queries_per_step 20480 --coalesce 1 --slots 4 > "$OUT/bench_coalesce1_slots4.json" 2>/dev/null
+run 300 python bench.py --no_cpu_baseline --timed_only --steps 4 --warmup 2 --queries_per_step 20480 --coalesce 1 --slots 4 --set mlp_nsplit=0 > "$OUT/bench_coalesce1_slots4_nsplit0.json" 2>/dev/null
+trace coalesce1 python bench.py --no_cpu_baseline --timed_only --steps 2 --warmup 1 --queries_per_step 8192 --coalesce 1
+[ -f deeprecsys_amd/libdrs_hip_tl.so ] && TL_ROWS=80 run 200 python tools/mlp_timeline.py --coalesce 1 > "$OUT/mlp_timeline_one_query_nsplit4.txt" 2>&1
+[ -f deeprecsys_amd/libdrs_hip_tl.so ] && TL_ROWS=80 run 200 python tools/mlp_timeline.py --coalesce 1 --set mlp_nsplit=0 > "$OUT/mlp_timeline_one_query_plain.txt" 2>&1
 # the 8-wave packed MLP launch in place of stream4_kernel (what each costs
 # the gather beside it), and launch sets of 8 instead of 12 queries
 run 300 python bench.py --no_cpu_baseline --steps 5 --warmup 2 --set mlp_stream=2 > "$OUT/bench_mlp_stream2.json" 2>/dev/null
