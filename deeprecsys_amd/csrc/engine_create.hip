@@ -182,8 +182,13 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       !cfg->ln_top || cfg->max_batch <= 0 || cfg->max_lookups <= 0 || cfg->num_staged_batches < 0)
     return fail(nullptr, DRS_ERR_BAD_ARG, "bad model config");
   const int D = cfg->sparse_dim;
-  if (D <= 0 || D > 256 || (D & 3))
-    return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d must be a multiple of 4 in [4, 256]", D);
+  // Every shipped config has D % 4 == 0 and D <= 256 (rows read as 16-byte pieces); DLRM, W&D, MT-WnD and NCF take any
+  // other width through the generic forms (sls_any_kernel, chain_kernel / fc_kernel's scalar paths): the reference only
+  // asks m_spa == ln_bot[-1] (models/dlrm_s_caffe2.py:435-437).  DIN / DIEN keep their own shape lists below.
+  const bool generic_ok = cfg->model_kind == DRS_MODEL_DLRM || cfg->model_kind == DRS_MODEL_WND ||
+                          cfg->model_kind == DRS_MODEL_MTWND || cfg->model_kind == DRS_MODEL_NCF;
+  if (D <= 0 || D > 4096 || ((D > 256 || (D & 3)) && !generic_ok))
+    return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d: this model kind needs a multiple of 4 in [4, 256] (DLRM / W&D / MT-WnD / NCF: any width up to 4096)", D);
   int ndev = 0;
   hipError_t r = hipGetDeviceCount(&ndev);
   if (r != hipSuccess || ndev <= 0)
@@ -229,7 +234,6 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     case DRS_MODEL_WND: {
       if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "W&D has no bottom MLP layers");
       e->m_den = e->w0 = e->bot.ln.front();
-      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
       e->num_int = T * D + e->w0;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
       e->n_out = e->top.ln.back();
@@ -238,7 +242,6 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     case DRS_MODEL_MTWND: {
       if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "MT-W&D has no bottom MLP layers");
       e->m_den = e->w0 = e->bot.ln.front();
-      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
       e->num_int = T * D + e->w0;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
       if (cfg->n_task < 2 || !cfg->ln_task || cfg->num_tasks < 1 || cfg->num_tasks > 64)

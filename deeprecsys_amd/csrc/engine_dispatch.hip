@@ -707,7 +707,7 @@ int32_t drs_sls(drs_handle e, const float* d_W, int64_t rows, int32_t D, const i
   if (rc) return rc;
   if (!d_W || !d_len || !d_out || (!d_idx && n_idx > 0) || n_bags < 0 || n_idx < 0 || rows <= 0)
     return fail(e, DRS_ERR_BAD_ARG, "bad arguments");
-  if (D <= 0 || D > 256 || (D & 3)) return fail(e, DRS_ERR_UNSUPPORTED, "D=%d must be a multiple of 4 in [4,256]", D);
+  if (D <= 0 || D > 4096) return fail(e, DRS_ERR_UNSUPPORTED, "D=%d must be in [1, 4096]", D);
   if (rows * (int64_t)D >= (1ll << 33) || n_bags >= (1ll << 31) || n_idx >= (1ll << 31))
     return fail(e, DRS_ERR_UNSUPPORTED, "operand too large");
   if (n_bags == 0) return n_idx == 0 ? DRS_OK : fail(e, DRS_ERR_LENGTHS_SUM, "indices without bags");

@@ -566,6 +566,70 @@ __global__ __launch_bounds__(64) void sls_flatc_kernel(SlsArgs a, int L) {
   }
 }
 
+// ANY row width: the generic form behind the ABI's total boundary.  The reference only asks m_spa == ln_bot[-1]
+// (models/dlrm_s_caffe2.py:435-437); every kernel above reads a row as 16-byte pieces (D % 4 == 0, D <= 256), which
+// every shipped config satisfies.  Other widths -- D = 10, 50, 300 -- take this one: a wave per bag, lane c takes columns
+// c, c + 64, ... (dword loads: rows need no alignment), rows strictly in index order, i.e. Caffe2's own summation order
+// (bit-identical to the oracle), ragged bags through the prefix sums.  Slow by design (one row at a time), never wrong.
+__global__ __launch_bounds__(64) void sls_any_kernel(SlsArgs a) {
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+  const int lane = threadIdx.x;
+  const int64_t bag = blockIdx.x;
+  const int smp = (int)(bag / a.T);
+  const int t = (int)(bag - (int64_t)smp * a.T);
+  int b = smp, vrow = a.q.vstart[0] + smp, ulen = a.uniform_len[0];
+  const int32_t* qidx = a.idx[0];
+  const int32_t* qoff = a.off[0];
+#pragma unroll
+  for (int i = 1; i < DRS_MAX_COALESCE; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    ulen = in ? a.uniform_len[i] : ulen;
+    qidx = in ? a.idx[i] : qidx;
+    qoff = in ? a.off[i] : qoff;
+  }
+  int beg, end;
+  if (ulen >= 0) {
+    beg = b * ulen;
+    end = beg + ulen;
+  } else {
+    const int32_t* __restrict__ offp = qoff + (int64_t)t * a.off_stride;
+    beg = offp[b];
+    end = offp[b + 1];
+  }
+  const int32_t* __restrict__ ip = qidx + (int64_t)t * a.idx_stride;
+  const float* __restrict__ W = a.tables + a.tab_off[t];
+  const uint32_t rows = (uint32_t)a.tab_rows[t];
+  const int D = a.D;
+  float* o = a.out + (int64_t)vrow * a.ld_out + a.col0 + (int64_t)t * D;
+  bool bad = false;
+  for (int c0 = 0; c0 < D; c0 += 64 * 4) {          // four columns per lane and pass
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = beg; j < end; ++j) {
+      uint32_t r = (uint32_t)ip[j];
+      bad |= r >= rows;
+      r = r < rows ? r : 0u;
+      const float* row = W + (int64_t)r * D;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + lane + 64 * k;
+        acc[k] += c < D ? row[c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + lane + 64 * k;
+      if (c < D) o[c] = acc[k];
+    }
+  }
+  if (bad) atomicOr(a.err, 1);
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
 // stop: optional event recorded BY the kernel dispatch itself (its completion signal) -- no
 // separate marker packet between this launch and the next one on the stream
 template <typename K, typename... X>
@@ -686,10 +750,13 @@ hipError_t launch_flat(const SlsArgs& a, const FlatPlan& p, hipStream_t s, hipEv
 
 // Tunables (drs_set_option, kept per engine in Tune): "sls_flat" / "sls_bpw" the flat variant and its bags
 // per wave (0 = auto), "sls_nt" non-temporal row loads.
-bool sls_flat_applicable(const SlsArgs& a, const Tune& tune) { return flat_plan(a, tune).ok; }
+static inline bool any_width(int D) { return (D & 3) || D > 256; }      // widths only sls_any_kernel takes
+
+bool sls_flat_applicable(const SlsArgs& a, const Tune& tune) { return !any_width(a.D) && flat_plan(a, tune).ok; }
 
 int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
   const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
+  if (any_width(a.D)) return n_bags;
   if (!exact) {
     const FlatPlan p = flat_plan(a, tune);
     return p.ok ? (int64_t)p.grid : n_bags;
@@ -701,7 +768,14 @@ int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
 
 hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t s, hipEvent_t stop) {
   const int D = a.D;
-  if (D <= 0 || D > 256 || (D & 3)) return hipErrorInvalidValue;
+  if (D <= 0) return hipErrorInvalidValue;
+  if (any_width(D)) {            // the generic form: any width, sequential order
+    const int64_t n_bags = (int64_t)a.q.cum[a.q.n_q] * a.T;
+    if (n_bags == 0) return hipSuccess;
+    log_launch(tune.log, "sls_any_kernel[%lld wg, D=%d]", (long long)n_bags, D);
+    launch_k(sls_any_kernel, dim3((unsigned)n_bags), s, stop, a);
+    return hipGetLastError();
+  }
   if (!exact) {
     const FlatPlan p = flat_plan(a, tune);
     if (p.ok) {

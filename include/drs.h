@@ -106,7 +106,9 @@ typedef struct drs_model_cfg {
   int32_t model_kind;           /* DRS_MODEL_*                                          */
   int32_t num_tables;           /* len(arch_embedding_size)                             */
   const int64_t* table_rows;    /* [num_tables] rows of each table                      */
-  int32_t sparse_dim;           /* arch_sparse_feature_size (D); multiple of 4, <= 256  */
+  int32_t sparse_dim;           /* arch_sparse_feature_size (D).  Multiples of 4 up to 256 (every shipped config) take
+                                 * the fast kernels; DLRM / W&D / MT-WnD / NCF accept any width up to 4096 through
+                                 * the generic forms (same results, slower); DIN: 32 | 64, DIEN: 16 | 32 | 64      */
   int32_t n_bot;                /* len(ln_bot)   (1 => no bottom MLP, W&D style)        */
   const int32_t* ln_bot;        /* [n_bot]                                              */
   int32_t n_top;                /* len(ln_top) including num_int                        */

@@ -1519,6 +1519,74 @@ def test_enable_profiling_prints_the_per_operator_type_table(capsys):
         net.engine.close()
 
 
+@pytest.mark.parametrize("D,T,L,bot,top,op", [
+    (10, 3, 4, "7-12-10", "9-1", "cat"),          # nothing a multiple of 4: rows of 40 bytes, dense 7, top input 40
+    (10, 3, 4, "7-12-10", "9-1", "dot"),          # ... and the dot interaction over 10-wide features
+    (6, 5, 1, "13-6", "8-3-1", "dot"),            # one lookup per bag
+    (50, 2, 7, "16-50", "32-1", "cat"),           # 200-byte rows
+    (300, 2, 3, "20-300", "64-1", "cat"),         # wider than the 256 columns the 16-byte forms serve
+])
+def test_any_embedding_width_is_served_and_matches_oracle(D, T, L, bot, top, op):
+    """The reference only requires m_spa == ln_bot[-1] (models/dlrm_s_caffe2.py:435-437); every shipped config has
+    D % 4 == 0, which the fast kernels assume.  Other widths take the generic forms (sls_any_kernel: sequential order;
+    chain_kernel / fc_kernel / interact_dot_kernel's scalar paths): pooled sums, interaction tensor bit-exact, outputs
+    to 1e-6 against the oracle, staged and per-call inputs, single and coalesced, ragged bags included."""
+    rows, B = 997, 70
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, L, bot, top, B, nb=2, seed=11, op=op)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        eng = net.engine
+        lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
+        net.emb_w = [orc.fill_table_uniform(rows, D, t, lo, hi, args.numpy_rand_seed, nthreads=0) for t in range(T)]
+        om = H.oracle_model(net)
+        ref = {}
+        for bid in (0, 1):
+            for bs in (B, 33, 1):
+                got = net.run_staged(bid, bs)
+                assert any("sls_any_kernel" in d for d in eng.last_dispatch(0)), eng.last_dispatch(0)
+                exp, R_exp = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+                assert np.array_equal(eng.fetch_interaction(bs), R_exp), (bid, bs)
+                assert H.close(got, exp, rtol=1e-6, atol=1e-7), (bid, bs)
+                ref[(bid, bs)] = got
+        jobs = [(0, B), (1, 33), (1, 1), (0, 33)]
+        for o, (bid, bs) in zip(net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs]), jobs):
+            assert np.array_equal(o, ref[(bid, bs)]), (bid, bs)
+        # per-call inputs with RAGGED bags (prefix sums): every second bag loses its last lookup
+        rng = np.random.RandomState(3)
+        lens = [np.where(np.arange(B) % 2 == 0, L, max(L - 1, 0)).astype(np.int32) for _ in range(T)]
+        ids = [rng.randint(0, rows, size=int(l.sum())).astype(np.int64) for l in lens]
+        got = eng.forward_inputs(lX[0], ids, lens, B)
+        assert H.close(got, om.forward(lX[0], ids, lens, bs=B, nthreads=0), rtol=1e-6, atol=1e-7)
+        with pytest.raises(N.DrsError):                  # Caffe2's ENFORCE still fires from the generic kernel
+            bad = [i.copy() for i in ids]
+            bad[T - 1][0] = rows
+            eng.forward_inputs(lX[0], bad, lens, B)
+    finally:
+        net.engine.close()
+
+
+def test_wide_and_deep_with_an_odd_dense_width():
+    """W&D's Concat(dense, embeddings) with a dense width that is not a multiple of 4 (the reference takes any
+    arch_mlp_bot, models/wide_and_deep.py:271-281): scalar row copy + the scalar FC paths."""
+    rows, T, D, B = 500, 3, 12, 40
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join([str(rows)] * T), arch_mlp_bot="13",
+                       arch_mlp_top="20-6-1", arch_interaction_op="cat", num_indices_per_lookup=1, num_batches=2,
+                       max_mini_batch_size=B, mini_batch_size=B, numpy_rand_seed=5, model_type="wnd", accel_slots=3)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        om = H.oracle_model(net)
+        for bid in (0, 1):
+            for bs in (B, 17, 1):
+                n = min(bs, len(lS_l[bid][0]))
+                got = net.run_staged(bid, n)
+                assert H.close(got, om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=n, nthreads=0), rtol=1e-6, atol=1e-7), (bid, bs)
+    finally:
+        net.engine.close()
+
+
 def test_create_rejects_what_the_int32_offsets_cannot_hold():
     """Prefix sums and bag * length products are int32 on the device: a staging capacity at
     2^31 / 8 coalesced queries is refused at drs_create, not left to overflow."""
