@@ -35,8 +35,11 @@ def DeepRecSys(args=None, cpu_engine=None, quiet=False):
         say(key, getattr(args, key))
     say("============================================================")
     if not args.queue:
-        sys.exit("ERROR: this build serves through the queue harness only (--queue); for a "
-                 "stand-alone timing run use bench.py")
+        # reference DeepRecSys.py:184-185: "No queue, run DeepRecSys in standalone mode" -> inferenceEngine(args), whose
+        # queue-less branch times nepochs passes over the generated batches (inferenceEngine.py:137-173); here the same
+        # loop on the accelerator (this package has no CPU forward)
+        from .dlrm_s_hip import standalone
+        return standalone(args)
 
     n_accel = accel_engine_count(args)
     n_cpu = int(args.inference_engines)

@@ -706,9 +706,15 @@ def main(argv=None):
     package has no CPU forward).  Prints the six `***` lines that
     accelerator/nvidia_gtx_1080_ti/generate_data.py:20 collects into `results_<model>.txt`,
     accelerator/predict_execution.py:10-29 parses and experiments/speedup/sweep_rt.py:158-183 sweeps."""
-    from .data_generator.dlrm_data import DLRMDataGenerator
     from .utils.utils import cli
-    args = cli(argv)
+    return standalone(cli(argv))
+
+
+def standalone(args):
+    """The stand-alone loop itself, on parsed arguments: what the reference's inferenceEngine() runs when it has no
+    request queue (inferenceEngine.py:137-173, reached from `DeepRecSys.py` without --queue, :184-185) -- nepochs passes
+    over the generated batches, then the six `***` lines."""
+    from .data_generator.dlrm_data import DLRMDataGenerator
     np.random.seed(args.numpy_rand_seed)
     np.set_printoptions(precision=args.print_precision)
     print("Using %d Accel(s)..." % max(N.device_count(), 0))

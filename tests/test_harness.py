@@ -342,6 +342,32 @@ def test_stand_alone_model_entry_on_the_gpu(tmp_path):
     assert 0.005 < comp_it < 5.0 and 0.005 < load_it < 20.0            # ms per iteration
 
 
+def test_orchestrator_without_a_queue_runs_the_stand_alone_loop(tmp_path, capsys):
+    """`DeepRecSys.py` without --queue (reference :184-185: "No queue, run DeepRecSys in standalone mode"): the engine's
+    queue-less branch -- nepochs passes over the generated batches and the six `***` lines (inferenceEngine.py:137-173).
+    Here on the CPU restatement of the ABI; the GPU suite runs the same loop through `python -m deeprecsys_amd.dlrm_s_hip`."""
+    from deeprecsys_amd import _native
+    from deeprecsys_amd.utils.utils import cli
+    from tests.cpu_abi_entry import bind_cpu_abi
+    prev = _native._lib
+    bind_cpu_abi()
+    try:
+        a = cli(["--inference_only", "--model_type", "dlrm", "--arch_sparse_feature_size", "8", "--arch_embedding_size", "200-300",
+                 "--arch_mlp_bot", "13-16-8", "--arch_mlp_top", "16-1", "--arch_interaction_op", "dot", "--num_indices_per_lookup", "4",
+                 "--nepochs", "3", "--num_batches", "4", "--mini_batch_size", "16", "--max_mini_batch_size", "16"])
+        assert not a.queue
+        DeepRecSys(a, quiet=True)
+    finally:
+        _native._lib = prev
+    out = capsys.readouterr().out
+    f = str(tmp_path / "results.txt")
+    open(f, "w").write(out)
+    rows = latency_table.parse_results(f)
+    assert len(rows) == 1
+    load, load_it, comp, comp_it, tot, tot_it = rows[0]
+    assert tot == pytest.approx(load + comp) and tot_it == pytest.approx(tot / 12) and tot > 0
+
+
 @pytest.mark.gpu
 def test_harness_with_a_real_accelerator_engine(tmp_path):
     a = _args(tmp_path, accel_backend="hip", num_accels=1, arch_sparse_feature_size=16,
