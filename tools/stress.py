@@ -4,7 +4,7 @@ fixed time, every result compared BIT FOR BIT with the same query served alone o
 engine.  Any stale read (gather -> MLP across streams, slot reuse, completion hand-off,
 coalescing offsets) shows up as a mismatch.
 
-    python tools/stress.py --seconds 30 [--workload rmc1] [--set key=value ...]
+    python tools/stress.py --seconds 30 [--max_set k] [--workload rmc1] [--set key=value ...]
 """
 import os
 import sys
@@ -25,6 +25,11 @@ def main():
     if "--seconds" in argv:
         i = argv.index("--seconds")
         seconds = float(argv[i + 1])
+        del argv[i:i + 2]
+    max_set = 16                          # --max_set k: launch sets of 1 .. k queries (small k: the small-set launch forms)
+    if "--max_set" in argv:
+        i = argv.index("--max_set")
+        max_set = max(1, min(16, int(argv[i + 1])))
         del argv[i:i + 2]
     sys.argv = ["bench.py", "--num_batches", "8", "--slots", "4"] + argv
     opt = bench.parse()
@@ -60,7 +65,7 @@ def main():
         slot = int(rng.randint(slots))
         if inflight[slot] is not None:
             check(slot)
-        k = int(rng.randint(1, 17))          # 1 .. DRS_MAX_COALESCE queries per launch set
+        k = int(rng.randint(1, max_set + 1))     # 1 .. max_set (default DRS_MAX_COALESCE) queries per launch set
         jobs = [(int(rng.randint(nb)), int(sizes[rng.randint(len(sizes))])) for _ in range(k)]
         eng.forward_multi_async(slot, [b for b, _ in jobs], [s for _, s in jobs])
         inflight[slot] = jobs
