@@ -16,7 +16,7 @@ inference_end_time when the result is on the host.  Requests that are already wa
 in the queue when the engine comes back for work (up to --accel_coalesce, max 16; 0 = what the engine prefers for the model) are
 served by ONE set of launches (drs_forward_multi_async): the gather then runs long
 enough to amortise its start-up and tail, which is worth ~15% HBM efficiency.  Up to
---accel_slots (default: the engine's preference, 3; NCF 6) such sets are in flight at a time: the library runs the gather
+--accel_slots (default: the engine's preference, 3; MLP-bound models 6) such sets are in flight at a time: the library runs the gather
 of one beside the MLP of the previous one while this loop is already pulling the next
 requests off the queue.  `--accel_backend sim` keeps the reference behaviour
 (latency_table.py) for runs without a GPU.

@@ -133,6 +133,7 @@ static void choose_launch_forms(drs_engine* e) {
   const double bytes = (double)T * e->max_lookups * D * 4.0;
   const bool mlp_bound = flop / bytes > 20.0;
   e->mlp_streams = mlp_bound ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
+  e->mlp_bound = mlp_bound ? 1 : 0;      // ("preferred_slots": MLP-bound models ask their feeder for six launch sets in flight)
   // In between: a gather-bound DLRM whose full launch set gathers FASTER than its latency-bound MLP launch runs (the
   // reference's own dlrm_rm1.json, D = 32: 33 us of gather against a 40 us launch): two MLP streams hand the pace back to
   // the gather (186 k -> 200 k queries/s; RMC1 BASELINE within noise; DIN 158 k -> 147 k, hence an estimate instead of a

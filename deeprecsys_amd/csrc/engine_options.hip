@@ -143,9 +143,12 @@ const OptDesc kOptions[] = {
     {"table_spacer", 0, kBig, nullptr, 0, [](drs_engine* e) -> int64_t { return (int64_t)e->spacers.size() << 30; }, nullptr, set_table_spacer},
     // what the engine tells its feeder (read only)
     OPT_RO("preferred_coalesce", return e->mlp_streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8);),
-    // launch sets the feeder should keep in flight: 3 (gather | MLP | enqueue); NCF's sets are one latency-bound
-    // launch of small layers that writes 1 MB of outputs over PCIe -- six of them in flight keep three resident
-    OPT_RO("preferred_slots", return e->kind == DRS_MODEL_NCF ? 6 : 3;),
+    // launch sets the feeder should keep in flight: 3 for the gather-bound models (gather | MLP | enqueue; more only adds
+    // latency: dlrm_rm1.json 258 k queries/s at 3 .. 8, DIN 175-176 k); 6 for the MLP-bound ones, whose sets are chains of
+    // MFMA-bound launches that overlap each other on up to four MLP streams (round 6, same box, 3 -> 6: DIEN 158 k -> 185 k
+    // (198 k at 5), W&D 98.1 k -> 104.7 k, RM3 config 3 34.1 k -> 35.1 k, RM3 JSON 67.8 k -> 70.6 k, MT-WnD 68.5 k -> 70.6 k,
+    // NCF 297 k -> 417 k; p99 doubles and stays under 4 ms against the 25 ms SLA)
+    OPT_RO("preferred_slots", return e->mlp_bound ? 6 : 3;),
     OPT_RO("gather_bound", return e->gather_bound;),
     OPT_RO("device", return e->device;),
     OPT_RO("table_placements", return (int64_t)e->arenas.size();),

@@ -75,24 +75,33 @@ class _HipNet(object):
     # -- device -------------------------------------------------------------------
     def _num_slots(self):
         """--accel_slots n launch sets in flight; 0 (default): what the engine asks for (drs_get_option
-        "preferred_slots": 3 -- gather | MLP | enqueue --, 6 for NCF, whose sets are one short latency-bound launch)."""
+        "preferred_slots": 3 -- gather | MLP | enqueue -- for the gather-bound models, 6 for the MLP-bound ones, whose
+        sets are chains of MFMA-bound launches that overlap each other).  The engine decides the class from the model's
+        shapes at creation: this is the first guess, _build_engine re-creates the (still empty) engine when it differs."""
         req = int(getattr(self.args, "accel_slots", 0) or 0)
-        return req if req > 0 else (6 if self.kind == N.MODEL_NCF else 3)
+        return req if req > 0 else (3 if self.kind in (N.MODEL_DLRM, N.MODEL_DIN) else 6)
 
     def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top, ln_task=None, num_tasks=0):
         a = self.args
         n_stage = max(int(getattr(a, "num_batches", 0)), 1)
         max_batch = max(int(getattr(a, "max_mini_batch_size", 1)), int(getattr(a, "mini_batch_size", 1)), 1)
-        eng = N.Engine(self.kind, self.ln_emb, self.m_spa, ln_bot_cfg, ln_top_cfg,
-                       interaction_op=interaction_op, interaction_itself=itself,
-                       sigmoid_top=sigmoid_top, max_batch=max_batch,
-                       max_lookups=max(int(a.num_indices_per_lookup), 1),
-                       num_staged_batches=n_stage,
-                       num_slots=self._num_slots(), device=self._device,
-                       ln_task=ln_task, num_tasks=num_tasks)
+        def make(n_slots):
+            return N.Engine(self.kind, self.ln_emb, self.m_spa, ln_bot_cfg, ln_top_cfg,
+                            interaction_op=interaction_op, interaction_itself=itself,
+                            sigmoid_top=sigmoid_top, max_batch=max_batch,
+                            max_lookups=max(int(a.num_indices_per_lookup), 1),
+                            num_staged_batches=n_stage,
+                            num_slots=n_slots, device=self._device,
+                            ln_task=ln_task, num_tasks=num_tasks)
+        eng = make(self._num_slots())
         if int(getattr(a, "accel_slots", 0) or 0) <= 0 and eng.get_option("preferred_slots") != eng.num_slots:
-            raise RuntimeError("accel_slots 0: created %d slots, the engine prefers %d" % (
-                eng.num_slots, eng.get_option("preferred_slots")))
+            # (an MLP-bound DLRM such as RM3: the class follows from the shapes, which the engine has just read)
+            want = int(eng.get_option("preferred_slots"))
+            eng.close()
+            eng = make(want)
+            if eng.get_option("preferred_slots") != eng.num_slots:
+                raise RuntimeError("accel_slots 0: created %d slots, the engine prefers %d" % (
+                    eng.num_slots, eng.get_option("preferred_slots")))
         # A/B aid for runs through the queue harness: DRS_ENGINE_OPTS="key=value,key=value"
         import os
         for kv in filter(None, os.environ.get("DRS_ENGINE_OPTS", "").split(",")):

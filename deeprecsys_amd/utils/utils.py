@@ -70,7 +70,7 @@ EXTRA_FLAGS = [
     ("accel_device_offset", _I, 0),   # first GPU ordinal used by the accel engines
     ("accel_table_init", _S, "numpy"),  # "numpy": reference RNG stream | "device": counter-based fill
     ("accel_table_placements", _I, 12),  # places in HBM tried for the table arena at engine start (1 = wherever hipMalloc put it)
-    ("accel_slots", _I, 0),           # launch sets in flight per accel engine; 0 = the engine's preference (3: gather | MLP | enqueue; NCF 6)
+    ("accel_slots", _I, 0),           # launch sets in flight per accel engine; 0 = the engine's preference (3: gather | MLP | enqueue; MLP-bound models 6)
     ("accel_req_batch", _I, 16),      # requests per put on accelRequestQueue / responses per put back (1 = the reference's one packet per put)
     ("accel_response_blocks", _I, 0),  # > 0: an accel engine answers in ResponseBlocks of up to this many responses (columns, one put) instead of ServiceResponse packets
     ("accel_coalesce", _I, 0),        # queued requests an accel engine may serve per launch set (0 = what the engine prefers for the model: 12 | 16 | 8)

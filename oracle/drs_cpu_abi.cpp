@@ -626,8 +626,7 @@ int32_t drs_kernel_bytes(drs_handle e, int32_t, int64_t* bytes) {
 int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
   if (!e || !key || !value) return DRS_ERR_BAD_ARG;
   *value = 0;
-  if (!strcmp(key, "preferred_slots")) { *value = e->kind == DRS_MODEL_NCF ? 6 : 3; return DRS_OK; }   // (csrc/engine_options.hip kOptions)
-  if (!strcmp(key, "preferred_coalesce")) {
+  if (!strcmp(key, "preferred_coalesce") || !strcmp(key, "preferred_slots")) {
     // the engine's own rule (csrc/engine_create.hip choose_launch_forms, engine_options.hip), so the host code above the ABI
     // runs with the launch-set sizes the product uses: 16 when the model's MLP launches overlap each
     // other (MLP FLOP per gathered byte > 20, or a DLRM whose MLP launch outlasts its gather), 12 for
@@ -637,6 +636,8 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       for (size_t i = 0; i + 1 < mm->ln.size(); ++i) flop += 2.0 * mm->ln[i] * (mm->ln[i + 1] > 0 ? mm->ln[i + 1] : 64);
     for (const Mlp& rn : e->rnn) flop += 2.0 * (e->T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
     const double bytes = (double)e->T * e->max_lookups * e->D * 4.0;
+    // launch sets in flight: 6 for the MLP-bound class (their MFMA-bound launches overlap each other), 3 otherwise
+    if (!strcmp(key, "preferred_slots")) { *value = flop / bytes > 20.0 ? 6 : 3; return DRS_OK; }
     int streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
     if (streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
       double weights = 0;
