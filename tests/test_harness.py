@@ -305,13 +305,13 @@ def test_bench_self_spawn_n1_equals_plain_n1_line_shape():
 
 @pytest.mark.gpu
 def test_bench_line_verifies_the_timed_regions_own_outputs():
-    """VERDICT r3 #1c, r4 #1: what the pipelined engine produced for the LAST launch sets of the timed region and for one set half-way through it
+    """VERDICT r3 #1c, r4 #1: what the pipelined engine produced for the LAST launch sets of the timed region and for sixteen sets spread over it
     (default flat gather, 12 queries per set, 3 sets in flight, MLP on its own stream) is compared with the
     oracle's forward inside bench.py, at BASELINE configs[1]'s full size."""
     out = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--queries_per_step", "3000", "--no_cpu_baseline"])
     v = out["verified"]
-    # the last three sets and (round 5) one set from the middle of the timed region
-    assert v["ok"] is True and v["launch_sets"] == 4 and v["mid_region_sets"] == 1 and out["verified_queries"] == 48
+    # the last three sets and (round 6) sixteen sets spread evenly over the timed region: 19 x 12 queries
+    assert v["ok"] is True and v["launch_sets"] == 19 and v["mid_region_sets"] == 16 and out["verified_queries"] == 228
     assert v["max_rel_err"] <= 1e-4
 
 
