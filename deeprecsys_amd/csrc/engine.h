@@ -238,6 +238,7 @@ struct drs_engine {
   int mlp_layout = 0;
   int gather_bound = 0;             // set by choose_launch_forms (read only for callers)
   int mlp_bound = 0;                // ... the other class: MLP FLOP per gathered byte > 20 (RM3, W&D, MT-WnD, NCF, DIEN)
+  int pref_slots = 3;               // "preferred_slots": launch sets the engine asks its feeder to keep in flight (choose_launch_forms)
   int gemm_split = 1;               // W&D / MT-WnD: the first top layer reads the dense columns from the queries' arrays (no copy launch)
   int gather_priority = 0;
   int mlp_cu_mask = 0, gather_cu_complement = 1;   // "mlp_cu_mask": CUs reserved for the MLP streams (0: none)

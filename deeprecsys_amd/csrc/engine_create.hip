@@ -132,8 +132,16 @@ static void choose_launch_forms(drs_engine* e) {
   for (const Mlp& rn : e->rnn) flop += 2.0 * (T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
   const double bytes = (double)T * e->max_lookups * D * 4.0;
   const bool mlp_bound = flop / bytes > 20.0;
-  e->mlp_streams = mlp_bound ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
-  e->mlp_bound = mlp_bound ? 1 : 0;      // ("preferred_slots": MLP-bound models ask their feeder for six launch sets in flight)
+  // How many streams, and how many sets in flight the engine asks its feeder for ("preferred_slots"), round 6, one box,
+  // (sets in flight, streams) -> k queries/s:  RM3 config 3 (3,3) 34.1 (6,4) 35.0 (4,2) 31.7 | RM3 JSON 67.8 / 70.8 / 70.9 |
+  // W&D 98.1 / 104.9 / 100.0 | NCF 297 / 389-417 / 346 | MT-WnD 68.5 / 70.8 / 73.0-74.8 | DIEN 158 / 185 / 214: with three
+  // sets one of four streams idles; DIEN's and MT-WnD's launches (two workgroups per CU each) thrash when four of them
+  // run at once and do best two at a time with a second set queued behind each (profiles/r06_slots.md).
+  const bool two_at_a_time = e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND;
+  const int want_streams = two_at_a_time ? 2 : 4;
+  e->mlp_streams = mlp_bound ? (e->n_slots < want_streams ? e->n_slots : want_streams) : 1;
+  e->mlp_bound = mlp_bound ? 1 : 0;
+  e->pref_slots = !mlp_bound ? 3 : two_at_a_time ? 4 : 6;
   // In between: a gather-bound DLRM whose full launch set gathers FASTER than its latency-bound MLP launch runs (the
   // reference's own dlrm_rm1.json, D = 32: 33 us of gather against a 40 us launch): two MLP streams hand the pace back to
   // the gather (186 k -> 200 k queries/s; RMC1 BASELINE within noise; DIN 158 k -> 147 k, hence an estimate instead of a

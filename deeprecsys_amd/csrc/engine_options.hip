@@ -148,7 +148,8 @@ const OptDesc kOptions[] = {
     // MFMA-bound launches that overlap each other on up to four MLP streams (round 6, same box, 3 -> 6: DIEN 158 k -> 185 k
     // (198 k at 5), W&D 98.1 k -> 104.7 k, RM3 config 3 34.1 k -> 35.1 k, RM3 JSON 67.8 k -> 70.6 k, MT-WnD 68.5 k -> 70.6 k,
     // NCF 297 k -> 417 k; p99 doubles and stays under 4 ms against the 25 ms SLA)
-    OPT_RO("preferred_slots", return e->mlp_bound ? 6 : 3;),
+    // (DIEN and MT-WnD: 4, two at a time on two MLP streams: 214 k against 185 k, 74 k against 71 k)
+    OPT_RO("preferred_slots", return e->pref_slots;),
     OPT_RO("gather_bound", return e->gather_bound;),
     OPT_RO("device", return e->device;),
     OPT_RO("table_placements", return (int64_t)e->arenas.size();),

@@ -79,7 +79,7 @@ class _HipNet(object):
         sets are chains of MFMA-bound launches that overlap each other).  The engine decides the class from the model's
         shapes at creation: this is the first guess, _build_engine re-creates the (still empty) engine when it differs."""
         req = int(getattr(self.args, "accel_slots", 0) or 0)
-        return req if req > 0 else (3 if self.kind in (N.MODEL_DLRM, N.MODEL_DIN) else 6)
+        return req if req > 0 else (3 if self.kind in (N.MODEL_DLRM, N.MODEL_DIN) else 4 if self.kind in (N.MODEL_DIEN, N.MODEL_MTWND) else 6)
 
     def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top, ln_task=None, num_tasks=0):
         a = self.args

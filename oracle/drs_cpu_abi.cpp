@@ -637,8 +637,12 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
     for (const Mlp& rn : e->rnn) flop += 2.0 * (e->T - 3) * ((double)rn.ln[0] * rn.ln[1] + (double)rn.ln[1] * rn.ln[2]);
     const double bytes = (double)e->T * e->max_lookups * e->D * 4.0;
     // launch sets in flight: 6 for the MLP-bound class (their MFMA-bound launches overlap each other), 3 otherwise
-    if (!strcmp(key, "preferred_slots")) { *value = flop / bytes > 20.0 ? 6 : 3; return DRS_OK; }
-    int streams = flop / bytes > 20.0 ? (e->n_slots < 4 ? e->n_slots : 4) : 1;
+    if (!strcmp(key, "preferred_slots")) {
+      *value = !(flop / bytes > 20.0) ? 3 : (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND) ? 4 : 6;
+      return DRS_OK;
+    }
+    const int want = (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND) ? 2 : 4;
+    int streams = flop / bytes > 20.0 ? (e->n_slots < want ? e->n_slots : want) : 1;
     if (streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
       double weights = 0;
       for (const Mlp* mm : {&e->bot, &e->top})
