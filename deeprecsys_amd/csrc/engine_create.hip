@@ -156,6 +156,17 @@ static void choose_launch_forms(drs_engine* e) {
   }
   const bool dlrm = e->kind == DRS_MODEL_DLRM;
   const bool gather_bound_dlrm = dlrm && !mlp_bound && !in_between;
+  // A gather-bound DLRM whose MLP side is THREE launches -- chain, a stand-alone wide layer, chain (RM2's 2112 x 128 first top
+  // layer) -- keeps two MLP streams: beside the next set's gather the GEMM launch does not get its 256-thread workgroups
+  // onto CUs the gather's one-wave workgroups keep backfilling (kernel trace, profiles/r06_rm2_timeline.txt: 513-533 us for
+  // 1.7 GFLOP, ending 28 us after the gather it ran beside), and on ONE stream the next set's bottom chain queues behind it:
+  // 58 us between two gather launches.  Two streams let that chain run meanwhile: RM2 21.6 k -> 22.7 k queries/s.
+  if (gather_bound_dlrm && e->mlp_split && e->n_slots >= 2) {
+    bool wide = false;
+    for (const Mlp* mm : {&e->bot, &e->top})
+      for (size_t i = 0; i + 1 < mm->ln.size(); ++i) wide = wide || (int64_t)mm->ln[i] * mm->ln[i + 1] >= e->mlp_wide_kn;
+    if (wide) e->mlp_streams = 2;
+  }
   // ("gather_bound", read only: the models whose set period is their gather launch -- where the tables live and which
   //  policy their rows are read with is worth a search, DLRM_Net.tune_table_placement)
   e->gather_bound = (dlrm && !mlp_bound) || e->kind == DRS_MODEL_DIN;

@@ -648,6 +648,10 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       for (const Mlp* mm : {&e->bot, &e->top})
         for (size_t i = 0; i + 1 < mm->ln.size(); ++i) weights += (double)mm->ln[i] * mm->ln[i + 1];
       if (12.0 + weights / 4500.0 > 2048.0 * bytes / 5.5e6) streams = 2;
+      // ... or whose MLP side has a stand-alone wide layer between two chains (RM2's 2112 x 128: K N >= 256 K weights)
+      for (const Mlp* mm : {&e->bot, &e->top})
+        for (size_t i = 0; i + 1 < mm->ln.size(); ++i)
+          if ((int64_t)mm->ln[i] * mm->ln[i + 1] >= 262144) streams = 2;
     }
     *value = streams > 1 ? DRS_MAX_COALESCE : (e->kind == DRS_MODEL_DLRM ? 12 : 8);
   }

@@ -282,5 +282,6 @@ def test_cpu_abi_answers_the_engines_launch_set_preference(cpu_abi):
     assert pref(N.MODEL_NCF, [1000, 1000, 200, 200], 64, [512], [128, 256, 128, 64, 64], 1, key="preferred_slots") == 6
     assert pref(N.MODEL_DLRM, [1000] * 8, 64, [128, 64, 64], [576, 256, 64, 1], 80, sigmoid_top=3) == 12        # RMC1
     assert pref(N.MODEL_DLRM, [1000] * 12, 32, [2560, 1024, 256, 32], [416, 512, 256, 1], 20, sigmoid_top=3) == 16   # RM3
+    assert pref(N.MODEL_DLRM, [1000] * 32, 64, [256, 128, 64], [2112, 128, 64, 1], 120, sigmoid_top=3) == 16     # RM2: a wide layer between two chains
     assert pref(N.MODEL_WND, [1000] * 27, 32, [512], [1376, 1024, 512, 256, 1], 1, sigmoid_top=4) == 16
     assert pref(N.MODEL_DIN, [1000] * 254, 32, [96, 1, 32], [128, 200, 80, 2], 3) == 8
