@@ -14,6 +14,7 @@
 
 #include "drs_internal.h"
 #include "mlp_dev.h"
+#include "rnn_dev.h"
 
 namespace drs {
 namespace {
@@ -856,33 +857,15 @@ __global__ __launch_bounds__(256) void dien_pack_kernel(const float* const* __re
   int64_t off = 0;
   for (int m = 0; m < 4; ++m) {
     const float* W = w[src[m]];
-    for (int i = threadIdx.x; i < K[m] * H; i += blockDim.x) {
-      const int k = i / H, j = i - k * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)K[m] * H; i += (int64_t)gridDim.x * blockDim.x) {
+      const int k = (int)(i / H), j = (int)(i - (int64_t)k * H);
       packed[off + i] = W[(int64_t)j * K[m] + k];
     }
     off += (int64_t)K[m] * H;
   }
   const int bsrc[4] = {1, 3, 5, 7};
   for (int m = 0; m < 4; ++m)
-    for (int j = threadIdx.x; j < H; j += blockDim.x) packed[off + (int64_t)m * H + j] = w[bsrc[m]][j];
-}
-
-// tanh for the recurrence: 8 values per lane and step in the matrix-core form, where the library
-// tanhf (two divergent paths, ~50 instructions) cost more than the MFMAs.  |x| < 0.25: the odd
-// Taylor polynomial through x^9 (next term < 2e-9 relative); else 1 - 2 / (e^{2|x|} + 1) on
-// v_exp_f32 / v_rcp_f32.  Within ~8 ulp of libm's tanhf (worst near |x| = 0.25); both DIEN kernels
-// use it, so they agree bitwise with each other and with the oracle to the tolerance in
-// tests/test_gpu_parity.py.
-__device__ __forceinline__ float tanh_rnn(float x) {
-  const float ax = fabsf(x);
-  const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);          // e^{2|x|}
-  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  const float x2 = ax * ax;
-  float p = fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);        // 62/2835, -17/315
-  p = fmaf(x2, p, 0.13333333333333333f);                                    // 2/15
-  p = fmaf(x2, p, -0.33333333333333331f);
-  p = fmaf(x2, p, 1.0f) * ax;
-  return copysignf(ax < 0.25f ? p : big, x);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < H; j += gridDim.x * blockDim.x) packed[off + (int64_t)m * H + j] = w[bsrc[m]][j];
 }
 
 template <int K>
@@ -1374,7 +1357,8 @@ bool dien_applicable(int32_t D, int32_t H) { return (D == 16 || D == 32 || D == 
 int64_t dien_packed_floats(int32_t D, int32_t H) { return (int64_t)D * H + 3ll * H * H + 4ll * H; }
 
 hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int32_t H, hipStream_t s) {
-  hipLaunchKernelGGL(dien_pack_kernel, dim3(1), dim3(256), 0, s, w, packed, D, H);
+  const int64_t blocks = ((int64_t)(D > H ? D : H) * H + 255) / 256;
+  hipLaunchKernelGGL(dien_pack_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, w, packed, D, H);
   return hipGetLastError();
 }
 
@@ -1400,6 +1384,9 @@ hipError_t launch_dien_rnn(const float* T, int64_t ldt, const QTable& q, int32_t
   const int64_t n = q.cum[q.n_q];
   if (n <= 0) return hipSuccess;
   bool ok = false;
+  // shapes without an instance of their own (and "dien_mfma" 3, which the parity tests use): the any-shape form
+  if (!dien_applicable(D, H) || mfma == 3)
+    return top && top->n > 0 ? hipErrorInvalidValue : launch_dien_rnn_any(T, ldt, q, Tn, D, H, packed, R, ldr, s);
   if (top && top->n > 0 && !(mfma && H % 16 == 0)) return hipErrorInvalidValue;   // (the engine asks dien_top_fusable first)
   if (mfma && H % 16 == 0) {
     DienW W;

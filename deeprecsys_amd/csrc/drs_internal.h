@@ -237,6 +237,16 @@ hipError_t launch_din_fused(const SlsArgs& a, int32_t h, const float* packed, fl
 // DIEN (din.hip; models/dien.py:308-432).  w: 8 device pointers {i2h_w, i2h_b, gates_t_w, gates_t_b} of
 // layer 1 then layer 2; launch_dien_rnn: T [rows, Tn*D] pooled rows of the coalesced queries q ->
 // R [rows, H + 3*D] = [ last state of layer 2 | profile | ad | context ].
+// Any-shape forms (din_any.hip): attention units of any depth and width -- d_ln: the unit's n_ln widths on the device,
+// d_att: per unit and layer {W, b}, maxw: the widest hidden layer -- and the recurrence for any D and H (packed as
+// launch_dien_pack lays it out).  *_fits: the sample's activations fit the 160 KB of LDS.
+bool din_any_fits(int32_t D, int32_t maxw);
+bool dien_any_fits(int32_t D, int32_t H);
+hipError_t launch_din_attention_any(const float* T, int64_t ldt, int64_t M, int32_t Tn, int32_t D, int32_t n_ln,
+                                    const int32_t* d_ln, const float* const* d_att, int32_t maxw, float* R, int64_t ldr,
+                                    hipStream_t stream);
+hipError_t launch_dien_rnn_any(const float* T, int64_t ldt, const QTable& q, int32_t Tn, int32_t D, int32_t H,
+                               const float* packed, float* R, int64_t ldr, hipStream_t stream);
 bool dien_applicable(int32_t D, int32_t H);
 int64_t dien_packed_floats(int32_t D, int32_t H);
 hipError_t launch_dien_pack(const float* const* w, float* packed, int32_t D, int32_t H, hipStream_t stream);

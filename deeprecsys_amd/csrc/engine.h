@@ -203,8 +203,11 @@ struct drs_engine {
   const float** d_att = nullptr; // device: 4 pointers per unit (W1, b1, W2, b2) ...
   float* d_att_packed = nullptr; // ... and the units' weights packed for the DIN kernels (din.hip)
   bool att_dirty = true;         // a unit's weights changed since the last pack
+  bool din_any = false;          // DIN: units din.hip has no form for (depth != 2, wide hidden layer, D not 4 k <= 256) -> din_any.hip
+  int din_maxw = 0;              // ... their widest hidden layer
+  int32_t* d_att_ln = nullptr;   // ... and the units' widths on the device
   int dien_fuse_top = 1;         // DIEN: the top MLP inside the recurrence's launch when it fits (din.hip dien_top_fusable)
-  int dien_mfma = 2;             // DIEN recurrence on the matrix cores, 16 samples per workgroup: 2 = one wave set per layer | 1 = every wave both layers | 0 one wave per sample (VALU)
+  int dien_mfma = 2;             // DIEN recurrence on the matrix cores, 16 samples per workgroup: 2 = one wave set per layer | 1 = every wave both layers | 0 one wave per sample (VALU) | 3 the any-shape form (din_any.hip)
   int din_fused = 1;             // gather + attention units + Concat in one launch (default mode)
   std::vector<Mlp> rnn;          // DIEN: the two BasicRNN layers, each {i2h, gates_t}; packed into d_att_packed
   float* w_arena = nullptr;      // all FC weights + biases in ONE allocation (large pages: the

@@ -202,13 +202,10 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       !cfg->ln_top || cfg->max_batch <= 0 || cfg->max_lookups <= 0 || cfg->num_staged_batches < 0)
     return fail(nullptr, DRS_ERR_BAD_ARG, "bad model config");
   const int D = cfg->sparse_dim;
-  // Every shipped config has D % 4 == 0 and D <= 256 (rows read as 16-byte pieces); DLRM, W&D, MT-WnD and NCF take any
-  // other width through the generic forms (sls_any_kernel, chain_kernel / fc_kernel's scalar paths): the reference only
-  // asks m_spa == ln_bot[-1] (models/dlrm_s_caffe2.py:435-437).  DIN / DIEN keep their own shape lists below.
-  const bool generic_ok = cfg->model_kind == DRS_MODEL_DLRM || cfg->model_kind == DRS_MODEL_WND ||
-                          cfg->model_kind == DRS_MODEL_MTWND || cfg->model_kind == DRS_MODEL_NCF;
-  if (D <= 0 || D > 4096 || ((D > 256 || (D & 3)) && !generic_ok))
-    return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d: this model kind needs a multiple of 4 in [4, 256] (DLRM / W&D / MT-WnD / NCF: any width up to 4096)", D);
+  // Every shipped config has D % 4 == 0 and D <= 256 (rows read as 16-byte pieces); any other width goes through the
+  // generic forms (sls_any_kernel, chain_kernel / fc_kernel's scalar paths, din_any.hip): the reference only asks
+  // m_spa == ln_bot[-1] (models/dlrm_s_caffe2.py:435-437).
+  if (D <= 0 || D > 4096) return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d must be in [1, 4096]", D);
   int ndev = 0;
   hipError_t r = hipGetDeviceCount(&ndev);
   if (r != hipSuccess || ndev <= 0)
@@ -280,17 +277,22 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     }
     case DRS_MODEL_DIN: {
       if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIN needs at least 4 embedding tables");
-      if (cfg->n_bot != 3 || e->bot.ln[0] != 3 * D || e->bot.ln[2] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
-        return bail(DRS_ERR_UNSUPPORTED, "DIN attention unit must be 3*D -> h -> D with 1 <= h <= 64");
-      // the two-launch attention kernel (the only path for sls_exact = 1 and for shapes the fused launch is
-      // not instantiated for) keeps 4 samples x (T - 3) units x h hidden values in 64 KB of LDS
-      if ((int64_t)(T - 3) * e->bot.ln[1] > 4096)
-        return bail(DRS_ERR_UNSUPPORTED, "DIN: (num_tables - 3) * hidden width must not exceed 4096");
+      // an attention unit is create_mlp over 3*D - <arch_mlp_bot> - D (models/din.py:255-277): any depth, any widths
+      if (cfg->n_bot < 2 || e->bot.ln.front() != 3 * D || e->bot.ln.back() != D)
+        return bail(DRS_ERR_BAD_ARG, "DIN attention unit must be 3*D -> ... -> D");
+      for (int w : e->bot.ln) if (w < 1) return bail(DRS_ERR_BAD_ARG, "DIN attention unit with an empty layer");
+      // din.hip's forms: one hidden layer of <= 64 units, rows in 16-byte pieces; the two-launch attention kernel (the only
+      // path for sls_exact = 1 and for shapes the fused launch is not instantiated for) keeps 4 samples x (T - 3) units x
+      // h hidden values in 64 KB of LDS.  Everything else: din_any.hip.
+      e->din_any = cfg->n_bot != 3 || e->bot.ln[1] > 64 || (int64_t)(T - 3) * e->bot.ln[1] > 4096 || (D & 3) || D > 256;
+      for (int l = 1; l + 1 < cfg->n_bot; ++l) e->din_maxw = std::max(e->din_maxw, e->bot.ln[l]);
+      if (e->din_any && !din_any_fits(D, e->din_maxw))
+        return bail(DRS_ERR_UNSUPPORTED, "DIN: 4*D + 2*(widest hidden layer of a unit) floats must fit 160 KB of LDS");
       e->m_den = 0; e->w0 = 0;
       e->num_int = 4 * D;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
       e->att.resize(T - 3);
-      for (auto& au : e->att) { au.ln = e->bot.ln; au.layers.resize(2); au.sigmoid_layer = -1; }
+      for (auto& au : e->att) { au.ln = e->bot.ln; au.layers.resize(cfg->n_bot - 1); au.sigmoid_layer = -1; }
       e->bot.ln = {0}; e->bot.layers.clear();      // no bottom MLP of its own
       e->top.sigmoid_layer = -1;
       e->n_out = e->top.ln.back();
@@ -298,8 +300,10 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     }
     case DRS_MODEL_DIEN: {
       if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIEN needs at least 4 embedding tables");
-      if (cfg->n_bot != 2 || e->bot.ln[0] != D || !dien_applicable(D, e->bot.ln[1]))
-        return bail(DRS_ERR_UNSUPPORTED, "DIEN: ln_bot must be [D, hidden_size], D in {16, 32, 64}, hidden_size in {8, 16, 32, 64}");
+      if (cfg->n_bot != 2 || e->bot.ln[0] != D || e->bot.ln[1] < 1) return bail(DRS_ERR_BAD_ARG, "DIEN: ln_bot must be [D, hidden_size]");
+      // D in {16, 32, 64} with hidden_size in {8, 16, 32, 64}: din.hip's forms; any other pair: din_any.hip
+      if (!dien_applicable(D, e->bot.ln[1]) && !dien_any_fits(D, e->bot.ln[1]))
+        return bail(DRS_ERR_UNSUPPORTED, "DIEN: D + 4*hidden_size floats must fit 160 KB of LDS");
       const int H = e->bot.ln[1];
       e->m_den = 0; e->w0 = 0;
       e->num_int = H + 3 * D;
@@ -524,6 +528,7 @@ int32_t drs_destroy(drs_handle e) {
   e->rnn.clear();
   if (e->d_att) (void)hipFree(e->d_att);
   if (e->d_att_packed) (void)hipFree(e->d_att_packed);
+  if (e->d_att_ln) (void)hipFree(e->d_att_ln);
   if (e->w_arena) (void)hipFree(e->w_arena);
   for (Arena& a : e->arenas) arena_free(a);
   for (auto& h : e->spacers) (void)hipMemRelease(h);

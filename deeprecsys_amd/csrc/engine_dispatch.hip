@@ -210,6 +210,19 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     HIP_TRY(e, hipStreamSynchronize(nullptr));
     e->att_dirty = false;
   }
+  if (!e->att.empty() && e->att_dirty && e->din_any) {
+    // any-shape units (din_any.hip): the kernel reads the layers where drs_set_fc put them
+    if (!e->d_att) {
+      std::vector<const float*> hp;
+      for (auto& au : e->att)
+        for (auto& L : au.layers) { hp.push_back(L.W); hp.push_back(L.b); }
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att), sizeof(float*) * hp.size()));
+      HIP_TRY(e, hipMemcpy(e->d_att, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice));
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_att_ln), sizeof(int32_t) * e->att[0].ln.size()));
+      HIP_TRY(e, hipMemcpy(e->d_att_ln, e->att[0].ln.data(), sizeof(int32_t) * e->att[0].ln.size(), hipMemcpyHostToDevice));
+    }
+    e->att_dirty = false;
+  }
   if (!e->att.empty() && e->att_dirty) {
     const int U = (int)e->att.size(), h = e->att[0].ln[1];
     if (!e->d_att) {
@@ -296,7 +309,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   // bags share a wave and all of its row loads are in flight at once)
   const int exact_now = e->sls_exact || (short_bags && !sls_flat_applicable(a, e->tune));
   // DIN, default mode: the attention units are fused into the gather launch (din.hip)
-  const bool din_fused = e->kind == DRS_MODEL_DIN && !e->sls_exact && e->din_fused &&
+  const bool din_fused = e->kind == DRS_MODEL_DIN && !e->sls_exact && e->din_fused && !e->din_any &&
                          din_fused_applicable(e->D, e->att[0].ln[1]);
   s.ts_blocks = prof ? (din_fused ? din_fused_grid(a, e->tune) : sls_grid_blocks(a, exact_now, e->tune)) : 0;
   if (prof) {
@@ -362,7 +375,10 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
     DienTop tp;
     memset(&tp, 0, sizeof tp);
     const int nt = (int)e->top.layers.size();
-    if (e->dien_fuse_top && e->dien_mfma && Hh % 16 == 0 && nt >= 1 && nt <= 4 && e->top.layers[0].packed &&
+    // 3: the any-shape form (din_any.hip) -- every shape without an instance in din.hip, or on request
+    const int form = dien_applicable(e->D, Hh) ? e->dien_mfma : 3;
+    const bool mfma_form = form != 3 && form && Hh % 16 == 0;
+    if (e->dien_fuse_top && mfma_form && nt >= 1 && nt <= 4 && e->top.layers[0].packed &&
         dien_top_fusable(nt, e->top.ln.data(), Hh) && e->top.ln[0] == Hh + 3 * e->D) {
       tp.n = nt; tp.sc1 = dp ? 1 : 0; tp.out = out; tp.ldo = e->n_out;
       for (int l = 0; l < nt; ++l) {
@@ -372,16 +388,21 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       }
       tp.kmax = dien_top_kmax(nt, e->top.ln.data());
     }
-    log_launch(e->tune.log, "%s<%d,%d%s>[%d wg]", e->dien_mfma && Hh % 16 == 0 ? "dien_rnn_mfma_kernel" : "dien_rnn_kernel", e->D, Hh,
-               tp.n ? ",top" : "", e->dien_mfma && Hh % 16 == 0 ? (c + 15) / 16 : (c + 3) / 4);
-    HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, Hh, e->d_att_packed, rw, e->dien_mfma, s.R,
+    log_launch(e->tune.log, "%s<%d,%d%s>[%d wg]", form == 3 ? "dien_rnn_any_kernel" : mfma_form ? "dien_rnn_mfma_kernel" : "dien_rnn_kernel",
+               e->D, Hh, tp.n ? ",top" : "", form == 3 ? c : mfma_form ? (c + 15) / 16 : (c + 3) / 4);
+    HIP_TRY(e, launch_dien_rnn(s.T, e->ldT, q, e->T, e->D, Hh, e->d_att_packed, rw, form, s.R,
                                e->ldR, s.stream, tp.n ? &tp : nullptr, dp));
     if (!tp.n && (rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
   } else if (e->kind == DRS_MODEL_DIN) {
     // attention units over the pooled rows -> top MLP input R [rows, 4D] -> top MLP (all ReLU)
     HIP_TRY(e, join());
-    if (!din_fused) log_launch(e->tune.log, "din_attention_kernel[%lld wg]", (long long)((Mv + 3) / 4));
-    if (!din_fused)
+    if (e->din_any) {
+      log_launch(e->tune.log, "din_attention_any_kernel[%lld wg]", (long long)Mv);
+      HIP_TRY(e, launch_din_attention_any(s.T, e->ldT, Mv, e->T, e->D, (int)e->att[0].ln.size(), e->d_att_ln, e->d_att, e->din_maxw,
+                                          s.R, e->ldR, s.stream));
+    }
+    if (!din_fused && !e->din_any) log_launch(e->tune.log, "din_attention_kernel[%lld wg]", (long long)((Mv + 3) / 4));
+    if (!din_fused && !e->din_any)
       HIP_TRY(e, launch_din_attention(s.T, e->ldT, Mv, e->T, e->D, e->att[0].ln[1], e->d_att_packed, s.R, e->ldR, s.stream));
     if ((rc = run_mlp(e, s, e->top, s.R, e->ldR, Mv, out, e->n_out, dp))) return rc;
   } else if (e->kind == DRS_MODEL_NCF) {

@@ -105,7 +105,7 @@ const OptDesc kOptions[] = {
     OPT("din_pipe", 0, 1, nullptr, O_BOOL, tune.din_pipe),
     OPT("din_s", 0, 4, [](int64_t v) { return v != 3; }, 0, tune.din_s),
     OPT("din_nt", 0, 1, nullptr, O_BOOL, tune.din_nt),
-    OPT("dien_mfma", 0, 2, nullptr, 0, dien_mfma),
+    OPT("dien_mfma", 0, 3, nullptr, 0, dien_mfma),
     OPT("dien_fuse_top", 0, 1, nullptr, 0, dien_fuse_top),
     // MLP side
     OPT("gemm_split", 0, 1, nullptr, O_BOOL, gemm_split),

@@ -57,10 +57,12 @@ enum {
   ,
   DRS_MODEL_DIN = 4   /* models/din.py:247-330: tables = [user profile | U behaviour tables |
                          candidate ad | context], U = num_tables - 3; per behaviour table an
-                         attention unit with its OWN two-layer MLP over Concat(u_i, ad, u_i + ad);
+                         attention unit with its OWN MLP over Concat(u_i, ad, u_i + ad);
                          atten_out = Sum over the units; top MLP over Concat(profile, atten_out,
                          ad, context); every activation ReLU.  cfg: ln_bot = the unit's widths
-                         [3*D, h, D] (arch_mlp_bot "h"), ln_top = [4*D, ...], no dense input      */
+                         [3*D, <arch_mlp_bot>, D] -- any number of hidden layers of any width (the
+                         shipped "1": the fused launch; others: slower forms, same results) --,
+                         ln_top = [4*D, ...], no dense input                                      */
   ,
   DRS_MODEL_DIEN = 5  /* models/dien.py:308-432: tables as DIN.  The U behaviour embeddings of a query,
                          Concat'ed [bs, U*D] and Reshape'd (row-major reinterpretation, as the reference
@@ -68,7 +70,8 @@ enum {
                          zero initial state, D -> H and H -> H; the FC + Softmax between them is dead in
                          the reference graph and not computed); top MLP (all ReLU) over Concat(last
                          state, profile, ad, context).  cfg: ln_bot = [D, H] (--hidden_size),
-                         ln_top = [H + 3*D, ...], no dense input.  H <= 64.                           */
+                         ln_top = [H + 3*D, ...], no dense input.  Any D and H whose D + 4 H floats fit
+                         160 KB (D in {16, 32, 64} with H in {8, 16, 32, 64}: the matrix-core form).   */
 };
 
 /* feature interaction (models/dlrm_s_caffe2.py:331-365) */
@@ -106,9 +109,9 @@ typedef struct drs_model_cfg {
   int32_t model_kind;           /* DRS_MODEL_*                                          */
   int32_t num_tables;           /* len(arch_embedding_size)                             */
   const int64_t* table_rows;    /* [num_tables] rows of each table                      */
-  int32_t sparse_dim;           /* arch_sparse_feature_size (D).  Multiples of 4 up to 256 (every shipped config) take
-                                 * the fast kernels; DLRM / W&D / MT-WnD / NCF accept any width up to 4096 through
-                                 * the generic forms (same results, slower); DIN: 32 | 64, DIEN: 16 | 32 | 64      */
+  int32_t sparse_dim;           /* arch_sparse_feature_size (D), 1 .. 4096.  Multiples of 4 up to 256 (every shipped
+                                 * config) take the fast kernels, any other width the generic forms (same results,
+                                 * slower)                                                                          */
   int32_t n_bot;                /* len(ln_bot)   (1 => no bottom MLP, W&D style)        */
   const int32_t* ln_bot;        /* [n_bot]                                              */
   int32_t n_top;                /* len(ln_top) including num_int                        */

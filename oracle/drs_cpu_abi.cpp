@@ -295,8 +295,7 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       !cfg->ln_top || cfg->max_batch <= 0 || cfg->max_lookups <= 0 || cfg->num_staged_batches < 0)
     return fail(nullptr, DRS_ERR_BAD_ARG, "bad model config");
   const int D = cfg->sparse_dim;
-  if (D <= 0 || D > 256 || (D & 3))
-    return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d must be a multiple of 4 in [4, 256]", D);
+  if (D <= 0 || D > 4096) return fail(nullptr, DRS_ERR_UNSUPPORTED, "sparse_dim=%d must be in [1, 4096]", D);
   if (device_id != 0) return fail(nullptr, DRS_ERR_BAD_ARG, "device %d of 1", device_id);
   drs_engine* e = new drs_engine();
   e->kind = cfg->model_kind; e->T = cfg->num_tables; e->D = D;
@@ -322,7 +321,6 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     case DRS_MODEL_WND:
       if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "W&D has no bottom MLP layers");
       e->m_den = e->w0 = e->bot.ln.front();
-      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
       e->num_int = T * D + e->w0;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
       e->n_out = e->top.ln.back();
@@ -330,7 +328,6 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     case DRS_MODEL_MTWND:
       if (cfg->n_bot != 1) return bail(DRS_ERR_BAD_ARG, "MT-W&D has no bottom MLP layers");
       e->m_den = e->w0 = e->bot.ln.front();
-      if (e->w0 & 3) return bail(DRS_ERR_UNSUPPORTED, "dense width must be a multiple of 4");
       e->num_int = T * D + e->w0;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "num_int does not match first dim of top mlp");
       if (cfg->n_task < 2 || !cfg->ln_task || cfg->num_tasks < 1 || cfg->num_tasks > 64)
@@ -343,10 +340,16 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       break;
     case DRS_MODEL_DIN:
       if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIN needs at least 4 embedding tables");
-      if (cfg->n_bot != 3 || e->bot.ln[0] != 3 * D || e->bot.ln[2] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
-        return bail(DRS_ERR_UNSUPPORTED, "DIN attention unit must be 3*D -> h -> D with 1 <= h <= 64");
-      if ((int64_t)(T - 3) * e->bot.ln[1] > 4096)   // same limit as the HIP engine (its attention kernel's LDS)
-        return bail(DRS_ERR_UNSUPPORTED, "DIN: (num_tables - 3) * hidden width must not exceed 4096");
+      if (cfg->n_bot < 2 || e->bot.ln.front() != 3 * D || e->bot.ln.back() != D)
+        return bail(DRS_ERR_BAD_ARG, "DIN attention unit must be 3*D -> ... -> D");
+      for (int w : e->bot.ln) if (w < 1) return bail(DRS_ERR_BAD_ARG, "DIN attention unit with an empty layer");
+      {   // same limit as the HIP engine (din_any.hip: a sample's activations in 160 KB of LDS)
+        int maxw = 0;
+        for (int l = 1; l + 1 < cfg->n_bot; ++l) maxw = e->bot.ln[l] > maxw ? e->bot.ln[l] : maxw;
+        const bool any = cfg->n_bot != 3 || e->bot.ln[1] > 64 || (int64_t)(T - 3) * e->bot.ln[1] > 4096 || (D & 3) || D > 256;
+        if (any && sizeof(float) * (4 * (size_t)D + 2 * (size_t)maxw) > 160 * 1024)
+          return bail(DRS_ERR_UNSUPPORTED, "DIN: 4*D + 2*(widest hidden layer of a unit) floats must fit 160 KB of LDS");
+      }
       e->m_den = 0; e->w0 = 0;
       e->num_int = 4 * D;
       if (e->num_int != e->top.ln.front()) return bail(DRS_ERR_BAD_ARG, "# of feature interactions does not match first dim of top mlp");
@@ -358,8 +361,9 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
       break;
     case DRS_MODEL_DIEN: {
       if (T < 4) return bail(DRS_ERR_BAD_ARG, "DIEN needs at least 4 embedding tables");
-      if (cfg->n_bot != 2 || e->bot.ln[0] != D || e->bot.ln[1] < 1 || e->bot.ln[1] > 64)
-        return bail(DRS_ERR_UNSUPPORTED, "DIEN: ln_bot must be [D, hidden_size] with hidden_size <= 64");
+      if (cfg->n_bot != 2 || e->bot.ln[0] != D || e->bot.ln[1] < 1) return bail(DRS_ERR_BAD_ARG, "DIEN: ln_bot must be [D, hidden_size]");
+      if (sizeof(float) * ((size_t)D + 4 * (size_t)e->bot.ln[1]) > 160 * 1024)   // (the HIP engine's any-shape recurrence)
+        return bail(DRS_ERR_UNSUPPORTED, "DIEN: D + 4*hidden_size floats must fit 160 KB of LDS");
       const int H = e->bot.ln[1];
       e->m_den = 0; e->w0 = 0;
       e->num_int = H + 3 * D;

@@ -232,6 +232,40 @@ def test_product_binding_refuses_anything_but_the_hip_build(monkeypatch):
         importlib.reload(N)
 
 
+@pytest.mark.parametrize("kind,over", [
+    ("din", dict(arch_sparse_feature_size=10, arch_mlp_bot="8-4")),         # a unit with two hidden layers over 40-byte rows
+    ("din", dict(arch_sparse_feature_size=16, arch_mlp_bot="100")),         # a hidden layer wider than 64
+    ("dien", dict(arch_sparse_feature_size=24, hidden_size=100)),           # neither one of din.hip's instances
+    ("dlrm", dict(arch_sparse_feature_size=10, arch_mlp_bot="7-12-10", arch_mlp_top="9-1")),
+])
+def test_boundary_takes_the_shapes_the_reference_takes(cpu_abi, kind, over):
+    """The reference builds its attention units / recurrent layers / MLPs from whatever widths the command line
+    names (models/din.py:255-277, models/dien.py:308-380, models/dlrm_s_caffe2.py:435-437); round 6 made the boundary
+    total (din_any.hip, sls_any_kernel).  Here: the restated ABI accepts the same shapes (it mirrors drs_create's
+    checks) and the host wrappers build, feed and serve them -- outputs equal to the oracle driven directly."""
+    rows = [60] + [40] * 3 + [70, 50] if kind != "dlrm" else [60, 40, 50]
+    B = 12
+    base = dict(arch_embedding_size="-".join(map(str, rows)), arch_mlp_top="24-2", arch_interaction_op="cat",
+                num_indices_per_lookup=3, num_batches=1, max_mini_batch_size=B, mini_batch_size=B, numpy_rand_seed=3,
+                model_type=kind, accel_slots=2)
+    base.update(over)
+    args = H.args_from({}, **base)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    net.create(None if kind != "dlrm" else lX[0], lS_l[0], lS_i[0], None)
+    try:
+        net.stage_batches(None if kind != "dlrm" else lX, lS_l, lS_i)
+        om = H.oracle_model(net)
+        for bs in (B, 5, 1):
+            exp = om.forward(None if kind != "dlrm" else lX[0], lS_i[0], lS_l[0], bs=bs)
+            assert np.array_equal(net.run_staged(0, bs), exp), (kind, bs)
+    finally:
+        net.engine.close()
+    # what still has no form: a sample's activations beyond the 160 KB of LDS the any-shape kernels keep them in
+    with pytest.raises(N.DrsError) as ei:
+        N.Engine(N.MODEL_DIEN, [10] * 5, 32, [32, 16384], [16384 + 96, 2], max_batch=4, max_lookups=1, num_staged_batches=1, num_slots=1)
+    assert ei.value.code == N.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("case", ["dlrm_rm1_mini", "ncf_mini", "din_mini"])
 def test_stand_alone_model_entry_prints_the_reference_table_lines(cpu_abi, case, capsys, tmp_path):
     """`python -m deeprecsys_amd.dlrm_s_hip <reference flags>` (models/dlrm_s_caffe2.py:575-661, models/run.sh):

@@ -843,15 +843,171 @@ def test_dien_recurrent_layers_match_oracle(D, Hs, U, init):
                 ref[(b, bs)] = got
         jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1)]
         assert eng.get_option("dien_fuse_top") == 1
-        for mfma, fuse in ((1, 1), (2, 0), (2, 1), (1, 0), (0, 1)):
-            # the matrix-core form (16 samples per workgroup; hidden sizes that are multiples of 16)
-            # and the one-wave-per-sample form run the same fma chains: the same bits -- with the top MLP
-            # inside the recurrence's launch (its default when it fits) or in a launch of its own behind it
+        for mfma, fuse in ((1, 1), (2, 0), (2, 1), (1, 0), (0, 1), (3, 1), (3, 0)):
+            # the matrix-core form (16 samples per workgroup; hidden sizes that are multiples of 16),
+            # the one-wave-per-sample form and the any-shape form (3: one workgroup per sample, din_any.hip)
+            # run the same fma chains: the same bits -- with the top MLP inside the recurrence's launch
+            # (its default when it fits) or in a launch of its own behind it
             eng.set_option("dien_mfma", mfma)
             eng.set_option("dien_fuse_top", fuse)
             outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
             for (b, bs), o in zip(jobs, outs):
                 assert np.array_equal(o, ref[(b, bs)]), (mfma, fuse, b, bs)
+            assert any("dien_rnn_any_kernel" in d for d in eng.last_dispatch()) == (mfma == 3), eng.last_dispatch()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("D,bot,U", [(32, "8-4", 5),        # two hidden layers
+                                     (32, "100", 4),         # one hidden layer, wider than din.hip's 64
+                                     (10, "3", 6),           # rows that are not 16-byte pieces
+                                     (300, "5-7-9", 3),      # rows wider than 256 columns, three hidden layers
+                                     (16, "600", 8),         # (T - 3) * h beyond the two-launch kernel's LDS
+                                     (6, "2-300-1", 3)])     # a hidden layer wider than a workgroup
+def test_din_attention_units_of_any_shape_match_oracle(D, bot, U):
+    """An attention unit is create_mlp over 3*D - <arch_mlp_bot> - D, any depth and widths (models/din.py:255-277);
+    din.hip serves one hidden layer of <= 64 units over 16-byte row pieces, everything else takes
+    din_attention_any_kernel (din_any.hip: each output its own k-ordered fmaf chain, the oracle's order).  The top
+    MLP's input row bit-exact after the sequential-order gather, outputs to 1e-6; ragged bags (empty ones included),
+    query sizes 1 .. B, coalesced queries equal to the same queries alone."""
+    rng = np.random.RandomState(D + U)
+    rows = [500] + [300] * U + [700, 400]
+    T, B, Lmax = len(rows), 70, 4
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_bot=bot, arch_mlp_top="24-2", arch_interaction_op="cat",
+                       num_indices_per_lookup=Lmax, num_batches=2, max_mini_batch_size=B,
+                       mini_batch_size=B, numpy_rand_seed=3, model_type="din", accel_slots=2)
+    np.random.seed(3)
+    net = H.M.DIN_Net(args)
+    om = H.oracle_model(net)
+    sets = []
+    for b in range(2):
+        lens = [rng.randint(0, Lmax + 1, size=B).astype(np.int32) for _ in range(T)]
+        lens[T - 2][:3] = 0
+        idx = [rng.randint(0, rows[t], size=int(lens[t].sum())).astype(np.int64) for t in range(T)]
+        sets.append((idx, lens))
+    net.create(None, sets[0][1], sets[0][0], None)
+    eng = net.engine
+    try:
+        for b, (idx, lens) in enumerate(sets):
+            eng.stage_batch(b, None, idx, lens)
+        sequential_anyway = D % 4 != 0 or D > 256          # sls_any_kernel sums in index order in either mode
+        ref = {}
+        for exact in (1, 0):
+            eng.set_option("sls_exact", exact)
+            for b, (idx, lens) in enumerate(sets):
+                for bs in (B, 33, 1):
+                    got = net.run_staged(b, bs)
+                    assert any("din_attention_any_kernel" in d for d in eng.last_dispatch()), eng.last_dispatch()
+                    R = eng.fetch_interaction(bs)
+                    exp, R_exp = om.forward(None, idx, lens, bs=bs, want_R=True)
+                    assert R.shape == (bs, 4 * D)
+                    if exact or sequential_anyway:
+                        assert np.array_equal(R, R_exp), (exact, b, bs, np.abs(R - R_exp).max())
+                        assert H.close(got, exp, rtol=1e-6, atol=1e-7), (exact, b, bs)
+                    else:
+                        assert H.close(R, R_exp, rtol=1e-5, atol_scale=2e-6), (b, bs, np.abs(R - R_exp).max())
+                        # (an output a ReLU holds near zero is a cancellation: the floor of the R check)
+                        assert H.close(got, exp, rtol=H.RTOL_OUT, atol_scale=2e-6), (b, bs, np.abs(got - exp).max())
+                    ref[(exact, b, bs)] = got
+            jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 1)]
+            outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+            for (b, bs), o in zip(jobs, outs):
+                assert np.array_equal(o, ref[(exact, b, bs)]), (exact, b, bs)
+        # per-call inputs take the same path
+        idx, lens = sets[1]
+        assert np.array_equal(eng.forward_inputs(None, idx, lens, B), ref[(0, 1, B)])
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("D,Hs,U", [(32, 100, 7),      # hidden size beyond din.hip's 64
+                                    (24, 40, 5),        # neither is one of din.hip's instances
+                                    (10, 7, 4),         # rows that are not 16-byte pieces, odd hidden size
+                                    (64, 128, 6),       # a multiple of 16 the matrix-core form has no instance for
+                                    (300, 20, 3),       # rows wider than 256 columns
+                                    (16, 600, 3)])      # more hidden units than a workgroup has threads
+def test_dien_recurrence_of_any_shape_matches_oracle(D, Hs, U):
+    """rnn_cell.BasicRNN(arch_sparse_feature_size -> hidden_size) for any two integers (models/dien.py:308-380): the
+    pairs din.hip has no instance for take dien_rnn_any_kernel (din_any.hip).  Pass-through features bitwise, the
+    recurrent state within the tanh tolerance of test_dien_recurrent_layers_match_oracle; query sizes 1 .. B (the
+    Reshape makes a sample's sequence depend on its query's size), ragged bags, coalesced = alone."""
+    rng = np.random.RandomState(D + Hs + U)
+    rows = [500] + [300] * U + [700, 400]
+    T, B, Lmax = len(rows), 50, 3
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_top="24-2", hidden_size=Hs, arch_interaction_op="cat",
+                       num_indices_per_lookup=Lmax, num_batches=2, max_mini_batch_size=B,
+                       mini_batch_size=B, numpy_rand_seed=3, model_type="dien", accel_slots=2)
+    args.dien_rnn_init = "xavier"
+    np.random.seed(3)
+    net = H.M.DIEN_Net(args)
+    om = H.oracle_model(net)
+    sets = []
+    for b in range(2):
+        lens = [rng.randint(0, Lmax + 1, size=B).astype(np.int32) for _ in range(T)]
+        idx = [rng.randint(0, rows[t], size=int(lens[t].sum())).astype(np.int64) for t in range(T)]
+        sets.append((idx, lens))
+    net.create(None, sets[0][1], sets[0][0], None)
+    eng = net.engine
+    try:
+        for b, (idx, lens) in enumerate(sets):
+            eng.stage_batch(b, None, idx, lens)
+        eng.set_option("sls_exact", 1)
+        ref = {}
+        for b, (idx, lens) in enumerate(sets):
+            for bs in (B, 33, 2, 1):
+                got = net.run_staged(b, bs)
+                assert any("dien_rnn_any_kernel" in d for d in eng.last_dispatch()), eng.last_dispatch()
+                R = eng.fetch_interaction(bs)
+                exp, R_exp = om.forward(None, idx, lens, bs=bs, want_R=True)
+                assert R.shape == (bs, Hs + 3 * D)
+                assert np.array_equal(R[:, Hs:], R_exp[:, Hs:]), (b, bs)
+                assert H.close(R, R_exp, rtol=2e-5, atol=2e-6), (b, bs, np.abs(R - R_exp).max())
+                assert H.close(got, exp, rtol=max(2e-5, H.RTOL_OUT), atol=2e-6), (b, bs, np.abs(got - exp).max())
+                ref[(b, bs)] = got
+        jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1)]
+        outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+        for (b, bs), o in zip(jobs, outs):
+            assert np.array_equal(o, ref[(b, bs)]), (b, bs)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("kind,D,width", [("din", 4096, 3000), ("dien", 64, 5000)])
+def test_any_shape_forms_with_more_than_64_kb_of_lds(kind, D, width):
+    """The any-shape kernels keep a sample's activations in LDS, up to the CU's 160 KB (drs_create refuses what does not
+    fit): a DIN unit 12288 -> 3000 -> 4096 (88 KB) and a DIEN recurrence 64 -> 5000 (78 KB) against the oracle."""
+    U = 1 if kind == "din" else 2
+    rows = [50] + [40] * U + [60, 30]
+    T, B = len(rows), 6
+    over = dict(arch_mlp_bot=str(width)) if kind == "din" else dict(hidden_size=width)
+    args = H.args_from({}, arch_sparse_feature_size=D, arch_embedding_size="-".join(map(str, rows)),
+                       arch_mlp_top="16-2", arch_interaction_op="cat", num_indices_per_lookup=2, num_batches=1,
+                       max_mini_batch_size=B, mini_batch_size=B, numpy_rand_seed=3, model_type=kind, accel_slots=1, **over)
+    np.random.seed(3)
+    net = (H.M.DIN_Net if kind == "din" else H.M.DIEN_Net)(args)
+    om = H.oracle_model(net)
+    rng = np.random.RandomState(1)
+    lens = [np.full(B, 2, dtype=np.int32) for _ in range(T)]
+    idx = [rng.randint(0, rows[t], size=2 * B).astype(np.int64) for t in range(T)]
+    net.create(None, lens, idx, None)
+    eng = net.engine
+    try:
+        eng.stage_batch(0, None, idx, lens)
+        eng.set_option("sls_exact", 1)
+        for bs in (B, 1):
+            got = net.run_staged(0, bs)
+            assert any(("%s_" % kind) in d and "any_kernel" in d for d in eng.last_dispatch()), eng.last_dispatch()
+            R = eng.fetch_interaction(bs)
+            exp, R_exp = om.forward(None, idx, lens, bs=bs, want_R=True)
+            if kind == "din":
+                assert np.array_equal(R, R_exp), np.abs(R - R_exp).max()
+                assert H.close(got, exp, rtol=1e-6, atol=1e-7)
+            else:
+                assert np.array_equal(R[:, width:], R_exp[:, width:])
+                assert H.close(R, R_exp, rtol=2e-5, atol=2e-6), np.abs(R - R_exp).max()
+                assert H.close(got, exp, rtol=H.RTOL_OUT, atol=2e-6)
     finally:
         eng.close()
 
