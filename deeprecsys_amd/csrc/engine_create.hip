@@ -395,9 +395,13 @@ int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out)
     CREATE_TRY(hipMalloc(&s.d_out, sizeof(float) * out_words));
     CREATE_TRY(hipMalloc(&s.d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&s.d_counter, sizeof(uint32_t)));
+#ifdef DRS_LAB
+    // "mlp_early" (lab only): its stream, and the word a RUNNING kernel polls while another stream's write lands in it --
+    // fine-grained memory, so that the write is visible across the XCDs' L2s
     CREATE_TRY(hipStreamCreateWithFlags(&s.early_stream, hipStreamNonBlocking));
-    CREATE_TRY(hipMalloc(&s.d_gflag, sizeof(uint32_t)));
+    CREATE_TRY(hipExtMallocWithFlags(reinterpret_cast<void**>(&s.d_gflag), sizeof(uint32_t), hipDeviceMallocFinegrained));
     CREATE_TRY(hipMemset(s.d_gflag, 0, sizeof(uint32_t)));
+#endif
     CREATE_TRY(hipMemset(s.d_err, 0, sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s.d_counter, 0, sizeof(uint32_t)));
     // column-split MLP launches (mlp.hip NSplit; DLRM's first top layer): up to 4 096 rows of that layer's outputs

@@ -443,6 +443,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
       // bottom + top MLP is ONE stream4_kernel launch: the launch goes on a second stream WITHOUT waiting for the gather,
       // runs its prologue and the bottom chain beside it and polls the slot's flag -- a 32-bit write queued behind the
       // gather -- before it fetches the pooled rows (mlp.hip, Done::wait_flag).  <= 512 rows: at most 32 workgroups spin.
+#ifdef DRS_LAB
       bool early = false;
       if (e->mlp_early && e->shared_stream == 2 && !piped && gstream == s.own_stream && Mv <= 512 && dp && s.early_stream &&
           e->kind == DRS_MODEL_DLRM) {
@@ -460,6 +461,7 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
         s.stream = s.early_stream;
         log_launch(e->tune.log, "early");
       }
+#endif
       if (fused_applicable(e, s, Mv, &xs)) HIP_TRY(e, join());
       fused = try_fused_bottom_top(e, s, Mv, out, dp, &xs, &rc);
       if (rc) return rc;
