@@ -67,6 +67,7 @@ struct Tune {
   int sls_flat = 1;              // fixed-length bags: all row loads of a wave in flight at once
   int sls_bpw = 0;               // ... bags per wave of that variant (0 = auto | 1 | 2 | 4)
   int sls_nt = 1;                // table rows are read with non-temporal loads (every gather kernel of sls.hip)
+  int sls_one = 1;               // fixed bags of ONE row (W&D, MT-WnD, NCF, DIEN): the copy form (sls_one_kernel); 1 = 64 samples per wave, 16 for small launches | 64 | 16 | 0 off
   int din_nt = 1;                // fused DIN launch: non-temporal row loads ("din_nt": +2.5 % queries/s, 0.527 -> 0.545 of peak)
   int din_pipe = 1;              // fused DIN launch, hidden width 1: indices staged in LDS, units pipelined (din_pipe_kernel)
   int din_s = 0;                 // fused DIN launch: samples per workgroup (0 = by launch size | 1 | 2 | 4)

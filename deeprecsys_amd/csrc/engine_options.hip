@@ -101,6 +101,7 @@ const OptDesc kOptions[] = {
     OPT("sls_flat", 0, 2, nullptr, 0, tune.sls_flat),
     OPT("sls_bpw", 0, 4, [](int64_t v) { return v != 3; }, 0, tune.sls_bpw),
     OPT("sls_nt", 0, 1, nullptr, O_BOOL, tune.sls_nt),
+    OPT("sls_one", 0, 64, [](int64_t v) { return v == 0 || v == 1 || v == 16 || v == 64; }, 0, tune.sls_one),
     OPT("din_fused", 0, 1, nullptr, O_BOOL, din_fused),
     OPT("din_pipe", 0, 1, nullptr, O_BOOL, tune.din_pipe),
     OPT("din_s", 0, 4, [](int64_t v) { return v != 3; }, 0, tune.din_s),

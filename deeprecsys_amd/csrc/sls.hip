@@ -276,6 +276,81 @@ __global__ __launch_bounds__(64) void sls_kernel(SlsArgs a) {
 
 
 // ---------------------------------------------------------------------------
+// ONE lookup per bag (W&D, MT-WnD, NCF, DIEN: num_indices_per_lookup 1, fixed): the pooled "sum" is an indexed row
+// copy, and the lane-group-per-bag walk above spends it waiting -- three dependent round trips (index, row, store)
+// for the 1 KB a wave has in flight.  Here a wave takes 64 samples of ONE table: lane i reads sample i's index (one
+// coalesced request per query the tile touches) and finds its output row; lane group g then copies bags g G ..
+// g G + G - 1, M = min(G, 8) rows in flight per lane (8 KB per wave at D 32), the row numbers and output rows
+// coming over the cross-lane network.  The value stored is 0.0f + row, the sequential form's single addition:
+// the same bits.  D == 4 G exactly.  BW = samples per wave: 64, or 16 for launches that would otherwise be a few dozen
+// waves (one query of NCF: 4 tables x 256 samples) -- lanes 0 .. 15 fetch the indices then.
+template <int G, int BW>
+__global__ __launch_bounds__(64) void sls_one_kernel(SlsArgs a, int tiles) {
+  constexpr int NG = 64 / G, PER = BW / NG;          // bags a lane group copies
+  constexpr int M = PER < 8 ? PER : 8;               // ... M at a time
+  static_assert(PER >= 1 && PER % M == 0, "whole rounds");
+  if (a.ts && threadIdx.x == 0) a.ts[2 * blockIdx.x] = wall_clock64();
+  const int lane = threadIdx.x;
+  const int g = lane / G, gl = lane - g * G;
+  const int n_smp = a.q.cum[a.q.n_q];
+  const int t = (int)blockIdx.x / tiles;                   // (uniform: table bases and row counts are scalar loads)
+  const int smp = ((int)blockIdx.x - t * tiles) * BW + lane;
+  const bool ok = lane < BW && smp < n_smp;
+  int b = smp, vrow = a.q.vstart[0] + smp;
+  const int32_t* qidx = a.idx[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) {
+    const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+    b = in ? smp - a.q.cum[i] : b;
+    vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+    qidx = in ? a.idx[i] : qidx;
+  }
+  if (a.q.n_q > 8) {
+#pragma unroll
+    for (int i = 8; i < DRS_MAX_COALESCE; ++i) {
+      const bool in = i < a.q.n_q && smp >= a.q.cum[i];
+      b = in ? smp - a.q.cum[i] : b;
+      vrow = in ? a.q.vstart[i] + smp - a.q.cum[i] : vrow;
+      qidx = in ? a.idx[i] : qidx;
+    }
+  }
+  const uint32_t rows = (uint32_t)a.tab_rows[t];
+  uint32_t r = ok ? (uint32_t)qidx[(int64_t)t * a.idx_stride + b] : 0u;
+  const bool bad = r >= rows;                               // Caffe2's ENFORCE: flag it, contribute zero
+  if (bad) atomicOr(a.err, 1);
+  r = bad ? 0u : r;
+  // what the copying lanes need of sample i: its row number, and its output row (-1: nothing to store)
+  const int dst = ok ? vrow : -1;
+  const int keep = bad ? 0 : 1;
+  const float4* __restrict__ W = reinterpret_cast<const float4*>(a.tables + a.tab_off[t]) + gl;
+  float* __restrict__ out = a.out + a.col0 + (int64_t)t * (4 * G) + gl * 4;
+#pragma unroll
+  for (int j0 = 0; j0 < PER; j0 += M) {
+    float4 v[M];
+    int vr[M], kp[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int src = g * PER + j0 + j;
+      const uint32_t rj = (uint32_t)__shfl((int)r, src);
+      vr[j] = __shfl(dst, src);
+      kp[j] = __shfl(keep, src);
+      v[j] = W[(uint64_t)(rj * (uint32_t)G)];                // rows * D / 4 < 2^32 (enforced at table creation)
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+      if (vr[j] >= 0) {
+        const float4 o = make_float4(0.f + (kp[j] ? v[j].x : 0.f), 0.f + (kp[j] ? v[j].y : 0.f),
+                                     0.f + (kp[j] ? v[j].z : 0.f), 0.f + (kp[j] ? v[j].w : 0.f));
+        *reinterpret_cast<float4*>(out + (int64_t)vr[j] * a.ld_out) = o;
+      }
+  }
+  if (a.ts) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) a.ts[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // FLAT variant: fixed-length bags, G lanes per row (16 B per lane), NL loads per lane, BPW
 // bags (same sample, consecutive tables) per wave.  Requires L * BPW <= NL * (64 / G) and
 // T % BPW == 0 (checked by launch_sls).
@@ -751,6 +826,21 @@ hipError_t launch_flat(const SlsArgs& a, const FlatPlan& p, hipStream_t s, hipEv
 // Tunables (drs_set_option, kept per engine in Tune): "sls_flat" / "sls_bpw" the flat variant and its bags
 // per wave (0 = auto), "sls_nt" non-temporal row loads.
 static inline bool any_width(int D) { return (D & 3) || D > 256; }      // widths only sls_any_kernel takes
+// the one-lookup copy form: every coalesced query has fixed bags of ONE row, a row is 4 / 8 / 16 / 32 lanes x 16 B
+static inline bool one_lookup(const SlsArgs& a, const Tune& tune) {
+  if (!tune.sls_one || a.q.n_q < 1 || !(a.D == 16 || a.D == 32 || a.D == 64 || a.D == 128)) return false;
+  for (int i = 0; i < a.q.n_q; ++i) if (a.uniform_len[i] != 1) return false;
+  return true;
+}
+// samples per wave: 64, unless that leaves the launch under 1 024 waves ("sls_one" 64 / 16 force one)
+static inline int one_lookup_tile(const SlsArgs& a, const Tune& tune) {
+  if (tune.sls_one == 64 || tune.sls_one == 16) return tune.sls_one;
+  return (int64_t)a.T * ((a.q.cum[a.q.n_q] + 63) / 64) < 1024 ? 16 : 64;
+}
+static inline int64_t one_lookup_grid(const SlsArgs& a, const Tune& tune) {
+  const int bw = one_lookup_tile(a, tune);
+  return (int64_t)a.T * ((a.q.cum[a.q.n_q] + bw - 1) / bw);
+}
 
 bool sls_flat_applicable(const SlsArgs& a, const Tune& tune) { return !any_width(a.D) && flat_plan(a, tune).ok; }
 
@@ -761,6 +851,7 @@ int64_t sls_grid_blocks(const SlsArgs& a, int exact, const Tune& tune) {
     const FlatPlan p = flat_plan(a, tune);
     return p.ok ? (int64_t)p.grid : n_bags;
   }
+  if (one_lookup(a, tune)) return one_lookup_grid(a, tune);
   int G = lanes_per_row(a.D);
   const int bags = 64 / G;
   return (n_bags + bags - 1) / bags;
@@ -783,6 +874,25 @@ hipError_t launch_sls(const SlsArgs& a, int exact, const Tune& tune, hipStream_t
                  p.coal ? "" : (p.BPW == 4 ? ",bpw4" : p.BPW == 2 ? ",bpw2" : ",bpw1"), p.nt ? ",nt" : "", p.grid, p.L);
       return launch_flat(a, p, s, stop);
     }
+  }
+  if (exact && one_lookup(a, tune)) {
+    const int bw = one_lookup_tile(a, tune);
+    const int tiles = (a.q.cum[a.q.n_q] + bw - 1) / bw;
+    if (tiles == 0) return hipSuccess;
+    const dim3 grid((unsigned)one_lookup_grid(a, tune));
+    log_launch(tune.log, "sls_one_kernel<%d,%d>[%u wg]", D / 4, bw, grid.x);
+    if (bw == 64) {
+      if (D == 16) launch_k(sls_one_kernel<4, 64>, grid, s, stop, a, tiles);
+      else if (D == 32) launch_k(sls_one_kernel<8, 64>, grid, s, stop, a, tiles);
+      else if (D == 64) launch_k(sls_one_kernel<16, 64>, grid, s, stop, a, tiles);
+      else launch_k(sls_one_kernel<32, 64>, grid, s, stop, a, tiles);
+    } else {
+      if (D == 16) launch_k(sls_one_kernel<4, 16>, grid, s, stop, a, tiles);
+      else if (D == 32) launch_k(sls_one_kernel<8, 16>, grid, s, stop, a, tiles);
+      else if (D == 64) launch_k(sls_one_kernel<16, 16>, grid, s, stop, a, tiles);
+      else launch_k(sls_one_kernel<32, 16>, grid, s, stop, a, tiles);
+    }
+    return hipGetLastError();
   }
   log_launch(tune.log, "sls_kernel<%d,%s>[%lld wg]", lanes_per_row(D), exact ? "sequential" : (tune.sls_nt ? "split,nt" : "split"),
              (long long)sls_grid_blocks(a, exact, tune));

@@ -537,7 +537,7 @@ RUN_SCRIPT_SHAPES = {
 # first token of a launch set's dispatch: the gather kernel the shape takes by default / with sls_exact
 GATHER_FORM = {"rmc1": ("sls_flatc_kernel<16,20,nt>", "sls_kernel<16,sequential>"),
                "rm2": ("sls_kernel<16,split,nt>", "sls_kernel<16,sequential>"),
-               "wnd": ("sls_kernel<8,sequential>", "sls_kernel<8,sequential>")}
+               "wnd": ("sls_one_kernel<8,", "sls_one_kernel<8,")}      # one lookup per bag: the copy form in either mode
 
 
 @pytest.mark.parametrize("name", sorted(RUN_SCRIPT_SHAPES))
@@ -586,7 +586,11 @@ def test_engine_built_as_the_run_scripts_build_it(name):
             assert np.array_equal(R, R_exp), (name, "sequential gather", bs)
             assert H.close(got, exp, rtol=1e-6, atol=1e-7), (name, bs, np.abs(got - exp).max())
             forms["single %d, sls_exact" % bs] = eng.last_dispatch()
-            assert forms["single %d, sls_exact" % bs][1] == "%s[%d wg]" % (GATHER_FORM[name][1], -(-bs * T // (64 // (16 if D == 64 else 8)))), forms
+            if L == 1:          # 64 samples of one table per wave; 16 while that leaves the launch under 1 024 waves
+                bw = 16 if T * -(-bs // 64) < 1024 else 64
+                assert forms["single %d, sls_exact" % bs][1] == "%s%d>[%d wg]" % (GATHER_FORM[name][1], bw, T * -(-bs // bw)), forms
+            else:
+                assert forms["single %d, sls_exact" % bs][1] == "%s[%d wg]" % (GATHER_FORM[name][1], -(-bs * T // (64 // (16 if D == 64 else 8)))), forms
         eng.set_option("sls_exact", 0)
         for bs in singles:
             bid = (bs + 1) % 2
@@ -1721,6 +1725,70 @@ def test_any_embedding_width_is_served_and_matches_oracle(D, T, L, bot, top, op)
             eng.forward_inputs(lX[0], bad, lens, B)
     finally:
         net.engine.close()
+
+
+@pytest.mark.parametrize("D", [16, 32, 64, 128])
+def test_one_lookup_copy_form_equals_the_sequential_form(D):
+    """Fixed bags of ONE row (W&D, MT-WnD, NCF, DIEN) take sls_one_kernel -- 64 samples of one table per wave, the
+    lookup as an indexed row copy with 8 rows in flight per lane -- instead of the lane-group-per-bag walk: same bits
+    ("sls_one" 0 selects the walk), pooled rows bit-exact against the oracle; query sizes that do not fill a 64-sample
+    tile, coalesced sets whose tiles straddle queries, more than 8 queries per set, ragged bags (lengths 0 / 1: the
+    walk serves them), -0.0 in a table (0.0f + row, like the sequential sum) and Caffe2's index ENFORCE."""
+    rows, T, B = 997, 5, 150
+    args, net, lX, lS_l, lS_i = _big_case(rows, D, T, 1, "13-%d" % D, "24-1", B, nb=2, seed=7)
+    net.create(lX[0], lS_l[0], lS_i[0], None)
+    eng = net.engine
+    try:
+        net.stage_batches(lX, lS_l, lS_i)
+        lo, hi = -float(np.sqrt(1 / rows)), float(np.sqrt(1 / rows))
+        net.emb_w = [orc.fill_table_uniform(rows, D, t, lo, hi, args.numpy_rand_seed, nthreads=0) for t in range(T)]
+        net.emb_w[1][int(lS_i[0][1][0])] = -0.0            # a row of negative zeros: pooled to +0.0 by either form
+        eng.set_table(1, net.emb_w[1])
+        om = H.oracle_model(net)
+        jobs = [(0, B), (1, 33), (1, 1), (0, 70), (1, B), (0, 64), (1, 65), (0, 2), (0, 33), (1, 129)]
+        ref = {}
+        for one in (1, 0, 64, 16):                        # 1: 64 samples per wave, 16 for small launches; or forced
+            eng.set_option("sls_one", one)
+            for bid in (0, 1):
+                for bs in (B, 65, 64, 1):
+                    got = net.run_staged(bid, bs)
+                    assert any("sls_one_kernel" in d for d in eng.last_dispatch()) == bool(one), eng.last_dispatch()
+                    R = eng.fetch_interaction(bs)
+                    if one == 1:
+                        exp, R_exp = om.forward(lX[bid], lS_i[bid], lS_l[bid], bs=bs, want_R=True, nthreads=0)
+                        assert np.array_equal(R.view(np.uint32), R_exp.view(np.uint32)), (bid, bs)
+                        assert H.close(got, exp, rtol=1e-6, atol=1e-7)
+                        ref[(bid, bs)] = (got, R)
+                    else:
+                        assert np.array_equal(got, ref[(bid, bs)][0]) and np.array_equal(R.view(np.uint32), ref[(bid, bs)][1].view(np.uint32))
+            outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
+            if one == 1:
+                ref["multi"] = outs
+                for (bid, bs), o in zip(jobs, outs):
+                    if (bid, bs) in ref:
+                        assert np.array_equal(o, ref[(bid, bs)][0]), (bid, bs)
+            else:
+                assert all(np.array_equal(x, y) for x, y in zip(outs, ref["multi"]))
+        eng.set_option("sls_one", 1)
+        # ragged bags (0 or 1 lookups) read the prefix sums: the walk
+        rng = np.random.RandomState(3)
+        lens = [(rng.rand(B) < 0.7).astype(np.int32) for _ in range(T)]
+        ids = [rng.randint(0, rows, size=int(l.sum())).astype(np.int64) for l in lens]
+        got = eng.forward_inputs(lX[0], ids, lens, B)
+        assert not any("sls_one_kernel" in d for d in eng.last_dispatch())
+        assert H.close(got, om.forward(lX[0], ids, lens, bs=B, nthreads=0), rtol=1e-6, atol=1e-7)
+        # fixed one-row bags through the per-call path: the copy form again; an index past the table is Caffe2's ENFORCE
+        ones = [np.ones(B, dtype=np.int32) for _ in range(T)]
+        ids = [rng.randint(0, rows, size=B).astype(np.int64) for _ in range(T)]
+        got = eng.forward_inputs(lX[0], ids, ones, B)
+        assert any("sls_one_kernel" in d for d in eng.last_dispatch())
+        assert H.close(got, om.forward(lX[0], ids, ones, bs=B, nthreads=0), rtol=1e-6, atol=1e-7)
+        with pytest.raises(N.DrsError):
+            bad = [i.copy() for i in ids]
+            bad[T - 1][B - 1] = rows
+            eng.forward_inputs(lX[0], bad, ones, B)
+    finally:
+        eng.close()
 
 
 def test_wide_and_deep_with_an_odd_dense_width():
