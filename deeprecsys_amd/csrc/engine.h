@@ -89,6 +89,8 @@ struct Slot {
   hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // ... events that order a set's launches across the two kinds of stream
   int n_ev = 0;
   hipEvent_t ev_sls = nullptr;           // pipelined mode: gather done -> the MLP stream may go on
+  hipEvent_t ev_dma = nullptr;           // "out_dma": last kernel done -> the copy stream may take the outputs
+  bool on_dma = false;                   // ... the job in flight hands over through the copy stream
   hipEvent_t ev_in = nullptr;            // pipelined mode: per-call inputs copied -> the gather may start
   Batch zc;                              // per-call inputs read in place from host-mapped pinned memory
   float* T = nullptr;        // [max_batch, ldT]  concat buffer: dense_out | emb_0 | ...
@@ -227,6 +229,7 @@ struct drs_engine {
   int sls_exact = 0, mlp_split = 1, zero_copy = 1, sls_uniform = 1, shared_stream = 2, mlp_fuse = 1;
   int dispatch_log = 0;             // "dispatch_log": keep the per-slot record of the kernel forms chosen (drs_last_dispatch)
   hipStream_t stream_g = nullptr;   // shared_stream == 2: all gathers, back to back
+  hipStream_t stream_dma = nullptr; // "out_dma": the copy-engine transfers of the outputs and the flag writes behind them
 #ifdef DRS_LAB
   hipStream_t stream_g2 = nullptr;  // lab ("gather_streams" 2): the gathers of consecutive slots alternate between two streams
   int gather_streams = 1;

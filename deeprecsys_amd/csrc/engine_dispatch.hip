@@ -520,10 +520,16 @@ int32_t enqueue_forward(drs_engine* e, Slot& s, int n, const Batch* const* bts, 
   }
   if (out_dma) {
     log_launch(e->tune.log, "out_dma[%lld B]", (long long)(sizeof(float) * (size_t)Mv * e->n_out));
+    // ... on the engine's copy stream, behind an event: queued on s.stream itself, the transfer (2 MB = ~40 us of PCIe
+    // per MT-WnD set) held up the NEXT set's launches on that MLP stream -- the chip idled 13.5 % of the time
+    // (profiles/r06_mtwnd_kernel_overlap_before.txt)
+    HIP_TRY(e, hipEventRecord(s.ev_dma, s.stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream_dma, s.ev_dma, 0));
     HIP_TRY(e, hipMemcpyAsync(s.h_out + kOutOffset, s.d_out, sizeof(float) * (size_t)Mv * e->n_out,
-                              hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(e, hipStreamWriteValue32(s.stream, s.dm_out, s.seq, 0));
+                              hipMemcpyDeviceToHost, e->stream_dma));
+    HIP_TRY(e, hipStreamWriteValue32(e->stream_dma, s.dm_out, s.seq, 0));
   }
+  s.on_dma = out_dma;
   s.polled = e->zero_copy != 0;
   return DRS_OK;
 }
@@ -562,6 +568,7 @@ int32_t wait_slot(drs_engine* e, Slot& s, float* h_out, int64_t h_cap) {
       if ((spins & 0xfffff) == 0 &&
           std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
         HIP_TRY(e, hipStreamSynchronize(s.stream));
+        if (s.on_dma) HIP_TRY(e, hipStreamSynchronize(e->stream_dma));
         if (*flag != s.seq) {
           s.busy = false;
           return fail(e, DRS_ERR_HIP, "completion flag never arrived (seq %u, flag %u)", s.seq, *flag);

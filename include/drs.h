@@ -275,9 +275,9 @@ int32_t drs_interact_dot(drs_handle h, const float* d_T, int64_t B, int32_t F, i
  * Results never depend on an option except where noted (sls_exact: the gather's fp32 summation order).
  * The product library takes the keys below; unknown key or value -> DRS_ERR_BAD_ARG.
  *   gather        "sls_exact" 0|1 (1: sequential order, bit-identical to Caffe2's SparseLengthsSum)
- *                 "sls_flat" 0|1|2   "sls_bpw" 0|1|2|4   "sls_nt" 0|1
+ *                 "sls_flat" 0|1|2   "sls_bpw" 0|1|2|4   "sls_nt" 0|1   "sls_one" 0|1|16|64
  *                 "din_fused" 0|1   "din_pipe" 0|1   "din_s" 0|1|2|4   "din_nt" 0|1
- *                 "dien_mfma" 0|1|2   "dien_fuse_top" 0|1
+ *                 "dien_mfma" 0|1|2|3   "dien_fuse_top" 0|1
  *   MLP side      "mlp_fuse" 0|1   "mlp_split" 0|1   "mlp_wide_kn" n   "gemm_split" 0|1
  *                 "mlp_stream" 2|4   "mlp_stream_2cu" 0|1   "mlp_rows32" n
  *                 "mlp_nsplit" 0|2|4   "mlp_nsplit_rows" n   "mlp_gemm_tile" 0|22|12|21|11|214|322|321|312|311
