@@ -97,7 +97,7 @@ def parse(argv=None):
                     help="places in HBM tried for the table arena before the warm-up (the engine's own launch sets time "
                          "each, the fastest stays: DLRM_Net.tune_table_placement); 1 = wherever hipMalloc put it")
     ap.add_argument("--slots", type=int, default=0,
-                    help="launch sets in flight; 0 = what the engine asks for (drs_get_option preferred_slots: 3 gather-bound models, 6 MLP-bound ones)")
+                    help="launch sets in flight; 0 = what the engine asks for (drs_get_option preferred_slots: 3 gather-bound models, 4 or 6 MLP-bound ones)")
     ap.add_argument("--coalesce", type=int, default=0,
                     help="queries per launch set (the engine coalesces requests that are already queued); "
                          "0 = the engine's own preference for the model: 12 for gather-bound DLRM, 16 for the MLP-bound "

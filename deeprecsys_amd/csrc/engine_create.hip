@@ -137,7 +137,8 @@ static void choose_launch_forms(drs_engine* e) {
   // W&D 98.1 / 104.9 / 100.0 | NCF 297 / 389-417 / 346 | MT-WnD 68.5 / 70.8 / 73.0-74.8 | DIEN 158 / 185 / 214: with three
   // sets one of four streams idles; DIEN's and MT-WnD's launches (two workgroups per CU each) thrash when four of them
   // run at once and do best two at a time with a second set queued behind each (profiles/r06_slots.md).
-  const bool two_at_a_time = e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND;
+  // (W&D joined them when its gather became sls_one_kernel: (4, 2) 110.8 k at p99 0.59 ms, (6, 4) 110.4 k at 1.01 ms.)
+  const bool two_at_a_time = e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND;
   const int want_streams = two_at_a_time ? 2 : 4;
   e->mlp_streams = mlp_bound ? (e->n_slots < want_streams ? e->n_slots : want_streams) : 1;
   e->mlp_bound = mlp_bound ? 1 : 0;

@@ -76,10 +76,10 @@ class _HipNet(object):
     def _num_slots(self):
         """--accel_slots n launch sets in flight; 0 (default): what the engine asks for (drs_get_option
         "preferred_slots": 3 -- gather | MLP | enqueue -- for the gather-bound models, 6 for the MLP-bound ones, whose
-        sets are chains of MFMA-bound launches that overlap each other).  The engine decides the class from the model's
+        sets are chains of MFMA-bound launches that overlap each other; 4 for DIEN, MT-WnD and W&D, two sets at a time).  The engine decides the class from the model's
         shapes at creation: this is the first guess, _build_engine re-creates the (still empty) engine when it differs."""
         req = int(getattr(self.args, "accel_slots", 0) or 0)
-        return req if req > 0 else (3 if self.kind in (N.MODEL_DLRM, N.MODEL_DIN) else 4 if self.kind in (N.MODEL_DIEN, N.MODEL_MTWND) else 6)
+        return req if req > 0 else (3 if self.kind in (N.MODEL_DLRM, N.MODEL_DIN) else 4 if self.kind in (N.MODEL_DIEN, N.MODEL_MTWND, N.MODEL_WND) else 6)
 
     def _build_engine(self, ln_bot_cfg, ln_top_cfg, interaction_op, itself, sigmoid_top, ln_task=None, num_tasks=0):
         a = self.args

@@ -642,10 +642,10 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
     const double bytes = (double)e->T * e->max_lookups * e->D * 4.0;
     // launch sets in flight: 6 for the MLP-bound class (their MFMA-bound launches overlap each other), 3 otherwise
     if (!strcmp(key, "preferred_slots")) {
-      *value = !(flop / bytes > 20.0) ? 3 : (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND) ? 4 : 6;
+      *value = !(flop / bytes > 20.0) ? 3 : (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND) ? 4 : 6;
       return DRS_OK;
     }
-    const int want = (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND) ? 2 : 4;
+    const int want = (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND) ? 2 : 4;
     int streams = flop / bytes > 20.0 ? (e->n_slots < want ? e->n_slots : want) : 1;
     if (streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
       double weights = 0;

@@ -433,7 +433,7 @@ def test_full_size_reference_shapes_match_oracle(name):
         om = H.oracle_model(net)
         ref = {}
         # (launch sets in flight the engine asks for: 6 for the MLP-bound class -- streams per slot --, 3 for the gather-bound)
-        assert eng.get_option("preferred_slots") == (3 if eng.get_option("gather_bound") else 4 if w["kind"] in ("dien", "mtwnd") else 6)
+        assert eng.get_option("preferred_slots") == (3 if eng.get_option("gather_bound") else 4 if w["kind"] in ("dien", "mtwnd", "wnd") else 6)
         eng.set_option("sls_exact", 1)
         for bid in (0, 1):
             for bs in (B, 165, 1):

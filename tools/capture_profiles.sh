@@ -121,6 +121,17 @@ for w in rmc1_ref rmc2_ref rmc3_ref rmc1_dot wnd ncf mtwnd din dien; do
 done
 run 400 python bench.py --workload rmc3 --batch 512 --no_cpu_baseline --steps 5 --warmup 2 --queries_per_step 2048 > "$OUT/bench_rmc3.json" 2>/dev/null
 run 600 python bench.py --workload rmc3 --batch 512 --steps 3 --warmup 1 --queries_per_step 2048 --timed_only > /dev/null 2>&1
+# round 6: the one-lookup gather as a row copy (sls_one_kernel) against the lane-group-per-bag walk ("sls_one" 0), arms alternating;
+# kernel traces of W&D and MT-WnD (is some kernel running all the time?  MT-WnD's output transfer has its own stream now)
+for rep in 1 2; do
+  for w in wnd mtwnd dien ncf; do
+    for one in 0 1; do
+      run 300 python bench.py --workload $w --no_cpu_baseline --steps 5 --warmup 2 --set sls_one=$one > "$OUT/bench_${w}_sls_one${one}_$rep.json" 2>/dev/null
+    done
+  done
+done
+trace wnd python bench.py --workload wnd --no_cpu_baseline --timed_only --steps 3 --warmup 1
+trace mtwnd python bench.py --workload mtwnd --no_cpu_baseline --timed_only --steps 3 --warmup 1
 # CPU baseline legs on the MLP-bound shapes as well (port + torch)
 run 600 python bench.py --workload wnd --steps 3 --warmup 1 --queries_per_step 4096 > "$OUT/bench_wnd_cpu.json" 2>/dev/null
 # 5b. DIN (fused gather + attention launch) and DIEN (recurrence on the matrix cores): per-kernel
