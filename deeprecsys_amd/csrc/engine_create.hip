@@ -139,7 +139,8 @@ static void choose_launch_forms(drs_engine* e) {
   // run at once and do best two at a time with a second set queued behind each (profiles/r06_slots.md).
   // (W&D joined them when its gather became sls_one_kernel: (4, 2) 110.8 k at p99 0.59 ms, (6, 4) 110.4 k at 1.01 ms.)
   const bool two_at_a_time = e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND;
-  const int want_streams = two_at_a_time ? 2 : 4;
+  // (NCF: six sets on three streams 530-552 k against 519-524 k on four, alternating three times on one box.)
+  const int want_streams = two_at_a_time ? 2 : e->kind == DRS_MODEL_NCF ? 3 : 4;
   e->mlp_streams = mlp_bound ? (e->n_slots < want_streams ? e->n_slots : want_streams) : 1;
   e->mlp_bound = mlp_bound ? 1 : 0;
   e->pref_slots = !mlp_bound ? 3 : two_at_a_time ? 4 : 6;

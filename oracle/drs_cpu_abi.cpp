@@ -645,7 +645,7 @@ int32_t drs_get_option(drs_handle e, const char* key, int64_t* value) {
       *value = !(flop / bytes > 20.0) ? 3 : (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND) ? 4 : 6;
       return DRS_OK;
     }
-    const int want = (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND) ? 2 : 4;
+    const int want = (e->kind == DRS_MODEL_DIEN || e->kind == DRS_MODEL_MTWND || e->kind == DRS_MODEL_WND) ? 2 : e->kind == DRS_MODEL_NCF ? 3 : 4;
     int streams = flop / bytes > 20.0 ? (e->n_slots < want ? e->n_slots : want) : 1;
     if (streams == 1 && e->n_slots >= 2 && e->kind == DRS_MODEL_DLRM) {
       double weights = 0;
