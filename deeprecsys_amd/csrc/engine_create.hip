@@ -194,7 +194,11 @@ static void choose_launch_forms(drs_engine* e) {
   // MT-WnD 69.2 | 71.8 | 66.4; RM3 reference JSON 66.5 | 68.1 | 72.2; RM3 config 3 34.8 | 35.2 | 34.7; W&D 96.0 | 94.7 | 97.0)
   e->tune.gemm_2cu = dlrm || e->kind == DRS_MODEL_WND;
   if (e->kind == DRS_MODEL_MTWND || (dlrm && e->mlp_streams > 1)) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 256; }
-  if (e->kind == DRS_MODEL_WND) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 512; }
+  // W&D: the first layer from 3 072 rows on (384 workgroups; the second layer's 256 at full sets stay with gemm_kernel, the
+  // 94.7 above).  Until round 6 the bar was 512 = full sets of 256-sample queries only: 15 queries per set 99.9 k -> 106.0 k,
+  // 8 / 12 / 16 equal; at 2 560-2 640 rows (10 x 256, or 16 queries of the run scripts' ~165 samples) the two kernels are
+  // within 1 % of each other either way (profiles/r06_wnd_set_sizes.txt)
+  if (e->kind == DRS_MODEL_WND) { e->tune.gemm32_small = 12; e->tune.gemm32_small_blocks = 384; }
 }
 
 int32_t drs_create(const drs_model_cfg* cfg, int32_t device_id, drs_handle* out) {
