@@ -617,8 +617,21 @@ def test_engine_built_as_the_run_scripts_build_it(name):
                     outs = [eng.wait(s, sum(n for _, n in sets[s])) for s in range(3)]
                 for s in range(3):
                     vrows = sum((n + 63) // 64 * 64 for _, n in sets[s])
-                    Rv = eng.fetch_interaction(vrows, slot=s)
                     forms["%s, %d queries, %d rows" % (dist, per_set, vrows)] = eng.last_dispatch(s)
+                    if any("gemm32_kernel" in d and ",split" in d for d in eng.last_dispatch(s)):
+                        # W&D from 3 072 rows on: the first top layer read the dense columns from the queries' own arrays,
+                        # the interaction tensor was never whole -- the fetch says so; the same set with "gemm_split" 0
+                        # (same bits out) materialises it
+                        with pytest.raises(N.DrsError) as ei:
+                            eng.fetch_interaction(vrows, slot=s)
+                        assert ei.value.code == N.ERR_STATE
+                        eng.set_option("gemm_split", 0)
+                        eng.forward_multi_async(s, [b for b, _ in sets[s]], [n for _, n in sets[s]])
+                        assert np.array_equal(eng.wait(s, sum(n for _, n in sets[s])), outs[s])
+                        Rv = eng.fetch_interaction(vrows, slot=s)
+                        eng.set_option("gemm_split", 1)
+                    else:
+                        Rv = eng.fetch_interaction(vrows, slot=s)
                     o = v = 0
                     for k, (bid, n) in enumerate(sets[s]):
                         exp, R_exp = oracle(bid, n)
