@@ -927,7 +927,7 @@ def test_din_attention_units_of_any_shape_match_oracle(D, bot, U):
                         # (an output a ReLU holds near zero is a cancellation: the floor of the R check)
                         assert H.close(got, exp, rtol=H.RTOL_OUT, atol_scale=2e-6), (b, bs, np.abs(got - exp).max())
                     ref[(exact, b, bs)] = got
-            jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 1)]
+            jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 1), (0, 1), (1, 33), (0, B), (1, 1), (0, 33)]
             outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
             for (b, bs), o in zip(jobs, outs):
                 assert np.array_equal(o, ref[(exact, b, bs)]), (exact, b, bs)
@@ -983,7 +983,8 @@ def test_dien_recurrence_of_any_shape_matches_oracle(D, Hs, U):
                 assert H.close(R, R_exp, rtol=2e-5, atol=2e-6), (b, bs, np.abs(R - R_exp).max())
                 assert H.close(got, exp, rtol=max(2e-5, H.RTOL_OUT), atol=2e-6), (b, bs, np.abs(got - exp).max())
                 ref[(b, bs)] = got
-        jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1)]
+        # (12 queries: the upper half of the kernels' per-query argument tables)
+        jobs = [(0, B), (1, 33), (0, 1), (1, B), (0, 33), (1, 2), (0, 2), (1, 1), (0, B), (1, 2), (0, 33), (1, 33)]
         outs = net.run_staged_multi([b for b, _ in jobs], [n for _, n in jobs])
         for (b, bs), o in zip(jobs, outs):
             assert np.array_equal(o, ref[(b, bs)]), (b, bs)
