@@ -268,3 +268,33 @@ def test_torch_cpu_forward_second_opinion(case):
     assert H.close(got, exp, rtol=2e-5, atol=1e-6), np.abs(got - exp).max()
     out = H.oracle_model(net).forward(dense, lS_i[0], lS_l[0])
     assert H.close(got, out, rtol=2e-5, atol=1e-6), np.abs(got - out).max()
+
+
+@pytest.mark.parametrize("kind,over", [
+    ("din", dict(arch_sparse_feature_size=10, arch_mlp_bot="8-4")),          # attention unit with two hidden layers, 40-byte rows
+    ("din", dict(arch_sparse_feature_size=16, arch_mlp_bot="100")),          # a hidden layer wider than 64
+    ("din", dict(arch_sparse_feature_size=6, arch_mlp_bot="2-300-1")),
+    ("dien", dict(arch_sparse_feature_size=24, hidden_size=100)),
+    ("dien", dict(arch_sparse_feature_size=10, hidden_size=7)),
+    ("dlrm", dict(arch_sparse_feature_size=10, arch_mlp_bot="7-12-10", arch_mlp_top="9-1", arch_interaction_op="dot")),
+    ("wnd", dict(arch_sparse_feature_size=12, arch_mlp_bot="13", arch_mlp_top="20-6-1", num_indices_per_lookup=1)),
+])
+def test_oracle_agrees_with_torch_cpu_on_the_shapes_only_the_generic_kernels_serve(kind, over):
+    """The reference's fixtures hold the shipped shapes only; the shapes the generic kernels admit (any embedding
+    width, attention units of any depth, any hidden size -- din_any.hip, sls_any_kernel) are checked on the GPU
+    against the C oracle, so the oracle itself gets its torch-CPU second opinion on them here."""
+    import torch
+    rows = [60] + [40] * 3 + [70, 50] if kind in ("din", "dien") else [60, 40, 50]
+    B = 9
+    base = dict(arch_embedding_size="-".join(map(str, rows)), arch_mlp_top="24-2", arch_interaction_op="cat",
+                num_indices_per_lookup=3, num_batches=1, max_mini_batch_size=B, mini_batch_size=B, numpy_rand_seed=3,
+                model_type=kind)
+    base.update(over)
+    args = H.args_from({}, **base)
+    net, lX, lS_l, lS_i, lT = H.materialize(args)
+    dense = None if kind in H.NO_DENSE else lX[0]
+    with torch.no_grad():
+        got = _torch_forward(net, kind, dense, lS_i[0], lS_l[0])
+    out = H.oracle_model(net).forward(dense, lS_i[0], lS_l[0])
+    assert got.shape == out.shape
+    assert H.close(got, out, rtol=2e-5, atol=1e-6), np.abs(got - out).max()
